@@ -1,0 +1,82 @@
+/*
+ * oracle.h — TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU restatement ("port") of the reference algorithms on the hot path, used by
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg as the *checker*.  The product
+ * path (fplll_amd/, include/) never links, loads or calls anything declared here.
+ *
+ * Parity pin: every function here is checked against the real reference build
+ * (oracle/_ref/libfplll.so, built from /root/reference by oracle/Makefile) by
+ * oracle/ref_driver.cpp → tests/golden/*.json and tests/test_oracle_vs_ref.py.
+ */
+#ifndef FPLLL_AMD_ORACLE_H
+#define FPLLL_AMD_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORACLE_MAX_DIM 256
+
+/* Solution sink.  Mirrors extenum_cb_process_sol (fplll/enum/enumerate_ext_api.h:62-63):
+ * receives the squared norm and the coefficient vector, returns the NEW enumeration bound. */
+typedef double (*oracle_sol_cb)(void *user, double dist, const double *sol);
+/* Mirrors extenum_cb_process_subsol (enumerate_ext_api.h:70-71). */
+typedef void (*oracle_subsol_cb)(void *user, double dist, const double *subsol, int offset);
+
+/*
+ * SVP enumeration (no target, no subtree, primal), restating
+ *   EnumerationDyn::prepare_enumeration   fplll/enum/enumerate.cpp:161-216
+ *   EnumerationBase::enumerate_loop       fplll/enum/enumerate_base.cpp:152-195 (prologue)
+ *   EnumerationBase::enumerate_recursive  fplll/enum/enumerate_base.cpp:24-118
+ *   EnumerationDyn::set_bounds/process_solution/process_subsolution  enumerate.cpp:218-249
+ *
+ * mut     : d×d row-major, mut[i*d+j] = mu(j,i) for j>i (the layout callback_set_config fills with
+ *           mutranspose=true, enumerate_ext.cpp:108-121); other entries ignored.
+ * rdiag   : r_ii (normalised), pruning : d coefficients or NULL (= all 1.0).
+ * cb      : NULL → behave like FastEvaluator(max_sols=1, BEST_N): new bound = dist, best kept in
+ *           best_sol/best_dist.
+ * nodes   : [d+1] per-level counts, "fplll rule" (count after the bound test, :31-33), including the
+ *           nodes[i]-- compensation of enumerate_base.cpp:181-184.
+ * returns : number of solutions passed to cb (or accepted by the built-in evaluator).
+ */
+int64_t oracle_enumerate(int d, const double *mut, const double *rdiag, const double *pruning,
+                         double maxdist, int findsubsols, oracle_sol_cb cb, oracle_subsol_cb subcb,
+                         void *user, uint64_t *nodes, double *best_sol, double *best_dist);
+
+/* ------------------------------------------------------------------------------------------
+ * GSO / size reduction for ZT=long, FT=double, GSO_ROW_EXPO on (the BKZ fast path,
+ * fplll/bkz.cpp:816-829).  State layout = one contiguous lattice; see gso_oracle.c.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct oracle_gso oracle_gso;
+
+oracle_gso *oracle_gso_create(int d, int n, const int64_t *b /* d×n row-major */, int row_expo);
+void oracle_gso_destroy(oracle_gso *g);
+/* MatGSOInterface::update_gso_row(i, last_j)   gso_interface.cpp:131-164.  returns 0 on non-finite mu */
+int oracle_gso_update_row(oracle_gso *g, int i, int last_j);
+/* MatGSOInterface::update_gso()                gso_interface.h:767-775 */
+int oracle_gso_update_all(oracle_gso *g);
+/* LLLReduction::babai(kappa, sr_end=kappa, sr_start=0)   lll.cpp:166-224.
+ * returns 1 ok, 0 = RED_GSO_FAILURE, -1 = RED_BABAI_FAILURE */
+int oracle_gso_babai(oracle_gso *g, int kappa, int sr_end, int sr_start, double eta);
+/* LLLReduction::size_reduction(kappa_min,kappa_end)      lll.h:107-122 */
+int oracle_gso_size_reduction(oracle_gso *g, int kappa_min, int kappa_end, double eta);
+/* LLLReduction::lll(kappa_min, kappa_start, kappa_end)   lll.cpp:44-164 (no early red., no siegel) */
+int oracle_gso_lll(oracle_gso *g, int kappa_min, int kappa_start, int kappa_end, double delta,
+                   double eta, int64_t *n_swaps);
+/* raw (scaled) state access; true values need the row exponents (gso_interface.h:694-732) */
+const double *oracle_gso_mu(const oracle_gso *g);      /* d×d */
+const double *oracle_gso_r(const oracle_gso *g);       /* d×d */
+const double *oracle_gso_bf(const oracle_gso *g);      /* d×n */
+const int64_t *oracle_gso_b(const oracle_gso *g);      /* d×n */
+const int64_t *oracle_gso_row_expo(const oracle_gso *g); /* d */
+/* get_mu / get_r with exponents applied (gso_interface.h:706-732) */
+double oracle_gso_get_mu(const oracle_gso *g, int i, int j);
+double oracle_gso_get_r(const oracle_gso *g, int i, int j);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,321 @@
+/*
+ * ref_driver.cpp — TEST INFRASTRUCTURE ONLY.
+ *
+ * Drives the REAL reference (oracle/_ref/libfplll.so, built from /root/reference by
+ * oracle/Makefile) through its public API to
+ *   (1) generate golden fixtures for tests/golden/ (command `enumfix`, `gsofix`), and
+ *   (2) run the reference's drivers with OUR external enumerator plugged in through
+ *       fplll::set_external_enumerator (command `plugin`), the reference's own test axis
+ *       ("swap the enumerator, results must still pass").
+ * Only public reference headers are included; no reference source is copied.
+ * Built into oracle/_ref/ref_driver (git-ignored).
+ */
+#include <fplll/fplll.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <dlfcn.h>
+#include <iostream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+using namespace fplll;
+using std::vector;
+
+typedef Z_NR<mpz_t> ZT;
+typedef FP_NR<double> FT;
+
+// ---- a recording external enumerator: grabs exactly what a plugin is handed, then declines ----
+struct Recorded
+{
+  int d = 0;
+  double maxdist = 0;
+  bool dual = false, findsubsols = false;
+  vector<double> mut, rdiag, pruning;
+  int calls = 0;
+} g_rec;
+
+static std::array<uint64_t, FPLLL_EXTENUM_MAX_EXTENUM_DIM>
+recording_enumerator(const int dim, double maxdist, std::function<extenum_cb_set_config> cbfunc,
+                     std::function<extenum_cb_process_sol>, std::function<extenum_cb_process_subsol>,
+                     bool dual, bool findsubsols)
+{
+  g_rec.d           = dim;
+  g_rec.maxdist     = maxdist;
+  g_rec.dual        = dual;
+  g_rec.findsubsols = findsubsols;
+  g_rec.mut.assign((size_t)dim * dim, 0.0);
+  g_rec.rdiag.assign(dim, 0.0);
+  g_rec.pruning.assign(dim, 0.0);
+  cbfunc(g_rec.mut.data(), dim, true, g_rec.rdiag.data(), g_rec.pruning.data());
+  g_rec.calls++;
+  std::array<uint64_t, FPLLL_EXTENUM_MAX_EXTENUM_DIM> out{};
+  out[0] = ~uint64_t(0);  // decline → fplll falls back to its own enumerator (enumerate_ext.cpp:88)
+  return out;
+}
+
+// ---- an evaluator that logs every eval_sol call (normalised dist + coefficients) ----
+struct LoggingEvaluator : public FastEvaluator<FT>
+{
+  vector<std::pair<double, vector<double>>> log;
+  LoggingEvaluator(size_t n, EvaluatorStrategy s) : FastEvaluator<FT>(n, s, false) {}
+  void eval_sol(const vector<FT> &c, const enumf &dist, enumf &max_dist) override
+  {
+    vector<double> x(c.size());
+    for (size_t i = 0; i < c.size(); ++i)
+      x[i] = c[i].get_d();
+    log.emplace_back(dist, x);
+    FastEvaluator<FT>::eval_sol(c, dist, max_dist);
+  }
+};
+
+static std::string hexd(double v)
+{
+  char buf[64];
+  snprintf(buf, sizeof buf, "\"%a\"", v);
+  return buf;
+}
+static void dump_vec(std::ostream &os, const char *name, const vector<double> &v, bool comma = true)
+{
+  os << "\"" << name << "\":[";
+  for (size_t i = 0; i < v.size(); ++i)
+    os << (i ? "," : "") << hexd(v[i]);
+  os << "]" << (comma ? ",\n" : "\n");
+}
+
+static void make_basis(ZZ_mat<mpz_t> &A, int n, int k, int bits, int seed, int bkz_pre)
+{
+  RandGen::init_with_seed(seed);
+  A.resize(n, n);
+  A.gen_qary_prime(k, bits);
+  lll_reduction(A, LLL_DEF_DELTA, LLL_DEF_ETA, LM_WRAPPER, FT_DEFAULT, 0, LLL_DEFAULT);
+  if (bkz_pre > 0)
+  {
+    vector<Strategy> strategies;
+    BKZParam par(bkz_pre, strategies);
+    par.flags = BKZ_AUTO_ABORT;
+    bkz_reduction(&A, NULL, par, FT_DOUBLE, 0);
+  }
+}
+
+static vector<double> make_pruning(const std::string &spec, int d)
+{
+  vector<double> pr;
+  if (spec == "none")
+    return pr;
+  if (spec.rfind("linear:", 0) == 0)
+  {
+    int level = atoi(spec.c_str() + 7);
+    return PruningParams::LinearPruningParams(d, level).coefficients;
+  }
+  fprintf(stderr, "bad pruning spec %s\n", spec.c_str());
+  exit(2);
+}
+
+/* enumfix n k bits seed bkz_pre first d pruning max_sols strategy radius_factor
+ *   → one JSON fixture on stdout: the plugin inputs + the reference's internal-enumerator outputs */
+static int cmd_enumfix(int argc, char **argv)
+{
+  if (argc < 12)
+  {
+    fprintf(stderr, "usage: enumfix n k bits seed bkz_pre first d pruning max_sols strategy rfac\n");
+    return 2;
+  }
+  int n = atoi(argv[2]), k = atoi(argv[3]), bits = atoi(argv[4]), seed = atoi(argv[5]);
+  int bkz_pre = atoi(argv[6]), first = atoi(argv[7]), d = atoi(argv[8]);
+  std::string prspec = argv[9];
+  size_t max_sols    = (size_t)atol(argv[10]);
+  int strategy       = atoi(argv[11]);
+  double rfac        = argc > 12 ? atof(argv[12]) : 0.99;
+
+  ZZ_mat<mpz_t> A, U, UT;
+  make_basis(A, n, k, bits, seed, bkz_pre);
+  MatGSO<ZT, FT> M(A, U, UT, GSO_ROW_EXPO);
+  M.update_gso();
+
+  long expo;
+  FT max_dist = M.get_r_exp(first, first, expo);
+  max_dist *= rfac;  // bkz.cpp:311-318 (delta)
+  if (d > 30 && rfac <= 1.0)
+  {
+    FT root_det = M.get_root_det(first, first + d);
+    adjust_radius_to_gh_bound(max_dist, expo, d, root_det, 1.1);  // bkz.cpp:319-323
+  }
+  vector<double> pruning = make_pruning(prspec, d);
+
+  set_external_enumerator(recording_enumerator);
+  LoggingEvaluator ev(max_sols, (EvaluatorStrategy)strategy);
+  Enumeration<ZT, FT> E(M, ev);
+  auto t0 = std::chrono::steady_clock::now();
+  E.enumerate(first, first + d, max_dist, expo, vector<FT>(), vector<enumxt>(), pruning);
+  double secs =
+      std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  auto nodes = E.get_nodes_array();
+
+  // final bound, normalised like the plugin sees it (enumerate.cpp:150-152 inverse)
+  FT fin;
+  fin.mul_2si(max_dist, expo - ev.normExp);
+
+  std::ostringstream os;
+  os << "{\n\"desc\":\"qary n=" << n << " k=" << k << " bits=" << bits << " seed=" << seed
+     << " bkz_pre=" << bkz_pre << " first=" << first << " d=" << d << " pruning=" << prspec
+     << " max_sols=" << max_sols << " strategy=" << strategy << " rfac=" << rfac << "\",\n";
+  os << "\"d\":" << d << ",\n\"max_sols\":" << max_sols << ",\n\"strategy\":" << strategy << ",\n";
+  os << "\"maxdist\":" << hexd(g_rec.maxdist) << ",\n";
+  dump_vec(os, "mut", g_rec.mut);
+  dump_vec(os, "rdiag", g_rec.rdiag);
+  dump_vec(os, "pruning", g_rec.pruning);
+  os << "\"nodes\":[";
+  uint64_t tot = 0;
+  for (int i = 0; i <= d; ++i)
+  {
+    os << (i ? "," : "") << nodes[i];
+    tot += nodes[i];
+  }
+  os << "],\n\"total_nodes\":" << tot << ",\n\"ref_seconds\":" << secs << ",\n";
+  os << "\"final_maxdist\":" << hexd(fin.get_d()) << ",\n";
+  os << "\"sol_log\":[";
+  for (size_t s = 0; s < ev.log.size(); ++s)
+  {
+    os << (s ? ",\n" : "\n") << "{\"dist\":" << hexd(ev.log[s].first) << ",\"x\":[";
+    for (int i = 0; i < d; ++i)
+      os << (i ? "," : "") << (long)ev.log[s].second[i];
+    os << "]}";
+  }
+  os << "]\n}\n";
+  std::cout << os.str();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// plugin: install OUR external enumerator (from libfplll_hip_extenum.so) and run reference drivers
+// ---------------------------------------------------------------------------------------------
+typedef std::array<uint64_t, FPLLL_EXTENUM_MAX_EXTENUM_DIM>(extenum_fn)(
+    const int, double, std::function<extenum_cb_set_config>, std::function<extenum_cb_process_sol>,
+    std::function<extenum_cb_process_subsol>, bool, bool);
+
+static extenum_fn *load_plugin(const char *path)
+{
+  void *h = dlopen(path, RTLD_NOW | RTLD_GLOBAL);
+  if (!h)
+  {
+    fprintf(stderr, "dlopen %s: %s\n", path, dlerror());
+    exit(3);
+  }
+  void *sym = dlsym(h, "fplll_hip_extenum_entry");
+  if (!sym)
+  {
+    fprintf(stderr, "dlsym: %s\n", dlerror());
+    exit(3);
+  }
+  // the .so exports a C getter returning the address of the C++ function with fplll's signature
+  typedef void *(getter_t)();
+  return (extenum_fn *)((getter_t *)sym)();
+}
+
+struct EnumOut
+{
+  uint64_t total = 0;
+  vector<uint64_t> nodes;
+  bool found = false;
+  double dist = 0;  // de-normalised first solution norm
+  vector<double> x;
+  double secs = 0;
+};
+
+static EnumOut run_enum(MatGSO<ZT, FT> &M, int first, int d, const vector<double> &pruning,
+                        double rfac, size_t max_sols, int strategy)
+{
+  long expo;
+  FT max_dist = M.get_r_exp(first, first, expo);
+  max_dist *= rfac;
+  if (d > 30 && rfac <= 1.0)
+  {
+    FT root_det = M.get_root_det(first, first + d);
+    adjust_radius_to_gh_bound(max_dist, expo, d, root_det, 1.1);
+  }
+  FastEvaluator<FT> ev(max_sols, (EvaluatorStrategy)strategy, false);
+  Enumeration<ZT, FT> E(M, ev);
+  auto t0 = std::chrono::steady_clock::now();
+  E.enumerate(first, first + d, max_dist, expo, vector<FT>(), vector<enumxt>(), pruning);
+  EnumOut o;
+  o.secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  auto na = E.get_nodes_array();
+  for (int i = 0; i <= d; ++i)
+  {
+    o.nodes.push_back(na[i]);
+    o.total += na[i];
+  }
+  if (!ev.empty())
+  {
+    o.found = true;
+    o.dist  = ev.begin()->first.get_d();
+    for (auto &c : ev.begin()->second)
+      o.x.push_back(c.get_d());
+  }
+  return o;
+}
+
+/* plugin <so> n k bits seed bkz_pre first d pruning max_sols strategy rfac
+ * Runs the same enumeration with (a) the internal enumerator and (b) our plugin; prints a JSON
+ * comparison.  Exit 0 iff the parity contract holds: same best squared norm; if max_sols is large
+ * (bound never shrinks) identical per-level node counts. */
+static int cmd_plugin(int argc, char **argv)
+{
+  if (argc < 14)
+  {
+    fprintf(stderr, "usage: plugin so n k bits seed bkz_pre first d pruning max_sols strategy rfac\n");
+    return 2;
+  }
+  const char *so = argv[2];
+  int n = atoi(argv[3]), k = atoi(argv[4]), bits = atoi(argv[5]), seed = atoi(argv[6]);
+  int bkz_pre = atoi(argv[7]), first = atoi(argv[8]), d = atoi(argv[9]);
+  std::string prspec = argv[10];
+  size_t max_sols    = (size_t)atol(argv[11]);
+  int strategy       = atoi(argv[12]);
+  double rfac        = atof(argv[13]);
+
+  ZZ_mat<mpz_t> A, U, UT;
+  make_basis(A, n, k, bits, seed, bkz_pre);
+  MatGSO<ZT, FT> M(A, U, UT, GSO_ROW_EXPO);
+  M.update_gso();
+  vector<double> pruning = make_pruning(prspec, d);
+
+  set_external_enumerator(nullptr);
+  EnumOut ref = run_enum(M, first, d, pruning, rfac, max_sols, strategy);
+  extenum_fn *fn = load_plugin(so);
+  set_external_enumerator(fn);
+  EnumOut ours = run_enum(M, first, d, pruning, rfac, max_sols, strategy);
+  // warm second run for timing
+  EnumOut ours2 = run_enum(M, first, d, pruning, rfac, max_sols, strategy);
+
+  bool ok = (ref.found == ours.found) && (!ref.found || ref.dist == ours.dist);
+  bool counts_equal = ref.nodes == ours.nodes;
+  if (max_sols >= 1000000 && strategy == 0)
+    ok = ok && counts_equal;
+  printf("{\"ok\":%s,\"counts_equal\":%s,\"ref_found\":%d,\"ours_found\":%d,\"ref_dist\":%.17g,"
+         "\"ours_dist\":%.17g,\"ref_nodes\":%llu,\"ours_nodes\":%llu,\"ref_secs\":%.6f,"
+         "\"ours_secs\":%.6f,\"ours_secs_warm\":%.6f}\n",
+         ok ? "true" : "false", counts_equal ? "true" : "false", (int)ref.found, (int)ours.found,
+         ref.dist, ours.dist, (unsigned long long)ref.total, (unsigned long long)ours.total,
+         ref.secs, ours.secs, ours2.secs);
+  return ok ? 0 : 1;
+}
+
+int main(int argc, char **argv)
+{
+  if (argc < 2)
+  {
+    fprintf(stderr, "commands: enumfix | plugin\n");
+    return 2;
+  }
+  std::string cmd = argv[1];
+  if (cmd == "enumfix")
+    return cmd_enumfix(argc, argv);
+  if (cmd == "plugin")
+    return cmd_plugin(argc, argv);
+  fprintf(stderr, "unknown command %s\n", cmd.c_str());
+  return 2;
+}
