@@ -1,0 +1,62 @@
+// enum_device.h — structures shared by the enumeration kernel and its host driver.
+#ifndef FPHIP_ENUM_DEVICE_H
+#define FPHIP_ENUM_DEVICE_H
+
+#include <stdint.h>
+
+#define FPHIP_MAX_BLOCK 512
+#define FPHIP_RING_CAP 1024u
+#define FPHIP_MAX_LAUNCHES 256
+#define FPHIP_TRI64 2016 /* 64*63/2 mu entries */
+
+#define FPHIP_ERR_RING_TIMEOUT 1u
+#define FPHIP_FLAG_TASK_OVERFLOW 2u
+
+namespace fphip
+{
+
+// One solution record in pinned host memory (device → host).
+struct __attribute__((aligned(16))) SolRec
+{
+  unsigned long long seq;  // == global index + 1 once the record is complete
+  double dist;
+  double x[64];
+};
+
+// Pinned, host-coherent control block (hipHostMallocCoherent).
+struct HostCtl
+{
+  unsigned long long bound_bits;  // host → device: current maxdist (bit pattern of a double >= 0)
+  unsigned long long consumed;    // host → device: number of ring records consumed so far
+  unsigned long long pad[6];
+  SolRec ring[FPHIP_RING_CAP];
+};
+
+// Device-resident per-enumeration state.
+struct DevShared
+{
+  double rdiag[64];
+  double pruning[64];
+  unsigned long long nodes[64];
+  unsigned long long sol_head;  // monotonically increasing across calls (ring sequence)
+  unsigned long long iters;     // walk-loop iterations (diagnostics)
+  unsigned long long bound_bits;  // device mirror of HostCtl::bound_bits (only ever lowered)
+  unsigned int error_flags;
+  unsigned int pad;
+  unsigned int task_head[FPHIP_MAX_LAUNCHES];
+  double mu_tri[FPHIP_TRI64];  // mu_tri[k(k-1)/2 + i] = mu(k,i), i<k
+};
+
+// Subtree tasks (structure of arrays; col/x rows are 64 doubles so that a wave loads them coalesced).
+struct TaskBuf
+{
+  double *col;          // [cap][64]  S_L: rows i<L of the centre partial sums at the root
+  double *x;            // [cap][64]  coefficients of levels >= L
+  double *pd;           // [cap]      partial distance of the root node
+  int *level;           // [cap]      root level L of the task (it walks levels < L)
+  unsigned int *count;  // number of tasks written (may exceed cap: overflow handled inline)
+  unsigned int cap;
+};
+
+}  // namespace fphip
+#endif

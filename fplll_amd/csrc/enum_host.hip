@@ -1,0 +1,516 @@
+// enum_host.hip — host side of the C ABI for enumeration (include/fplll_hip.h): context,
+// top-of-tree phase planning, launches, and the solution ring consumer that runs the caller's
+// callback while the kernel is in flight.
+//
+// Reference counterparts: ExternalEnumeration::enumerate (fplll/enum/enumerate_ext.cpp:48-89) is
+// the caller; enumlib's enumerate_dim_detail (enum-parallel/enumlib_dim.cpp:47-104) is the
+// CPU plugin this replaces.
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../include/fplll_hip.h"
+#include "enum_device.h"
+
+namespace fphip
+{
+__global__ void enum_phase_kernel(DevShared *g, HostCtl *h, TaskBuf in, TaskBuf out, int d,
+                                  int Lmax, int stop, unsigned task_lo, unsigned task_hi,
+                                  unsigned shard_idx, unsigned shard_cnt, int launch_idx,
+                                  int count_nodes, unsigned budget);
+}
+using namespace fphip;
+
+struct fphip_ctx
+{
+  int device        = 0;
+  int num_cus       = 256;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[2]  = {nullptr, nullptr};
+  DevShared *g      = nullptr;  // device
+  DevShared *stage  = nullptr;  // pinned host staging copy
+  HostCtl *h        = nullptr;  // pinned, coherent; same pointer is valid on the device
+  TaskBuf buf[2];
+  unsigned cap                 = 0;
+  unsigned long long ring_next = 0;
+  char err[512]                = {0};
+  // GSO state lives in gso_host.hip, linked through this opaque slot
+  void *gso = nullptr;
+};
+
+static int fail(fphip_ctx *ctx, const char *fmt, ...)
+{
+  if (ctx)
+  {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(ctx->err, sizeof ctx->err, fmt, ap);
+    va_end(ap);
+  }
+  return FPHIP_ERROR;
+}
+
+#define HIPCHK(ctx, call)                                                                          \
+  do                                                                                               \
+  {                                                                                                \
+    hipError_t e_ = (call);                                                                        \
+    if (e_ != hipSuccess)                                                                          \
+      return fail(ctx, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+extern "C" int fphip_abi_version(void) { return 1; }
+
+extern "C" int fphip_device_count(void)
+{
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess)
+    return 0;
+  return n;
+}
+
+static int env_int(const char *name, int dflt)
+{
+  const char *s = getenv(name);
+  return (s && *s) ? atoi(s) : dflt;
+}
+
+extern "C" int fphip_create(int device, fphip_ctx **out)
+{
+  if (!out)
+    return FPHIP_ERROR;
+  *out           = nullptr;
+  fphip_ctx *ctx = new fphip_ctx();
+  ctx->device    = device;
+  int ndev       = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+  {
+    // fail loudly: there is no CPU fallback in the product path
+    fail(ctx, "no HIP device visible (hipGetDeviceCount)");
+    *out = ctx;
+    return FPHIP_ERROR;
+  }
+  *out = ctx;
+  HIPCHK(ctx, hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIPCHK(ctx, hipGetDeviceProperties(&prop, device));
+  ctx->num_cus = prop.multiProcessorCount;
+  HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  HIPCHK(ctx, hipEventCreate(&ctx->ev[0]));
+  HIPCHK(ctx, hipEventCreate(&ctx->ev[1]));
+  HIPCHK(ctx, hipMalloc((void **)&ctx->g, sizeof(DevShared)));
+  HIPCHK(ctx, hipHostMalloc((void **)&ctx->stage, sizeof(DevShared), hipHostMallocDefault));
+  HIPCHK(ctx, hipHostMalloc((void **)&ctx->h, sizeof(HostCtl),
+                            hipHostMallocCoherent | hipHostMallocMapped));
+  memset(ctx->h, 0, sizeof(HostCtl));
+  ctx->cap = (unsigned)env_int("FPHIP_TASK_CAP", 1 << 18);
+  for (int b = 0; b < 2; ++b)
+  {
+    HIPCHK(ctx, hipMalloc((void **)&ctx->buf[b].col, (size_t)ctx->cap * 64 * sizeof(double)));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->buf[b].x, (size_t)ctx->cap * 64 * sizeof(double)));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->buf[b].pd, (size_t)ctx->cap * sizeof(double)));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->buf[b].level, (size_t)ctx->cap * sizeof(int)));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->buf[b].count, 64));
+    ctx->buf[b].cap = ctx->cap;
+  }
+  HIPCHK(ctx, hipFuncSetAttribute((const void *)enum_phase_kernel,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  return FPHIP_OK;
+}
+
+extern "C" void fphip_gso_release_all(fphip_ctx *ctx);  // gso_host.hip
+
+extern "C" void fphip_destroy(fphip_ctx *ctx)
+{
+  if (!ctx)
+    return;
+  fphip_gso_release_all(ctx);
+  if (ctx->stream)
+    hipStreamSynchronize(ctx->stream);
+  for (int b = 0; b < 2; ++b)
+  {
+    if (ctx->buf[b].col)
+      hipFree(ctx->buf[b].col);
+    if (ctx->buf[b].x)
+      hipFree(ctx->buf[b].x);
+    if (ctx->buf[b].pd)
+      hipFree(ctx->buf[b].pd);
+    if (ctx->buf[b].level)
+      hipFree(ctx->buf[b].level);
+    if (ctx->buf[b].count)
+      hipFree(ctx->buf[b].count);
+  }
+  if (ctx->g)
+    hipFree(ctx->g);
+  if (ctx->stage)
+    hipHostFree(ctx->stage);
+  if (ctx->h)
+    hipHostFree(ctx->h);
+  if (ctx->ev[0])
+    hipEventDestroy(ctx->ev[0]);
+  if (ctx->ev[1])
+    hipEventDestroy(ctx->ev[1]);
+  if (ctx->stream)
+    hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+extern "C" const char *fphip_last_error(const fphip_ctx *ctx) { return ctx ? ctx->err : "null ctx"; }
+
+// accessors for sibling translation units
+hipStream_t fphip_ctx_stream(fphip_ctx *ctx) { return ctx->stream; }
+void **fphip_ctx_gso_slot(fphip_ctx *ctx) { return &ctx->gso; }
+char *fphip_ctx_errbuf(fphip_ctx *ctx) { return ctx->err; }
+int fphip_ctx_num_cus(fphip_ctx *ctx) { return ctx->num_cus; }
+
+// ---------------------------------------------------------------------------------------------
+// ring consumer
+// ---------------------------------------------------------------------------------------------
+static inline unsigned long long dbits(double v)
+{
+  unsigned long long b;
+  memcpy(&b, &v, 8);
+  return b;
+}
+static inline double bdbl(unsigned long long b)
+{
+  double v;
+  memcpy(&v, &b, 8);
+  return v;
+}
+
+static void drain(fphip_ctx *ctx, int dim, fphip_sol_cb cb, void *user, uint64_t *nsol)
+{
+  for (;;)
+  {
+    SolRec *r            = &ctx->h->ring[ctx->ring_next % FPHIP_RING_CAP];
+    unsigned long long s = __atomic_load_n(&r->seq, __ATOMIC_ACQUIRE);
+    if (s != ctx->ring_next + 1)
+      return;
+    double x[64];
+    double dist = r->dist;
+    memcpy(x, (const void *)r->x, sizeof(double) * 64);
+    double nb = cb(user, dist, x);  // extenum_cb_process_sol: returns the new bound
+    if (!(nb >= 0.0))
+      nb = 0.0;
+    __atomic_store_n(&ctx->h->bound_bits, dbits(nb), __ATOMIC_RELEASE);
+    ctx->ring_next++;
+    __atomic_store_n(&ctx->h->consumed, ctx->ring_next, __ATOMIC_RELEASE);
+    (void)dim;
+    (*nsol)++;
+  }
+}
+
+// wait for the stream while serving the ring
+static int wait_serving(fphip_ctx *ctx, int dim, fphip_sol_cb cb, void *user, uint64_t *nsol)
+{
+  for (;;)
+  {
+    drain(ctx, dim, cb, user, nsol);
+    hipError_t q = hipStreamQuery(ctx->stream);
+    if (q == hipSuccess)
+    {
+      drain(ctx, dim, cb, user, nsol);
+      return FPHIP_OK;
+    }
+    if (q != hipErrorNotReady)
+      return fail(ctx, "hipStreamQuery: %s", hipGetErrorString(q));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Gaussian-heuristic node estimate per level (only used to place the phase cuts; never affects
+// results).  logN[k] = log( 1/2 · V_{d-k}(R_k) / prod_{i>=k} sqrt(rdiag_i) ),  R_k^2 = pruning_k·maxdist.
+// ---------------------------------------------------------------------------------------------
+static void estimate_levels(int d, const double *rdiag, const double *pruning, double maxdist,
+                            double *logN /* d+1 */)
+{
+  double sumlog = 0.0;
+  logN[d]       = 0.0;
+  for (int k = d - 1; k >= 0; --k)
+  {
+    sumlog += 0.5 * std::log(rdiag[k] > 0 ? rdiag[k] : 1e-300);
+    int n       = d - k;
+    double R2   = (pruning ? pruning[k] : 1.0) * maxdist;
+    double logV = 0.5 * n * std::log(M_PI) - std::lgamma(0.5 * n + 1.0);
+    logN[k]     = std::log(0.5) + logV + 0.5 * n * std::log(R2 > 0 ? R2 : 1e-300) - sumlog;
+  }
+}
+
+// level at which to cut next, or -1 to walk to the leaves
+static int choose_stop(const double *logN, int L, double C, double target_final, double growth)
+{
+  double want = std::min(target_final, C * growth);
+  int argmax  = -1;
+  double best = -1e300;
+  for (int k = L - 1; k >= 1; --k)
+  {
+    double est = std::log(C) + logN[k] - logN[L];
+    if (est >= std::log(want))
+      return k;
+    if (est > best)
+    {
+      best   = est;
+      argmax = k;
+    }
+  }
+  if (argmax >= 1 && best >= std::log(4.0 * C))
+    return argmax;
+  return -1;
+}
+
+extern "C" int fphip_enum_run(fphip_ctx *ctx, int dim, double maxdist, const double *mut,
+                              const double *rdiag, const double *pruning,
+                              const fphip_enum_opts *opts_in, fphip_sol_cb cb,
+                              fphip_subsol_cb subcb, void *user, uint64_t *nodes_out,
+                              fphip_enum_stats *stats)
+{
+  (void)subcb;
+  if (!ctx)
+    return FPHIP_ERROR;
+  if (!ctx->g)
+    return fail(ctx, "context has no device (creation failed): %s", ctx->err);
+  if (!mut || !rdiag || !cb || !nodes_out)
+    return fail(ctx, "null argument");
+  auto t_begin = std::chrono::steady_clock::now();
+  fphip_enum_opts o;
+  memset(&o, 0, sizeof o);
+  if (opts_in)
+    o = *opts_in;
+  if (o.shard_count <= 0)
+  {
+    o.shard_count = 1;
+    o.shard_index = 0;
+  }
+  if (o.exchange_chunks <= 0)
+    o.exchange_chunks = 1;
+  const int d = dim;
+  if (d < 2 || d > FPHIP_ENUM_MAX_DIM || o.dual || o.findsubsols)
+    return FPHIP_UNSUPPORTED;  // → ~uint64_t(0): fplll falls back (enumerate_ext.cpp:88)
+  if (!(maxdist >= 0.0))
+    return FPHIP_UNSUPPORTED;
+  for (int i = 0; i < d; ++i)
+    if (!(rdiag[i] > 0.0) || !std::isfinite(rdiag[i]))
+      return FPHIP_UNSUPPORTED;
+
+  const double target_final =
+      o.target_tasks > 0 ? o.target_tasks : env_int("FPHIP_TARGET_TASKS", 32768);
+  const double growth = o.phase_growth > 0 ? o.phase_growth : env_int("FPHIP_PHASE_GROWTH", 96);
+  const int wpb_final =
+      std::max(1, std::min(8, o.waves_per_block > 0 ? o.waves_per_block
+                                                    : env_int("FPHIP_WAVES_PER_BLOCK", 4)));
+
+  double logN[FPHIP_ENUM_MAX_DIM + 1];
+  estimate_levels(d, rdiag, pruning, maxdist, logN);
+  if (o.min_nodes_decline > 0)
+  {
+    double tot = 0;
+    for (int k = 0; k < d; ++k)
+      tot += std::exp(std::min(logN[k], 700.0));
+    if (tot < (double)o.min_nodes_decline)
+      return FPHIP_UNSUPPORTED;
+  }
+
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  // ---- upload the block: rdiag, pruning, mu rows (triangular) ---------------------------------
+  DevShared *st = ctx->stage;
+  memset(st, 0, sizeof(DevShared));
+  for (int i = 0; i < d; ++i)
+  {
+    st->rdiag[i]   = rdiag[i];
+    st->pruning[i] = pruning ? pruning[i] : 1.0;
+  }
+  for (int k = 1; k < d; ++k)
+    for (int i = 0; i < k; ++i)
+      st->mu_tri[(k * (k - 1)) / 2 + i] = mut[(size_t)i * d + k];  // mu(k,i)
+  st->sol_head   = ctx->ring_next;
+  st->bound_bits = dbits(maxdist);
+  __atomic_store_n(&ctx->h->bound_bits, dbits(maxdist), __ATOMIC_RELEASE);
+  __atomic_store_n(&ctx->h->consumed, ctx->ring_next, __ATOMIC_RELEASE);
+  HIPCHK(ctx, hipMemcpyAsync(ctx->g, st, sizeof(DevShared), hipMemcpyHostToDevice, ctx->stream));
+  // root task: level d, zero partial sums, zero prefix, zero partial distance
+  int cur = 0;
+  HIPCHK(ctx, hipMemsetAsync(ctx->buf[cur].col, 0, 64 * sizeof(double), ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(ctx->buf[cur].x, 0, 64 * sizeof(double), ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(ctx->buf[cur].pd, 0, sizeof(double), ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(ctx->buf[cur].level, &d, sizeof(int), hipMemcpyHostToDevice,
+                             ctx->stream));
+
+  const int debug     = env_int("FPHIP_DEBUG", 0);
+  uint64_t nsol       = 0;
+  double kernel_ms    = 0.0, final_ms = 0.0;
+  int launches        = 0, launch_idx = 0;
+  int L               = d;  // highest root level among the current tasks (LDS geometry)
+  unsigned C          = 1;  // number of current tasks
+  int final_tasks     = 0, final_L = d;
+  const int max_split = env_int("FPHIP_MAX_SPLIT_PHASES", 6);
+  // Work-donation budget (loop iterations a task may run before it sheds its upper subtrees).
+  // Sized from the Gaussian-heuristic node estimate so that a wave sees ~8 budgets of work.
+  double est_nodes = 0;
+  for (int k = 0; k < d; ++k)
+    est_nodes += std::exp(std::min(logN[k], 60.0));
+  unsigned budget = (unsigned)env_int("FPHIP_BUDGET", 0);
+  if (budget == 0)
+  {
+    double b = 2.0 * est_nodes / (8.0 * 32.0 * ctx->num_cus);
+    budget   = (unsigned)std::min(std::max(b, 512.0), 1048576.0);
+  }
+  if (debug)
+    fprintf(stderr, "[fphip] d=%d est_nodes=%.3e budget=%u\n", d, est_nodes, budget);
+  bool in_final       = false;  // false: level-cut splitting phases; true: budgeted walk rounds
+  int round           = 0;
+  unsigned prevC      = 0;
+
+  bool others_active = false;  // multi-GPU: some other rank still has tasks
+  while (C > 0 || others_active)
+  {
+    int stop = -1;
+    if (!in_final)
+    {
+      if (launches < max_split && (double)C < 0.5 * target_final)
+        stop = choose_stop(logN, L, (double)C, target_final, growth);
+      if (stop >= L)
+        stop = L - 1;
+      if (stop < 1)
+        stop = -1;
+      if (stop < 0)
+      {
+        in_final    = true;
+        final_tasks = (int)C;
+        final_L     = L;
+      }
+    }
+    const int wpb     = (in_final && C >= 1024) ? wpb_final : 1;
+    const int triL    = L * (L + 1) / 2;
+    const size_t lds  = (size_t)(wpb + 1) * triL * sizeof(double);
+    if (lds > 160 * 1024)
+      return fail(ctx, "LDS request too large (%zu)", lds);
+    int blocks_per_cu = (int)std::max<size_t>(1, std::min<size_t>(32 / wpb, (160 * 1024) / lds));
+    const int nxt     = cur ^ 1;
+    // only the first final round is sharded across GPUs; donated tasks stay on their GPU
+    const bool shard_now  = in_final && round == 0;
+    const int chunks      = shard_now ? o.exchange_chunks : 1;
+    const unsigned sidx   = shard_now ? (unsigned)o.shard_index : 0u;
+    const unsigned scnt   = shard_now ? (unsigned)o.shard_count : 1u;
+    const int count_nodes = (in_final || o.shard_index == 0) ? 1 : 0;
+    HIPCHK(ctx, hipMemsetAsync(ctx->buf[nxt].count, 0, 4, ctx->stream));
+
+    for (int ch = 0; ch < chunks; ++ch)
+    {
+      unsigned lo = (unsigned)(((unsigned long long)C * ch) / chunks);
+      unsigned hi = (unsigned)(((unsigned long long)C * (ch + 1)) / chunks);
+      if (hi <= lo && !(in_final && o.exchange))
+        continue;
+      unsigned mine = hi - lo;  // every rank scans the whole list and keeps its residue class
+      unsigned grid = std::min<unsigned>((mine + wpb - 1) / wpb,
+                                         (unsigned)(ctx->num_cus * blocks_per_cu));
+      if (grid == 0)
+        grid = 1;
+      if (launch_idx >= FPHIP_MAX_LAUNCHES)
+        return fail(ctx, "too many launches");
+      if (hi > lo)
+      {
+        HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+        hipLaunchKernelGGL(enum_phase_kernel, dim3(grid), dim3(wpb * 64), lds, ctx->stream, ctx->g,
+                           ctx->h, ctx->buf[cur], ctx->buf[nxt], d, L, stop, lo, hi, sidx, scnt,
+                           launch_idx, count_nodes, in_final ? budget : 0u);
+        HIPCHK(ctx, hipGetLastError());
+        HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+        ++launch_idx;
+        int rc = wait_serving(ctx, d, cb, user, &nsol);
+        if (rc != FPHIP_OK)
+          return rc;
+        float ms = 0.f;
+        HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+        kernel_ms += ms;
+        if (in_final)
+          final_ms += ms;
+        if (debug)
+        {
+          unsigned long long it = 0;
+          hipMemcpy(&it, &ctx->g->iters, 8, hipMemcpyDeviceToHost);
+          fprintf(stderr,
+                  "[fphip] launch %d %s tasks [%u,%u) L=%d stop=%d budget=%u grid=%u wpb=%d lds=%zu "
+                  "-> %.3f ms, iters so far %llu\n",
+                  launch_idx - 1, in_final ? "walk" : "split", lo, hi, L, stop,
+                  in_final ? budget : 0u, grid, wpb, lds, ms, it);
+        }
+      }
+      if (in_final && o.exchange && ch + 1 < chunks)
+      {  // multi-GPU: agree on the best bound at every chunk boundary (collective: every rank
+         // makes the same sequence of exchange calls)
+        double local = bdbl(__atomic_load_n(&ctx->h->bound_bits, __ATOMIC_ACQUIRE));
+        int any      = 1;
+        double glob  = o.exchange(o.exchange_user, local, 1, &any);
+        if (glob < local)
+          __atomic_store_n(&ctx->h->bound_bits, dbits(glob), __ATOMIC_RELEASE);
+      }
+    }
+    ++launches;
+    unsigned cnt = 0;
+    HIPCHK(ctx, hipMemcpy(&cnt, ctx->buf[nxt].count, 4, hipMemcpyDeviceToHost));
+    if (cnt > ctx->cap)
+      cnt = ctx->cap;
+    if (in_final && o.exchange)
+    {  // round boundary: exchange the bound and learn whether any rank still has tasks
+      double local = bdbl(__atomic_load_n(&ctx->h->bound_bits, __ATOMIC_ACQUIRE));
+      int any      = cnt > 0;
+      double glob  = o.exchange(o.exchange_user, local, cnt > 0, &any);
+      if (glob < local)
+        __atomic_store_n(&ctx->h->bound_bits, dbits(glob), __ATOMIC_RELEASE);
+      others_active = any != 0;
+    }
+    if (in_final)
+    {
+      // donated tasks are rooted strictly below the level their donor was rooted at
+      ++round;
+      if (cnt > 2 * prevC && cnt > (unsigned)(8 * ctx->num_cus * 32) && budget < (1u << 30))
+        budget *= 2;  // the frontier is still growing: coarser tasks
+      prevC = cnt;
+      if (L > 1)
+        L = L - 1;
+    }
+    else
+    {
+      L = stop;
+    }
+    C   = cnt;
+    cur = nxt;
+  }
+  const int phases = launches;
+
+  // ---- results --------------------------------------------------------------------------------
+  HIPCHK(ctx, hipMemcpy(st, ctx->g, offsetof(DevShared, task_head), hipMemcpyDeviceToHost));
+  if (st->error_flags & FPHIP_ERR_RING_TIMEOUT)
+    return fail(ctx, "device timed out waiting for the host ring consumer");
+  uint64_t total = 0;
+  for (int k = 0; k <= d; ++k)
+    nodes_out[k] = (k < d) ? st->nodes[k] : 0;
+  if (o.shard_index == 0)
+    for (int k = 1; k < d; ++k)
+      nodes_out[k]--;  // enumerate_base.cpp:181-184: the initial descent is not counted
+  for (int k = 0; k < d; ++k)
+    total += nodes_out[k];
+  if (stats)
+  {
+    stats->total_nodes      = total;
+    stats->solutions        = nsol;
+    stats->kernel_ms        = kernel_ms;
+    stats->final_kernel_ms  = final_ms;
+    stats->phases           = phases;
+    stats->final_tasks      = final_tasks;
+    stats->final_root_level = final_L;
+    stats->overflowed       = (st->error_flags & FPHIP_FLAG_TASK_OVERFLOW) ? 1 : 0;
+    stats->wall_ms =
+        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin)
+            .count();
+  }
+  return FPHIP_OK;
+}

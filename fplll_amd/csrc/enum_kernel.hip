@@ -1,0 +1,354 @@
+// enum_kernel.hip — wavefront-per-subtree Schnorr-Euchner / KFP enumeration for gfx950 (CDNA4).
+//
+// Reference behaviour reproduced (fplll v5.5.0): the tree walk of
+//   EnumerationBase::enumerate_recursive   fplll/enum/enumerate_base.cpp:24-118
+// with the bound handling of EnumerationDyn::set_bounds/process_solution (enumerate.cpp:218-239)
+// and the subtree split of enumlib (enum-parallel/enumeration.h:311-380, 412-505) as structural
+// precedent.  This is not a translation of either: the data layout is built around one wave64.
+//
+// Design (MI355X-first)
+// ---------------------
+// * One wavefront walks one subtree depth-first.  Control flow (the level k, enter/step mode) is
+//   wave-uniform, so there is no divergence; the 64 lanes are used as DATA lanes:
+//     - lane l of the "level registers" xs/cs/pds/dxs/ddxs/cnt holds the value for tree level l
+//       (x[l], center[l], partdist[l], dx[l], ddx[l], nodes[l]); a level is read with
+//       v_readlane (uniform index in an SGPR) and written with a lane-masked select;
+//     - lane i of the "row registers" holds row i of the centre partial sums
+//       center_partsums[i][·] (enumerate_base.h:84).  Choosing x[k] updates ALL rows i<k with one
+//       vector multiply + subtract:  S_k[i] = S_{k+1}[i] - x[k]*mu(k,i).  The reference's lazy
+//       center_partsum_begin bookkeeping (enumerate_base.cpp:58-68) exists to avoid exactly this
+//       O(k) work on a scalar CPU; here it is one VALU instruction pair, and every value is still
+//       produced by the same operation sequence (j = d-1 … k, multiply then subtract, no FMA), so
+//       centres, distances, node counts and solutions are bit-identical to the reference.
+// * Backtracking needs S_{k+1} again when the next sibling x[k] is tried, so each wave keeps a
+//   triangular stack of columns S_1..S_L in LDS (slot k holds k doubles, lane i touches only
+//   row i → conflict-free ds_read_b64/ds_write_b64, no cross-lane traffic through LDS).
+//   mu rows (row k = mu(k,0..k-1)) are staged once per workgroup in LDS, same triangular packing.
+// * The tree is split level-wise into phases: a phase walks every input task (a subtree root at
+//   level L) down to a stop level and emits each surviving node there as a task for the next
+//   phase (root column S, partial distance, coefficient prefix).  The final phase walks to the
+//   leaves.  Tasks are pulled from a device-wide atomic counter (persistent waves).
+// * Solutions go to a ring in pinned host memory; the host thread runs the caller's callback
+//   while the kernel is running and publishes the new bound through a pinned word that waves
+//   poll (system-scope loads) — the same contract enumlib implements with a mutex and an
+//   atomic<double> (enum-parallel/enumeration.h:66,286-299).
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off  (no FMA contraction: fplll's
+// arithmetic is separate multiply and add, nr/nr_FP_d.inl:178, baseline x86-64 build).
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "enum_device.h"
+
+namespace fphip
+{
+
+__device__ __forceinline__ double rl_f64(double v, int lane)
+{
+  int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ int rl_i32(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+__device__ __forceinline__ unsigned long long rfl_u64(unsigned long long v)
+{
+  unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+  unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ int tri_off(int k) { return (k * (k - 1)) >> 1; }  // slot k starts here
+
+__device__ __forceinline__ unsigned long long load_sys_u64(const unsigned long long *p)
+{
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// One enumeration launch.  Lmax = highest root level among the input tasks (a task rooted at
+// level Lt walks levels < Lt), stop = level at which surviving nodes are emitted as tasks for the
+// next launch (stop < 0: walk to the leaves).  budget > 0 bounds the work of one task: after
+// `budget` loop iterations the wave keeps only the subtree it is currently in and hands every
+// remaining sibling subtree above it to the next launch (work donation: `donate` is the lowest
+// level whose surviving nodes are emitted instead of descended into).  Emission never changes
+// which nodes are visited or how they are counted, only which wave visits them.
+//
+// Loop structure.  A node "survives" when its distance passes the level bound (the reference's
+// test, enumerate_base.cpp:31/93).  The walk alternates between two states:
+//   CHILD(k, S, nd): a surviving node at level k with column S = S_k and distance nd is known.
+//       Peek at its first child (centre S[k-1], rounded coefficient, distance): if the child fails
+//       the node has no surviving children — stay at level k (this merges the reference's
+//       "descend, test, return" :53-72/:31-32 into one step and is the common case in the bulk
+//       of a pruned tree).  Otherwise emit the node as a task (k == stop / donation) or descend:
+//       push S on the LDS stack, record level k-1 in the level registers, count the child, and
+//       loop in CHILD with the child as the current node.
+//   STEP(k): the subtree below the current coefficient x[k] is exhausted — advance x[k] in
+//       zig-zag order (:80-89), test (:91-94): fail → STEP(k+1), survive → CHILD.
+__global__ void __launch_bounds__(FPHIP_MAX_BLOCK)
+    enum_phase_kernel(DevShared *__restrict__ g, HostCtl *__restrict__ h, TaskBuf in, TaskBuf out,
+                      int d, int Lmax, int stop, unsigned task_lo, unsigned task_hi,
+                      unsigned shard_idx, unsigned shard_cnt, int launch_idx, int count_nodes,
+                      unsigned budget)
+{
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int triL = (Lmax * (Lmax + 1)) >> 1;  // doubles for slots 1..Lmax
+  double *mu_s   = smem;                       // mu rows 1..Lmax-1, packed like slots
+  double *stk    = smem + triL + wave * triL;
+
+  {
+    const int nmu = (Lmax * (Lmax - 1)) >> 1;
+    for (int i = threadIdx.x; i < nmu; i += blockDim.x)
+      mu_s[i] = g->mu_tri[i];
+  }
+  __syncthreads();
+
+  const double rd = g->rdiag[lane];
+  const double pr = g->pruning[lane];
+  // The bound lives in two places: the pinned host word the callback thread writes, and a
+  // device-memory mirror.  Waves poll the mirror (L2) often and the host word (PCIe) rarely;
+  // whoever sees a smaller host value lowers the mirror for everybody.
+  unsigned long long mbits = rfl_u64(load_sys_u64(&h->bound_bits));
+  double maxdist           = __longlong_as_double((long long)mbits);
+  double bnd               = pr * maxdist;
+
+  // level registers (lane = level) and counters
+  double xs = 0.0, cs = 0.0, pds = 0.0;
+  int dxs = 0, ddxs = 0;
+  unsigned long long cnt = 0;
+  unsigned iter          = 0;
+
+#define FPHIP_REFRESH_BOUND(from_host)                                                            \
+  do                                                                                              \
+  {                                                                                               \
+    unsigned long long nb_;                                                                       \
+    if (from_host)                                                                                \
+    {                                                                                             \
+      nb_ = rfl_u64(load_sys_u64(&h->bound_bits));                                                \
+      if (nb_ < mbits && lane == 0)                                                               \
+        atomicMin(&g->bound_bits, nb_);                                                           \
+    }                                                                                             \
+    else                                                                                          \
+    {                                                                                             \
+      nb_ = rfl_u64(__hip_atomic_load(&g->bound_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); \
+    }                                                                                             \
+    if (nb_ < mbits)                                                                              \
+    {                                                                                             \
+      mbits   = nb_;                                                                              \
+      maxdist = __longlong_as_double((long long)mbits);                                           \
+      bnd     = pr * maxdist;                                                                     \
+    }                                                                                             \
+  } while (0)
+
+  for (;;)
+  {
+    // ---- pull a task ------------------------------------------------------------------------
+    unsigned t = 0;
+    if (lane == 0)
+      t = atomicAdd(&g->task_head[launch_idx], 1u);
+    t = (unsigned)__builtin_amdgcn_readfirstlane((int)t);
+    const unsigned long long ti = (unsigned long long)task_lo + t;
+    if (ti >= task_hi)
+      break;
+
+    const int Lt      = __builtin_amdgcn_readfirstlane(in.level[ti]);  // root level of this task
+    const double xpre = in.x[ti * 64 + lane];                          // coefficients of levels >= Lt
+    if (shard_cnt > 1u)
+    {  // multi-GPU partition by task CONTENT (the order of tasks in the buffer is not
+       // deterministic, their coefficient prefixes are): every rank walks the same task list
+       // and keeps the tasks whose prefix hash falls in its residue class
+      unsigned hsh = (lane >= Lt && lane < d)
+                         ? (unsigned)(int)xpre * (2654435761u * (unsigned)(lane + 1))
+                         : 0u;
+      for (int off = 32; off > 0; off >>= 1)
+        hsh += (unsigned)__shfl_xor((int)hsh, off);
+      hsh = (unsigned)__builtin_amdgcn_readfirstlane((int)hsh);
+      hsh ^= hsh >> 15;
+      if (hsh % shard_cnt != shard_idx)
+        continue;
+    }
+    const double col0 = in.col[ti * 64 + lane];  // S_Lt rows (lane < Lt)
+    const double pd0  = in.pd[ti];
+    int donate        = 1 << 20;
+    unsigned titer    = 0;
+    FPHIP_REFRESH_BOUND((t & 63u) == 0u);
+
+    // the task root is a surviving node at level Lt whose column and distance are given
+    int k      = Lt;
+    double S   = col0;  // S_k of the current node (rows < k valid)
+    double nd  = pd0;   // its distance
+    bool child = true;  // state: CHILD (true) or STEP (false)
+
+    for (;;)
+    {
+      k = __builtin_amdgcn_readfirstlane(k);
+      if (child)
+      {
+        // ---------------- CHILD(k, S, nd): peek at the first child ----------------------------
+        const int kc    = k - 1;
+        const double c1 = rl_f64(S, kc);  // center[kk-1] = center_partsums[kk-1][kk]
+        const double x1 = round(c1);      // roundto(): half away from zero, enumerate_base.h:33-34
+        const double a1 = x1 - c1;
+        const double n1 = nd + a1 * a1 * rl_f64(rd, kc);  // :28-29
+        if (!(n1 <= rl_f64(bnd, kc)))
+        {  // :31-32 the child level is empty: next sibling at level k (or done, at the root)
+          child = false;
+          if (k >= Lt)
+            break;
+          continue;
+        }
+        if ((k == stop || k >= donate) && k < Lt)
+        {  // hand the subtree below this node to the next launch
+          unsigned oi = 0;
+          if (lane == 0)
+            oi = atomicAdd(out.count, 1u);
+          oi = (unsigned)__builtin_amdgcn_readfirstlane((int)oi);
+          if (oi < out.cap)
+          {
+            out.col[(unsigned long long)oi * 64 + lane] = S;
+            const double xf                             = (lane < Lt) ? xs : xpre;
+            out.x[(unsigned long long)oi * 64 + lane]   = xf;
+            if (lane == 0)
+            {
+              out.pd[oi]    = nd;
+              out.level[oi] = k;
+            }
+            child = false;
+            continue;
+          }
+          // buffer full: keep walking this subtree inline (results stay exact)
+          if (lane == 0)
+            atomicOr(&g->error_flags, FPHIP_FLAG_TASK_OVERFLOW);
+        }
+        // descend: level kc becomes the current level
+        if (lane < k)
+          stk[tri_off(k) + lane] = S;  // needed again when x[kc] steps to its next sibling
+        {
+          const int s1  = (c1 >= x1) ? 1 : -1;  // :71 / :114
+          const bool me = lane == kc;
+          cs            = me ? c1 : cs;
+          xs            = me ? x1 : xs;
+          pds           = me ? nd : pds;
+          dxs           = me ? s1 : dxs;
+          ddxs          = me ? s1 : ddxs;
+          cnt += me ? 1ull : 0ull;  // ++nodes[kk-1]
+        }
+        k  = kc;
+        nd = n1;
+        if (k == 0)
+        {
+          if (nd > 0.0)
+            goto report_solution;  // process_solution, :42-46
+          child = false;
+          continue;
+        }
+        {
+          const double mk = (lane < k) ? mu_s[tri_off(k) + lane] : 0.0;
+          S               = S - x1 * mk;  // S_k = S_{k+1} - x[k]*mu(k,·), :53-58
+        }
+        continue;
+      }
+
+      // ---------------- STEP(k): next sibling at level k ---------------------------------------
+      if (budget != 0u && ++titer >= budget)
+      {  // over budget: donate every sibling subtree above the current level
+        titer  = 0;
+        donate = min(donate, k + 1);
+      }
+      if (((++iter) & 63u) == 0u)
+        FPHIP_REFRESH_BOUND((iter & 16383u) == 0u);
+      {
+        // speculative loads for the surviving case (LDS latency overlaps the test)
+        const double par = (lane <= k) ? stk[tri_off(k + 1) + lane] : 0.0;  // S_{k+1}
+        const double mk  = (lane < k) ? mu_s[tri_off(k) + lane] : 0.0;
+        double xk        = rl_f64(xs, k);
+        const double ck  = rl_f64(cs, k);
+        const double pdk = rl_f64(pds, k);
+        int dxk = rl_i32(dxs, k), ddxk = rl_i32(ddxs, k);
+        if (pdk != 0.0)
+        {  // :80-89 (is_svp is always true here)
+          xk += (double)dxk;
+          ddxk = -ddxk;
+          dxk  = ddxk - dxk;
+        }
+        else
+        {
+          xk += 1.0;
+        }
+        const bool me = lane == k;
+        xs            = me ? xk : xs;
+        dxs           = me ? dxk : dxs;
+        ddxs          = me ? ddxk : ddxs;
+        const double a = xk - ck;
+        nd             = pdk + a * a * rl_f64(rd, k);  // :91-92
+        if (!(nd <= rl_f64(bnd, k)))
+        {  // :93-94 → the parent steps to its next sibling
+          ++k;
+          if (k >= Lt)
+            break;
+          continue;
+        }
+        cnt += me ? 1ull : 0ull;  // ++nodes[kk]
+        if (k == 0)
+        {
+          if (nd > 0.0)
+            goto report_solution;  // :97-101
+          continue;
+        }
+        S     = par - xk * mk;  // :104-110
+        child = true;
+        continue;
+      }
+
+    report_solution:
+    {
+      unsigned long long idx = 0;
+      if (lane == 0)
+        idx = atomicAdd(&g->sol_head, 1ull);
+      idx = rfl_u64(idx);
+      // flow control against the host consumer
+      for (unsigned spin = 0; idx >= load_sys_u64(&h->consumed) + FPHIP_RING_CAP; ++spin)
+      {
+        __builtin_amdgcn_s_sleep(64);
+        if (spin > (1u << 24))
+        {
+          if (lane == 0)
+            atomicOr(&g->error_flags, FPHIP_ERR_RING_TIMEOUT);
+          break;
+        }
+      }
+      SolRec *r  = &h->ring[idx % FPHIP_RING_CAP];
+      double xf  = (lane < Lt) ? xs : xpre;
+      r->x[lane] = (lane < d) ? xf : 0.0;
+      if (lane == 0)
+        r->dist = nd;
+      __threadfence_system();
+      if (lane == 0)
+        __hip_atomic_store(&r->seq, idx + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      // wait for the host's verdict (enumlib processes solutions synchronously too,
+      // enumeration.h:286-299) so that this wave continues with the updated bound
+      for (unsigned spin = 0; load_sys_u64(&h->consumed) <= idx; ++spin)
+      {
+        __builtin_amdgcn_s_sleep(32);
+        if (spin > (1u << 24))
+        {
+          if (lane == 0)
+            atomicOr(&g->error_flags, FPHIP_ERR_RING_TIMEOUT);
+          break;
+        }
+      }
+      FPHIP_REFRESH_BOUND(true);
+      child = false;  // level 0 has no children: next sibling
+      continue;
+    }
+    }
+  }
+#undef FPHIP_REFRESH_BOUND
+
+  if (count_nodes && cnt != 0)
+    atomicAdd(&g->nodes[lane], cnt);
+  if (lane == 0)
+    atomicAdd(&g->iters, (unsigned long long)iter);
+}
+
+}  // namespace fphip

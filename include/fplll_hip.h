@@ -1,0 +1,119 @@
+/*
+ * fplll_hip.h — the drop-in boundary: a C ABI (plain pointers and sizes) over the MI355X-native
+ * (gfx950, HIP) implementation of fplll's hot path.  libfplll_hip.so exports exactly these
+ * symbols; everything above them (the std::function adapter for fplll's external-enumerator hook,
+ * the MatGSO look-alike, the Python mirror in fplll_amd/) is host glue that only calls this ABI.
+ *
+ * Reference interfaces replaced (file:line under fplll/ of the reference, v5.5.0):
+ *   fphip_enum_run        ← extenum_fc_enumerate                enum/enumerate_ext_api.h:88-92
+ *                           (called from ExternalEnumeration::enumerate, enum/enumerate_ext.cpp:81-86;
+ *                            default implementation enumlib_enumerate, enum-parallel/enumlib.cpp:94)
+ *   fphip_sol_cb          ← extenum_cb_process_sol              enum/enumerate_ext_api.h:62-63
+ *   fphip_subsol_cb       ← extenum_cb_process_subsol           enum/enumerate_ext_api.h:70-71
+ *   (mut, rdiag, pruning) ← what extenum_cb_set_config fills    enum/enumerate_ext_api.h:52-53,
+ *                            enum/enumerate_ext.cpp:91-148 (mutranspose=true layout)
+ *   fphip_gso_*           ← MatGSO<Z_NR<long>,FP_NR<double>>    gso.h:33, gso_interface.h:59
+ *       fphip_gso_update        ← MatGSOInterface::update_gso_row / update_gso
+ *                                 gso_interface.cpp:131-164, gso_interface.h:767-775
+ *       fphip_gso_size_reduce   ← LLLReduction::size_reduction → babai   lll.h:107-122, lll.cpp:166-224
+ *       fphip_gso_get_*         ← get_mu_exp/get_r_exp/row_expo accessors gso_interface.h:675-732
+ *
+ * Error convention: 0 = FPHIP_OK; FPHIP_UNSUPPORTED = instance declined, the caller must fall
+ * back exactly as fplll does for a plugin returning ~uint64_t(0) (enum/enumerate_ext.cpp:88,
+ * enum/enumerate.h:104-110); negative = hard error, message via fphip_last_error().
+ * No C++ exception ever crosses this boundary.  Not thread-safe per context (fplll: "multiple
+ * threads on the same object is not supported", README.md:310).
+ */
+#ifndef FPLLL_HIP_H
+#define FPLLL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FPHIP_OK 0
+#define FPHIP_UNSUPPORTED 1
+#define FPHIP_ERROR (-1)
+
+/* largest enumeration dimension handled on the device (levels are lane-indexed in one wave64);
+ * larger blocks are declined (FPHIP_UNSUPPORTED → fplll's own enumerator) */
+#define FPHIP_ENUM_MAX_DIM 64
+
+typedef struct fphip_ctx fphip_ctx;
+
+/* Context bound to one HIP device (one process per GPU; device = LOCAL_RANK under torchrun). */
+int fphip_create(int device, fphip_ctx **out);
+void fphip_destroy(fphip_ctx *ctx);
+const char *fphip_last_error(const fphip_ctx *ctx);
+int fphip_device_count(void);
+/* library/ABI version, bumped when a signature changes */
+int fphip_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Enumeration                                                                                  */
+/* ------------------------------------------------------------------------------------------ */
+
+/* Receives a candidate (squared norm `dist`, coefficients sol[0..dim)), returns the NEW
+ * enumeration bound (unchanged, smaller, or 0 to stop).  Calls are serialised, made on the thread
+ * that called fphip_enum_run, while the kernel is still running. */
+typedef double (*fphip_sol_cb)(void *user, double dist, const double *sol);
+typedef void (*fphip_subsol_cb)(void *user, double dist, const double *subsol, int offset);
+/* Multi-GPU: called at every chunk / round boundary of the final phase — the SAME number of times
+ * on every rank (it is a collective) — with this rank's current bound and whether it still has
+ * subtree tasks; returns the bound to continue with and sets *any_active if some rank still has
+ * tasks (the host glue makes it an RCCL all-reduce: MIN on the bound, MAX on the flag). */
+typedef double (*fphip_exchange_cb)(void *user, double local_bound, int local_active,
+                                    int *any_active);
+
+typedef struct fphip_enum_opts
+{
+  int dual;        /* 1 → declined (the reference adapter does not transform mu/r for dual) */
+  int findsubsols; /* 1 → declined in this round */
+  /* subtree sharding across GPUs: this context handles final-phase tasks t with
+   * t % shard_count == shard_index; the (cheap) top-of-tree phases are replicated */
+  int shard_index;
+  int shard_count;
+  fphip_exchange_cb exchange;
+  void *exchange_user;
+  int exchange_chunks; /* number of chunks the final phase is cut into (>=1) */
+  /* tuning; 0 = default */
+  int target_tasks;    /* subtree tasks wanted for the final phase */
+  int phase_growth;    /* wanted task growth per splitting phase */
+  int waves_per_block; /* final-phase workgroup = waves_per_block * 64 threads */
+  int min_nodes_decline; /* decline when the Gaussian-heuristic node estimate is below this */
+} fphip_enum_opts;
+
+typedef struct fphip_enum_stats
+{
+  uint64_t total_nodes;  /* sum over levels (64-bit) */
+  uint64_t solutions;    /* candidates handed to the callback */
+  double wall_ms;        /* whole call */
+  double kernel_ms;      /* sum of kernel durations (HIP events on the launch stream) */
+  double final_kernel_ms;
+  int phases;
+  int final_tasks;
+  int final_root_level;
+  int overflowed; /* task-buffer overflow happened (handled inline, results still exact) */
+} fphip_enum_stats;
+
+/*
+ * SVP enumeration of a dim-dimensional block.
+ *   mut     : dim×dim row-major, mut[i*dim+j] = mu(j,i) for j>i (other entries ignored)
+ *   rdiag   : r_ii · 2^-normexp ;  pruning : dim coefficients in (0,1] (NULL = all 1.0)
+ *   maxdist : initial squared radius (normalised like rdiag)
+ *   nodes_out[0..dim] : per-level node counts, fplll's counting rule
+ *                       (enum/enumerate_base.cpp:31-33 incl. the :181-184 compensation)
+ * Level bound = pruning[k]*maxdist; a node survives iff newdist <= bound (NaN-safe form).
+ */
+int fphip_enum_run(fphip_ctx *ctx, int dim, double maxdist, const double *mut, const double *rdiag,
+                   const double *pruning, const fphip_enum_opts *opts, fphip_sol_cb cb,
+                   fphip_subsol_cb subcb, void *user, uint64_t *nodes_out,
+                   fphip_enum_stats *stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,114 @@
+import ctypes
+import glob
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+def hexvec(a):
+    return np.array([float.fromhex(s) for s in a], dtype=np.float64)
+
+
+def load_fixture(path):
+    with open(path) as f:
+        j = json.load(f)
+    d = j["d"]
+    j["mut"] = hexvec(j["mut"]).reshape(d, d)
+    j["rdiag"] = hexvec(j["rdiag"])
+    j["pruning"] = hexvec(j["pruning"])
+    j["maxdist"] = float.fromhex(j["maxdist"])
+    j["final_maxdist"] = float.fromhex(j["final_maxdist"])
+    j["sol_log"] = [(float.fromhex(s["dist"]), [float(v) for v in s["x"]]) for s in j["sol_log"]]
+    j["name"] = os.path.basename(path)[:-5]
+    return j
+
+
+def enum_fixtures():
+    return sorted(glob.glob(os.path.join(GOLDEN, "enum_*.json")))
+
+
+# ---- the C restatement oracle (test infrastructure; built on demand with gcc) -------------------
+_oracle = None
+SOLCB = ctypes.CFUNCTYPE(ctypes.c_double, ctypes.c_void_p, ctypes.c_double,
+                         ctypes.POINTER(ctypes.c_double))
+
+
+def oracle_lib():
+    global _oracle
+    if _oracle is None:
+        so = os.path.join(ROOT, "oracle", "liboracle.so")
+        srcs = [os.path.join(ROOT, "oracle", f) for f in ("enum_oracle.c", "gso_oracle.c", "oracle.h")]
+        if (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+            subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "port"])
+        lib = ctypes.CDLL(so)
+        lib.oracle_enumerate.restype = ctypes.c_int64
+        lib.oracle_enumerate.argtypes = [
+            ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double,
+            ctypes.c_int, SOLCB, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+            ctypes.c_void_p
+        ]
+        _oracle = lib
+    return _oracle
+
+
+def oracle_enumerate(mut, rdiag, pruning, maxdist, evaluator, log=None):
+    """Run the C oracle with a Python evaluator (same protocol as the device path)."""
+    lib = oracle_lib()
+    mut = np.ascontiguousarray(mut, dtype=np.float64)
+    d = mut.shape[0]
+    rdiag = np.ascontiguousarray(rdiag, dtype=np.float64)
+    pr = None
+    if pruning is not None and len(pruning):
+        pruning = np.ascontiguousarray(pruning, dtype=np.float64)
+        pr = pruning.ctypes.data_as(ctypes.c_void_p)
+    state = {"m": float(maxdist)}
+
+    def cb(_u, dist, sol):
+        x = [sol[i] for i in range(d)]
+        if log is not None:
+            log.append((dist, x))
+        state["m"] = float(evaluator.eval_sol(x, dist, state["m"]))
+        return state["m"]
+
+    c = SOLCB(cb)
+    nodes = np.zeros(d + 1, dtype=np.uint64)
+    lib.oracle_enumerate(d, mut.ctypes.data_as(ctypes.c_void_p), rdiag.ctypes.data_as(ctypes.c_void_p),
+                         pr, ctypes.c_double(maxdist), 0, c, None, None,
+                         nodes.ctypes.data_as(ctypes.c_void_p), None, None)
+    return nodes, state["m"]
+
+
+def synthetic_block(d, seed, slope=0.045, radius_factor=1.05):
+    """A seeded GSO-like block: mu uniform in [-1/2,1/2], log r_ii decreasing linearly (what a
+    BKZ-reduced block looks like); radius^2 = radius_factor * GH^2 (Gaussian heuristic of the
+    block), so tree sizes behave like real SVP instances."""
+    import math
+    rng = np.random.default_rng(seed)
+    mu = np.tril(rng.uniform(-0.5, 0.5, size=(d, d)), -1)
+    mut = np.ascontiguousarray(mu.T)  # mut[i][j] = mu(j,i), j>i
+    rdiag = np.exp(-2.0 * slope * np.arange(d)) * rng.uniform(0.9, 1.1, size=d)
+    rdiag = rdiag / rdiag.max()
+    log_gh2 = (2.0 / d) * math.lgamma(d / 2.0 + 1.0) - math.log(math.pi) + np.log(rdiag).mean()
+    maxdist = float(radius_factor * math.exp(log_gh2))
+    return mut, rdiag, maxdist
+
+
+@pytest.fixture(scope="session")
+def ctx():
+    import fplll_amd
+    c = fplll_amd.Context(int(os.environ.get("LOCAL_RANK", "0")))
+    yield c
+    c.close()

@@ -1,0 +1,70 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol that
+include/*.h declares; no compute call is made (there is no GPU here)."""
+import ctypes
+import glob
+import os
+import re
+
+import pytest
+
+import conftest as C
+
+
+def declared_symbols():
+    syms = set()
+    for h in glob.glob(os.path.join(C.ROOT, "include", "*.h")):
+        src = open(h).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        for m in re.finditer(r"\b(fphip_[a-z0-9_]+)\s*\(", src):
+            name = m.group(1)
+            # typedef'd callback types are not exported symbols
+            if re.search(r"\(\s*\*\s*%s\s*\)" % name, src):
+                continue
+            syms.add(name)
+    return sorted(syms)
+
+
+def test_library_exports_every_declared_symbol():
+    import fplll_amd
+    lib = fplll_amd.load()
+    missing = []
+    for s in declared_symbols():
+        try:
+            getattr(lib, s)
+        except AttributeError:
+            missing.append(s)
+    assert not missing, missing
+    assert len(declared_symbols()) >= 6
+    assert lib.fphip_abi_version() >= 1
+
+
+def test_shim_exports_plugin_entry():
+    so = os.path.join(C.ROOT, "fplll_amd", "lib", "libfplll_hip_extenum.so")
+    assert os.path.exists(so), "run __graft_entry__.build()"
+    lib = ctypes.CDLL(so)
+    lib.fplll_hip_extenum_entry.restype = ctypes.c_void_p
+    assert lib.fplll_hip_extenum_entry()
+
+
+def test_product_path_fails_loudly_without_gpu():
+    import fplll_amd
+    lib = fplll_amd.load()
+    if lib.fphip_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(fplll_amd.HipError):
+        fplll_amd.Context(0)
+
+
+def test_product_code_never_touches_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may use oracle/."""
+    bad = []
+    for root, _, files in os.walk(os.path.join(C.ROOT, "fplll_amd")):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".cpp", ".h")):
+                p = os.path.join(root, fn)
+                txt = open(p).read()
+                if re.search(r"liboracle|oracle\.h|oracle_enumerate|oracle_gso|oracle/_ref", txt):
+                    if fn == "build.py":
+                        continue  # build_oracle() compiles the checker; it never calls it
+                    bad.append(p)
+    assert not bad, bad
