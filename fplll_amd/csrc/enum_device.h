@@ -44,6 +44,7 @@ struct DevShared
   unsigned int error_flags;
   unsigned int pad;
   unsigned int task_head[FPHIP_MAX_LAUNCHES];
+  unsigned int drain[FPHIP_MAX_LAUNCHES];  // set when a launch's task queue ran dry
   double mu_tri[FPHIP_TRI64];  // mu_tri[k(k-1)/2 + i] = mu(k,i), i<k
 };
 

@@ -110,7 +110,7 @@ extern "C" int fphip_create(int device, fphip_ctx **out)
   HIPCHK(ctx, hipHostMalloc((void **)&ctx->h, sizeof(HostCtl),
                             hipHostMallocCoherent | hipHostMallocMapped));
   memset(ctx->h, 0, sizeof(HostCtl));
-  ctx->cap = (unsigned)env_int("FPHIP_TASK_CAP", 1 << 18);
+  ctx->cap = (unsigned)env_int("FPHIP_TASK_CAP", 1 << 19);
   for (int b = 0; b < 2; ++b)
   {
     HIPCHK(ctx, hipMalloc((void **)&ctx->buf[b].col, (size_t)ctx->cap * 64 * sizeof(double)));
@@ -356,12 +356,9 @@ extern "C" int fphip_enum_run(fphip_ctx *ctx, int dim, double maxdist, const dou
   double est_nodes = 0;
   for (int k = 0; k < d; ++k)
     est_nodes += std::exp(std::min(logN[k], 60.0));
-  unsigned budget = (unsigned)env_int("FPHIP_BUDGET", 0);
-  if (budget == 0)
-  {
-    double b = 2.0 * est_nodes / (8.0 * 32.0 * ctx->num_cus);
-    budget   = (unsigned)std::min(std::max(b, 512.0), 1048576.0);
-  }
+  // hard per-task cap; the operative trigger is the drained-queue signal inside the kernel
+  unsigned budget       = (unsigned)env_int("FPHIP_BUDGET", 1 << 22);
+  const int max_rounds  = env_int("FPHIP_MAX_ROUNDS", 24);
   if (debug)
     fprintf(stderr, "[fphip] d=%d est_nodes=%.3e budget=%u\n", d, est_nodes, budget);
   bool in_final       = false;  // false: level-cut splitting phases; true: budgeted walk rounds
@@ -420,7 +417,8 @@ extern "C" int fphip_enum_run(fphip_ctx *ctx, int dim, double maxdist, const dou
         HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
         hipLaunchKernelGGL(enum_phase_kernel, dim3(grid), dim3(wpb * 64), lds, ctx->stream, ctx->g,
                            ctx->h, ctx->buf[cur], ctx->buf[nxt], d, L, stop, lo, hi, sidx, scnt,
-                           launch_idx, count_nodes, in_final ? budget : 0u);
+                           launch_idx, count_nodes,
+                           (in_final && round < max_rounds) ? budget : 0u);
         HIPCHK(ctx, hipGetLastError());
         HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
         ++launch_idx;
@@ -471,8 +469,6 @@ extern "C" int fphip_enum_run(fphip_ctx *ctx, int dim, double maxdist, const dou
     {
       // donated tasks are rooted strictly below the level their donor was rooted at
       ++round;
-      if (cnt > 2 * prevC && cnt > (unsigned)(8 * ctx->num_cus * 32) && budget < (1u << 30))
-        budget *= 2;  // the frontier is still growing: coarser tasks
       prevC = cnt;
       if (L > 1)
         L = L - 1;

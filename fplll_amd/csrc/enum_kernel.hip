@@ -66,11 +66,12 @@ __device__ __forceinline__ unsigned long long load_sys_u64(const unsigned long l
 
 // One enumeration launch.  Lmax = highest root level among the input tasks (a task rooted at
 // level Lt walks levels < Lt), stop = level at which surviving nodes are emitted as tasks for the
-// next launch (stop < 0: walk to the leaves).  budget > 0 bounds the work of one task: after
-// `budget` loop iterations the wave keeps only the subtree it is currently in and hands every
-// remaining sibling subtree above it to the next launch (work donation: `donate` is the lowest
-// level whose surviving nodes are emitted instead of descended into).  Emission never changes
-// which nodes are visited or how they are counted, only which wave visits them.
+// next launch (stop < 0: walk to the leaves).  budget > 0 enables work donation: when the task
+// queue of this launch has run dry (idle waves exist) or a task has run `budget` iterations, the
+// wave keeps only the subtree it is currently in and hands every remaining sibling subtree
+// above it to the next launch (`donate` is the lowest level whose surviving nodes are emitted
+// instead of descended into).  Emission never changes which nodes are visited or how they are
+// counted, only which wave visits them.
 //
 // Loop structure.  A node "survives" when its distance passes the level bound (the reference's
 // test, enumerate_base.cpp:31/93).  The walk alternates between two states:
@@ -149,7 +150,11 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK)
     t = (unsigned)__builtin_amdgcn_readfirstlane((int)t);
     const unsigned long long ti = (unsigned long long)task_lo + t;
     if (ti >= task_hi)
+    {  // queue empty: tell the waves still walking to shed work for the next launch
+      if (budget != 0u && lane == 0)
+        __hip_atomic_store(&g->drain[launch_idx], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       break;
+    }
 
     const int Lt      = __builtin_amdgcn_readfirstlane(in.level[ti]);  // root level of this task
     const double xpre = in.x[ti * 64 + lane];                          // coefficients of levels >= Lt
@@ -250,13 +255,20 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK)
       }
 
       // ---------------- STEP(k): next sibling at level k ---------------------------------------
-      if (budget != 0u && ++titer >= budget)
-      {  // over budget: donate every sibling subtree above the current level
-        titer  = 0;
-        donate = min(donate, k + 1);
-      }
+      ++titer;
       if (((++iter) & 63u) == 0u)
+      {
         FPHIP_REFRESH_BOUND((iter & 16383u) == 0u);
+        if (budget != 0u && titer >= 256u)
+        {  // work donation: once the task queue has run dry (other waves are idle), or this task
+           // exceeded its budget, keep only the subtree below the current level and emit every
+           // sibling subtree above it as a task for the next launch
+          const unsigned dr = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(
+              &g->drain[launch_idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+          if (dr != 0u || titer >= budget)
+            donate = min(donate, k + 1);
+        }
+      }
       {
         // speculative loads for the surviving case (LDS latency overlaps the test)
         const double par = (lane <= k) ? stk[tri_off(k + 1) + lane] : 0.0;  // S_{k+1}

@@ -15,7 +15,9 @@
 #include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <cmath>
 #include <dlfcn.h>
+#include <fstream>
 #include <iostream>
 #include <sstream>
 #include <string>
@@ -52,6 +54,8 @@ recording_enumerator(const int dim, double maxdist, std::function<extenum_cb_set
   cbfunc(g_rec.mut.data(), dim, true, g_rec.rdiag.data(), g_rec.pruning.data());
   g_rec.calls++;
   std::array<uint64_t, FPLLL_EXTENUM_MAX_EXTENUM_DIM> out{};
+  if (getenv("REFDRV_INPUT_ONLY"))
+    return out;           // pretend "done, nothing found": only the plugin inputs are wanted
   out[0] = ~uint64_t(0);  // decline → fplll falls back to its own enumerator (enumerate_ext.cpp:88)
   return out;
 }
@@ -100,11 +104,28 @@ static void make_basis(ZZ_mat<mpz_t> &A, int n, int k, int bits, int seed, int b
   }
 }
 
-static vector<double> make_pruning(const std::string &spec, int d)
+static vector<double> make_pruning(const std::string &spec, int d, MatGSO<ZT, FT> *M = nullptr,
+                                   int first = 0, double radius = 0.0)
 {
   vector<double> pr;
   if (spec == "none")
     return pr;
+  if (spec.rfind("prune:", 0) == 0)
+  {
+    // the default.json substitute of SURVEY §8(d) C3: the reference's own pruner
+    // (fplll/pruner/pruner.h:187-193) on this block's r-profile
+    double target = atof(spec.c_str() + 6);
+    vector<double> r;
+    for (int i = 0; i < d; ++i)
+    {
+      FT t;
+      M->get_r(t, first + i, first + i);
+      r.push_back(t.get_d());
+    }
+    PruningParams pp;
+    prune<FT>(pp, radius, 1e7, r, target, PRUNER_METRIC_PROBABILITY_OF_SHORTEST, PRUNER_GRADIENT);
+    return pp.coefficients;
+  }
   if (spec.rfind("linear:", 0) == 0)
   {
     int level = atoi(spec.c_str() + 7);
@@ -131,7 +152,18 @@ static int cmd_enumfix(int argc, char **argv)
   double rfac        = argc > 12 ? atof(argv[12]) : 0.99;
 
   ZZ_mat<mpz_t> A, U, UT;
-  make_basis(A, n, k, bits, seed, bkz_pre);
+  if (n == 0)
+  {  // basis from a file written by `dumpbasis` (argv[3])
+    std::ifstream is(argv[3]);
+    is >> A;
+    if (A.get_rows() == 0)
+    {
+      fprintf(stderr, "cannot read basis %s\n", argv[3]);
+      return 2;
+    }
+  }
+  else
+    make_basis(A, n, k, bits, seed, bkz_pre);
   MatGSO<ZT, FT> M(A, U, UT, GSO_ROW_EXPO);
   M.update_gso();
 
@@ -143,7 +175,10 @@ static int cmd_enumfix(int argc, char **argv)
     FT root_det = M.get_root_det(first, first + d);
     adjust_radius_to_gh_bound(max_dist, expo, d, root_det, 1.1);  // bkz.cpp:319-323
   }
-  vector<double> pruning = make_pruning(prspec, d);
+  if (getenv("REFDRV_RADIUS_SCALE"))
+    max_dist *= atof(getenv("REFDRV_RADIUS_SCALE"));
+  vector<double> pruning =
+      make_pruning(prspec, d, &M, first, max_dist.get_d() * std::pow(2.0, (double)expo));
 
   set_external_enumerator(recording_enumerator);
   LoggingEvaluator ev(max_sols, (EvaluatorStrategy)strategy);
@@ -159,7 +194,7 @@ static int cmd_enumfix(int argc, char **argv)
   fin.mul_2si(max_dist, expo - ev.normExp);
 
   std::ostringstream os;
-  os << "{\n\"desc\":\"qary n=" << n << " k=" << k << " bits=" << bits << " seed=" << seed
+  os << "{\n\"desc\":\"" << (n == 0 ? argv[3] : "") << " qary n=" << n << " k=" << k << " bits=" << bits << " seed=" << seed
      << " bkz_pre=" << bkz_pre << " first=" << first << " d=" << d << " pruning=" << prspec
      << " max_sols=" << max_sols << " strategy=" << strategy << " rfac=" << rfac << "\",\n";
   os << "\"d\":" << d << ",\n\"max_sols\":" << max_sols << ",\n\"strategy\":" << strategy << ",\n";
@@ -304,6 +339,17 @@ static int cmd_plugin(int argc, char **argv)
   return ok ? 0 : 1;
 }
 
+/* dumpbasis n k bits seed bkz_pre  → the reduced basis in fplll's text format on stdout */
+static int cmd_dumpbasis(int argc, char **argv)
+{
+  if (argc < 7)
+    return 2;
+  ZZ_mat<mpz_t> A;
+  make_basis(A, atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), atoi(argv[6]));
+  std::cout << A << std::endl;
+  return 0;
+}
+
 int main(int argc, char **argv)
 {
   if (argc < 2)
@@ -316,6 +362,8 @@ int main(int argc, char **argv)
     return cmd_enumfix(argc, argv);
   if (cmd == "plugin")
     return cmd_plugin(argc, argv);
+  if (cmd == "dumpbasis")
+    return cmd_dumpbasis(argc, argv);
   fprintf(stderr, "unknown command %s\n", cmd.c_str());
   return 2;
 }
