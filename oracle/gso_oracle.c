@@ -1,2 +1,312 @@
-/* filled in below */
+/*
+ * gso_oracle.c — TEST INFRASTRUCTURE ONLY (see oracle.h).
+ *
+ * Plain-C restatement of fplll's floating-point Gram-Schmidt + size reduction for
+ * MatGSO<Z_NR<long>, FP_NR<double>> with GSO_ROW_EXPO (the BKZ fast path, fplll/bkz.cpp:816-829),
+ * all rows discovered (the state after update_gso()), no transform matrices, no integer Gram.
+ * Pinned bit-exact against the real reference by tests/test_gso_oracle_vs_ref.py
+ * (fixtures from oracle/ref_driver.cpp `gsofix`).
+ *
+ * Every sum keeps the reference's order and its separate multiply / add roundings
+ * (nr/nr_FP_d.inl:178; compile with -ffp-contract=off).
+ */
 #include "oracle.h"
+
+#include <limits.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+struct oracle_gso
+{
+  int d, n;           /* rows, columns */
+  int row_expo_on;
+  int64_t *b;         /* d×n */
+  double *bf;         /* d×n   (gso_interface.h:548) */
+  double *gf;         /* d×d   lazy float Gram, NaN = invalid (gso_interface.h:575) */
+  double *mu, *r;     /* d×d   (gso_interface.h:589,604) */
+  int64_t *row_expo;  /* d     (gso_interface.h:167) */
+  int *valid_cols;    /* gso_valid_cols (gso_interface.h:608) */
+  int n_known_cols;
+  double *babai_mu;
+  int64_t *babai_expo;
+  int64_t *tmp_col_expo;
+};
+
+#define B(g, i, j) ((g)->b[(size_t)(i) * (g)->n + (j)])
+#define BF(g, i, j) ((g)->bf[(size_t)(i) * (g)->n + (j)])
+#define GF(g, i, j) ((g)->gf[(size_t)(i) * (g)->d + (j)])
+#define MU(g, i, j) ((g)->mu[(size_t)(i) * (g)->d + (j)])
+#define R(g, i, j) ((g)->r[(size_t)(i) * (g)->d + (j)])
+
+static long fexponent(double x) { return (long)ilogb(x) + 1; } /* nr_FP_d.inl:44 */
+
+/* MatGSO::update_bf, gso.cpp:24-48 */
+static void update_bf(oracle_gso *g, int i)
+{
+  int n = g->n_known_cols;
+  if (g->row_expo_on)
+  {
+    long max_expo = LONG_MIN;
+    for (int j = 0; j < n; j++)
+    {
+      int e;
+      BF(g, i, j)        = frexp((double)B(g, i, j), &e); /* nr_Z_misc.inl:17-22 */
+      g->tmp_col_expo[j] = e;
+      if (e > max_expo)
+        max_expo = e;
+    }
+    for (int j = 0; j < n; j++)
+      BF(g, i, j) = ldexp(BF(g, i, j), (int)(g->tmp_col_expo[j] - max_expo));
+    g->row_expo[i] = max_expo;
+  }
+  else
+  {
+    for (int j = 0; j < n; j++)
+      BF(g, i, j) = (double)B(g, i, j);
+    g->row_expo[i] = 0;
+  }
+}
+
+oracle_gso *oracle_gso_create(int d, int n, const int64_t *b, int row_expo)
+{
+  oracle_gso *g   = (oracle_gso *)calloc(1, sizeof *g);
+  g->d            = d;
+  g->n            = n;
+  g->row_expo_on  = row_expo;
+  g->b            = (int64_t *)malloc(sizeof(int64_t) * d * n);
+  g->bf           = (double *)calloc((size_t)d * n, sizeof(double));
+  g->gf           = (double *)malloc(sizeof(double) * d * d);
+  g->mu           = (double *)calloc((size_t)d * d, sizeof(double));
+  g->r            = (double *)calloc((size_t)d * d, sizeof(double));
+  g->row_expo     = (int64_t *)calloc(d, sizeof(int64_t));
+  g->valid_cols   = (int *)calloc(d, sizeof(int));
+  g->babai_mu     = (double *)calloc(d, sizeof(double));
+  g->babai_expo   = (int64_t *)calloc(d, sizeof(int64_t));
+  g->tmp_col_expo = (int64_t *)calloc(n, sizeof(int64_t));
+  memcpy(g->b, b, sizeof(int64_t) * d * n);
+  /* all rows discovered: n_known_cols = max over rows of size_nz (gso.cpp:56-82) */
+  int nk = 1;
+  for (int i = 0; i < d; ++i)
+    for (int j = n - 1; j >= 0; --j)
+      if (B(g, i, j) != 0)
+      {
+        if (j + 1 > nk)
+          nk = j + 1;
+        break;
+      }
+  g->n_known_cols = nk;
+  for (int i = 0; i < d; ++i)
+  {
+    update_bf(g, i);
+    for (int j = 0; j < d; ++j)
+      GF(g, i, j) = NAN;
+  }
+  return g;
+}
+
+void oracle_gso_destroy(oracle_gso *g)
+{
+  if (!g)
+    return;
+  free(g->b);
+  free(g->bf);
+  free(g->gf);
+  free(g->mu);
+  free(g->r);
+  free(g->row_expo);
+  free(g->valid_cols);
+  free(g->babai_mu);
+  free(g->babai_expo);
+  free(g->tmp_col_expo);
+  free(g);
+}
+
+/* MatGSO::get_gram, gso.h:314-331 with NumVect::dot_product, nr/numvect.h:386-396 */
+static double get_gram(oracle_gso *g, int i, int j)
+{
+  if (isnan(GF(g, i, j)))
+  {
+    double res = BF(g, i, 0) * BF(g, j, 0);
+    for (int c = 1; c < g->n_known_cols; c++)
+      res = res + BF(g, i, c) * BF(g, j, c);
+    GF(g, i, j) = res;
+  }
+  return GF(g, i, j);
+}
+
+/* MatGSOInterface::update_gso_row, gso_interface.cpp:131-164 */
+int oracle_gso_update_row(oracle_gso *g, int i, int last_j)
+{
+  int j = g->valid_cols[i] > 0 ? g->valid_cols[i] : 0;
+  for (; j <= last_j; j++)
+  {
+    double ftmp1 = get_gram(g, i, j);
+    for (int k = 0; k < j; k++)
+    {
+      double ftmp2 = MU(g, j, k) * R(g, i, k);
+      ftmp1        = ftmp1 - ftmp2;
+    }
+    R(g, i, j) = ftmp1;
+    if (i > j)
+    {
+      MU(g, i, j) = ftmp1 / R(g, j, j);
+      if (!isfinite(MU(g, i, j)))
+        return 0;
+    }
+  }
+  g->valid_cols[i] = j;
+  return 1;
+}
+
+int oracle_gso_update_all(oracle_gso *g)
+{
+  for (int i = 0; i < g->d; i++)
+    if (!oracle_gso_update_row(g, i, i))
+      return 0;
+  return 1;
+}
+
+/* MatGSOInterface::row_op_end(first=i,last=i+1), gso_interface.cpp:32-53 */
+static void row_op_end(oracle_gso *g, int i)
+{
+  update_bf(g, i);
+  for (int j = 0; j <= i; j++) /* invalidate_gram_row, gso.cpp:50-54 */
+    GF(g, i, j) = NAN;
+  for (int j = i + 1; j < g->d; j++)
+    GF(g, j, i) = NAN;
+  g->valid_cols[i] = 0;
+  for (int j = i + 1; j < g->d; j++)
+    if (g->valid_cols[j] > i)
+      g->valid_cols[j] = i;
+}
+
+/* MatGSO::row_addmul_we for ZT=long without OP_FORCE_LONG, gso.cpp:236-262;
+ * returns 0 when the multiplier needs the 2^expo path (not restated: never taken when
+ * |X·2^expo_add| < 2^63) */
+static int row_addmul_we(oracle_gso *g, int i, int j, double x, long expo_add)
+{
+  long expo;
+  if (x == 0)
+    expo = 0;
+  else
+  {
+    expo = fexponent(x) + expo_add - 63; /* numeric_limits<long>::digits */
+    if (expo < 0)
+      expo = 0;
+  }
+  long lx = (long)ldexp(x, (int)(expo_add - expo)); /* nr_FP_d.inl:46-53 */
+  if (expo != 0)
+    return 0;
+  int n = g->n_known_cols;
+  if (lx == 1)
+    for (int c = n - 1; c >= 0; c--) /* row_add → NumVect::add, numvect.h:268-272 */
+      B(g, i, c) = (int64_t)((uint64_t)B(g, i, c) + (uint64_t)B(g, j, c));
+  else if (lx == -1)
+    for (int c = n - 1; c >= 0; c--)
+      B(g, i, c) = (int64_t)((uint64_t)B(g, i, c) - (uint64_t)B(g, j, c));
+  else if (lx != 0)
+    for (int c = n - 1; c >= 0; c--) /* addmul_si, numvect.h:324-329 */
+      B(g, i, c) = (int64_t)((uint64_t)B(g, i, c) + (uint64_t)B(g, j, c) * (uint64_t)lx);
+  return 1;
+}
+
+/* MatGSOInterface::get_max_mu_exp, gso_interface.cpp:88-98 */
+static long get_max_mu_exp(oracle_gso *g, int i, int ncols)
+{
+  long max_expo = LONG_MIN;
+  for (int j = 0; j < ncols; j++)
+  {
+    long expo  = g->row_expo[i] - g->row_expo[j];
+    long expo2 = fexponent(MU(g, i, j));
+    if (expo + expo2 > max_expo)
+      max_expo = expo + expo2;
+  }
+  return max_expo;
+}
+
+/* LLLReduction::babai, lll.cpp:166-224 */
+int oracle_gso_babai(oracle_gso *g, int kappa, int sr_end, int sr_start, double eta)
+{
+  long max_expo = LONG_MAX;
+  for (int iter = 0;; iter++)
+  {
+    if (!oracle_gso_update_row(g, kappa, sr_end - 1))
+      return 0; /* RED_GSO_FAILURE */
+    int loop_needed = 0;
+    for (int j = sr_end - 1; j >= sr_start && !loop_needed; j--)
+    {
+      double f = ldexp(MU(g, kappa, j), (int)(g->row_expo[kappa] - g->row_expo[j])); /* get_mu */
+      f        = fabs(f);
+      loop_needed |= (f > eta);
+    }
+    if (!loop_needed)
+      break;
+    if (iter >= 2)
+    {
+      long new_max_expo = get_max_mu_exp(g, kappa, sr_end);
+      if (new_max_expo > max_expo - 5) /* SIZE_RED_FAILURE_THRESH, defs.h:146 */
+        return -1;                     /* RED_BABAI_FAILURE */
+      max_expo = new_max_expo;
+    }
+    for (int j = sr_start; j < sr_end; j++)
+    {
+      g->babai_mu[j]   = MU(g, kappa, j);
+      g->babai_expo[j] = g->row_expo[kappa] - g->row_expo[j];
+    }
+    for (int j = sr_end - 1; j >= sr_start; j--)
+    {
+      /* rnd_we, nr_FP_d.inl:226-233 */
+      double bm = g->babai_mu[j], X;
+      long e    = g->babai_expo[j];
+      if (fexponent(bm) + e >= 53)
+        X = bm;
+      else
+        X = ldexp(rint(ldexp(bm, (int)e)), (int)-e);
+      if (X == 0.0)
+        continue;
+      for (int k = sr_start; k < j; k++)
+      {
+        double t       = X * MU(g, j, k);
+        g->babai_mu[k] = g->babai_mu[k] - t;
+      }
+      if (!row_addmul_we(g, kappa, j, -X, e))
+        return -2; /* multiplier beyond 63 bits: path not restated */
+    }
+    row_op_end(g, kappa);
+  }
+  return 1;
+}
+
+/* LLLReduction::size_reduction, lll.h:107-122 */
+int oracle_gso_size_reduction(oracle_gso *g, int kappa_min, int kappa_end, double eta)
+{
+  for (int k = kappa_min; k < kappa_end; k++)
+  {
+    if (k > 0)
+    {
+      int rc = oracle_gso_babai(g, k, k, 0, eta);
+      if (rc != 1)
+        return rc;
+    }
+    if (!oracle_gso_update_row(g, k, k))
+      return 0;
+  }
+  return 1;
+}
+
+const double *oracle_gso_mu(const oracle_gso *g) { return g->mu; }
+const double *oracle_gso_r(const oracle_gso *g) { return g->r; }
+const double *oracle_gso_bf(const oracle_gso *g) { return g->bf; }
+const int64_t *oracle_gso_b(const oracle_gso *g) { return g->b; }
+const int64_t *oracle_gso_row_expo(const oracle_gso *g) { return g->row_expo; }
+
+/* get_mu / get_r, gso_interface.h:694-732 */
+double oracle_gso_get_mu(const oracle_gso *g, int i, int j)
+{
+  return ldexp(MU(g, i, j), (int)(g->row_expo[i] - g->row_expo[j]));
+}
+double oracle_gso_get_r(const oracle_gso *g, int i, int j)
+{
+  return ldexp(R(g, i, j), (int)(g->row_expo[i] + g->row_expo[j]));
+}

@@ -339,6 +339,85 @@ static int cmd_plugin(int argc, char **argv)
   return ok ? 0 : 1;
 }
 
+// ---------------------------------------------------------------------------------------------
+// gsofix: MatGSO<Z_NR<long>,FP_NR<double>> + LLLReduction::size_reduction golden vectors
+// ---------------------------------------------------------------------------------------------
+template <class M> static void dump_mat_hex(std::ostream &os, const char *name, const M &m, int d,
+                                            bool lower_incl_diag)
+{
+  os << "\"" << name << "\":[";
+  bool first = true;
+  for (int i = 0; i < d; ++i)
+    for (int j = 0; j < d; ++j)
+    {
+      double v = (j < i || (lower_incl_diag && j == i)) ? m(i, j).get_d() : 0.0;
+      os << (first ? "" : ",") << hexd(v);
+      first = false;
+    }
+  os << "],\n";
+}
+
+/* gsofix n k bits seed perturb  → JSON: input basis (long), state after update_gso(), state after
+ * LLLReduction::size_reduction(0,d) (eta = 0.51) */
+static int cmd_gsofix(int argc, char **argv)
+{
+  if (argc < 7)
+    return 2;
+  int n = atoi(argv[2]), k = atoi(argv[3]), bits = atoi(argv[4]), seed = atoi(argv[5]);
+  int perturb = atoi(argv[6]);
+  ZZ_mat<mpz_t> A;
+  make_basis(A, n, k, bits, seed, 0);
+  ZZ_mat<long> b(n, n), u, ut;
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j)
+      b(i, j) = A(i, j).get_si();
+  // deterministic unimodular perturbation so that rows are NOT size-reduced any more
+  uint64_t lcg = 0x9E3779B97F4A7C15ull ^ (uint64_t)seed;
+  for (int i = 1; i < n && perturb > 0; ++i)
+    for (int t = 0; t < perturb; ++t)
+    {
+      lcg    = lcg * 6364136223846793005ull + 1442695040888963407ull;
+      int j  = (int)((lcg >> 33) % (uint64_t)i);
+      lcg    = lcg * 6364136223846793005ull + 1442695040888963407ull;
+      long c = (long)((lcg >> 33) % 7) - 3;
+      for (int col = 0; col < n; ++col)
+        b(i, col) = b(i, col).get_si() + c * b(j, col).get_si();
+    }
+  std::ostringstream os;
+  os << "{\n\"desc\":\"qary n=" << n << " k=" << k << " bits=" << bits << " seed=" << seed
+     << " LLL then " << perturb << " random row ops per row\",\n\"d\":" << n << ",\n\"n\":" << n
+     << ",\n\"b_in\":[";
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j)
+      os << ((i || j) ? "," : "") << b(i, j).get_si();
+  os << "],\n";
+
+  MatGSO<Z_NR<long>, FP_NR<double>> M(b, u, ut, GSO_ROW_EXPO);
+  M.update_gso();
+  dump_mat_hex(os, "mu0", M.get_mu_matrix(), n, false);
+  dump_mat_hex(os, "r0", M.get_r_matrix(), n, true);
+  os << "\"row_expo0\":[";
+  for (int i = 0; i < n; ++i)
+    os << (i ? "," : "") << M.row_expo[i];
+  os << "],\n";
+
+  LLLReduction<Z_NR<long>, FP_NR<double>> L(M, LLL_DEF_DELTA, LLL_DEF_ETA, LLL_DEFAULT);
+  bool ok = L.size_reduction(0, n, 0);
+  os << "\"status\":" << (ok ? 1 : 0) << ",\n\"b_out\":[";
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j)
+      os << ((i || j) ? "," : "") << b(i, j).get_si();
+  os << "],\n";
+  dump_mat_hex(os, "mu1", M.get_mu_matrix(), n, false);
+  dump_mat_hex(os, "r1", M.get_r_matrix(), n, true);
+  os << "\"row_expo1\":[";
+  for (int i = 0; i < n; ++i)
+    os << (i ? "," : "") << M.row_expo[i];
+  os << "]\n}\n";
+  std::cout << os.str();
+  return 0;
+}
+
 /* dumpbasis n k bits seed bkz_pre  → the reduced basis in fplll's text format on stdout */
 static int cmd_dumpbasis(int argc, char **argv)
 {
@@ -364,6 +443,8 @@ int main(int argc, char **argv)
     return cmd_plugin(argc, argv);
   if (cmd == "dumpbasis")
     return cmd_dumpbasis(argc, argv);
+  if (cmd == "gsofix")
+    return cmd_gsofix(argc, argv);
   fprintf(stderr, "unknown command %s\n", cmd.c_str());
   return 2;
 }

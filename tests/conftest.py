@@ -112,3 +112,88 @@ def ctx():
     c = fplll_amd.Context(int(os.environ.get("LOCAL_RANK", "0")))
     yield c
     c.close()
+
+
+# ---- GSO oracle wrappers ---------------------------------------------------------------------
+def gso_fixtures():
+    return sorted(glob.glob(os.path.join(GOLDEN, "gso_*.json")))
+
+
+def load_gso_fixture(path):
+    with open(path) as f:
+        j = json.load(f)
+    d, n = j["d"], j["n"]
+    out = {"d": d, "n": n, "name": os.path.basename(path)[:-5], "status": j["status"]}
+    out["b_in"] = np.array(j["b_in"], dtype=np.int64).reshape(d, n)
+    out["b_out"] = np.array(j["b_out"], dtype=np.int64).reshape(d, n)
+    for k in ("mu0", "r0", "mu1", "r1"):
+        out[k] = hexvec(j[k]).reshape(d, d)
+    out["row_expo0"] = np.array(j["row_expo0"], dtype=np.int64)
+    out["row_expo1"] = np.array(j["row_expo1"], dtype=np.int64)
+    return out
+
+
+class OracleGSO:
+    """ctypes handle on oracle/gso_oracle.c (MatGSO<long,double> + LLLReduction::size_reduction)."""
+
+    def __init__(self, b, row_expo=True):
+        lib = oracle_lib()
+        lib.oracle_gso_create.restype = ctypes.c_void_p
+        lib.oracle_gso_create.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+        lib.oracle_gso_destroy.argtypes = [ctypes.c_void_p]
+        lib.oracle_gso_update_all.argtypes = [ctypes.c_void_p]
+        lib.oracle_gso_size_reduction.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                                  ctypes.c_double]
+        for name, rt in (("oracle_gso_mu", ctypes.POINTER(ctypes.c_double)),
+                         ("oracle_gso_r", ctypes.POINTER(ctypes.c_double)),
+                         ("oracle_gso_bf", ctypes.POINTER(ctypes.c_double)),
+                         ("oracle_gso_b", ctypes.POINTER(ctypes.c_int64)),
+                         ("oracle_gso_row_expo", ctypes.POINTER(ctypes.c_int64))):
+            getattr(lib, name).restype = rt
+            getattr(lib, name).argtypes = [ctypes.c_void_p]
+        self.lib = lib
+        b = np.ascontiguousarray(b, dtype=np.int64)
+        self.d, self.n = b.shape
+        self.h = lib.oracle_gso_create(self.d, self.n, b.ctypes.data_as(ctypes.c_void_p),
+                                       1 if row_expo else 0)
+
+    def update_all(self):
+        return self.lib.oracle_gso_update_all(self.h)
+
+    def size_reduction(self, kmin, kend, eta=0.51):
+        return self.lib.oracle_gso_size_reduction(self.h, kmin, kend, eta)
+
+    def _arr(self, fn, shape, dtype):
+        p = getattr(self.lib, fn)(self.h)
+        return np.ctypeslib.as_array(p, shape=shape).astype(dtype).copy()
+
+    @property
+    def mu(self):
+        return np.tril(self._arr("oracle_gso_mu", (self.d, self.d), np.float64), -1)
+
+    @property
+    def r(self):
+        return np.tril(self._arr("oracle_gso_r", (self.d, self.d), np.float64))
+
+    @property
+    def b(self):
+        return self._arr("oracle_gso_b", (self.d, self.n), np.int64)
+
+    @property
+    def bf(self):
+        return self._arr("oracle_gso_bf", (self.d, self.n), np.float64)
+
+    @property
+    def row_expo(self):
+        return self._arr("oracle_gso_row_expo", (self.d,), np.int64)
+
+    def close(self):
+        if self.h:
+            self.lib.oracle_gso_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
