@@ -1,0 +1,35 @@
+// gso_device.h — device-resident GSO state for a BATCH of independent lattices
+// (ZT = long, FT = double, GSO_ROW_EXPO), shared by gso_kernel.hip and gso_host.hip.
+//
+// Layout in HBM (one lattice after another; every array is a dense [batch][...] slab):
+//   b    [batch][d][n]   int64   integer basis, row-major  (rows are AXPY'd: coalesced over columns)
+//   bfT  [batch][n][d]   double  float basis, COLUMN-major: bfT[c][j] = bf(j,c) — a Gram row is
+//                                "lane j walks column c": coalesced over j
+//   mu   [batch][d][d]   double  row-major  mu(j,k), k<j      (size-reduction sweep reads rows)
+//   muT  [batch][d][d]   double  muT[k][j] = mu(j,k)          (GSO recurrence reads columns)
+//   r    [batch][d][d]   double  row-major  r(i,j), j<=i
+//   rdg  [batch][d]      double  r(j,j)
+//   rexp [batch][d]      int64   row_expo (gso_interface.h:167)
+//   status[batch]        int     1 ok, 0 RED_GSO_FAILURE, -1 RED_BABAI_FAILURE, -2 multiplier > 63 bits
+#ifndef FPHIP_GSO_DEVICE_H
+#define FPHIP_GSO_DEVICE_H
+
+#include <stdint.h>
+
+namespace fphip
+{
+struct GsoBatch
+{
+  int batch, d, n;
+  int row_expo;
+  long long *b;
+  double *bfT;
+  double *mu;
+  double *muT;
+  double *r;
+  double *rdg;
+  long long *rexp;
+  int *status;
+};
+}  // namespace fphip
+#endif

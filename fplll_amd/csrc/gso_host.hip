@@ -1,3 +1,253 @@
-// placeholder until the GSO device path lands; keeps the context teardown symmetric
+// gso_host.hip — C ABI (include/fplll_hip.h) for the batched device-resident GSO:
+// MatGSO<Z_NR<long>, FP_NR<double>> look-alike entry points at SWEEP granularity
+// (update_gso / size_reduction over a row range), because a per-row device call would be
+// launch-bound (SURVEY.md §7 "Granularity").
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
 #include "../../include/fplll_hip.h"
+#include "gso_device.h"
+
+namespace fphip
+{
+template <int NQ> __global__ void gso_sweep_kernel(GsoBatch P, int kmin, int kend, double eta, int mode);
+}
+using namespace fphip;
+
+hipStream_t fphip_ctx_stream(fphip_ctx *ctx);
+char *fphip_ctx_errbuf(fphip_ctx *ctx);
+int fphip_ctx_num_cus(fphip_ctx *ctx);
+
+struct fphip_gso
+{
+  fphip_ctx *ctx;
+  GsoBatch P;
+  hipEvent_t ev[2];
+  float last_ms;
+  int waves_per_block;
+  int blocks_per_cu;
+};
+
+static int gfail(fphip_ctx *ctx, const char *what, hipError_t e)
+{
+  snprintf(fphip_ctx_errbuf(ctx), 512, "%s failed: %s", what, hipGetErrorString(e));
+  return FPHIP_ERROR;
+}
+#define GCHK(call)                            \
+  do                                          \
+  {                                           \
+    hipError_t e_ = (call);                   \
+    if (e_ != hipSuccess)                     \
+      return gfail(g->ctx, #call, e_);        \
+  } while (0)
+
 extern "C" void fphip_gso_release_all(fphip_ctx *ctx) { (void)ctx; }
+
+extern "C" int fphip_gso_create(fphip_ctx *ctx, int batch, int d, int n, int row_expo,
+                                fphip_gso **out)
+{
+  if (!ctx || !out)
+    return FPHIP_ERROR;
+  *out = nullptr;
+  if (batch <= 0 || d <= 0 || n <= 0)
+  {
+    snprintf(fphip_ctx_errbuf(ctx), 512, "fphip_gso_create: bad shape");
+    return FPHIP_ERROR;
+  }
+  if (d > 256 || n > 256)
+    return FPHIP_UNSUPPORTED;  // caller keeps the lattice on the CPU path (fplll's MatGSO)
+  if (!fphip_ctx_stream(ctx))
+  {
+    snprintf(fphip_ctx_errbuf(ctx), 512, "fphip_gso_create: context has no device");
+    return FPHIP_ERROR;
+  }
+  fphip_gso *g = new fphip_gso();
+  memset(g, 0, sizeof *g);
+  g->ctx        = ctx;
+  g->P.batch    = batch;
+  g->P.d        = d;
+  g->P.n        = n;
+  g->P.row_expo = row_expo ? 1 : 0;
+  const size_t B = (size_t)batch;
+  GCHK(hipMalloc((void **)&g->P.b, B * d * n * sizeof(long long)));
+  GCHK(hipMalloc((void **)&g->P.bfT, B * n * d * sizeof(double)));
+  GCHK(hipMalloc((void **)&g->P.mu, B * d * d * sizeof(double)));
+  GCHK(hipMalloc((void **)&g->P.muT, B * d * d * sizeof(double)));
+  GCHK(hipMalloc((void **)&g->P.r, B * d * d * sizeof(double)));
+  GCHK(hipMalloc((void **)&g->P.rdg, B * d * sizeof(double)));
+  GCHK(hipMalloc((void **)&g->P.rexp, B * d * sizeof(long long)));
+  GCHK(hipMalloc((void **)&g->P.status, B * sizeof(int)));
+  GCHK(hipMemsetAsync(g->P.mu, 0, B * d * d * sizeof(double), fphip_ctx_stream(ctx)));
+  GCHK(hipMemsetAsync(g->P.muT, 0, B * d * d * sizeof(double), fphip_ctx_stream(ctx)));
+  GCHK(hipMemsetAsync(g->P.r, 0, B * d * d * sizeof(double), fphip_ctx_stream(ctx)));
+  GCHK(hipEventCreate(&g->ev[0]));
+  GCHK(hipEventCreate(&g->ev[1]));
+  const char *w      = getenv("FPHIP_GSO_WAVES_PER_BLOCK");
+  g->waves_per_block = w ? atoi(w) : 4;
+  const char *bp     = getenv("FPHIP_GSO_BLOCKS_PER_CU");
+  g->blocks_per_cu   = bp ? atoi(bp) : 4;
+  *out               = g;
+  return FPHIP_OK;
+}
+
+extern "C" void fphip_gso_destroy(fphip_gso *g)
+{
+  if (!g)
+    return;
+  hipStreamSynchronize(fphip_ctx_stream(g->ctx));
+  hipFree(g->P.b);
+  hipFree(g->P.bfT);
+  hipFree(g->P.mu);
+  hipFree(g->P.muT);
+  hipFree(g->P.r);
+  hipFree(g->P.rdg);
+  hipFree(g->P.rexp);
+  hipFree(g->P.status);
+  hipEventDestroy(g->ev[0]);
+  hipEventDestroy(g->ev[1]);
+  delete g;
+}
+
+static int launch(fphip_gso *g, int kmin, int kend, double eta, int mode)
+{
+  const int need = (g->P.d > g->P.n ? g->P.d : g->P.n);
+  const int nq   = (need + 63) / 64;
+  const int wpb  = g->waves_per_block;
+  int grid       = (g->P.batch + wpb - 1) / wpb;
+  const int cap  = fphip_ctx_num_cus(g->ctx) * g->blocks_per_cu;
+  if (grid > cap)
+    grid = cap;
+  hipStream_t s = fphip_ctx_stream(g->ctx);
+  GCHK(hipEventRecord(g->ev[0], s));
+  switch (nq)
+  {
+  case 1:
+    hipLaunchKernelGGL(gso_sweep_kernel<1>, dim3(grid), dim3(wpb * 64), 0, s, g->P, kmin, kend, eta, mode);
+    break;
+  case 2:
+    hipLaunchKernelGGL(gso_sweep_kernel<2>, dim3(grid), dim3(wpb * 64), 0, s, g->P, kmin, kend, eta, mode);
+    break;
+  case 3:
+    hipLaunchKernelGGL(gso_sweep_kernel<3>, dim3(grid), dim3(wpb * 64), 0, s, g->P, kmin, kend, eta, mode);
+    break;
+  default:
+    hipLaunchKernelGGL(gso_sweep_kernel<4>, dim3(grid), dim3(wpb * 64), 0, s, g->P, kmin, kend, eta, mode);
+    break;
+  }
+  GCHK(hipGetLastError());
+  GCHK(hipEventRecord(g->ev[1], s));
+  GCHK(hipStreamSynchronize(s));
+  GCHK(hipEventElapsedTime(&g->last_ms, g->ev[0], g->ev[1]));
+  return FPHIP_OK;
+}
+
+static int fetch_status(fphip_gso *g, int *status)
+{
+  if (status)
+    GCHK(hipMemcpy(status, g->P.status, sizeof(int) * g->P.batch, hipMemcpyDeviceToHost));
+  return FPHIP_OK;
+}
+
+extern "C" int fphip_gso_set_basis(fphip_gso *g, int first, int count, const int64_t *b)
+{
+  if (!g || !b || first < 0 || count <= 0 || first + count > g->P.batch)
+    return FPHIP_ERROR;
+  const size_t per = (size_t)g->P.d * g->P.n;
+  GCHK(hipMemcpy(g->P.b + (size_t)first * per, b, per * count * sizeof(long long),
+                 hipMemcpyHostToDevice));
+  return FPHIP_OK;
+}
+
+// replicate lattice `src` into every slot of the batch (device-side copies; used by benchmarks)
+extern "C" int fphip_gso_broadcast_basis(fphip_gso *g, int src)
+{
+  if (!g || src < 0 || src >= g->P.batch)
+    return FPHIP_ERROR;
+  const size_t per = (size_t)g->P.d * g->P.n * sizeof(long long);
+  for (int L = 0; L < g->P.batch; ++L)
+    if (L != src)
+      GCHK(hipMemcpyAsync(g->P.b + (size_t)L * g->P.d * g->P.n,
+                          g->P.b + (size_t)src * g->P.d * g->P.n, per, hipMemcpyDeviceToDevice,
+                          fphip_ctx_stream(g->ctx)));
+  GCHK(hipStreamSynchronize(fphip_ctx_stream(g->ctx)));
+  return FPHIP_OK;
+}
+
+extern "C" int fphip_gso_get_basis(fphip_gso *g, int first, int count, int64_t *b)
+{
+  if (!g || !b || first < 0 || count <= 0 || first + count > g->P.batch)
+    return FPHIP_ERROR;
+  const size_t per = (size_t)g->P.d * g->P.n;
+  GCHK(hipMemcpy(b, g->P.b + (size_t)first * per, per * count * sizeof(long long),
+                 hipMemcpyDeviceToHost));
+  return FPHIP_OK;
+}
+
+// (re)float every row from the integer basis: MatGSO::update_bf for all rows, gso.cpp:24-48
+extern "C" int fphip_gso_refresh(fphip_gso *g)
+{
+  if (!g)
+    return FPHIP_ERROR;
+  return launch(g, 0, g->P.d, 0.0, 2);
+}
+
+// MatGSOInterface::update_gso(), gso_interface.h:767-775, for every lattice of the batch
+extern "C" int fphip_gso_update(fphip_gso *g, int *status)
+{
+  if (!g)
+    return FPHIP_ERROR;
+  int rc = launch(g, 0, g->P.d, 0.0, 0);
+  if (rc != FPHIP_OK)
+    return rc;
+  return fetch_status(g, status);
+}
+
+// LLLReduction::size_reduction(kappa_min, kappa_end), lll.h:107-122, for every lattice
+extern "C" int fphip_gso_size_reduce(fphip_gso *g, int kappa_min, int kappa_end, double eta,
+                                     int *status)
+{
+  if (!g)
+    return FPHIP_ERROR;
+  if (kappa_end < 0)
+    kappa_end = g->P.d;
+  if (kappa_min < 0 || kappa_min > kappa_end || kappa_end > g->P.d)
+    return FPHIP_ERROR;
+  int rc = launch(g, kappa_min, kappa_end, eta, 1);
+  if (rc != FPHIP_OK)
+    return rc;
+  return fetch_status(g, status);
+}
+
+extern "C" int fphip_gso_get_mu(fphip_gso *g, int lattice, double *mu)
+{
+  if (!g || !mu || lattice < 0 || lattice >= g->P.batch)
+    return FPHIP_ERROR;
+  const size_t per = (size_t)g->P.d * g->P.d;
+  GCHK(hipMemcpy(mu, g->P.mu + (size_t)lattice * per, per * sizeof(double), hipMemcpyDeviceToHost));
+  return FPHIP_OK;
+}
+
+extern "C" int fphip_gso_get_r(fphip_gso *g, int lattice, double *r)
+{
+  if (!g || !r || lattice < 0 || lattice >= g->P.batch)
+    return FPHIP_ERROR;
+  const size_t per = (size_t)g->P.d * g->P.d;
+  GCHK(hipMemcpy(r, g->P.r + (size_t)lattice * per, per * sizeof(double), hipMemcpyDeviceToHost));
+  return FPHIP_OK;
+}
+
+extern "C" int fphip_gso_get_row_expo(fphip_gso *g, int lattice, int64_t *row_expo)
+{
+  if (!g || !row_expo || lattice < 0 || lattice >= g->P.batch)
+    return FPHIP_ERROR;
+  GCHK(hipMemcpy(row_expo, g->P.rexp + (size_t)lattice * g->P.d, sizeof(long long) * g->P.d,
+                 hipMemcpyDeviceToHost));
+  return FPHIP_OK;
+}
+
+extern "C" double fphip_gso_last_kernel_ms(const fphip_gso *g) { return g ? g->last_ms : 0.0; }

@@ -1,0 +1,213 @@
+"""Host-side mirror of the reference's GSO interface for a BATCH of lattices on the GPU.
+
+``MatGSOBatch`` keeps the names of fplll's ``MatGSO`` / ``LLLReduction`` members
+(update_gso, size_reduction, get_mu, get_r, row_expo — fplll/gso_interface.h, fplll/lll.h) at sweep
+granularity; every number is computed by the HIP kernels behind include/fplll_hip.h.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+LLL_DEF_ETA = 0.51  # fplll/defs.h:143-151
+
+
+def _bind(lib):
+    if getattr(lib, "_gso_bound", False):
+        return
+    vp = ctypes.c_void_p
+    lib.fphip_gso_create.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                     ctypes.POINTER(vp)]
+    lib.fphip_gso_create.restype = ctypes.c_int
+    lib.fphip_gso_destroy.argtypes = [vp]
+    lib.fphip_gso_destroy.restype = None
+    for name in ("fphip_gso_set_basis", "fphip_gso_get_basis"):
+        getattr(lib, name).argtypes = [vp, ctypes.c_int, ctypes.c_int, vp]
+        getattr(lib, name).restype = ctypes.c_int
+    lib.fphip_gso_broadcast_basis.argtypes = [vp, ctypes.c_int]
+    lib.fphip_gso_broadcast_basis.restype = ctypes.c_int
+    lib.fphip_gso_refresh.argtypes = [vp]
+    lib.fphip_gso_refresh.restype = ctypes.c_int
+    lib.fphip_gso_update.argtypes = [vp, vp]
+    lib.fphip_gso_update.restype = ctypes.c_int
+    lib.fphip_gso_size_reduce.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_double, vp]
+    lib.fphip_gso_size_reduce.restype = ctypes.c_int
+    for name in ("fphip_gso_get_mu", "fphip_gso_get_r", "fphip_gso_get_row_expo"):
+        getattr(lib, name).argtypes = [vp, ctypes.c_int, vp]
+        getattr(lib, name).restype = ctypes.c_int
+    lib.fphip_gso_last_kernel_ms.argtypes = [vp]
+    lib.fphip_gso_last_kernel_ms.restype = ctypes.c_double
+    lib._gso_bound = True
+
+
+class MatGSOBatch:
+    """`batch` independent d×n integer lattices, GSO state resident in HBM."""
+
+    def __init__(self, ctx, batch, d, n, row_expo=True):
+        self.ctx = ctx
+        self.lib = ctx.lib
+        _bind(self.lib)
+        self.batch, self.d, self.n = batch, d, n
+        self.h = ctypes.c_void_p()
+        rc = self.lib.fphip_gso_create(ctx.handle, batch, d, n, 1 if row_expo else 0,
+                                       ctypes.byref(self.h))
+        if rc == _lib.FPHIP_UNSUPPORTED:
+            raise NotImplementedError("d, n > 256 are not handled on the device")
+        if rc != _lib.FPHIP_OK:
+            raise _lib.HipError("fphip_gso_create: " + ctx.last_error())
+
+    def _chk(self, rc, what):
+        if rc != _lib.FPHIP_OK:
+            raise _lib.HipError("%s: %s" % (what, self.ctx.last_error()))
+
+    def set_basis(self, b, first=0):
+        b = np.ascontiguousarray(b, dtype=np.int64)
+        if b.ndim == 2:
+            b = b[None]
+        assert b.shape[1:] == (self.d, self.n)
+        self._chk(self.lib.fphip_gso_set_basis(self.h, first, b.shape[0],
+                                               b.ctypes.data_as(ctypes.c_void_p)), "set_basis")
+        self._chk(self.lib.fphip_gso_refresh(self.h), "refresh")
+
+    def broadcast_basis(self, src=0):
+        self._chk(self.lib.fphip_gso_broadcast_basis(self.h, src), "broadcast_basis")
+        self._chk(self.lib.fphip_gso_refresh(self.h), "refresh")
+
+    def get_basis(self, first=0, count=None):
+        count = self.batch - first if count is None else count
+        b = np.empty((count, self.d, self.n), dtype=np.int64)
+        self._chk(self.lib.fphip_gso_get_basis(self.h, first, count,
+                                               b.ctypes.data_as(ctypes.c_void_p)), "get_basis")
+        return b
+
+    def update_gso(self):
+        st = np.zeros(self.batch, dtype=np.int32)
+        self._chk(self.lib.fphip_gso_update(self.h, st.ctypes.data_as(ctypes.c_void_p)), "update_gso")
+        return st
+
+    def size_reduction(self, kappa_min=0, kappa_end=-1, eta=LLL_DEF_ETA):
+        st = np.zeros(self.batch, dtype=np.int32)
+        self._chk(self.lib.fphip_gso_size_reduce(self.h, kappa_min, kappa_end, eta,
+                                                 st.ctypes.data_as(ctypes.c_void_p)), "size_reduction")
+        return st
+
+    def get_mu_matrix(self, lattice=0):
+        m = np.empty((self.d, self.d), dtype=np.float64)
+        self._chk(self.lib.fphip_gso_get_mu(self.h, lattice, m.ctypes.data_as(ctypes.c_void_p)), "get_mu")
+        return np.tril(m, -1)
+
+    def get_r_matrix(self, lattice=0):
+        m = np.empty((self.d, self.d), dtype=np.float64)
+        self._chk(self.lib.fphip_gso_get_r(self.h, lattice, m.ctypes.data_as(ctypes.c_void_p)), "get_r")
+        return np.tril(m)
+
+    def row_expo(self, lattice=0):
+        e = np.empty(self.d, dtype=np.int64)
+        self._chk(self.lib.fphip_gso_get_row_expo(self.h, lattice, e.ctypes.data_as(ctypes.c_void_p)),
+                  "get_row_expo")
+        return e
+
+    def get_mu(self, lattice, i, j):
+        """mu(i,j) with the row exponents applied (gso_interface.h:694-702)."""
+        e = self.row_expo(lattice)
+        return float(np.ldexp(self.get_mu_matrix(lattice)[i, j], int(e[i] - e[j])))
+
+    def get_r(self, lattice, i, j):
+        e = self.row_expo(lattice)
+        return float(np.ldexp(self.get_r_matrix(lattice)[i, j], int(e[i] + e[j])))
+
+    @property
+    def last_kernel_ms(self):
+        return float(self.lib.fphip_gso_last_kernel_ms(self.h))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.fphip_gso_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ---------------------------------------------------------------------------------------------
+def sweep_bytes(d, n):
+    """ALGORITHMIC bytes of one size-reduction sweep of a d×n lattice in which every row needs
+    exactly one effective babai iteration followed by the confirming pass:
+    per row kappa, B_sweep = 8 kappa^2 + 8 n (2 kappa + 2)  [one babai iteration: mu triangle read
+    twice, kappa basis rows + RMW of row kappa, kappa float rows for the Gram row] plus the
+    confirming update_gso_row: 8 kappa^2/2 (mu columns) + 8 n kappa (Gram row)."""
+    tot = 0
+    for k in range(d):
+        tot += 8 * k * k + 8 * n * (2 * k + 2)
+        tot += 4 * k * k + 8 * n * k
+    return tot
+
+
+def _unreduced_copy(b, ops_per_row=3, seed=1):
+    """LLL-reduced basis → same lattice with rows that need size reduction again (every row gets a
+    few multiples of earlier rows added; deterministic)."""
+    rng = np.random.default_rng(seed)
+    b = b.copy()
+    d = b.shape[0]
+    for i in range(1, d):
+        for _ in range(ops_per_row):
+            j = int(rng.integers(0, i))
+            c = int(rng.integers(-3, 4))
+            b[i] += c * b[j]
+    return b
+
+
+def bench_roofline(ctx, batch=None, reps=2):
+    """Batched size-reduction sweep on `batch` copies of the C3 basis (180×180, BKZ-20-reduced then
+    un-size-reduced), timed with HIP events; returns the `roofline` object of bench.py."""
+    import os
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(here, "tests", "golden", "basis_q180_seed0_lll_bkz20.txt")
+    txt = open(path).read().replace("[", " ").replace("]", " ").split()
+    vals = np.array([int(t) for t in txt], dtype=np.int64)
+    d = int(round(len(vals) ** 0.5))
+    b = _unreduced_copy(vals.reshape(d, d))
+    if batch is None:
+        batch = int(os.environ.get("FPHIP_GSO_BENCH_BATCH", "4096"))
+    g = MatGSOBatch(ctx, batch, d, d)
+    try:
+        best = None
+        for _ in range(reps):
+            g.set_basis(b, first=0)
+            g.broadcast_basis(0)
+            st = g.size_reduction(0, d)
+            assert int(st.min()) == 1 and int(st.max()) == 1, "size reduction failed on device"
+            ms = g.last_kernel_ms
+            best = ms if best is None else min(best, ms)
+        alg = sweep_bytes(d, d) * batch
+        achieved = alg / (best * 1e-3) / 1e9
+        return {
+            "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+            "frac": achieved / 8000.0, "traffic": None,
+            "kernel": "gso_sweep_kernel<3> (size_reduction sweep, %d lattices of %dx%d)" % (batch, d, d),
+            "algorithmic_bytes_per_launch": alg, "kernel_ms": best,
+        }
+    finally:
+        g.close()
+
+
+def smoke(ctx, C):
+    """Small batched sweep vs the reference golden vector (bit-exact)."""
+    import os
+    f = C.load_gso_fixture(os.path.join(C.GOLDEN, "gso_q48_p3.json"))
+    g = MatGSOBatch(ctx, 3, f["d"], f["n"])
+    g.set_basis(np.stack([f["b_in"]] * 3))
+    st = g.size_reduction(0, f["d"])
+    assert list(st) == [1, 1, 1]
+    for L in range(3):
+        assert np.array_equal(g.get_basis(L, 1)[0], f["b_out"])
+        assert np.array_equal(g.get_mu_matrix(L), f["mu1"])
+        assert np.array_equal(g.get_r_matrix(L), f["r1"])
+        assert np.array_equal(g.row_expo(L), f["row_expo1"])
+    print("smoke: batched size_reduction d=%d == reference (b, mu, r, row_expo bit-exact), %.3f ms"
+          % (f["d"], g.last_kernel_ms))
+    g.close()

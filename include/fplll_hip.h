@@ -113,6 +113,40 @@ int fphip_enum_run(fphip_ctx *ctx, int dim, double maxdist, const double *mut, c
                    fphip_subsol_cb subcb, void *user, uint64_t *nodes_out,
                    fphip_enum_stats *stats);
 
+/* ------------------------------------------------------------------------------------------ */
+/* Batched, device-resident Gram-Schmidt + size reduction                                       */
+/*   MatGSO<Z_NR<long>, FP_NR<double>> with GSO_ROW_EXPO (the BKZ fast path, bkz.cpp:816-829),  */
+/*   for `batch` independent d×n lattices.  Entry points are SWEEPS, not single rows: a per-row  */
+/*   device call would be launch-bound (4.1 M babai calls of ~0.3-1 us each in one BKZ-20 run).  */
+/*   Results are bit-identical to the reference: integer basis, mu, r, row exponents.            */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct fphip_gso fphip_gso;
+
+/* d, n <= 256; larger → FPHIP_UNSUPPORTED (the lattice stays on fplll's CPU MatGSO). */
+int fphip_gso_create(fphip_ctx *ctx, int batch, int d, int n, int row_expo, fphip_gso **out);
+void fphip_gso_destroy(fphip_gso *g);
+/* integer basis in/out, row-major b[lattice][row][col] (Matrix<Z_NR<long>>, nr/matrix.h:117) */
+int fphip_gso_set_basis(fphip_gso *g, int first_lattice, int count, const int64_t *b);
+int fphip_gso_get_basis(fphip_gso *g, int first_lattice, int count, int64_t *b);
+/* copy lattice `src` into every slot (device-to-device; benchmarks) */
+int fphip_gso_broadcast_basis(fphip_gso *g, int src);
+/* MatGSO::update_bf for every row (gso.cpp:24-48): call after set_basis */
+int fphip_gso_refresh(fphip_gso *g);
+/* MatGSOInterface::update_gso() (gso_interface.h:767-775).  status[batch]: 1 ok, 0 = non-finite
+ * mu (RED_GSO_FAILURE, gso_interface.cpp:156) */
+int fphip_gso_update(fphip_gso *g, int *status);
+/* LLLReduction::size_reduction(kappa_min, kappa_end) (lll.h:107-122 → babai lll.cpp:166-224) with
+ * row_op_end bookkeeping; kappa_end = -1 means d.  status: 1 ok, 0 RED_GSO_FAILURE,
+ * -1 RED_BABAI_FAILURE (lll.cpp:187-195), -2 multiplier beyond 63 bits (caller falls back) */
+int fphip_gso_size_reduce(fphip_gso *g, int kappa_min, int kappa_end, double eta, int *status);
+/* raw stored values, d×d row-major; true values carry the row exponents exactly as
+ * get_mu/get_r do (gso_interface.h:694-732): mu·2^(e_i-e_j), r·2^(e_i+e_j) */
+int fphip_gso_get_mu(fphip_gso *g, int lattice, double *mu);
+int fphip_gso_get_r(fphip_gso *g, int lattice, double *r);
+int fphip_gso_get_row_expo(fphip_gso *g, int lattice, int64_t *row_expo);
+/* duration of the last sweep kernel, HIP events on the launch stream */
+double fphip_gso_last_kernel_ms(const fphip_gso *g);
+
 #ifdef __cplusplus
 }
 #endif

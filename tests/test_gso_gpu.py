@@ -1,0 +1,189 @@
+"""GPU parity tests for the batched GSO / size-reduction sweep (fphip_gso_* through the C ABI).
+Bar: bit-exact — integer basis, stored mu / r, row exponents — against golden vectors of the real
+reference and against the C oracle on seeded inputs, at every register-tiling width (NQ = 1..3),
+for ragged shapes, partial row ranges and heterogeneous batches."""
+import os
+
+import numpy as np
+import pytest
+
+import conftest as C
+
+pytestmark = pytest.mark.gpu
+
+
+def _load_c3_basis():
+    path = os.path.join(C.GOLDEN, "basis_q180_seed0_lll_bkz20.txt")
+    txt = open(path).read().replace("[", " ").replace("]", " ").split()
+    v = np.array([int(t) for t in txt], dtype=np.int64)
+    d = int(round(len(v) ** 0.5))
+    return v.reshape(d, d)
+
+
+def _check_against_oracle(g, L, b_in, kmin=0, kend=None, update_first=False):
+    o = C.OracleGSO(b_in)
+    if update_first:
+        assert o.update_all() == 1
+    rc = o.size_reduction(kmin, o.d if kend is None else kend)
+    assert rc == 1
+    assert np.array_equal(g.get_basis(L, 1)[0], o.b)
+    assert np.array_equal(g.row_expo(L), o.row_expo)
+    assert np.array_equal(g.get_mu_matrix(L), o.mu)
+    assert np.array_equal(g.get_r_matrix(L), o.r)
+    o.close()
+
+
+@pytest.mark.parametrize("path", C.gso_fixtures(), ids=lambda p: os.path.basename(p)[:-5])
+def test_reference_fixture_parity(ctx, path):
+    from fplll_amd.gso import MatGSOBatch
+    f = C.load_gso_fixture(path)
+    g = MatGSOBatch(ctx, 2, f["d"], f["n"])
+    g.set_basis(np.stack([f["b_in"], f["b_in"]]))
+    st = g.update_gso()
+    assert list(st) == [1, 1]
+    for L in range(2):
+        assert np.array_equal(g.row_expo(L), f["row_expo0"])
+        assert np.array_equal(g.get_mu_matrix(L), f["mu0"])
+        assert np.array_equal(g.get_r_matrix(L), f["r0"])
+    st = g.size_reduction(0, f["d"])
+    assert list(st) == [1, 1]
+    for L in range(2):
+        assert np.array_equal(g.get_basis(L, 1)[0], f["b_out"])
+        assert np.array_equal(g.row_expo(L), f["row_expo1"])
+        assert np.array_equal(g.get_mu_matrix(L), f["mu1"])
+        assert np.array_equal(g.get_r_matrix(L), f["r1"])
+    # idempotence: a size-reduced basis is a fixed point of the sweep
+    st = g.size_reduction(0, f["d"])
+    assert list(st) == [1, 1]
+    assert np.array_equal(g.get_basis(0, 1)[0], f["b_out"])
+    assert np.array_equal(g.get_mu_matrix(0), f["mu1"])
+    g.close()
+
+
+def test_heterogeneous_batch_and_ragged_shapes(ctx):
+    """Different lattices in one batch; d < n (non-square); tiny dimensions."""
+    from fplll_amd.gso import MatGSOBatch, _unreduced_copy
+    f = C.load_gso_fixture(os.path.join(C.GOLDEN, "gso_q48_p3.json"))
+    base = f["b_out"]
+    bs = [_unreduced_copy(base, ops_per_row=k, seed=10 + k) for k in range(1, 6)]
+    g = MatGSOBatch(ctx, len(bs), 48, 48)
+    g.set_basis(np.stack(bs))
+    st = g.size_reduction()
+    assert list(st) == [1] * len(bs)
+    for L, b in enumerate(bs):
+        _check_against_oracle(g, L, b)
+    g.close()
+    # ragged: keep only the first 20 rows (20×48) and a 1×5 / 2×3 corner
+    for (d, n) in ((20, 48), (1, 5), (2, 3), (3, 7)):
+        b = _unreduced_copy(base[:max(d, 2), :n], 2, 3)[:d]
+        if not np.any(b):
+            b[0, 0] = 1
+        for i in range(d):  # keep rows linearly independent enough: add a diagonal bump
+            b[i, min(i, n - 1)] += 7 + i
+        g = MatGSOBatch(ctx, 1, d, n)
+        g.set_basis(b)
+        assert list(g.size_reduction()) == [1]
+        _check_against_oracle(g, 0, b)
+        g.close()
+
+
+@pytest.mark.parametrize("d", [100, 130, 180])
+def test_wide_register_tilings_match_oracle(ctx, d):
+    """NQ = 2 and 3 (d = 100, 130, 180 = BASELINE C3 size) on the C3 basis, un-size-reduced."""
+    from fplll_amd.gso import MatGSOBatch, _unreduced_copy
+    full = _load_c3_basis()
+    b = _unreduced_copy(full[:d, :], 3, 5)
+    g = MatGSOBatch(ctx, 2, d, full.shape[1])
+    g.set_basis(np.stack([b, full[:d, :]]))
+    st = g.size_reduction()
+    assert list(st) == [1, 1]
+    _check_against_oracle(g, 0, b)
+    _check_against_oracle(g, 1, full[:d, :])
+    g.close()
+
+
+def test_partial_ranges_and_update_only(ctx):
+    from fplll_amd.gso import MatGSOBatch, _unreduced_copy
+    f = C.load_gso_fixture(os.path.join(C.GOLDEN, "gso_q64_p5.json"))
+    b = f["b_in"]
+    g = MatGSOBatch(ctx, 1, f["d"], f["n"])
+    g.set_basis(b)
+    assert list(g.update_gso()) == [1]
+    # BKZ calls size_reduction(0, kappa+1) (bkz.cpp:289): a prefix of the rows
+    assert list(g.size_reduction(0, 40)) == [1]
+    o = C.OracleGSO(b)
+    assert o.update_all() == 1 and o.size_reduction(0, 40) == 1
+    assert np.array_equal(g.get_basis(0, 1)[0], o.b)
+    assert np.array_equal(g.get_mu_matrix(0)[:40], o.mu[:40])
+    assert np.array_equal(g.get_r_matrix(0)[:40], o.r[:40])
+    # then the tail
+    assert list(g.size_reduction(40, 64)) == [1]
+    assert o.size_reduction(40, 64) == 1
+    assert np.array_equal(g.get_basis(0, 1)[0], o.b)
+    assert np.array_equal(g.get_mu_matrix(0), o.mu)
+    assert np.array_equal(g.get_r_matrix(0), o.r)
+    assert np.array_equal(g.row_expo(0), o.row_expo)
+    o.close()
+    g.close()
+
+
+def test_linearly_dependent_rows_report_gso_failure(ctx):
+    """More rows than columns: r_jj hits 0, mu is non-finite → RED_GSO_FAILURE (status 0), exactly
+    where the reference's update_gso_row returns false (gso_interface.cpp:154-157)."""
+    from fplll_amd.gso import MatGSOBatch
+    b = np.array([[3], [5], [7], [11], [2]], dtype=np.int64)
+    g = MatGSOBatch(ctx, 1, 5, 1)
+    g.set_basis(b)
+    st = g.size_reduction()
+    o = C.OracleGSO(b)
+    assert o.size_reduction(0, 5) == 0
+    assert list(st) == [0]
+    o.close()
+    g.close()
+
+
+def test_row_expo_off_and_accessors(ctx):
+    from fplll_amd.gso import MatGSOBatch
+    f = C.load_gso_fixture(os.path.join(C.GOLDEN, "gso_q30_p0.json"))
+    g = MatGSOBatch(ctx, 1, f["d"], f["n"], row_expo=False)
+    g.set_basis(f["b_in"])
+    assert list(g.size_reduction()) == [1]
+    o = C.OracleGSO(f["b_in"], row_expo=False)
+    assert o.size_reduction(0, f["d"]) == 1
+    assert np.array_equal(g.get_mu_matrix(0), o.mu) and np.array_equal(g.get_r_matrix(0), o.r)
+    assert np.all(g.row_expo(0) == 0)
+    o.close()
+    g.close()
+    # get_mu / get_r apply the exponents like gso_interface.h:694-732 → within 1e-9 of the plain
+    # (no row_expo) values, the north-star tolerance for mu / r
+    g2 = MatGSOBatch(ctx, 1, f["d"], f["n"], row_expo=True)
+    g2.set_basis(f["b_in"])
+    assert list(g2.size_reduction()) == [1]
+    o2 = C.OracleGSO(f["b_in"], row_expo=False)
+    o2.size_reduction(0, f["d"])
+    for (i, j) in ((5, 2), (17, 0), (29, 28)):
+        assert abs(g2.get_mu(0, i, j) - o2.mu[i, j]) <= 1e-9 * max(1.0, abs(o2.mu[i, j]))
+    assert abs(g2.get_r(0, 7, 7) - o2.r[7, 7]) <= 1e-9 * abs(o2.r[7, 7])
+    o2.close()
+    g2.close()
+
+
+def test_full_size_batch_is_consistent(ctx):
+    """BASELINE-size batch (many 180×180 lattices): every replica of the same input must return
+    the same bits (checksum of checksums), and one replica is checked against the oracle."""
+    from fplll_amd.gso import MatGSOBatch, _unreduced_copy
+    full = _load_c3_basis()
+    b = _unreduced_copy(full, 3, 7)
+    B = 96
+    g = MatGSOBatch(ctx, B, 180, 180)
+    g.set_basis(b)
+    g.broadcast_basis(0)
+    st = g.size_reduction()
+    assert int(st.min()) == 1 and int(st.max()) == 1
+    bs = g.get_basis()
+    assert all(np.array_equal(bs[0], bs[L]) for L in range(1, B))
+    mu0 = g.get_mu_matrix(0)
+    for L in (1, B // 2, B - 1):
+        assert np.array_equal(mu0, g.get_mu_matrix(L))
+    _check_against_oracle(g, B - 1, b)
+    g.close()
