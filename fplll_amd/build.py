@@ -48,8 +48,12 @@ def build_hip(force=False):
     out = os.path.join(LIBDIR, "libfplll_hip.so")
     srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES if os.path.exists(os.path.join(CSRC, s))]
     hdrs = [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HIP_HEADERS]
+    extra = []
+    if os.environ.get("FPHIP_GSO_U"):
+        extra.append("-DFPHIP_GSO_U=" + os.environ["FPHIP_GSO_U"])
+        force = True
     if force or _newer(out, srcs + hdrs):
-        _run([hipcc()] + HIPCC_FLAGS + ["-o", out] + srcs)
+        _run([hipcc()] + HIPCC_FLAGS + extra + ["-o", out] + srcs)
     return out
 
 

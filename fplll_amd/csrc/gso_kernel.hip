@@ -70,12 +70,33 @@ template <int NQ> struct Lattice
   double murow[NQ];  // mu(kappa, j) of the row last updated (lane j)
 };
 
+// ---------------------------------------------------------------------------------------------
+// Software-pipelined "chain" loops.  Every hot loop of this kernel has the shape
+//     for step s (in a fixed order):  v[q] = LOAD(s, lane);  state[q] = f(state[q], v[q], scalar_s)
+// where the loads do not depend on the state but scalar_s does (it is read from a lane of the
+// state with v_readlane).  The loads are issued U steps at a time, double-buffered (group g+1 is
+// in flight while group g is consumed), so a wave keeps ~2·U·(active chunks) 512-byte loads in
+// flight — that, times the waves per CU, is what hides HBM latency.  Steps are grouped inside a
+// 64-chunk so that the chunk index of the scalar's register is a compile-time constant.
+// ---------------------------------------------------------------------------------------------
+#ifndef FPHIP_GSO_U
+#define FPHIP_GSO_U 4
+#endif
+
+template <int NQ, int U> struct Grp
+{
+  double v[U][NQ];
+};
+
 // update_gso_row(kappa, last) recomputed from column 0 (identical values: every input is unchanged
 // since the row was invalidated).  Returns false on a non-finite mu (RED_GSO_FAILURE).
 template <int NQ> __device__ bool update_row(Lattice<NQ> &T, int kappa, int last)
 {
+  constexpr int U = FPHIP_GSO_U;
   const int d = T.d, n = T.n, lane = T.lane;
+  const int qact = (last >> 6) + 1;  // chunks holding a lane j <= last
   double bk[NQ], acc[NQ], rd[NQ];
+  unsigned jc[NQ];  // lane's row index per chunk, clamped into the slab for unconditional loads
 #pragma unroll
   for (int q = 0; q < NQ; ++q)
   {
@@ -83,28 +104,59 @@ template <int NQ> __device__ bool update_row(Lattice<NQ> &T, int kappa, int last
     bk[q]       = (c < n) ? T.bfT[(size_t)c * d + kappa] : 0.0;
     acc[q]      = 0.0;
     rd[q]       = (c < kappa) ? T.rdg[c] : 1.0;
+    jc[q]       = (unsigned)min(c, d - 1);
   }
   // ---- Gram row: g(kappa,j) = bf_kappa . bf_j, columns in ascending order (numvect.h:386-396)
 #pragma unroll
   for (int cq = 0; cq < NQ; ++cq)
   {
-#pragma unroll 8
-    for (int cc = 0; cc < 64; ++cc)
+    const int cbase = cq * 64;
+    if (cbase >= n)
+      break;
+    const int cnt = min(64, n - cbase);
+    auto load     = [&](Grp<NQ, U> &G, int g0)
     {
-      const int c = cq * 64 + cc;
-      if (c >= n)
-        break;
-      const double bkc = g_rl_f64(bk[cq], cc);
 #pragma unroll
-      for (int q = 0; q < NQ; ++q)
+      for (int u = 0; u < U; ++u)
       {
-        const int j = lane + 64 * q;
-        if (j <= last)
+        const int c = min(cbase + g0 + u, n - 1);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+          if (q < qact)
+            G.v[u][q] = (T.bfT + (size_t)c * d)[jc[q]];
+      }
+    };
+    auto proc = [&](const Grp<NQ, U> &G, int g0)
+    {
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+      {
+        if (g0 + u < cnt)
         {
-          const double v = T.bfT[(size_t)c * d + j];
-          const double p = bkc * v;
-          acc[q]         = (c == 0) ? p : acc[q] + p;
+          const double bkc = g_rl_f64(bk[cq], g0 + u);
+#pragma unroll
+          for (int q = 0; q < NQ; ++q)
+            if (q < qact)
+            {
+              const double p = bkc * G.v[u][q];
+              acc[q]         = (cbase + g0 + u == 0) ? p : acc[q] + p;
+            }
         }
+      }
+    };
+    Grp<NQ, U> A, B;
+    load(A, 0);
+#pragma unroll 1
+    for (int g0 = 0; g0 < cnt; g0 += 2 * U)
+    {
+      if (g0 + U < cnt)
+        load(B, g0 + U);
+      proc(A, g0);
+      if (g0 + U < cnt)
+      {
+        if (g0 + 2 * U < cnt)
+          load(A, g0 + 2 * U);
+        proc(B, g0 + U);
       }
     }
   }
@@ -113,29 +165,65 @@ template <int NQ> __device__ bool update_row(Lattice<NQ> &T, int kappa, int last
 #pragma unroll
   for (int kq = 0; kq < NQ; ++kq)
   {
-#pragma unroll 8
-    for (int kk = 0; kk < 64; ++kk)
+    const int kbase = kq * 64;
+    if (kbase > last)
+      break;
+    const int cnt = min(64, last - kbase + 1);
+    auto load     = [&](Grp<NQ, U> &G, int g0)
     {
-      const int k = kq * 64 + kk;
-      if (k > last)
-        break;
-      const double rk = g_rl_f64(acc[kq], kk);  // r(kappa,k) is final
-      double muk      = 0.0;
-      if (k < kappa)
-      {
-        muk = rk / g_rl_f64(rd[kq], kk);  // mu(kappa,k) = r(kappa,k) / r(k,k)
-        if (!isfinite(muk))
-          ok = false;
-      }
 #pragma unroll
-      for (int q = 0; q < NQ; ++q)
+      for (int u = 0; u < U; ++u)
       {
-        const int j = lane + 64 * q;
-        if (j > k && j <= last)
+        const int k = min(kbase + g0 + u, d - 1);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+          if (q < qact && q >= kq)  // rows j <= k hold zeros: chunks below kq are never needed
+            G.v[u][q] = (T.muT + (size_t)k * d)[jc[q]];
+      }
+    };
+    auto proc = [&](const Grp<NQ, U> &G, int g0)
+    {
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+      {
+        if (g0 + u < cnt)
         {
-          const double m = (j == kappa) ? muk : T.muT[(size_t)k * d + j];
-          acc[q]         = acc[q] - m * rk;
+          const int k     = kbase + g0 + u;
+          const double rk = g_rl_f64(acc[kq], g0 + u);  // r(kappa,k) is final
+          double muk      = 0.0;
+          if (k < kappa)
+          {
+            muk = rk / g_rl_f64(rd[kq], g0 + u);  // mu(kappa,k) = r(kappa,k) / r(k,k)
+            if (!isfinite(muk))
+              ok = false;
+          }
+#pragma unroll
+          for (int q = 0; q < NQ; ++q)
+            if (q < qact && q >= kq)
+            {
+              const int j = lane + 64 * q;
+              if (j > k && j <= last)
+              {
+                const double m = (j == kappa) ? muk : G.v[u][q];
+                acc[q]         = acc[q] - m * rk;
+              }
+            }
         }
+      }
+    };
+    Grp<NQ, U> A, B;
+    load(A, 0);
+#pragma unroll 1
+    for (int g0 = 0; g0 < cnt; g0 += 2 * U)
+    {
+      if (g0 + U < cnt)
+        load(B, g0 + U);
+      proc(A, g0);
+      if (g0 + U < cnt)
+      {
+        if (g0 + 2 * U < cnt)
+          load(A, g0 + 2 * U);
+        proc(B, g0 + U);
       }
     }
   }
@@ -167,8 +255,18 @@ template <int NQ> __device__ bool update_row(Lattice<NQ> &T, int kappa, int last
 // LLLReduction::babai(kappa, kappa, 0).  1 ok, 0 GSO failure, -1 babai failure, -2 multiplier.
 template <int NQ> __device__ int babai(Lattice<NQ> &T, int kappa, double eta)
 {
+  constexpr int U = FPHIP_GSO_U;
   const int d = T.d, n = T.n, lane = T.lane;
+  const int qact = ((kappa - 1) >> 6) + 1;  // chunks holding a row index < kappa
+  const int nq_c = ((n - 1) >> 6) + 1;      // chunks holding a column index < n
   long long max_expo = LLONG_MAX;
+  unsigned jc[NQ], cc[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+  {
+    jc[q] = (unsigned)min(lane + 64 * q, d - 1);
+    cc[q] = (unsigned)min(lane + 64 * q, n - 1);
+  }
   for (int iter = 0;; ++iter)
   {
     if (!update_row<NQ>(T, kappa, kappa - 1))
@@ -209,48 +307,86 @@ template <int NQ> __device__ int babai(Lattice<NQ> &T, int kappa, double eta)
       xl[q] = 0;
     }
     bool too_big = false;
-    // ---- lll.cpp:202-220, j = kappa-1 … 0
+    // ---- lll.cpp:202-220, j = kappa-1 … 0 (descending), lane k owns babai_mu[k]
 #pragma unroll
     for (int jq = NQ - 1; jq >= 0; --jq)
     {
-      for (int jj = 63; jj >= 0; --jj)
+      const int jbase = jq * 64;
+      if (jbase >= kappa)
+        continue;
+      const int top = min(63, kappa - 1 - jbase);  // first (highest) jj of this chunk
+      const int cnt = top + 1;                     // steps: jj = top, top-1, …, 0
+      auto load     = [&](Grp<NQ, U> &G, int g0)
       {
-        const int j = jq * 64 + jj;
-        if (j >= kappa)
-          continue;
-        const double bmj = g_rl_f64(bm[jq], jj);
-        const int ej     = __builtin_amdgcn_readlane(e[jq], jj);
-        double X;  // rnd_we, nr_FP_d.inl:226-233
-        if (fexponent(bmj) + ej >= 53)
-          X = bmj;
-        else
-          X = ldexp(rint(ldexp(bmj, ej)), -ej);
-        if (X == 0.0)
-          continue;
-        {  // row_addmul_we(kappa, j, -X, ej): get_si_exp_we, nr_FP_d.inl:46-53
-          const long long ex = fexponent(-X) + ej - 63;
-          if (ex > 0)
-            too_big = true;
-          const long long lx = (long long)ldexp(-X, ej);
-          xl[jq]             = (lane == jj) ? lx : xl[jq];
-        }
 #pragma unroll
-        for (int q = 0; q < NQ; ++q)
+        for (int u = 0; u < U; ++u)
         {
-          const int k = lane + 64 * q;
-          if (k < j)
+          const int j = jbase + max(top - (g0 + u), 0);
+#pragma unroll
+          for (int q = 0; q < NQ; ++q)
+            if (q <= jq)  // mu(j,k) = 0 for k >= j
+              G.v[u][q] = (T.mu + (size_t)j * d)[jc[q]];
+        }
+      };
+      auto proc = [&](const Grp<NQ, U> &G, int g0)
+      {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+        {
+          if (g0 + u < cnt)
           {
-            const double t = X * T.mu[(size_t)j * d + k];
-            bm[q]          = bm[q] - t;
+            const int jj     = top - (g0 + u);
+            const int j      = jbase + jj;
+            const double bmj = g_rl_f64(bm[jq], jj);
+            const int ej     = __builtin_amdgcn_readlane(e[jq], jj);
+            double X;  // rnd_we, nr_FP_d.inl:226-233
+            if (fexponent(bmj) + ej >= 53)
+              X = bmj;
+            else
+              X = ldexp(rint(ldexp(bmj, ej)), -ej);
+            if (X != 0.0)
+            {
+              {  // row_addmul_we(kappa, j, -X, ej): get_si_exp_we, nr_FP_d.inl:46-53
+                const long long ex = fexponent(-X) + ej - 63;
+                if (ex > 0)
+                  too_big = true;
+                const long long lx = (long long)ldexp(-X, ej);
+                xl[jq]             = (lane == jj) ? lx : xl[jq];
+              }
+#pragma unroll
+              for (int q = 0; q < NQ; ++q)
+                if (q <= jq)
+                {
+                  const int k = lane + 64 * q;
+                  if (k < j)
+                  {
+                    const double t = X * G.v[u][q];
+                    bm[q]          = bm[q] - t;
+                  }
+                }
+            }
           }
+        }
+      };
+      Grp<NQ, U> A, B;
+      load(A, 0);
+  #pragma unroll 1
+    for (int g0 = 0; g0 < cnt; g0 += 2 * U)
+      {
+        if (g0 + U < cnt)
+          load(B, g0 + U);
+        proc(A, g0);
+        if (g0 + U < cnt)
+        {
+          if (g0 + 2 * U < cnt)
+            load(A, g0 + 2 * U);
+          proc(B, g0 + U);
         }
       }
     }
     if (too_big)
       return -2;
     // ---- integer AXPY on row kappa (row_add / row_sub / row_addmul_si, gso.cpp:84-158)
-    long long bmax_e = 0;
-    (void)bmax_e;
     long long bv[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
@@ -261,21 +397,60 @@ template <int NQ> __device__ int babai(Lattice<NQ> &T, int kappa, double eta)
 #pragma unroll
     for (int jq = NQ - 1; jq >= 0; --jq)
     {
-      for (int jj = 63; jj >= 0; --jj)
+      const int jbase = jq * 64;
+      if (jbase >= kappa)
+        continue;
+      const int top = min(63, kappa - 1 - jbase);
+      const int cnt = top + 1;
+      struct GI
       {
-        const int j = jq * 64 + jj;
-        if (j >= kappa)
-          continue;
-        const long long lx = g_rl_i64(xl[jq], jj);
-        if (lx == 0)
-          continue;
+        long long v[U][NQ];
+      };
+      auto load = [&](GI &G, int g0)
+      {
 #pragma unroll
-        for (int q = 0; q < NQ; ++q)
+        for (int u = 0; u < U; ++u)
         {
-          const int c = lane + 64 * q;
-          if (c < n)
-            bv[q] = (long long)((unsigned long long)bv[q] +
-                                (unsigned long long)T.b[(size_t)j * n + c] * (unsigned long long)lx);
+          const int j = jbase + max(top - (g0 + u), 0);
+#pragma unroll
+          for (int q = 0; q < NQ; ++q)
+            if (q < nq_c)
+              G.v[u][q] = (T.b + (size_t)j * n)[cc[q]];
+        }
+      };
+      auto proc = [&](const GI &G, int g0)
+      {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+        {
+          if (g0 + u < cnt)
+          {
+            const int jj       = top - (g0 + u);
+            const long long lx = g_rl_i64(xl[jq], jj);
+            if (lx != 0)
+            {
+#pragma unroll
+              for (int q = 0; q < NQ; ++q)
+                if (q < nq_c)
+                  bv[q] = (long long)((unsigned long long)bv[q] +
+                                      (unsigned long long)G.v[u][q] * (unsigned long long)lx);
+            }
+          }
+        }
+      };
+      GI A, B;
+      load(A, 0);
+  #pragma unroll 1
+    for (int g0 = 0; g0 < cnt; g0 += 2 * U)
+      {
+        if (g0 + U < cnt)
+          load(B, g0 + U);
+        proc(A, g0);
+        if (g0 + U < cnt)
+        {
+          if (g0 + 2 * U < cnt)
+            load(A, g0 + 2 * U);
+          proc(B, g0 + U);
         }
       }
     }

@@ -1,0 +1,74 @@
+"""World-size-2 tests of the multi-GPU glue on CPU (gloo): the bound/active all-reduce, the
+termination consensus of the round protocol (every rank makes the same number of collective
+calls even when their round counts differ) and the content-hash partition (disjoint + complete,
+independent of task order)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    from fplll_amd.distributed import make_exchange, run_rounds
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ex = make_exchange(dist, "cpu")
+    # 1. plain collective
+    b, a = ex(1.0 + rank, rank == 1)
+    assert b == 1.0 and a is True
+    b, a = ex(5.0 - rank, False)
+    assert b == 4.0 and a is False
+    # 2. round protocol: rank 0 has 5 rounds of work, rank 1 only 2; rank 1 finds the best bound
+    rounds = {0: [(10, None), (8, 0.9), (5, None), (1, None), (0, None)],
+              1: [(3, 0.7), (0, None)]}[rank]
+    bound, calls = run_rounds(ex, rounds, 1.0)
+    q.put((rank, bound, calls))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_exchange_and_round_consensus_world2():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    for p in ps:
+        p.join(120)
+        assert p.exitcode == 0
+    res = sorted(q.get(timeout=10) for _ in range(2))
+    assert res[0][1] == res[1][1] == 0.7  # both ranks end with the global best bound
+    assert res[0][2] == res[1][2] == 5    # same number of collective calls on every rank
+
+
+def test_content_hash_partition_is_order_independent():
+    from fplll_amd.distributed import task_shard
+    rng = np.random.default_rng(0)
+    d, L = 60, 35
+    tasks = [rng.integers(-3, 4, size=d) for _ in range(5000)]
+    for world in (2, 4, 8):
+        owner = [task_shard(t, L, d, world) for t in tasks]
+        # complete and disjoint by construction; reasonably balanced
+        counts = np.bincount(owner, minlength=world)
+        assert counts.sum() == len(tasks)
+        assert counts.min() > 0.7 * len(tasks) / world
+        # a permuted task list gives every task the same owner
+        perm = rng.permutation(len(tasks))
+        assert [task_shard(tasks[i], L, d, world) for i in perm] == [owner[i] for i in perm]
+        # coefficients below the root level do not matter
+        t2 = tasks[0].copy()
+        t2[:L] = 99
+        assert task_shard(t2, L, d, world) == owner[0]
