@@ -49,8 +49,8 @@ def build_hip(force=False):
     srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES if os.path.exists(os.path.join(CSRC, s))]
     hdrs = [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HIP_HEADERS]
     extra = []
-    if os.environ.get("FPHIP_GSO_U"):
-        extra.append("-DFPHIP_GSO_U=" + os.environ["FPHIP_GSO_U"])
+    if os.environ.get("FPHIP_GSO_RING"):
+        extra.append("-DFPHIP_GSO_RING=" + os.environ["FPHIP_GSO_RING"])
         force = True
     if force or _newer(out, srcs + hdrs):
         _run([hipcc()] + HIPCC_FLAGS + extra + ["-o", out] + srcs)

@@ -21,6 +21,7 @@ namespace fphip
 struct GsoBatch
 {
   int batch, d, n;
+  int ldd, ldn;  // leading dimensions (d, n rounded up to even: rows start 16-byte aligned)
   int row_expo;
   long long *b;
   double *bfT;

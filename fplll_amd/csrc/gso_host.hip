@@ -13,6 +13,10 @@
 #include "../../include/fplll_hip.h"
 #include "gso_device.h"
 
+#ifndef FPHIP_GSO_RING
+#define FPHIP_GSO_RING 8
+#endif
+
 namespace fphip
 {
 template <int NQ> __global__ void gso_sweep_kernel(GsoBatch P, int kmin, int kend, double eta, int mode);
@@ -73,24 +77,32 @@ extern "C" int fphip_gso_create(fphip_ctx *ctx, int batch, int d, int n, int row
   g->P.d        = d;
   g->P.n        = n;
   g->P.row_expo = row_expo ? 1 : 0;
-  const size_t B = (size_t)batch;
-  GCHK(hipMalloc((void **)&g->P.b, B * d * n * sizeof(long long)));
-  GCHK(hipMalloc((void **)&g->P.bfT, B * n * d * sizeof(double)));
-  GCHK(hipMalloc((void **)&g->P.mu, B * d * d * sizeof(double)));
-  GCHK(hipMalloc((void **)&g->P.muT, B * d * d * sizeof(double)));
-  GCHK(hipMalloc((void **)&g->P.r, B * d * d * sizeof(double)));
+  g->P.ldd      = d + (d & 1);  // even leading dimensions: every row starts 16-byte aligned
+  g->P.ldn      = n + (n & 1);
+  const size_t B   = (size_t)batch;
+  const size_t ldd = g->P.ldd, ldn = g->P.ldn;
+  const size_t pad = 4096;  // the DMA ring reads whole 16-byte lanes past the end of a row
+  GCHK(hipMalloc((void **)&g->P.b, B * d * ldn * sizeof(long long) + pad));
+  GCHK(hipMalloc((void **)&g->P.bfT, B * n * ldd * sizeof(double) + pad));
+  GCHK(hipMalloc((void **)&g->P.mu, B * d * ldd * sizeof(double) + pad));
+  GCHK(hipMalloc((void **)&g->P.muT, B * d * ldd * sizeof(double) + pad));
+  GCHK(hipMalloc((void **)&g->P.r, B * d * ldd * sizeof(double) + pad));
   GCHK(hipMalloc((void **)&g->P.rdg, B * d * sizeof(double)));
   GCHK(hipMalloc((void **)&g->P.rexp, B * d * sizeof(long long)));
   GCHK(hipMalloc((void **)&g->P.status, B * sizeof(int)));
-  GCHK(hipMemsetAsync(g->P.mu, 0, B * d * d * sizeof(double), fphip_ctx_stream(ctx)));
-  GCHK(hipMemsetAsync(g->P.muT, 0, B * d * d * sizeof(double), fphip_ctx_stream(ctx)));
-  GCHK(hipMemsetAsync(g->P.r, 0, B * d * d * sizeof(double), fphip_ctx_stream(ctx)));
+  hipStream_t s0 = fphip_ctx_stream(ctx);
+  GCHK(hipMemsetAsync(g->P.b, 0, B * d * ldn * sizeof(long long) + pad, s0));
+  GCHK(hipMemsetAsync(g->P.bfT, 0, B * n * ldd * sizeof(double) + pad, s0));
+  GCHK(hipMemsetAsync(g->P.mu, 0, B * d * ldd * sizeof(double) + pad, s0));
+  GCHK(hipMemsetAsync(g->P.muT, 0, B * d * ldd * sizeof(double) + pad, s0));
+  GCHK(hipMemsetAsync(g->P.r, 0, B * d * ldd * sizeof(double) + pad, s0));
+  GCHK(hipStreamSynchronize(s0));  // uploads use blocking copies on the null stream
   GCHK(hipEventCreate(&g->ev[0]));
   GCHK(hipEventCreate(&g->ev[1]));
   const char *w      = getenv("FPHIP_GSO_WAVES_PER_BLOCK");
   g->waves_per_block = w ? atoi(w) : 4;
   const char *bp     = getenv("FPHIP_GSO_BLOCKS_PER_CU");
-  g->blocks_per_cu   = bp ? atoi(bp) : 4;
+  g->blocks_per_cu   = bp ? atoi(bp) : 0;  // 0 = as many as the LDS ring allows
   *out               = g;
   return FPHIP_OK;
 }
@@ -119,24 +131,34 @@ static int launch(fphip_gso *g, int kmin, int kend, double eta, int mode)
   const int nq   = (need + 63) / 64;
   const int wpb  = g->waves_per_block;
   int grid       = (g->P.batch + wpb - 1) / wpb;
-  const int cap  = fphip_ctx_num_cus(g->ctx) * g->blocks_per_cu;
+  hipStream_t s = fphip_ctx_stream(g->ctx);
+  // per-wave LDS-DMA ring: FPHIP_GSO_RING slots of IPS KiB (IPS = ceil(NQ/2))
+  const size_t lds = (size_t)wpb * FPHIP_GSO_RING * (size_t)((nq + 1) / 2) * 1024;
+  int bpc          = g->blocks_per_cu > 0 ? g->blocks_per_cu : (int)((160 * 1024) / lds);
+  if (bpc * wpb > 32)
+    bpc = 32 / wpb;
+  const int cap = fphip_ctx_num_cus(g->ctx) * (bpc > 0 ? bpc : 1);
   if (grid > cap)
     grid = cap;
-  hipStream_t s = fphip_ctx_stream(g->ctx);
+  if (lds > 64 * 1024)
+  {
+    snprintf(fphip_ctx_errbuf(g->ctx), 512, "gso: LDS ring of %zu bytes exceeds the 64 KiB the DMA base can address", lds);
+    return FPHIP_ERROR;
+  }
   GCHK(hipEventRecord(g->ev[0], s));
   switch (nq)
   {
   case 1:
-    hipLaunchKernelGGL(gso_sweep_kernel<1>, dim3(grid), dim3(wpb * 64), 0, s, g->P, kmin, kend, eta, mode);
+    hipLaunchKernelGGL(gso_sweep_kernel<1>, dim3(grid), dim3(wpb * 64), lds, s, g->P, kmin, kend, eta, mode);
     break;
   case 2:
-    hipLaunchKernelGGL(gso_sweep_kernel<2>, dim3(grid), dim3(wpb * 64), 0, s, g->P, kmin, kend, eta, mode);
+    hipLaunchKernelGGL(gso_sweep_kernel<2>, dim3(grid), dim3(wpb * 64), lds, s, g->P, kmin, kend, eta, mode);
     break;
   case 3:
-    hipLaunchKernelGGL(gso_sweep_kernel<3>, dim3(grid), dim3(wpb * 64), 0, s, g->P, kmin, kend, eta, mode);
+    hipLaunchKernelGGL(gso_sweep_kernel<3>, dim3(grid), dim3(wpb * 64), lds, s, g->P, kmin, kend, eta, mode);
     break;
   default:
-    hipLaunchKernelGGL(gso_sweep_kernel<4>, dim3(grid), dim3(wpb * 64), 0, s, g->P, kmin, kend, eta, mode);
+    hipLaunchKernelGGL(gso_sweep_kernel<4>, dim3(grid), dim3(wpb * 64), lds, s, g->P, kmin, kend, eta, mode);
     break;
   }
   GCHK(hipGetLastError());
@@ -157,9 +179,9 @@ extern "C" int fphip_gso_set_basis(fphip_gso *g, int first, int count, const int
 {
   if (!g || !b || first < 0 || count <= 0 || first + count > g->P.batch)
     return FPHIP_ERROR;
-  const size_t per = (size_t)g->P.d * g->P.n;
-  GCHK(hipMemcpy(g->P.b + (size_t)first * per, b, per * count * sizeof(long long),
-                 hipMemcpyHostToDevice));
+  const size_t rows = (size_t)g->P.d * count;
+  GCHK(hipMemcpy2D(g->P.b + (size_t)first * g->P.d * g->P.ldn, (size_t)g->P.ldn * 8, b,
+                   (size_t)g->P.n * 8, (size_t)g->P.n * 8, rows, hipMemcpyHostToDevice));
   return FPHIP_OK;
 }
 
@@ -168,11 +190,11 @@ extern "C" int fphip_gso_broadcast_basis(fphip_gso *g, int src)
 {
   if (!g || src < 0 || src >= g->P.batch)
     return FPHIP_ERROR;
-  const size_t per = (size_t)g->P.d * g->P.n * sizeof(long long);
+  const size_t per = (size_t)g->P.d * g->P.ldn * sizeof(long long);
   for (int L = 0; L < g->P.batch; ++L)
     if (L != src)
-      GCHK(hipMemcpyAsync(g->P.b + (size_t)L * g->P.d * g->P.n,
-                          g->P.b + (size_t)src * g->P.d * g->P.n, per, hipMemcpyDeviceToDevice,
+      GCHK(hipMemcpyAsync(g->P.b + (size_t)L * g->P.d * g->P.ldn,
+                          g->P.b + (size_t)src * g->P.d * g->P.ldn, per, hipMemcpyDeviceToDevice,
                           fphip_ctx_stream(g->ctx)));
   GCHK(hipStreamSynchronize(fphip_ctx_stream(g->ctx)));
   return FPHIP_OK;
@@ -182,9 +204,9 @@ extern "C" int fphip_gso_get_basis(fphip_gso *g, int first, int count, int64_t *
 {
   if (!g || !b || first < 0 || count <= 0 || first + count > g->P.batch)
     return FPHIP_ERROR;
-  const size_t per = (size_t)g->P.d * g->P.n;
-  GCHK(hipMemcpy(b, g->P.b + (size_t)first * per, per * count * sizeof(long long),
-                 hipMemcpyDeviceToHost));
+  const size_t rows = (size_t)g->P.d * count;
+  GCHK(hipMemcpy2D(b, (size_t)g->P.n * 8, g->P.b + (size_t)first * g->P.d * g->P.ldn,
+                   (size_t)g->P.ldn * 8, (size_t)g->P.n * 8, rows, hipMemcpyDeviceToHost));
   return FPHIP_OK;
 }
 
@@ -227,8 +249,8 @@ extern "C" int fphip_gso_get_mu(fphip_gso *g, int lattice, double *mu)
 {
   if (!g || !mu || lattice < 0 || lattice >= g->P.batch)
     return FPHIP_ERROR;
-  const size_t per = (size_t)g->P.d * g->P.d;
-  GCHK(hipMemcpy(mu, g->P.mu + (size_t)lattice * per, per * sizeof(double), hipMemcpyDeviceToHost));
+  GCHK(hipMemcpy2D(mu, (size_t)g->P.d * 8, g->P.mu + (size_t)lattice * g->P.d * g->P.ldd,
+                   (size_t)g->P.ldd * 8, (size_t)g->P.d * 8, g->P.d, hipMemcpyDeviceToHost));
   return FPHIP_OK;
 }
 
@@ -236,8 +258,8 @@ extern "C" int fphip_gso_get_r(fphip_gso *g, int lattice, double *r)
 {
   if (!g || !r || lattice < 0 || lattice >= g->P.batch)
     return FPHIP_ERROR;
-  const size_t per = (size_t)g->P.d * g->P.d;
-  GCHK(hipMemcpy(r, g->P.r + (size_t)lattice * per, per * sizeof(double), hipMemcpyDeviceToHost));
+  GCHK(hipMemcpy2D(r, (size_t)g->P.d * 8, g->P.r + (size_t)lattice * g->P.d * g->P.ldd,
+                   (size_t)g->P.ldd * 8, (size_t)g->P.d * 8, g->P.d, hipMemcpyDeviceToHost));
   return FPHIP_OK;
 }
 

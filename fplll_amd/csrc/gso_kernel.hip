@@ -62,7 +62,7 @@ __device__ __forceinline__ long long fexponent(double x)
 
 template <int NQ> struct Lattice
 {
-  int d, n, row_expo_on;
+  int d, n, ldd, ldn, row_expo_on;
   long long *b;
   double *bfT, *mu, *muT, *r, *rdg;
   long long *rexp;
@@ -71,41 +71,168 @@ template <int NQ> struct Lattice
 };
 
 // ---------------------------------------------------------------------------------------------
-// Software-pipelined "chain" loops.  Every hot loop of this kernel has the shape
-//     for step s (in a fixed order):  v[q] = LOAD(s, lane);  state[q] = f(state[q], v[q], scalar_s)
-// where the loads do not depend on the state but scalar_s does (it is read from a lane of the
-// state with v_readlane).  The loads are issued U steps at a time, double-buffered (group g+1 is
-// in flight while group g is consumed), so a wave keeps ~2·U·(active chunks) 512-byte loads in
-// flight — that, times the waves per CU, is what hides HBM latency.  Steps are grouped inside a
-// 64-chunk so that the chunk index of the scalar's register is a compile-time constant.
+// LDS-DMA ring ("chain" loops).  Every hot loop of this kernel has the shape
+//     for step s (in a fixed order):  v[q] = ROW_s[lane + 64 q];  state[q] = f(state[q], v[q], scalar_s)
+// where ROW_s is a contiguous row in HBM whose address does not depend on the state, while scalar_s
+// does (it is read from a lane of the state with v_readlane).  The rows are streamed into a per-wave
+// ring in LDS with global_load_lds_dwordx4 (16 B per lane, 1 KiB per instruction, no VGPRs), R-1
+// steps ahead of the consumer; the consumer waits with a COUNTED s_waitcnt vmcnt(pending·IPS) — loads
+// retire in order — and reads its 8 bytes with ds_read_b64.  A wave therefore keeps up to
+// (R-1)·IPS KiB of HBM reads in flight; that, times the waves per CU, is what hides HBM latency
+// (a register-buffered version of the same loops reached 24 % of the HBM roofline; the chain
+// itself is a handful of VALU ops per step).
+//   * hipcc neither counts nor orders these instructions (cdna_hip_programming.md §5.7): the ring
+//     code owns every vmcnt wait, and NO other vector-memory instruction (including scratch spills)
+//     may be issued between ring_begin() and ring_end() — ScratchSize must stay 0 for this kernel.
+//   * rows start 16-byte aligned: leading dimensions are padded to even (ldd, ldn).
 // ---------------------------------------------------------------------------------------------
-#ifndef FPHIP_GSO_U
-#define FPHIP_GSO_U 4
+#ifndef FPHIP_GSO_RING
+#define FPHIP_GSO_RING 8
 #endif
 
-template <int NQ, int U> struct Grp
+__device__ __forceinline__ void glds16(const void *gsrc, unsigned lds_dst)
 {
-  double v[U][NQ];
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+               "s_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_dst)
+               : "memory");
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt()
+{
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int NQ, int IPS> struct Ring
+{
+  static constexpr int R    = FPHIP_GSO_RING;
+  static constexpr int SLOT = IPS * 1024;
+  unsigned base;  // LDS byte address of this wave's ring (wave-uniform)
+  int lane;
+  int head, tail;
+
+  __device__ __forceinline__ void begin()
+  {
+    wait_vmcnt<0>();  // start counting from a clean slate
+    head = tail = 0;
+  }
+  __device__ __forceinline__ void end() { wait_vmcnt<0>(); }
+
+  // stream bytes [lo, hi) of one row (row = wave-uniform, 16-byte aligned global address).
+  // Every one of the IPS instructions is issued (lane 0 stays active) so that the vmcnt
+  // arithmetic of consume() holds; lanes outside the window are masked off and move no data.
+  __device__ __forceinline__ void issue(const void *row, int lo, int hi)
+  {
+    const char *g      = (const char *)row + lane * 16;
+    const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(base + head * SLOT));
+#pragma unroll
+    for (int i = 0; i < IPS; ++i)
+    {
+      const int off = lane * 16 + i * 1024;
+      if (lane == 0 || (off + 16 > lo && off < hi))
+        glds16(g + i * 1024, dst + i * 1024);
+    }
+    head = (head + 1 == R) ? 0 : head + 1;
+  }
+
+  template <int P> __device__ __forceinline__ void read(double (&v)[NQ], unsigned addr)
+  {
+    // wait until at most P newer steps are outstanding, then fetch this lane's elements
+    if constexpr (NQ == 1)
+      asm volatile("s_waitcnt vmcnt(%2)\n\tds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)"
+                   : "=&v"(v[0])
+                   : "v"(addr), "n"(P * IPS)
+                   : "memory");
+    else if constexpr (NQ == 2)
+      asm volatile("s_waitcnt vmcnt(%3)\n\tds_read_b64 %0, %2\n\tds_read_b64 %1, %2 offset:512\n\t"
+                   "s_waitcnt lgkmcnt(0)"
+                   : "=&v"(v[0]), "=&v"(v[1])
+                   : "v"(addr), "n"(P * IPS)
+                   : "memory");
+    else if constexpr (NQ == 3)
+      asm volatile("s_waitcnt vmcnt(%4)\n\tds_read_b64 %0, %3\n\tds_read_b64 %1, %3 offset:512\n\t"
+                   "ds_read_b64 %2, %3 offset:1024\n\ts_waitcnt lgkmcnt(0)"
+                   : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2])
+                   : "v"(addr), "n"(P * IPS)
+                   : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(%5)\n\tds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:512\n\t"
+                   "ds_read_b64 %2, %4 offset:1024\n\tds_read_b64 %3, %4 offset:1536\n\t"
+                   "s_waitcnt lgkmcnt(0)"
+                   : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
+                   : "v"(addr), "n"(P * IPS)
+                   : "memory");
+  }
+
+  // consume the oldest outstanding row; `pending` = rows issued after it (0..R-1)
+  __device__ __forceinline__ void consume(double (&v)[NQ], int pending)
+  {
+    const unsigned addr = base + tail * SLOT + lane * 8;
+    tail                = (tail + 1 == R) ? 0 : tail + 1;
+    switch (pending)
+    {
+    case 0: read<0>(v, addr); break;
+    case 1: read<1>(v, addr); break;
+    case 2: read<2>(v, addr); break;
+    case 3: read<3>(v, addr); break;
+    case 4: read<4>(v, addr); break;
+    case 5: read<5>(v, addr); break;
+    case 6: read<6>(v, addr); break;
+    default: read<(R - 1 < 7 ? R - 1 : 7)>(v, addr); break;
+    }
+  }
+
+  // Run `cnt` steps: row(s) gives the address of step s (bytes [lo,hi) of it are needed),
+  // body(s, v) consumes it.
+  template <class RowF, class BodyF>
+  __device__ __forceinline__ void run(int cnt, int lo, int hi, RowF row, BodyF body)
+  {
+    constexpr int AHEAD = (R - 1 < 7 ? R - 1 : 7);
+    begin();
+    const int pre = cnt < AHEAD ? cnt : AHEAD;
+    for (int s = 0; s < pre; ++s)
+      issue(row(s), lo, hi);
+    int s = 0;
+#pragma unroll 1
+    for (; s + AHEAD < cnt; ++s)
+    {  // steady state: exactly AHEAD newer rows are outstanding
+      issue(row(s + AHEAD), lo, hi);
+      double v[NQ];
+      const unsigned addr = base + tail * SLOT + lane * 8;
+      tail                = (tail + 1 == R) ? 0 : tail + 1;
+      read<AHEAD>(v, addr);
+      body(s, v);
+    }
+#pragma unroll 1
+    for (; s < cnt; ++s)
+    {  // drain: fewer rows behind this one
+      double v[NQ];
+      consume(v, cnt - 1 - s);
+      body(s, v);
+    }
+    end();
+  }
 };
 
 // update_gso_row(kappa, last) recomputed from column 0 (identical values: every input is unchanged
 // since the row was invalidated).  Returns false on a non-finite mu (RED_GSO_FAILURE).
-template <int NQ> __device__ bool update_row(Lattice<NQ> &T, int kappa, int last)
+template <int NQ, int IPS>
+__device__ bool update_row(Lattice<NQ> &T, Ring<NQ, IPS> &ring, int kappa, int last)
 {
-  constexpr int U = FPHIP_GSO_U;
-  const int d = T.d, n = T.n, lane = T.lane;
+  const int d = T.d, n = T.n, lane = T.lane, ldd = T.ldd;
   const int qact = (last >> 6) + 1;  // chunks holding a lane j <= last
   double bk[NQ], acc[NQ], rd[NQ];
-  unsigned jc[NQ];  // lane's row index per chunk, clamped into the slab for unconditional loads
 #pragma unroll
   for (int q = 0; q < NQ; ++q)
   {
     const int c = lane + 64 * q;
-    bk[q]       = (c < n) ? T.bfT[(size_t)c * d + kappa] : 0.0;
+    bk[q]       = (c < n) ? T.bfT[(size_t)c * ldd + kappa] : 0.0;
     acc[q]      = 0.0;
     rd[q]       = (c < kappa) ? T.rdg[c] : 1.0;
-    jc[q]       = (unsigned)min(c, d - 1);
   }
+  const int need_bytes = (last + 1) * 8;  // lanes j <= last of a row
   // ---- Gram row: g(kappa,j) = bf_kappa . bf_j, columns in ascending order (numvect.h:386-396)
 #pragma unroll
   for (int cq = 0; cq < NQ; ++cq)
@@ -113,52 +240,20 @@ template <int NQ> __device__ bool update_row(Lattice<NQ> &T, int kappa, int last
     const int cbase = cq * 64;
     if (cbase >= n)
       break;
-    const int cnt = min(64, n - cbase);
-    auto load     = [&](Grp<NQ, U> &G, int g0)
-    {
-#pragma unroll
-      for (int u = 0; u < U; ++u)
-      {
-        const int c = min(cbase + g0 + u, n - 1);
-#pragma unroll
-        for (int q = 0; q < NQ; ++q)
-          if (q < qact)
-            G.v[u][q] = (T.bfT + (size_t)c * d)[jc[q]];
-      }
-    };
-    auto proc = [&](const Grp<NQ, U> &G, int g0)
-    {
-#pragma unroll
-      for (int u = 0; u < U; ++u)
-      {
-        if (g0 + u < cnt)
+    ring.run(
+        min(64, n - cbase), 0, need_bytes,
+        [&](int s) { return (const void *)(T.bfT + (size_t)(cbase + s) * ldd); },
+        [&](int s, const double(&v)[NQ])
         {
-          const double bkc = g_rl_f64(bk[cq], g0 + u);
+          const double bkc = g_rl_f64(bk[cq], s);
 #pragma unroll
           for (int q = 0; q < NQ; ++q)
             if (q < qact)
             {
-              const double p = bkc * G.v[u][q];
-              acc[q]         = (cbase + g0 + u == 0) ? p : acc[q] + p;
+              const double p = bkc * v[q];
+              acc[q]         = (cbase + s == 0) ? p : acc[q] + p;
             }
-        }
-      }
-    };
-    Grp<NQ, U> A, B;
-    load(A, 0);
-#pragma unroll 1
-    for (int g0 = 0; g0 < cnt; g0 += 2 * U)
-    {
-      if (g0 + U < cnt)
-        load(B, g0 + U);
-      proc(A, g0);
-      if (g0 + U < cnt)
-      {
-        if (g0 + 2 * U < cnt)
-          load(A, g0 + 2 * U);
-        proc(B, g0 + U);
-      }
-    }
+        });
   }
   // ---- recurrence, gso_interface.cpp:143-158, column-oriented
   bool ok = true;
@@ -168,35 +263,16 @@ template <int NQ> __device__ bool update_row(Lattice<NQ> &T, int kappa, int last
     const int kbase = kq * 64;
     if (kbase > last)
       break;
-    const int cnt = min(64, last - kbase + 1);
-    auto load     = [&](Grp<NQ, U> &G, int g0)
-    {
-#pragma unroll
-      for (int u = 0; u < U; ++u)
-      {
-        const int k = min(kbase + g0 + u, d - 1);
-#pragma unroll
-        for (int q = 0; q < NQ; ++q)
-          if (q < qact && q >= kq)  // rows j <= k hold zeros: chunks below kq are never needed
-            G.v[u][q] = (T.muT + (size_t)k * d)[jc[q]];
-      }
-    };
-    auto proc = [&](const Grp<NQ, U> &G, int g0)
-    {
-#pragma unroll
-      for (int u = 0; u < U; ++u)
-      {
-        if (g0 + u < cnt)
+    ring.run(
+        min(64, last - kbase + 1), kbase * 8, need_bytes,
+        [&](int s) { return (const void *)(T.muT + (size_t)(kbase + s) * ldd); },
+        [&](int s, const double(&v)[NQ])
         {
-          const int k     = kbase + g0 + u;
-          const double rk = g_rl_f64(acc[kq], g0 + u);  // r(kappa,k) is final
+          const int k     = kbase + s;
+          const double rk = g_rl_f64(acc[kq], s);  // r(kappa,k) is final
           double muk      = 0.0;
-          if (k < kappa)
-          {
-            muk = rk / g_rl_f64(rd[kq], g0 + u);  // mu(kappa,k) = r(kappa,k) / r(k,k)
-            if (!isfinite(muk))
-              ok = false;
-          }
+          if (last == kappa && k < kappa)  // only the diagonal lane j == kappa consumes mu(kappa,k)
+            muk = rk / g_rl_f64(rd[kq], s);  // mu(kappa,k) = r(kappa,k) / r(k,k)
 #pragma unroll
           for (int q = 0; q < NQ; ++q)
             if (q < qact && q >= kq)
@@ -204,28 +280,11 @@ template <int NQ> __device__ bool update_row(Lattice<NQ> &T, int kappa, int last
               const int j = lane + 64 * q;
               if (j > k && j <= last)
               {
-                const double m = (j == kappa) ? muk : G.v[u][q];
+                const double m = (j == kappa) ? muk : v[q];
                 acc[q]         = acc[q] - m * rk;
               }
             }
-        }
-      }
-    };
-    Grp<NQ, U> A, B;
-    load(A, 0);
-#pragma unroll 1
-    for (int g0 = 0; g0 < cnt; g0 += 2 * U)
-    {
-      if (g0 + U < cnt)
-        load(B, g0 + U);
-      proc(A, g0);
-      if (g0 + U < cnt)
-      {
-        if (g0 + 2 * U < cnt)
-          load(A, g0 + 2 * U);
-        proc(B, g0 + U);
-      }
-    }
+        });
   }
   // ---- store the row
 #pragma unroll
@@ -235,13 +294,15 @@ template <int NQ> __device__ bool update_row(Lattice<NQ> &T, int kappa, int last
     T.murow[q]  = 0.0;
     if (j <= last)
     {
-      T.r[(size_t)kappa * d + j] = acc[q];
+      T.r[(size_t)kappa * ldd + j] = acc[q];
       if (j < kappa)
       {
-        const double m               = acc[q] / rd[q];
-        T.murow[q]                   = m;
-        T.mu[(size_t)kappa * d + j]  = m;
-        T.muT[(size_t)j * d + kappa] = m;
+        const double m = acc[q] / rd[q];  // mu(kappa,j) = r(kappa,j) / r(j,j), gso_interface.cpp:154
+        if (!isfinite(m))
+          ok = false;
+        T.murow[q]                     = m;
+        T.mu[(size_t)kappa * ldd + j]  = m;
+        T.muT[(size_t)j * ldd + kappa] = m;
       }
       else
       {
@@ -253,23 +314,15 @@ template <int NQ> __device__ bool update_row(Lattice<NQ> &T, int kappa, int last
 }
 
 // LLLReduction::babai(kappa, kappa, 0).  1 ok, 0 GSO failure, -1 babai failure, -2 multiplier.
-template <int NQ> __device__ int babai(Lattice<NQ> &T, int kappa, double eta)
+template <int NQ, int IPS>
+__device__ int babai(Lattice<NQ> &T, Ring<NQ, IPS> &ring, int kappa, double eta)
 {
-  constexpr int U = FPHIP_GSO_U;
-  const int d = T.d, n = T.n, lane = T.lane;
-  const int qact = ((kappa - 1) >> 6) + 1;  // chunks holding a row index < kappa
-  const int nq_c = ((n - 1) >> 6) + 1;      // chunks holding a column index < n
+  const int d = T.d, n = T.n, lane = T.lane, ldd = T.ldd, ldn = T.ldn;
+  (void)d;
   long long max_expo = LLONG_MAX;
-  unsigned jc[NQ], cc[NQ];
-#pragma unroll
-  for (int q = 0; q < NQ; ++q)
-  {
-    jc[q] = (unsigned)min(lane + 64 * q, d - 1);
-    cc[q] = (unsigned)min(lane + 64 * q, n - 1);
-  }
   for (int iter = 0;; ++iter)
   {
-    if (!update_row<NQ>(T, kappa, kappa - 1))
+    if (!update_row<NQ, IPS>(T, ring, kappa, kappa - 1))
       return 0;
     const long long rexpk = T.rexp[kappa];
     int e[NQ];
@@ -315,27 +368,12 @@ template <int NQ> __device__ int babai(Lattice<NQ> &T, int kappa, double eta)
       if (jbase >= kappa)
         continue;
       const int top = min(63, kappa - 1 - jbase);  // first (highest) jj of this chunk
-      const int cnt = top + 1;                     // steps: jj = top, top-1, …, 0
-      auto load     = [&](Grp<NQ, U> &G, int g0)
-      {
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-        {
-          const int j = jbase + max(top - (g0 + u), 0);
-#pragma unroll
-          for (int q = 0; q < NQ; ++q)
-            if (q <= jq)  // mu(j,k) = 0 for k >= j
-              G.v[u][q] = (T.mu + (size_t)j * d)[jc[q]];
-        }
-      };
-      auto proc = [&](const Grp<NQ, U> &G, int g0)
-      {
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-        {
-          if (g0 + u < cnt)
+      ring.run(
+          top + 1, 0, (jbase + top) * 8,  // row j needs k < j; the widest row of the chunk bounds it
+          [&](int s) { return (const void *)(T.mu + (size_t)(jbase + top - s) * ldd); },
+          [&](int s, const double(&v)[NQ])
           {
-            const int jj     = top - (g0 + u);
+            const int jj     = top - s;
             const int j      = jbase + jj;
             const double bmj = g_rl_f64(bm[jq], jj);
             const int ej     = __builtin_amdgcn_readlane(e[jq], jj);
@@ -360,29 +398,12 @@ template <int NQ> __device__ int babai(Lattice<NQ> &T, int kappa, double eta)
                   const int k = lane + 64 * q;
                   if (k < j)
                   {
-                    const double t = X * G.v[u][q];
+                    const double t = X * v[q];
                     bm[q]          = bm[q] - t;
                   }
                 }
             }
-          }
-        }
-      };
-      Grp<NQ, U> A, B;
-      load(A, 0);
-  #pragma unroll 1
-    for (int g0 = 0; g0 < cnt; g0 += 2 * U)
-      {
-        if (g0 + U < cnt)
-          load(B, g0 + U);
-        proc(A, g0);
-        if (g0 + U < cnt)
-        {
-          if (g0 + 2 * U < cnt)
-            load(A, g0 + 2 * U);
-          proc(B, g0 + U);
-        }
-      }
+          });
     }
     if (too_big)
       return -2;
@@ -392,7 +413,7 @@ template <int NQ> __device__ int babai(Lattice<NQ> &T, int kappa, double eta)
     for (int q = 0; q < NQ; ++q)
     {
       const int c = lane + 64 * q;
-      bv[q]       = (c < n) ? T.b[(size_t)kappa * n + c] : 0;
+      bv[q]       = (c < n) ? T.b[(size_t)kappa * ldn + c] : 0;
     }
 #pragma unroll
     for (int jq = NQ - 1; jq >= 0; --jq)
@@ -401,58 +422,21 @@ template <int NQ> __device__ int babai(Lattice<NQ> &T, int kappa, double eta)
       if (jbase >= kappa)
         continue;
       const int top = min(63, kappa - 1 - jbase);
-      const int cnt = top + 1;
-      struct GI
-      {
-        long long v[U][NQ];
-      };
-      auto load = [&](GI &G, int g0)
-      {
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-        {
-          const int j = jbase + max(top - (g0 + u), 0);
-#pragma unroll
-          for (int q = 0; q < NQ; ++q)
-            if (q < nq_c)
-              G.v[u][q] = (T.b + (size_t)j * n)[cc[q]];
-        }
-      };
-      auto proc = [&](const GI &G, int g0)
-      {
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-        {
-          if (g0 + u < cnt)
+      ring.run(
+          top + 1, 0, n * 8,
+          [&](int s) { return (const void *)(T.b + (size_t)(jbase + top - s) * ldn); },
+          [&](int s, const double(&v)[NQ])
           {
-            const int jj       = top - (g0 + u);
-            const long long lx = g_rl_i64(xl[jq], jj);
+            const long long lx = g_rl_i64(xl[jq], top - s);
             if (lx != 0)
             {
 #pragma unroll
               for (int q = 0; q < NQ; ++q)
-                if (q < nq_c)
-                  bv[q] = (long long)((unsigned long long)bv[q] +
-                                      (unsigned long long)G.v[u][q] * (unsigned long long)lx);
+                bv[q] = (long long)((unsigned long long)bv[q] +
+                                    (unsigned long long)__double_as_longlong(v[q]) *
+                                        (unsigned long long)lx);
             }
-          }
-        }
-      };
-      GI A, B;
-      load(A, 0);
-  #pragma unroll 1
-    for (int g0 = 0; g0 < cnt; g0 += 2 * U)
-      {
-        if (g0 + U < cnt)
-          load(B, g0 + U);
-        proc(A, g0);
-        if (g0 + U < cnt)
-        {
-          if (g0 + 2 * U < cnt)
-            load(A, g0 + 2 * U);
-          proc(B, g0 + U);
-        }
-      }
+          });
     }
     // ---- row_op_end: update_bf(kappa), gso.cpp:24-48
     int ce[NQ];
@@ -466,7 +450,7 @@ template <int NQ> __device__ int babai(Lattice<NQ> &T, int kappa, double eta)
       cm[q]       = 0.0;
       if (c < n)
       {
-        T.b[(size_t)kappa * n + c] = bv[q];
+        T.b[(size_t)kappa * ldn + c] = bv[q];
         if (T.row_expo_on)
         {
           int ex;
@@ -488,7 +472,7 @@ template <int NQ> __device__ int babai(Lattice<NQ> &T, int kappa, double eta)
     {
       const int c = lane + 64 * q;
       if (c < n)
-        T.bfT[(size_t)c * d + kappa] = T.row_expo_on ? ldexp(cm[q], ce[q] - emax) : cm[q];
+        T.bfT[(size_t)c * ldd + kappa] = T.row_expo_on ? ldexp(cm[q], ce[q] - emax) : cm[q];
     }
     if (lane == 0)
       T.rexp[kappa] = T.row_expo_on ? (long long)emax : 0;
@@ -504,21 +488,30 @@ template <int NQ>
 __global__ void __launch_bounds__(256)
     gso_sweep_kernel(GsoBatch P, int kmin, int kend, double eta, int mode)
 {
+  constexpr int IPS = (NQ + 1) / 2;  // 1 KiB DMA instructions per row (rows <= 64*NQ*8 bytes)
+  extern __shared__ __attribute__((aligned(16))) char gso_smem[];
   const int lane = threadIdx.x & 63;
   const int wpb  = blockDim.x >> 6;
-  const int wave = threadIdx.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  Ring<NQ, IPS> ring;
+  // the kernel declares no static LDS, so the dynamic segment starts at LDS address 0
+  ring.base = (unsigned)(wave * Ring<NQ, IPS>::R * Ring<NQ, IPS>::SLOT);
+  ring.lane = lane;
+  ring.head = ring.tail = 0;
   for (int L = blockIdx.x * wpb + wave; L < P.batch; L += gridDim.x * wpb)
   {
     Lattice<NQ> T;
     T.d           = P.d;
     T.n           = P.n;
+    T.ldd         = P.ldd;
+    T.ldn         = P.ldn;
     T.row_expo_on = P.row_expo;
     T.lane        = lane;
-    T.b           = P.b + (size_t)L * P.d * P.n;
-    T.bfT         = P.bfT + (size_t)L * P.n * P.d;
-    T.mu          = P.mu + (size_t)L * P.d * P.d;
-    T.muT         = P.muT + (size_t)L * P.d * P.d;
-    T.r           = P.r + (size_t)L * P.d * P.d;
+    T.b           = P.b + (size_t)L * P.d * P.ldn;
+    T.bfT         = P.bfT + (size_t)L * P.n * P.ldd;
+    T.mu          = P.mu + (size_t)L * P.d * P.ldd;
+    T.muT         = P.muT + (size_t)L * P.d * P.ldd;
+    T.r           = P.r + (size_t)L * P.d * P.ldd;
     T.rdg         = P.rdg + (size_t)L * P.d;
     T.rexp        = P.rexp + (size_t)L * P.d;
     int status    = 1;
@@ -537,7 +530,7 @@ __global__ void __launch_bounds__(256)
           cm[q]       = 0.0;
           if (c < P.n)
           {
-            const long long v = T.b[(size_t)i * P.n + c];
+            const long long v = T.b[(size_t)i * P.ldn + c];
             if (P.row_expo)
             {
               int ex;
@@ -559,7 +552,7 @@ __global__ void __launch_bounds__(256)
         {
           const int c = lane + 64 * q;
           if (c < P.n)
-            T.bfT[(size_t)c * P.d + i] = P.row_expo ? ldexp(cm[q], ce[q] - emax) : cm[q];
+            T.bfT[(size_t)c * P.ldd + i] = P.row_expo ? ldexp(cm[q], ce[q] - emax) : cm[q];
         }
         if (lane == 0)
           T.rexp[i] = P.row_expo ? (long long)emax : 0;
@@ -571,14 +564,14 @@ __global__ void __launch_bounds__(256)
       {
         if (mode == 1 && kappa > 0)
         {
-          const int rc = babai<NQ>(T, kappa, eta);
+          const int rc = babai<NQ, IPS>(T, ring, kappa, eta);
           if (rc != 1)
           {
             status = rc;
             break;
           }
         }
-        if (!update_row<NQ>(T, kappa, kappa))
+        if (!update_row<NQ, IPS>(T, ring, kappa, kappa))
         {
           status = 0;
           break;
