@@ -77,8 +77,16 @@ extern "C" int fphip_gso_create(fphip_ctx *ctx, int batch, int d, int n, int row
   g->P.d        = d;
   g->P.n        = n;
   g->P.row_expo = row_expo ? 1 : 0;
-  g->P.ldd      = d + (d & 1);  // even leading dimensions: every row starts 16-byte aligned
-  g->P.ldn      = n + (n & 1);
+  // leading dimensions padded to 16 elements: every row starts on a 128-byte line, so the DMA
+  // windows that begin at column 0 waste no partial line (FPHIP_GSO_LD_ALIGN=2 keeps them dense)
+  const char *la_s = getenv("FPHIP_GSO_LD_ALIGN");
+  const int la     = la_s ? atoi(la_s) : 16;
+  g->P.ldd         = (d + la - 1) / la * la;
+  g->P.ldn         = (n + la - 1) / la * la;
+  if (g->P.ldd > 256)
+    g->P.ldd = 256;
+  if (g->P.ldn > 256)
+    g->P.ldn = 256;
   const size_t B   = (size_t)batch;
   const size_t ldd = g->P.ldd, ldn = g->P.ldn;
   const size_t pad = 4096;  // the DMA ring reads whole 16-byte lanes past the end of a row
@@ -273,3 +281,36 @@ extern "C" int fphip_gso_get_row_expo(fphip_gso *g, int lattice, int64_t *row_ex
 }
 
 extern "C" double fphip_gso_last_kernel_ms(const fphip_gso *g) { return g ? g->last_ms : 0.0; }
+
+// FETCH_SIZE calibration (not part of the product ABI; used by scripts/calib_fetch.py only)
+namespace fphip
+{
+__global__ void gso_calib_kernel(const char *buf, size_t stride, int row_bytes, long long rows);
+}
+extern "C" int fphip_debug_stream(fphip_ctx *ctx, long long rows, int row_bytes, long long stride,
+                                  double *ms_out)
+{
+  char *buf = nullptr;
+  const size_t total = (size_t)rows * (size_t)stride + 4096;
+  if (hipMalloc((void **)&buf, total) != hipSuccess)
+    return FPHIP_ERROR;
+  hipMemset(buf, 1, total);
+  hipDeviceSynchronize();
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  hipStream_t s = fphip_ctx_stream(ctx);
+  hipEventRecord(e0, s);
+  hipLaunchKernelGGL(gso_calib_kernel, dim3(fphip_ctx_num_cus(ctx) * 2), dim3(256), 4 * 8 * 2048, s, buf,
+                     (size_t)stride, row_bytes, rows);
+  hipEventRecord(e1, s);
+  hipStreamSynchronize(s);
+  float ms = 0;
+  hipEventElapsedTime(&ms, e0, e1);
+  if (ms_out)
+    *ms_out = ms;
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  hipFree(buf);
+  return FPHIP_OK;
+}

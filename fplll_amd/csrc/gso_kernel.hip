@@ -68,6 +68,8 @@ template <int NQ> struct Lattice
   long long *rexp;
   int lane;
   double murow[NQ];  // mu(kappa, j) of the row last updated (lane j)
+  double rrow[NQ];   // r(kappa, j)  of the row last updated (lane j)
+  double bfk[NQ];    // bf(kappa, c) of the row last updated (lane c)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -100,46 +102,96 @@ __device__ __forceinline__ void glds16(const void *gsrc, unsigned lds_dst)
                : "memory");
 }
 
+// Make the compiler finish (wait for) an ordinary load NOW: an empty asm that reads and writes the
+// value.  hipcc places its own s_waitcnt vmcnt(0) at the FIRST USE of a loaded value; if that first
+// use sits inside a ring loop the wait would drain the DMA pipe on every iteration.
+__device__ __forceinline__ void settle(double &x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void settle(long long &x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void settle(int &x) { asm volatile("" : "+v"(x)); }
+
 template <int N> __device__ __forceinline__ void wait_vmcnt()
 {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+struct RowDesc
+{
+  const void *ptr;  // wave-uniform, 16-byte aligned start of the row
+  int lo, hi;       // bytes [lo, hi) of the row are needed
+};
+
+template <int Q> struct IC
+{
+  static constexpr int value = Q;
+};
+
+// f(IC<q>, idx - 64 q) for the (wave-uniform) chunk q = idx >> 6: gives loop bodies a COMPILE-TIME
+// register index for the chunk that owns step idx.
+template <int NQ, class F> __device__ __forceinline__ void dispatch_chunk(int idx, F f)
+{
+  if constexpr (NQ == 1)
+  {
+    f(IC<0>{}, idx);
+  }
+  else
+  {
+    const int q = idx >> 6;
+    if (q == 0)
+      f(IC<0>{}, idx);
+    else if (q == 1)
+      f(IC<1>{}, idx - 64);
+    else if constexpr (NQ >= 3)
+    {
+      if (q == 2)
+        f(IC<2>{}, idx - 128);
+      else if constexpr (NQ >= 4)
+        f(IC<3>{}, idx - 192);
+    }
+  }
+}
+
 template <int NQ, int IPS> struct Ring
 {
-  static constexpr int R    = FPHIP_GSO_RING;
-  static constexpr int SLOT = IPS * 1024;
+  static constexpr int R     = FPHIP_GSO_RING;
+  static constexpr int SLOT  = IPS * 1024;
+  static constexpr int AHEAD = (R - 1 < 7 ? R - 1 : 7);  // rows kept in flight behind the consumer
   unsigned base;  // LDS byte address of this wave's ring (wave-uniform)
   int lane;
   int head, tail;
+  int ahead;  // rows issued and not yet consumed
 
-  __device__ __forceinline__ void begin()
+  // Start a new stream: nothing of ours is in flight; also retires every older vector-memory
+  // operation (stores of the previous phase) so that the counted waits below only see ring loads.
+  __device__ __forceinline__ void reset()
   {
-    wait_vmcnt<0>();  // start counting from a clean slate
+    wait_vmcnt<0>();
     head = tail = 0;
+    ahead       = 0;
   }
-  __device__ __forceinline__ void end() { wait_vmcnt<0>(); }
 
-  // stream bytes [lo, hi) of one row (row = wave-uniform, 16-byte aligned global address).
-  // Every one of the IPS instructions is issued (lane 0 stays active) so that the vmcnt
-  // arithmetic of consume() holds; lanes outside the window are masked off and move no data.
-  __device__ __forceinline__ void issue(const void *row, int lo, int hi)
+  // stream bytes [lo, hi) of one row.  Every one of the IPS instructions is issued (lane 0 stays
+  // active) so that the vmcnt arithmetic of fetch() holds; lanes outside the window move no data.
+  __device__ __forceinline__ void issue(const RowDesc &r)
   {
-    const char *g      = (const char *)row + lane * 16;
+    const char *g      = (const char *)r.ptr + lane * 16;
     const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(base + head * SLOT));
 #pragma unroll
     for (int i = 0; i < IPS; ++i)
     {
       const int off = lane * 16 + i * 1024;
-      if (lane == 0 || (off + 16 > lo && off < hi))
+      // lane 0 is always active: an instruction none of whose lanes meets the window must still be
+      // issued, otherwise the consumer's vmcnt arithmetic is off by one (a ballot per instruction
+      // to find that case costs more than the occasional extra 16 bytes)
+      if (lane == 0 || (off + 16 > r.lo && off < r.hi))
         glds16(g + i * 1024, dst + i * 1024);
     }
     head = (head + 1 == R) ? 0 : head + 1;
+    ++ahead;
   }
 
   template <int P> __device__ __forceinline__ void read(double (&v)[NQ], unsigned addr)
   {
-    // wait until at most P newer steps are outstanding, then fetch this lane's elements
+    // wait until at most P newer rows are outstanding, then fetch this lane's elements
     if constexpr (NQ == 1)
       asm volatile("s_waitcnt vmcnt(%2)\n\tds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)"
                    : "=&v"(v[0])
@@ -166,11 +218,18 @@ template <int NQ, int IPS> struct Ring
                    : "memory");
   }
 
-  // consume the oldest outstanding row; `pending` = rows issued after it (0..R-1)
-  __device__ __forceinline__ void consume(double (&v)[NQ], int pending)
+  // consume the oldest row in flight (ahead - 1 newer rows are behind it)
+  __device__ __forceinline__ void fetch(double (&v)[NQ])
   {
     const unsigned addr = base + tail * SLOT + lane * 8;
     tail                = (tail + 1 == R) ? 0 : tail + 1;
+    const int pending   = ahead - 1;
+    --ahead;
+    if (pending == AHEAD)
+    {
+      read<AHEAD>(v, addr);
+      return;
+    }
     switch (pending)
     {
     case 0: read<0>(v, addr); break;
@@ -179,40 +238,39 @@ template <int NQ, int IPS> struct Ring
     case 3: read<3>(v, addr); break;
     case 4: read<4>(v, addr); break;
     case 5: read<5>(v, addr); break;
-    case 6: read<6>(v, addr); break;
-    default: read<(R - 1 < 7 ? R - 1 : 7)>(v, addr); break;
+    default: read<6>(v, addr); break;
     }
   }
 
-  // Run `cnt` steps: row(s) gives the address of step s (bytes [lo,hi) of it are needed),
-  // body(s, v) consumes it.
-  template <class RowF, class BodyF>
-  __device__ __forceinline__ void run(int cnt, int lo, int hi, RowF row, BodyF body)
+  // One phase of `cnt` steps.  Rows [0, ahead) of it may already be in flight (prefetched by the
+  // previous phase).  While consuming, keep the pipe full: first with this phase's remaining rows,
+  // then with the first rows of the NEXT phase (ncnt rows, nrow(s)) — phases are chained without
+  // draining the pipe whenever no other vector-memory instruction separates them.
+  template <class RowA, class BodyF, class RowB>
+  __device__ __forceinline__ void run(int cnt, RowA row, BodyF body, int ncnt, RowB nrow)
   {
-    constexpr int AHEAD = (R - 1 < 7 ? R - 1 : 7);
-    begin();
-    const int pre = cnt < AHEAD ? cnt : AHEAD;
-    for (int s = 0; s < pre; ++s)
-      issue(row(s), lo, hi);
-    int s = 0;
+    int issued  = ahead;  // rows of this phase issued so far
+    int nissued = 0;      // rows of the next phase issued so far
 #pragma unroll 1
-    for (; s + AHEAD < cnt; ++s)
-    {  // steady state: exactly AHEAD newer rows are outstanding
-      issue(row(s + AHEAD), lo, hi);
+    for (int s = 0; s < cnt; ++s)
+    {
+      while (ahead <= AHEAD)
+      {
+        if (issued < cnt)
+          issue(row(issued++));
+        else if (nissued < ncnt)
+          issue(nrow(nissued++));
+        else
+          break;
+      }
       double v[NQ];
-      const unsigned addr = base + tail * SLOT + lane * 8;
-      tail                = (tail + 1 == R) ? 0 : tail + 1;
-      read<AHEAD>(v, addr);
+      fetch(v);
       body(s, v);
     }
-#pragma unroll 1
-    for (; s < cnt; ++s)
-    {  // drain: fewer rows behind this one
-      double v[NQ];
-      consume(v, cnt - 1 - s);
-      body(s, v);
-    }
-    end();
+  }
+  template <class RowA, class BodyF> __device__ __forceinline__ void run(int cnt, RowA row, BodyF body)
+  {
+    run(cnt, row, body, 0, row);
   }
 };
 
@@ -221,9 +279,10 @@ template <int NQ, int IPS> struct Ring
 template <int NQ, int IPS>
 __device__ bool update_row(Lattice<NQ> &T, Ring<NQ, IPS> &ring, int kappa, int last)
 {
-  const int d = T.d, n = T.n, lane = T.lane, ldd = T.ldd;
+  const int n = T.n, lane = T.lane, ldd = T.ldd;
   const int qact = (last >> 6) + 1;  // chunks holding a lane j <= last
   double bk[NQ], acc[NQ], rd[NQ];
+  bool inrow[NQ];
 #pragma unroll
   for (int q = 0; q < NQ; ++q)
   {
@@ -231,67 +290,75 @@ __device__ bool update_row(Lattice<NQ> &T, Ring<NQ, IPS> &ring, int kappa, int l
     bk[q]       = (c < n) ? T.bfT[(size_t)c * ldd + kappa] : 0.0;
     acc[q]      = 0.0;
     rd[q]       = (c < kappa) ? T.rdg[c] : 1.0;
+    inrow[q]    = c <= last;
   }
   const int need_bytes = (last + 1) * 8;  // lanes j <= last of a row
-  // ---- Gram row: g(kappa,j) = bf_kappa . bf_j, columns in ascending order (numvect.h:386-396)
+  auto gram_row = [&](int c) { return RowDesc{T.bfT + (size_t)c * ldd, 0, need_bytes}; };
+  auto rec_row  = [&](int k) { return RowDesc{T.muT + (size_t)k * ldd, (k + 1) * 8, need_bytes}; };
+  bool ok       = true;
 #pragma unroll
-  for (int cq = 0; cq < NQ; ++cq)
+  for (int q = 0; q < NQ; ++q)
   {
-    const int cbase = cq * 64;
-    if (cbase >= n)
-      break;
-    ring.run(
-        min(64, n - cbase), 0, need_bytes,
-        [&](int s) { return (const void *)(T.bfT + (size_t)(cbase + s) * ldd); },
-        [&](int s, const double(&v)[NQ])
-        {
-          const double bkc = g_rl_f64(bk[cq], s);
-#pragma unroll
-          for (int q = 0; q < NQ; ++q)
-            if (q < qact)
-            {
-              const double p = bkc * v[q];
-              acc[q]         = (cbase + s == 0) ? p : acc[q] + p;
-            }
-        });
+    settle(bk[q]);
+    settle(rd[q]);
   }
+  ring.reset();
+  // ---- Gram row: g(kappa,j) = bf_kappa . bf_j, columns in ascending order (numvect.h:386-396);
+  //      the recurrence's first mu columns are prefetched behind it
+  ring.run(
+      n, gram_row,
+      [&](int c, const double(&v)[NQ])
+      {
+        dispatch_chunk<NQ>(c,
+                           [&](auto cq, int cc)
+                           {
+                             const double bkc = g_rl_f64(bk[decltype(cq)::value], cc);
+#pragma unroll
+                             for (int q = 0; q < NQ; ++q)
+                               if (q < qact)
+                               {
+                                 const double p = bkc * v[q];
+                                 acc[q]         = (c == 0) ? p : acc[q] + p;
+                               }
+                           });
+      },
+      last + 1, rec_row);
   // ---- recurrence, gso_interface.cpp:143-158, column-oriented
-  bool ok = true;
+  ring.run(last + 1, rec_row,
+           [&](int k, const double(&v)[NQ])
+           {
+             dispatch_chunk<NQ>(
+                 k,
+                 [&](auto kq_, int kk)
+                 {
+                   constexpr int kq = decltype(kq_)::value;
+                   const double rk  = g_rl_f64(acc[kq], kk);  // r(kappa,k) is final
+                   double muk       = 0.0;
+                   if (last == kappa && k < kappa)  // only the diagonal lane j == kappa needs it
+                     muk = rk / g_rl_f64(rd[kq], kk);  // mu(kappa,k) = r(kappa,k) / r(k,k)
 #pragma unroll
-  for (int kq = 0; kq < NQ; ++kq)
-  {
-    const int kbase = kq * 64;
-    if (kbase > last)
-      break;
-    ring.run(
-        min(64, last - kbase + 1), kbase * 8, need_bytes,
-        [&](int s) { return (const void *)(T.muT + (size_t)(kbase + s) * ldd); },
-        [&](int s, const double(&v)[NQ])
-        {
-          const int k     = kbase + s;
-          const double rk = g_rl_f64(acc[kq], s);  // r(kappa,k) is final
-          double muk      = 0.0;
-          if (last == kappa && k < kappa)  // only the diagonal lane j == kappa consumes mu(kappa,k)
-            muk = rk / g_rl_f64(rd[kq], s);  // mu(kappa,k) = r(kappa,k) / r(k,k)
-#pragma unroll
-          for (int q = 0; q < NQ; ++q)
-            if (q < qact && q >= kq)
-            {
-              const int j = lane + 64 * q;
-              if (j > k && j <= last)
-              {
-                const double m = (j == kappa) ? muk : v[q];
-                acc[q]         = acc[q] - m * rk;
-              }
-            }
-        });
-  }
+                   for (int q = kq; q < NQ; ++q)
+                     if (q < qact)
+                     {
+                       const int j = lane + 64 * q;
+                       // chunks above kq hold only rows j > k; the diagonal chunk needs the test
+                       const bool on = inrow[q] && (q > kq || lane > kk);
+                       if (on)
+                       {
+                         const double m = (j == kappa) ? muk : v[q];
+                         acc[q]         = acc[q] - m * rk;
+                       }
+                     }
+                 });
+           });
   // ---- store the row
 #pragma unroll
   for (int q = 0; q < NQ; ++q)
   {
     const int j = lane + 64 * q;
     T.murow[q]  = 0.0;
+    T.rrow[q]   = acc[q];
+    T.bfk[q]    = bk[q];
     if (j <= last)
     {
       T.r[(size_t)kappa * ldd + j] = acc[q];
@@ -313,12 +380,45 @@ __device__ bool update_row(Lattice<NQ> &T, Ring<NQ, IPS> &ring, int kappa, int l
   return __all(ok);
 }
 
+// update_gso_row(kappa, kappa) right after update_gso_row(kappa, kappa-1): gso_valid_cols = kappa,
+// so the reference computes ONLY column j = kappa (gso_interface.cpp:141-152):
+//   g(kappa,kappa) = bf_kappa . bf_kappa (columns ascending), r(kappa,kappa) = g - sum_k mu(kappa,k) r(kappa,k)
+// (k ascending).  Both operands are still in registers (lane-distributed), so this is two short
+// v_readlane chains and no memory traffic.
+template <int NQ> __device__ void finish_diag(Lattice<NQ> &T, int kappa)
+{
+  const int n = T.n, ldd = T.ldd;
+  double g = 0.0;
+  for (int c = 0; c < n; ++c)
+  {
+    double a = 0.0;
+    dispatch_chunk<NQ>(c, [&](auto cq, int cc) { a = g_rl_f64(T.bfk[decltype(cq)::value], cc); });
+    const double p = a * a;
+    g              = (c == 0) ? p : g + p;
+  }
+  for (int k = 0; k < kappa; ++k)
+  {
+    double m = 0.0, r = 0.0;
+    dispatch_chunk<NQ>(k,
+                       [&](auto kq, int kk)
+                       {
+                         m = g_rl_f64(T.murow[decltype(kq)::value], kk);
+                         r = g_rl_f64(T.rrow[decltype(kq)::value], kk);
+                       });
+    g = g - m * r;
+  }
+  if (T.lane == 0)
+  {
+    T.r[(size_t)kappa * ldd + kappa] = g;
+    T.rdg[kappa]                     = g;
+  }
+}
+
 // LLLReduction::babai(kappa, kappa, 0).  1 ok, 0 GSO failure, -1 babai failure, -2 multiplier.
 template <int NQ, int IPS>
 __device__ int babai(Lattice<NQ> &T, Ring<NQ, IPS> &ring, int kappa, double eta)
 {
-  const int d = T.d, n = T.n, lane = T.lane, ldd = T.ldd, ldn = T.ldn;
-  (void)d;
+  const int n = T.n, lane = T.lane, ldd = T.ldd, ldn = T.ldn;
   long long max_expo = LLONG_MAX;
   for (int iter = 0;; ++iter)
   {
@@ -352,92 +452,94 @@ __device__ int babai(Lattice<NQ> &T, Ring<NQ, IPS> &ring, int kappa, double eta)
       max_expo = new_max;
     }
     double bm[NQ];
-    long long xl[NQ];
-#pragma unroll
-    for (int q = 0; q < NQ; ++q)
-    {
-      bm[q] = T.murow[q];
-      xl[q] = 0;
-    }
-    bool too_big = false;
-    // ---- lll.cpp:202-220, j = kappa-1 … 0 (descending), lane k owns babai_mu[k]
-#pragma unroll
-    for (int jq = NQ - 1; jq >= 0; --jq)
-    {
-      const int jbase = jq * 64;
-      if (jbase >= kappa)
-        continue;
-      const int top = min(63, kappa - 1 - jbase);  // first (highest) jj of this chunk
-      ring.run(
-          top + 1, 0, (jbase + top) * 8,  // row j needs k < j; the widest row of the chunk bounds it
-          [&](int s) { return (const void *)(T.mu + (size_t)(jbase + top - s) * ldd); },
-          [&](int s, const double(&v)[NQ])
-          {
-            const int jj     = top - s;
-            const int j      = jbase + jj;
-            const double bmj = g_rl_f64(bm[jq], jj);
-            const int ej     = __builtin_amdgcn_readlane(e[jq], jj);
-            double X;  // rnd_we, nr_FP_d.inl:226-233
-            if (fexponent(bmj) + ej >= 53)
-              X = bmj;
-            else
-              X = ldexp(rint(ldexp(bmj, ej)), -ej);
-            if (X != 0.0)
-            {
-              {  // row_addmul_we(kappa, j, -X, ej): get_si_exp_we, nr_FP_d.inl:46-53
-                const long long ex = fexponent(-X) + ej - 63;
-                if (ex > 0)
-                  too_big = true;
-                const long long lx = (long long)ldexp(-X, ej);
-                xl[jq]             = (lane == jj) ? lx : xl[jq];
-              }
-#pragma unroll
-              for (int q = 0; q < NQ; ++q)
-                if (q <= jq)
-                {
-                  const int k = lane + 64 * q;
-                  if (k < j)
-                  {
-                    const double t = X * v[q];
-                    bm[q]          = bm[q] - t;
-                  }
-                }
-            }
-          });
-    }
-    if (too_big)
-      return -2;
-    // ---- integer AXPY on row kappa (row_add / row_sub / row_addmul_si, gso.cpp:84-158)
-    long long bv[NQ];
+    long long xl[NQ], bv[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
     {
       const int c = lane + 64 * q;
+      bm[q]       = T.murow[q];
+      xl[q]       = 0;
       bv[q]       = (c < n) ? T.b[(size_t)kappa * ldn + c] : 0;
     }
-#pragma unroll
-    for (int jq = NQ - 1; jq >= 0; --jq)
+    bool too_big = false;
+    // step s of both loops handles row j = kappa-1-s (descending, lll.cpp:202)
+    auto mu_row = [&](int s)
     {
-      const int jbase = jq * 64;
-      if (jbase >= kappa)
-        continue;
-      const int top = min(63, kappa - 1 - jbase);
-      ring.run(
-          top + 1, 0, n * 8,
-          [&](int s) { return (const void *)(T.b + (size_t)(jbase + top - s) * ldn); },
-          [&](int s, const double(&v)[NQ])
-          {
-            const long long lx = g_rl_i64(xl[jq], top - s);
-            if (lx != 0)
-            {
+      const int j = kappa - 1 - s;
+      return RowDesc{T.mu + (size_t)j * ldd, 0, j * 8};  // mu(j,k) is needed for k < j
+    };
+    auto b_row = [&](int s) { return RowDesc{T.b + (size_t)(kappa - 1 - s) * ldn, 0, n * 8}; };
 #pragma unroll
-              for (int q = 0; q < NQ; ++q)
-                bv[q] = (long long)((unsigned long long)bv[q] +
-                                    (unsigned long long)__double_as_longlong(v[q]) *
-                                        (unsigned long long)lx);
-            }
-          });
+    for (int q = 0; q < NQ; ++q)
+    {
+      settle(e[q]);
+      settle(bv[q]);
+      settle(bm[q]);
     }
+    ring.reset();
+    // ---- lll.cpp:202-220: lane k owns babai_mu[k]; the basis rows of the integer AXPY are
+    //      prefetched behind the sweep
+    ring.run(
+        kappa, mu_row,
+        [&](int s, const double(&v)[NQ])
+        {
+          const int j = kappa - 1 - s;
+          dispatch_chunk<NQ>(
+              j,
+              [&](auto jq_, int jj)
+              {
+                constexpr int jq = decltype(jq_)::value;
+                const double bmj = g_rl_f64(bm[jq], jj);
+                const int ej     = __builtin_amdgcn_readlane(e[jq], jj);
+                double X;  // rnd_we, nr_FP_d.inl:226-233
+                if (fexponent(bmj) + ej >= 53)
+                  X = bmj;
+                else
+                  X = ldexp(rint(ldexp(bmj, ej)), -ej);
+                if (X != 0.0)
+                {
+                  {  // row_addmul_we(kappa, j, -X, ej): get_si_exp_we, nr_FP_d.inl:46-53
+                    const long long ex = fexponent(-X) + ej - 63;
+                    if (ex > 0)
+                      too_big = true;
+                    const long long lx = (long long)ldexp(-X, ej);
+                    xl[jq]             = (lane == jj) ? lx : xl[jq];
+                  }
+#pragma unroll
+                  for (int q = 0; q <= jq; ++q)
+                  {
+                    // chunks below jq hold only k < j; the chunk of j itself needs the test
+                    if (q < jq || lane < jj)
+                    {
+                      const double t = X * v[q];
+                      bm[q]          = bm[q] - t;
+                    }
+                  }
+                }
+              });
+        },
+        kappa, b_row);
+    // ---- integer AXPY on row kappa (row_add / row_sub / row_addmul_si, gso.cpp:84-158)
+    ring.run(kappa, b_row,
+             [&](int s, const double(&v)[NQ])
+             {
+               const int j = kappa - 1 - s;
+               dispatch_chunk<NQ>(j,
+                                  [&](auto jq_, int jj)
+                                  {
+                                    const long long lx = g_rl_i64(xl[decltype(jq_)::value], jj);
+                                    if (lx != 0)
+                                    {
+#pragma unroll
+                                      for (int q = 0; q < NQ; ++q)
+                                        bv[q] = (long long)((unsigned long long)bv[q] +
+                                                            (unsigned long long)__double_as_longlong(v[q]) *
+                                                                (unsigned long long)lx);
+                                    }
+                                  });
+             });
+    if (too_big)
+      return -2;  // nothing has been stored yet: the basis is unchanged
     // ---- row_op_end: update_bf(kappa), gso.cpp:24-48
     int ce[NQ];
     double cm[NQ];
@@ -498,6 +600,7 @@ __global__ void __launch_bounds__(256)
   ring.base = (unsigned)(wave * Ring<NQ, IPS>::R * Ring<NQ, IPS>::SLOT);
   ring.lane = lane;
   ring.head = ring.tail = 0;
+  ring.ahead = 0;
   for (int L = blockIdx.x * wpb + wave; L < P.batch; L += gridDim.x * wpb)
   {
     Lattice<NQ> T;
@@ -571,7 +674,11 @@ __global__ void __launch_bounds__(256)
             break;
           }
         }
-        if (!update_row<NQ, IPS>(T, ring, kappa, kappa))
+        if (mode == 1 && kappa > 0)
+        {
+          finish_diag<NQ>(T, kappa);  // babai left the row valid up to column kappa-1
+        }
+        else if (!update_row<NQ, IPS>(T, ring, kappa, kappa))
         {
           status = 0;
           break;
@@ -589,4 +696,40 @@ template __global__ void gso_sweep_kernel<2>(GsoBatch, int, int, double, int);
 template __global__ void gso_sweep_kernel<3>(GsoBatch, int, int, double, int);
 template __global__ void gso_sweep_kernel<4>(GsoBatch, int, int, double, int);
 
+}  // namespace fphip
+
+// ---------------------------------------------------------------------------------------------
+// Calibration kernel for the rocprofv3 FETCH_SIZE counter (MI355X_MICROARCH.md §HBM: "calibrate on
+// a known byte count in your own access pattern"): streams `rows` rows of `row_bytes` bytes with the
+// SAME instruction the sweep uses (global_load_lds_dwordx4, 16 B per lane, windowed), no reuse.
+// ---------------------------------------------------------------------------------------------
+namespace fphip
+{
+__global__ void __launch_bounds__(256)
+    gso_calib_kernel(const char *buf, size_t stride, int row_bytes, long long rows)
+{
+  extern __shared__ __attribute__((aligned(16))) char cal_smem[];
+  const int lane  = threadIdx.x & 63;
+  const int wave  = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wpb   = blockDim.x >> 6;
+  const long long gw = (long long)blockIdx.x * wpb + wave;
+  const long long nw = (long long)gridDim.x * wpb;
+  const unsigned base = (unsigned)(wave * 8 * 2048);
+  int slot = 0;
+  for (long long r = gw; r < rows; r += nw)
+  {
+    const char *g = buf + (size_t)r * stride + lane * 16;
+    const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(base + slot * 2048));
+    for (int i = 0; i < 2; ++i)
+    {
+      const int off = lane * 16 + i * 1024;
+      if (lane == 0 || off < row_bytes)
+        glds16(g + i * 1024, dst + i * 1024);
+    }
+    slot = (slot + 1) & 7;
+    if (slot == 0)
+      wait_vmcnt<0>();
+  }
+  wait_vmcnt<0>();
+}
 }  // namespace fphip
