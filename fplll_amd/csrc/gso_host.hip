@@ -14,7 +14,7 @@
 #include "gso_device.h"
 
 #ifndef FPHIP_GSO_RING
-#define FPHIP_GSO_RING 8
+#define FPHIP_GSO_RING 6
 #endif
 
 namespace fphip

@@ -89,7 +89,7 @@ template <int NQ> struct Lattice
 //   * rows start 16-byte aligned: leading dimensions are padded to even (ldd, ldn).
 // ---------------------------------------------------------------------------------------------
 #ifndef FPHIP_GSO_RING
-#define FPHIP_GSO_RING 8
+#define FPHIP_GSO_RING 6
 #endif
 
 __device__ __forceinline__ void glds16(const void *gsrc, unsigned lds_dst)
