@@ -134,6 +134,11 @@ class MatGSOBatch:
 
 
 # ---------------------------------------------------------------------------------------------
+# (2*FETCH_SIZE + WRITE_SIZE)*1024 / lattices, measured with rocprofv3 --pmc on the shipped kernel
+# (separate passes), 180x180 benchmark input: see profiles/r01_gso_traffic.md
+TRAFFIC_BYTES_PER_LATTICE_180 = 126959983
+
+
 def sweep_bytes(d, n):
     """ALGORITHMIC bytes of one size-reduction sweep of a d×n lattice in which every row needs
     exactly one effective babai iteration followed by the confirming pass:
@@ -185,9 +190,14 @@ def bench_roofline(ctx, batch=None, reps=2):
             best = ms if best is None else min(best, ms)
         alg = sweep_bytes(d, d) * batch
         achieved = alg / (best * 1e-3) / 1e9
+        # HBM traffic per launch from the rocprofv3 PMC passes of this kernel (profiles/
+        # r01_gso_traffic.md): FETCH_SIZE x2 (gfx950 correction, verified with the calibration
+        # kernel) + WRITE_SIZE, in KiB, scaled per lattice.  Measured outside bench.py (a PMC run
+        # must not be combined with the timed run), so it is a per-lattice constant here.
+        traffic = TRAFFIC_BYTES_PER_LATTICE_180 * batch if d == 180 else None
         return {
             "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-            "frac": achieved / 8000.0, "traffic": None,
+            "frac": achieved / 8000.0, "traffic": traffic,
             "kernel": "gso_sweep_kernel<3> (size_reduction sweep, %d lattices of %dx%d)" % (batch, d, d),
             "algorithmic_bytes_per_launch": alg, "kernel_ms": best,
         }
