@@ -418,6 +418,124 @@ static int cmd_gsofix(int argc, char **argv)
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// BKZ tour axis (SURVEY.md §8(d) metric (ii)): the reference's bkz_reduction, unchanged, with its
+// internal enumerator or with OUR plugin installed through set_external_enumerator.
+// ---------------------------------------------------------------------------------------------
+typedef std::array<uint64_t, FPLLL_EXTENUM_MAX_EXTENUM_DIM>(extenum_fn_fw)(
+    const int, double, std::function<extenum_cb_set_config>, std::function<extenum_cb_process_sol>,
+    std::function<extenum_cb_process_subsol>, bool, bool);
+static extenum_fn_fw *load_plugin(const char *path);
+static bool read_basis(const char *path, ZZ_mat<mpz_t> &A)
+{
+  std::ifstream is(path);
+  is >> A;
+  return A.get_rows() > 0;
+}
+
+/* genstrat basisfile beta → strategies JSON (load_strategies_json format, bkz_param.cpp:92-146):
+ * the default.json substitute of SURVEY Appendix A: for b in (24,beta] four pruning vectors from the
+ * reference's prune<>() on the r-profile of the middle block, radius = ghf*GH, target 0.5;
+ * preprocessing block b-24 for b >= 45. */
+static int cmd_genstrat(int argc, char **argv)
+{
+  if (argc < 4)
+    return 2;
+  ZZ_mat<mpz_t> A, U, UT;
+  if (!read_basis(argv[2], A))
+    return 2;
+  int beta = atoi(argv[3]);
+  int n    = A.get_rows();
+  MatGSO<ZT, FT> M(A, U, UT, GSO_ROW_EXPO);
+  M.update_gso();
+  std::ostringstream os;
+  os << "[";
+  bool first = true;
+  for (int b = 25; b <= beta; ++b)
+  {
+    int lo = (n - b) / 2;
+    vector<double> r;
+    for (int i = 0; i < b; ++i)
+    {
+      FT t;
+      M.get_r(t, lo + i, lo + i);
+      r.push_back(t.get_d());
+    }
+    os << (first ? "" : ",\n") << "{\"block_size\":" << b << ",\"preprocessing_block_sizes\":[";
+    first = false;
+    if (b >= 45)
+      os << (b - 24);
+    os << "],\"pruning_parameters\":[";
+    const double ghfs[4] = {1.0, 1.1, 1.2, 1.4};
+    for (int g = 0; g < 4; ++g)
+    {
+      FT max_dist = 1e300;  // "huge": adjust_radius_to_gh_bound then returns ghf*GH (bkz.cpp:92-96)
+      long expo   = 0;
+      FT root_det = M.get_root_det(lo, lo + b);
+      adjust_radius_to_gh_bound(max_dist, expo, b, root_det, ghfs[g]);
+      PruningParams pp;
+      prune<FT>(pp, max_dist.get_d(), 1e7, r, 0.5, PRUNER_METRIC_PROBABILITY_OF_SHORTEST,
+                PRUNER_GRADIENT);
+      os << (g ? "," : "") << "[" << ghfs[g] << ",[";
+      for (size_t i = 0; i < pp.coefficients.size(); ++i)
+      {
+        char buf[40];
+        snprintf(buf, sizeof buf, "%.17g", pp.coefficients[i]);
+        os << (i ? "," : "") << buf;
+      }
+      char pb[40];
+      snprintf(pb, sizeof pb, "%.17g", std::min(1.0, std::max(1e-9, pp.expectation)));
+      os << "]," << pb << "]";
+    }
+    os << "]}";
+  }
+  os << "]\n";
+  std::cout << os.str();
+  return 0;
+}
+
+/* bkztour basisfile strategies.json beta plugin.so|none → JSON: wall time of ONE BKZ-beta tour
+ * (BKZ_MAX_LOOPS=1, BKZ_GH_BND 1.1) and a fingerprint of the result */
+static int cmd_bkztour(int argc, char **argv)
+{
+  if (argc < 6)
+    return 2;
+  ZZ_mat<mpz_t> A;
+  if (!read_basis(argv[2], A))
+    return 2;
+  vector<Strategy> strategies = load_strategies_json(argv[3]);
+  int beta                    = atoi(argv[4]);
+  std::string plug            = argv[5];
+  if (plug == "none")
+    set_external_enumerator(nullptr);
+  else if (plug == "enumlib")
+    ;  // the reference's default plugin stays installed
+  else
+    set_external_enumerator(load_plugin(plug.c_str()));
+  BKZParam par(beta, strategies);
+  par.flags     = BKZ_MAX_LOOPS | BKZ_GH_BND;
+  par.max_loops = 1;
+  par.gh_factor = 1.1;
+  auto t0       = std::chrono::steady_clock::now();
+  int status    = bkz_reduction(&A, NULL, par, FT_DOUBLE, 0);
+  double secs   = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  ZZ_mat<mpz_t> U, UT;
+  MatGSO<ZT, FT> M(A, U, UT, GSO_ROW_EXPO);
+  M.update_gso();
+  FT r0;
+  M.get_r(r0, 0, 0);
+  double slope = M.get_current_slope(0, A.get_rows());
+  // order-independent fingerprint of the basis
+  unsigned long long fp = 1469598103934665603ull;
+  for (int i = 0; i < A.get_rows(); ++i)
+    for (int j = 0; j < A.get_cols(); ++j)
+      fp = (fp ^ (unsigned long long)A(i, j).get_si()) * 1099511628211ull;
+  printf("{\"plugin\":\"%s\",\"beta\":%d,\"status\":%d,\"tour_seconds\":%.3f,\"r00\":%.17g,"
+         "\"slope\":%.9f,\"basis_fnv\":\"%016llx\"}\n",
+         plug.c_str(), beta, status, secs, r0.get_d(), slope, fp);
+  return (status == RED_SUCCESS || status == RED_BKZ_LOOPS_LIMIT) ? 0 : 1;
+}
+
 /* dumpbasis n k bits seed bkz_pre  → the reduced basis in fplll's text format on stdout */
 static int cmd_dumpbasis(int argc, char **argv)
 {
@@ -445,6 +563,10 @@ int main(int argc, char **argv)
     return cmd_dumpbasis(argc, argv);
   if (cmd == "gsofix")
     return cmd_gsofix(argc, argv);
+  if (cmd == "genstrat")
+    return cmd_genstrat(argc, argv);
+  if (cmd == "bkztour")
+    return cmd_bkztour(argc, argv);
   fprintf(stderr, "unknown command %s\n", cmd.c_str());
   return 2;
 }
