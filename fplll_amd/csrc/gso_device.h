@@ -32,5 +32,18 @@ struct GsoBatch
   long long *rexp;
   int *status;
 };
+// Batched Householder state (MatHouseholder<Z_NR<long>, FP_NR<double>>): b, V, R are [batch][d][ldn]
+// row-major (lane = column), sigma / rexp [batch][d].
+struct HhBatch
+{
+  int batch, d, n, ldn;
+  int row_expo;
+  long long *b;
+  double *V;
+  double *R;
+  double *sigma;
+  long long *rexp;
+  int *status;
+};
 }  // namespace fphip
 #endif

@@ -314,3 +314,158 @@ extern "C" int fphip_debug_stream(fphip_ctx *ctx, long long rows, int row_bytes,
   hipFree(buf);
   return FPHIP_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Batched Householder R-factor: MatHouseholder<Z_NR<long>, FP_NR<double>> refresh_R_bf() +
+// update_R() (fplll/householder.h:532-536, 610-614)
+// ---------------------------------------------------------------------------------------------
+namespace fphip
+{
+template <int NQ> __global__ void hh_update_kernel(HhBatch P);
+}
+
+struct fphip_hh
+{
+  fphip_ctx *ctx;
+  HhBatch P;
+  hipEvent_t ev[2];
+  float last_ms;
+};
+
+#define HCHK(call)                     \
+  do                                   \
+  {                                    \
+    hipError_t e_ = (call);            \
+    if (e_ != hipSuccess)              \
+      return gfail(h->ctx, #call, e_); \
+  } while (0)
+
+extern "C" int fphip_hh_create(fphip_ctx *ctx, int batch, int d, int n, int row_expo, fphip_hh **out)
+{
+  if (!ctx || !out)
+    return FPHIP_ERROR;
+  *out = nullptr;
+  if (batch <= 0 || d <= 0 || n <= 0 || !fphip_ctx_stream(ctx))
+  {
+    snprintf(fphip_ctx_errbuf(ctx), 512, "fphip_hh_create: bad arguments or no device");
+    return FPHIP_ERROR;
+  }
+  if (d > 256 || n > 256)
+    return FPHIP_UNSUPPORTED;
+  fphip_hh *h = new fphip_hh();
+  memset(h, 0, sizeof *h);
+  h->ctx        = ctx;
+  h->P.batch    = batch;
+  h->P.d        = d;
+  h->P.n        = n;
+  h->P.ldn      = (n + 15) / 16 * 16;
+  if (h->P.ldn > 256)
+    h->P.ldn = 256;
+  h->P.row_expo = row_expo ? 1 : 0;
+  const size_t B = (size_t)batch, ld = h->P.ldn, pad = 4096;
+  HCHK(hipMalloc((void **)&h->P.b, B * d * ld * 8 + pad));
+  HCHK(hipMalloc((void **)&h->P.V, B * d * ld * 8 + pad));
+  HCHK(hipMalloc((void **)&h->P.R, B * d * ld * 8 + pad));
+  HCHK(hipMalloc((void **)&h->P.sigma, B * d * 8));
+  HCHK(hipMalloc((void **)&h->P.rexp, B * d * 8));
+  HCHK(hipMalloc((void **)&h->P.status, B * sizeof(int)));
+  HCHK(hipMemset(h->P.b, 0, B * d * ld * 8 + pad));
+  HCHK(hipMemset(h->P.V, 0, B * d * ld * 8 + pad));
+  HCHK(hipMemset(h->P.R, 0, B * d * ld * 8 + pad));
+  HCHK(hipEventCreate(&h->ev[0]));
+  HCHK(hipEventCreate(&h->ev[1]));
+  *out = h;
+  return FPHIP_OK;
+}
+
+extern "C" void fphip_hh_destroy(fphip_hh *h)
+{
+  if (!h)
+    return;
+  hipStreamSynchronize(fphip_ctx_stream(h->ctx));
+  hipFree(h->P.b);
+  hipFree(h->P.V);
+  hipFree(h->P.R);
+  hipFree(h->P.sigma);
+  hipFree(h->P.rexp);
+  hipFree(h->P.status);
+  hipEventDestroy(h->ev[0]);
+  hipEventDestroy(h->ev[1]);
+  delete h;
+}
+
+extern "C" int fphip_hh_set_basis(fphip_hh *h, int first, int count, const int64_t *b)
+{
+  if (!h || !b || first < 0 || count <= 0 || first + count > h->P.batch)
+    return FPHIP_ERROR;
+  HCHK(hipMemcpy2D(h->P.b + (size_t)first * h->P.d * h->P.ldn, (size_t)h->P.ldn * 8, b,
+                   (size_t)h->P.n * 8, (size_t)h->P.n * 8, (size_t)h->P.d * count,
+                   hipMemcpyHostToDevice));
+  return FPHIP_OK;
+}
+
+extern "C" int fphip_hh_broadcast_basis(fphip_hh *h, int src)
+{
+  if (!h || src < 0 || src >= h->P.batch)
+    return FPHIP_ERROR;
+  const size_t per = (size_t)h->P.d * h->P.ldn;
+  for (int L = 0; L < h->P.batch; ++L)
+    if (L != src)
+      HCHK(hipMemcpyAsync(h->P.b + (size_t)L * per, h->P.b + (size_t)src * per, per * 8,
+                          hipMemcpyDeviceToDevice, fphip_ctx_stream(h->ctx)));
+  HCHK(hipStreamSynchronize(fphip_ctx_stream(h->ctx)));
+  return FPHIP_OK;
+}
+
+// refresh_R_bf() + update_R() for every lattice; status[batch] = 1
+extern "C" int fphip_hh_update_R(fphip_hh *h, int *status)
+{
+  if (!h)
+    return FPHIP_ERROR;
+  const int nq  = (h->P.n + 63) / 64;
+  const int wpb = 4;
+  const size_t lds = (size_t)wpb * FPHIP_GSO_RING * (size_t)((nq + 1) / 2) * 1024;
+  int bpc          = (int)((160 * 1024) / lds);
+  if (bpc * wpb > 32)
+    bpc = 32 / wpb;
+  int grid = (h->P.batch + wpb - 1) / wpb;
+  if (grid > fphip_ctx_num_cus(h->ctx) * bpc)
+    grid = fphip_ctx_num_cus(h->ctx) * bpc;
+  hipStream_t s = fphip_ctx_stream(h->ctx);
+  HCHK(hipEventRecord(h->ev[0], s));
+  switch (nq)
+  {
+  case 1: hipLaunchKernelGGL(hh_update_kernel<1>, dim3(grid), dim3(wpb * 64), lds, s, h->P); break;
+  case 2: hipLaunchKernelGGL(hh_update_kernel<2>, dim3(grid), dim3(wpb * 64), lds, s, h->P); break;
+  case 3: hipLaunchKernelGGL(hh_update_kernel<3>, dim3(grid), dim3(wpb * 64), lds, s, h->P); break;
+  default: hipLaunchKernelGGL(hh_update_kernel<4>, dim3(grid), dim3(wpb * 64), lds, s, h->P); break;
+  }
+  HCHK(hipGetLastError());
+  HCHK(hipEventRecord(h->ev[1], s));
+  HCHK(hipStreamSynchronize(s));
+  HCHK(hipEventElapsedTime(&h->last_ms, h->ev[0], h->ev[1]));
+  if (status)
+    HCHK(hipMemcpy(status, h->P.status, sizeof(int) * h->P.batch, hipMemcpyDeviceToHost));
+  return FPHIP_OK;
+}
+
+// R as d×n row-major (only R(i, j<=i) is meaningful, as in the reference); exponents separately
+extern "C" int fphip_hh_get_R(fphip_hh *h, int lattice, double *R)
+{
+  if (!h || !R || lattice < 0 || lattice >= h->P.batch)
+    return FPHIP_ERROR;
+  HCHK(hipMemcpy2D(R, (size_t)h->P.n * 8, h->P.R + (size_t)lattice * h->P.d * h->P.ldn,
+                   (size_t)h->P.ldn * 8, (size_t)h->P.n * 8, h->P.d, hipMemcpyDeviceToHost));
+  return FPHIP_OK;
+}
+
+extern "C" int fphip_hh_get_row_expo(fphip_hh *h, int lattice, int64_t *row_expo)
+{
+  if (!h || !row_expo || lattice < 0 || lattice >= h->P.batch)
+    return FPHIP_ERROR;
+  HCHK(hipMemcpy(row_expo, h->P.rexp + (size_t)lattice * h->P.d, 8 * (size_t)h->P.d,
+                 hipMemcpyDeviceToHost));
+  return FPHIP_OK;
+}
+
+extern "C" double fphip_hh_last_kernel_ms(const fphip_hh *h) { return h ? h->last_ms : 0.0; }

@@ -699,6 +699,213 @@ template __global__ void gso_sweep_kernel<4>(GsoBatch, int, int, double, int);
 }  // namespace fphip
 
 // ---------------------------------------------------------------------------------------------
+// Householder R-factor (MatHouseholder<Z_NR<long>, FP_NR<double>>): refresh_R_bf() + update_R()
+// over all rows, fplll/householder.cpp:27-245, householder.h:532-536 — batched, one wavefront per
+// lattice, lane = COLUMN.  Row i lives in registers; the reflectors V[0..i) are streamed through
+// the LDS-DMA ring.  The reference's dot product is a SEQUENTIAL sum over the columns
+// (nr/numvect.h:386-396), so the per-lane products are added in ascending column order with a
+// v_readlane chain (bit-exact), while the AXPY R_i += (-s) V_j is a plain vector operation
+// (element-wise, two roundings, numvect.h:300-305).
+// ---------------------------------------------------------------------------------------------
+namespace fphip
+{
+
+// sum of p[c] for c in [from, to), ascending, starting from `init` if has_init, else from p[from]
+template <int NQ>
+__device__ __forceinline__ double seq_sum(const double (&p)[NQ], int from, int to)
+{
+  double s   = 0.0;
+  bool first = true;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+  {
+    const int lo = max(from, 64 * q) - 64 * q;
+    const int hi = min(to, 64 * q + 64) - 64 * q;
+    for (int cc = lo; cc < hi; ++cc)
+    {
+      const double v = g_rl_f64(p[q], cc);
+      s              = first ? v : s + v;
+      first          = false;
+    }
+  }
+  return s;
+}
+
+template <int NQ>
+__global__ void __launch_bounds__(256) hh_update_kernel(HhBatch P)
+{
+  constexpr int IPS = (NQ + 1) / 2;
+  extern __shared__ __attribute__((aligned(16))) char hh_smem[];
+  const int lane = threadIdx.x & 63;
+  const int wpb  = blockDim.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  Ring<NQ, IPS> ring;
+  ring.base = (unsigned)(wave * Ring<NQ, IPS>::R * Ring<NQ, IPS>::SLOT);
+  ring.lane = lane;
+  ring.head = ring.tail = 0;
+  ring.ahead            = 0;
+  const int d = P.d, n = P.n, ld = P.ldn;
+  for (int L = blockIdx.x * wpb + wave; L < P.batch; L += gridDim.x * wpb)
+  {
+    const long long *b = P.b + (size_t)L * d * ld;
+    double *V          = P.V + (size_t)L * d * ld;
+    double *R          = P.R + (size_t)L * d * ld;
+    double *sigma      = P.sigma + (size_t)L * d;
+    long long *rexp    = P.rexp + (size_t)L * d;
+    double sg[NQ];  // sigma[j] in lane j
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+      sg[q] = 0.0;
+    for (int i = 0; i < d; ++i)
+    {
+      // ---- refresh_R_bf(i): float the integer row (row exponent optional), householder.cpp:186-245
+      double Ri[NQ];
+      {
+        int ce[NQ];
+        double cm[NQ];
+        int emax = INT_MIN;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+        {
+          const int c = lane + 64 * q;
+          ce[q]       = INT_MIN;
+          cm[q]       = 0.0;
+          if (c < n)
+          {
+            const long long v = b[(size_t)i * ld + c];
+            if (P.row_expo)
+            {
+              int ex;
+              cm[q] = frexp((double)v, &ex);
+              ce[q] = ex;
+              emax  = max(emax, ex);
+            }
+            else
+            {
+              cm[q] = (double)v;
+              ce[q] = 0;
+              emax  = 0;
+            }
+          }
+        }
+        emax = wave_max_i32(emax);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+        {
+          const int c = lane + 64 * q;
+          Ri[q]       = (c < n) ? (P.row_expo ? ldexp(cm[q], ce[q] - emax) : cm[q]) : 0.0;
+        }
+        if (lane == 0)
+          rexp[i] = P.row_expo ? (long long)emax : 0;
+      }
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+      {
+        settle(Ri[q]);
+        settle(sg[q]);
+      }
+      __threadfence_block();  // V rows written for earlier i must be visible to the DMA reads
+      ring.reset();
+      // ---- update_R(i): apply reflectors j = 0 … i-1 in order, householder.cpp:157-178
+      ring.run(i, [&](int j) { return RowDesc{V + (size_t)j * ld, j * 8, n * 8}; },
+               [&](int j, const double(&v)[NQ])
+               {
+                 double p[NQ];
+#pragma unroll
+                 for (int q = 0; q < NQ; ++q)
+                 {
+                   const int c = lane + 64 * q;
+                   p[q]        = (c >= j && c < n) ? v[q] * Ri[q] : 0.0;
+                 }
+                 double s = seq_sum<NQ>(p, j, n);  // V_j . R_i over [j, n), ascending
+                 s        = -s;
+                 double sj = 0.0;
+                 dispatch_chunk<NQ>(j, [&](auto jq, int jj) { sj = g_rl_f64(sg[decltype(jq)::value], jj); });
+#pragma unroll
+                 for (int q = 0; q < NQ; ++q)
+                 {
+                   const int c = lane + 64 * q;
+                   if (c >= j && c < n)
+                   {
+                     double t = Ri[q] + v[q] * s;  // addmul: two roundings
+                     if (c == j)
+                       t = sj * t;  // R(i,j) = sigma[j] * R(i,j)
+                     Ri[q] = t;
+                   }
+                 }
+               });
+      // ---- update_R_last(i), householder.cpp:27-146
+      double sq[NQ];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+      {
+        const int c = lane + 64 * q;
+        sq[q]       = (c > i && c < n) ? Ri[q] * Ri[q] : 0.0;
+      }
+      double rii = 0.0;
+      dispatch_chunk<NQ>(i, [&](auto iq, int ii) { rii = g_rl_f64(Ri[decltype(iq)::value], ii); });
+      const double sgi = (rii < 0.0) ? -1.0 : 1.0;
+      double f3        = (i + 1 == n) ? 0.0 : seq_sum<NQ>(sq, i + 1, n);
+      double f1        = rii * rii;
+      f1               = f1 + f3;
+      double vii = 0.0, new_rii = 0.0, f0 = 1.0;
+      bool scale = false;
+      if (f1 != 0.0)
+      {
+        const double f2 = sqrt(f1);
+        f0              = sgi * f2;
+        f1              = rii + f0;
+        f3              = -f3;
+        f3              = f3 / f1;
+        if (f3 != 0.0)
+        {
+          f0      = -f0;
+          f0      = f0 * f3;
+          f0      = sqrt(f0);
+          vii     = f3 / f0;
+          new_rii = f2;
+          scale   = true;
+        }
+        else
+        {
+          vii     = 0.0;
+          new_rii = (rii < 0.0) ? -rii : rii;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+      {
+        const int c = lane + 64 * q;
+        if (c < n)
+        {
+          double vv = 0.0;
+          if (c == i)
+            vv = vii;
+          else if (c > i && scale)
+            vv = Ri[q] / f0;
+          V[(size_t)i * ld + c] = vv;
+          R[(size_t)i * ld + c] = (c == i) ? new_rii : Ri[q];
+          if (c == i)
+          {
+            sg[q]    = sgi;
+            sigma[i] = sgi;
+          }
+        }
+      }
+    }
+    if (lane == 0)
+      P.status[L] = 1;
+  }
+}
+
+template __global__ void hh_update_kernel<1>(HhBatch);
+template __global__ void hh_update_kernel<2>(HhBatch);
+template __global__ void hh_update_kernel<3>(HhBatch);
+template __global__ void hh_update_kernel<4>(HhBatch);
+
+}  // namespace fphip
+
+// ---------------------------------------------------------------------------------------------
 // Calibration kernel for the rocprofv3 FETCH_SIZE counter (MI355X_MICROARCH.md §HBM: "calibrate on
 // a known byte count in your own access pattern"): streams `rows` rows of `row_bytes` bytes with the
 // SAME instruction the sweep uses (global_load_lds_dwordx4, 16 B per lane, windowed), no reuse.

@@ -1,0 +1,84 @@
+"""Host-side mirror of fplll's MatHouseholder interface (fplll/householder.h) for a BATCH of
+lattices on the GPU: ``refresh_R_bf(); update_R(); get_R(expo)``.  No arithmetic here."""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+
+def _bind(lib):
+    if getattr(lib, "_hh_bound", False):
+        return
+    vp = ctypes.c_void_p
+    lib.fphip_hh_create.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                    ctypes.POINTER(vp)]
+    lib.fphip_hh_create.restype = ctypes.c_int
+    lib.fphip_hh_destroy.argtypes = [vp]
+    lib.fphip_hh_destroy.restype = None
+    lib.fphip_hh_set_basis.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp]
+    lib.fphip_hh_broadcast_basis.argtypes = [vp, ctypes.c_int]
+    lib.fphip_hh_update_R.argtypes = [vp, vp]
+    lib.fphip_hh_get_R.argtypes = [vp, ctypes.c_int, vp]
+    lib.fphip_hh_get_row_expo.argtypes = [vp, ctypes.c_int, vp]
+    lib.fphip_hh_last_kernel_ms.argtypes = [vp]
+    lib.fphip_hh_last_kernel_ms.restype = ctypes.c_double
+    lib._hh_bound = True
+
+
+class MatHouseholderBatch:
+    def __init__(self, ctx, batch, d, n, row_expo=False):
+        self.ctx, self.lib = ctx, ctx.lib
+        _bind(self.lib)
+        self.batch, self.d, self.n = batch, d, n
+        self.h = ctypes.c_void_p()
+        rc = self.lib.fphip_hh_create(ctx.handle, batch, d, n, 1 if row_expo else 0,
+                                      ctypes.byref(self.h))
+        if rc == _lib.FPHIP_UNSUPPORTED:
+            raise NotImplementedError("d, n > 256 are not handled on the device")
+        if rc != _lib.FPHIP_OK:
+            raise _lib.HipError("fphip_hh_create: " + ctx.last_error())
+
+    def _chk(self, rc, what):
+        if rc != _lib.FPHIP_OK:
+            raise _lib.HipError("%s: %s" % (what, self.ctx.last_error()))
+
+    def set_basis(self, b, first=0):
+        b = np.ascontiguousarray(b, dtype=np.int64)
+        if b.ndim == 2:
+            b = b[None]
+        assert b.shape[1:] == (self.d, self.n)
+        self._chk(self.lib.fphip_hh_set_basis(self.h, first, b.shape[0],
+                                              b.ctypes.data_as(ctypes.c_void_p)), "set_basis")
+
+    def broadcast_basis(self, src=0):
+        self._chk(self.lib.fphip_hh_broadcast_basis(self.h, src), "broadcast_basis")
+
+    def update_R(self):
+        """refresh_R_bf() + update_R() for every lattice."""
+        st = np.zeros(self.batch, dtype=np.int32)
+        self._chk(self.lib.fphip_hh_update_R(self.h, st.ctypes.data_as(ctypes.c_void_p)), "update_R")
+        return st
+
+    def get_R(self, lattice=0):
+        R = np.empty((self.d, self.n))
+        self._chk(self.lib.fphip_hh_get_R(self.h, lattice, R.ctypes.data_as(ctypes.c_void_p)), "get_R")
+        e = np.empty(self.d, dtype=np.int64)
+        self._chk(self.lib.fphip_hh_get_row_expo(self.h, lattice, e.ctypes.data_as(ctypes.c_void_p)),
+                  "get_row_expo")
+        return R, e
+
+    @property
+    def last_kernel_ms(self):
+        return float(self.lib.fphip_hh_last_kernel_ms(self.h))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.fphip_hh_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

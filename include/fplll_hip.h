@@ -147,6 +147,24 @@ int fphip_gso_get_row_expo(fphip_gso *g, int lattice, int64_t *row_expo);
 /* duration of the last sweep kernel, HIP events on the launch stream */
 double fphip_gso_last_kernel_ms(const fphip_gso *g);
 
+/* ------------------------------------------------------------------------------------------ */
+/* Batched Householder R-factor: MatHouseholder<Z_NR<long>, FP_NR<double>> (householder.h:38)    */
+/*   fphip_hh_update_R = refresh_R_bf() + update_R() over all rows (householder.h:532-536,       */
+/*   610-614; update_R householder.cpp:151-184, update_R_last :27-146, refresh_R_bf :186-245).   */
+/*   R(i, j<=i) and the row exponents are bit-identical to the reference's.                      */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct fphip_hh fphip_hh;
+int fphip_hh_create(fphip_ctx *ctx, int batch, int d, int n, int row_expo, fphip_hh **out);
+void fphip_hh_destroy(fphip_hh *h);
+int fphip_hh_set_basis(fphip_hh *h, int first_lattice, int count, const int64_t *b);
+int fphip_hh_broadcast_basis(fphip_hh *h, int src);
+int fphip_hh_update_R(fphip_hh *h, int *status);
+/* R as d×n row-major: MatHouseholder::get_R(expo) (householder.h:179); entries right of the
+ * diagonal are scratch, exactly as in the reference */
+int fphip_hh_get_R(fphip_hh *h, int lattice, double *R);
+int fphip_hh_get_row_expo(fphip_hh *h, int lattice, int64_t *row_expo);
+double fphip_hh_last_kernel_ms(const fphip_hh *h);
+
 #ifdef __cplusplus
 }
 #endif

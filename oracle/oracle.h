@@ -73,6 +73,14 @@ const int64_t *oracle_gso_row_expo(const oracle_gso *g); /* d */
 double oracle_gso_get_mu(const oracle_gso *g, int i, int j);
 double oracle_gso_get_r(const oracle_gso *g, int i, int j);
 
+/* ------------------------------------------------------------------------------------------
+ * Householder R-factor for MatHouseholder<Z_NR<long>, FP_NR<double>>: refresh_R_bf() + update_R()
+ * over all rows (householder.h:532-536, householder.cpp:27-245).  R, V: d×n; sigma, row_expo: d.
+ * Only R(i, j<=i) is meaningful to callers (the tail of a row is scratch in the reference too).
+ * ------------------------------------------------------------------------------------------ */
+int oracle_hh_update_all(int d, int n, const int64_t *b, int row_expo_on, double *R, double *V,
+                         double *sigma, int64_t *row_expo);
+
 #ifdef __cplusplus
 }
 #endif

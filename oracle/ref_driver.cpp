@@ -536,6 +536,53 @@ static int cmd_bkztour(int argc, char **argv)
   return (status == RED_SUCCESS || status == RED_BKZ_LOOPS_LIMIT) ? 0 : 1;
 }
 
+/* hhfix n k bits seed perturb row_expo → JSON: input basis (long) and the reference's Householder
+ * R-factor after refresh_R_bf() + update_R() (MatHouseholder<Z_NR<long>,FP_NR<double>>) */
+static int cmd_hhfix(int argc, char **argv)
+{
+  if (argc < 8)
+    return 2;
+  int n = atoi(argv[2]), k = atoi(argv[3]), bits = atoi(argv[4]), seed = atoi(argv[5]);
+  int perturb = atoi(argv[6]), rexp = atoi(argv[7]);
+  ZZ_mat<mpz_t> A;
+  make_basis(A, n, k, bits, seed, 0);
+  ZZ_mat<long> b(n, n), u, ut;
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j)
+      b(i, j) = A(i, j).get_si();
+  uint64_t lcg = 0x9E3779B97F4A7C15ull ^ (uint64_t)seed;
+  for (int i = 1; i < n && perturb > 0; ++i)
+    for (int t = 0; t < perturb; ++t)
+    {
+      lcg    = lcg * 6364136223846793005ull + 1442695040888963407ull;
+      int j  = (int)((lcg >> 33) % (uint64_t)i);
+      lcg    = lcg * 6364136223846793005ull + 1442695040888963407ull;
+      long c = (long)((lcg >> 33) % 7) - 3;
+      for (int col = 0; col < n; ++col)
+        b(i, col) = b(i, col).get_si() + c * b(j, col).get_si();
+    }
+  MatHouseholder<Z_NR<long>, FP_NR<double>> H(b, u, ut, rexp ? HOUSEHOLDER_ROW_EXPO : 0);
+  H.refresh_R_bf();
+  H.update_R();
+  std::ostringstream os;
+  os << "{\n\"desc\":\"qary n=" << n << " k=" << k << " bits=" << bits << " seed=" << seed
+     << " LLL then " << perturb << " row ops per row, row_expo=" << rexp << "\",\n\"d\":" << n
+     << ",\n\"n\":" << n << ",\n\"row_expo_on\":" << rexp << ",\n\"b_in\":[";
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j)
+      os << ((i || j) ? "," : "") << b(i, j).get_si();
+  os << "],\n";
+  vector<long> expo;
+  const Matrix<FP_NR<double>> &R = H.get_R(expo);
+  dump_mat_hex(os, "R", R, n, true);
+  os << "\"row_expo\":[";
+  for (int i = 0; i < n; ++i)
+    os << (i ? "," : "") << expo[i];
+  os << "]\n}\n";
+  std::cout << os.str();
+  return 0;
+}
+
 /* dumpbasis n k bits seed bkz_pre  → the reduced basis in fplll's text format on stdout */
 static int cmd_dumpbasis(int argc, char **argv)
 {
@@ -563,6 +610,8 @@ int main(int argc, char **argv)
     return cmd_dumpbasis(argc, argv);
   if (cmd == "gsofix")
     return cmd_gsofix(argc, argv);
+  if (cmd == "hhfix")
+    return cmd_hhfix(argc, argv);
   if (cmd == "genstrat")
     return cmd_genstrat(argc, argv);
   if (cmd == "bkztour")

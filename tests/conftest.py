@@ -197,3 +197,34 @@ class OracleGSO:
             self.close()
         except Exception:
             pass
+
+
+# ---- Householder oracle wrappers ----------------------------------------------------------------
+def hh_fixtures():
+    return sorted(glob.glob(os.path.join(GOLDEN, "hh_*.json")))
+
+
+def load_hh_fixture(path):
+    with open(path) as f:
+        j = json.load(f)
+    d, n = j["d"], j["n"]
+    return {"d": d, "n": n, "name": os.path.basename(path)[:-5], "row_expo_on": j["row_expo_on"],
+            "b_in": np.array(j["b_in"], dtype=np.int64).reshape(d, n),
+            "R": hexvec(j["R"]).reshape(d, d), "row_expo": np.array(j["row_expo"], dtype=np.int64)}
+
+
+def oracle_hh_update_all(b, row_expo_on):
+    """oracle/hh_oracle.c: returns (R d×n, V d×n, sigma d, row_expo d)."""
+    lib = oracle_lib()
+    b = np.ascontiguousarray(b, dtype=np.int64)
+    d, n = b.shape
+    R = np.zeros((d, n))
+    V = np.zeros((d, n))
+    sigma = np.zeros(d)
+    rexp = np.zeros(d, dtype=np.int64)
+    lib.oracle_hh_update_all.argtypes = [ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] + \
+        [ctypes.c_int] + [ctypes.c_void_p] * 4
+    lib.oracle_hh_update_all(d, n, b.ctypes.data_as(ctypes.c_void_p), int(row_expo_on),
+                             R.ctypes.data_as(ctypes.c_void_p), V.ctypes.data_as(ctypes.c_void_p),
+                             sigma.ctypes.data_as(ctypes.c_void_p), rexp.ctypes.data_as(ctypes.c_void_p))
+    return R, V, sigma, rexp
