@@ -179,28 +179,66 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK)
     FPHIP_REFRESH_BOUND((t & 63u) == 0u);
 
     // the task root is a surviving node at level Lt whose column and distance are given
-    int k      = Lt;
-    double S   = col0;  // S_k of the current node (rows < k valid)
-    double nd  = pd0;   // its distance
-    bool child = true;  // state: CHILD (true) or STEP (false)
+    int k     = Lt;
+    double S  = col0;  // S_k of the current node (rows < k valid)
+    double nd = pd0;   // its distance
 
-    for (;;)
+    // Reports a candidate (process_solution) and waits for the host's verdict, like enumlib's
+    // mutex-protected process_sol (enumeration.h:286-299).
+    auto report = [&](double dist)
     {
-      k = __builtin_amdgcn_readfirstlane(k);
-      if (child)
+      unsigned long long idx = 0;
+      if (lane == 0)
+        idx = atomicAdd(&g->sol_head, 1ull);
+      idx = rfl_u64(idx);
+      for (unsigned spin = 0; idx >= load_sys_u64(&h->consumed) + FPHIP_RING_CAP; ++spin)
+      {  // flow control against the host consumer
+        __builtin_amdgcn_s_sleep(64);
+        if (spin > (1u << 24))
+        {
+          if (lane == 0)
+            atomicOr(&g->error_flags, FPHIP_ERR_RING_TIMEOUT);
+          break;
+        }
+      }
+      SolRec *r  = &h->ring[idx % FPHIP_RING_CAP];
+      double xf  = (lane < Lt) ? xs : xpre;
+      r->x[lane] = (lane < d) ? xf : 0.0;
+      if (lane == 0)
+        r->dist = dist;
+      __threadfence_system();
+      if (lane == 0)
+        __hip_atomic_store(&r->seq, idx + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      for (unsigned spin = 0; load_sys_u64(&h->consumed) <= idx; ++spin)
       {
-        // ---------------- CHILD(k, S, nd): peek at the first child ----------------------------
+        __builtin_amdgcn_s_sleep(32);
+        if (spin > (1u << 24))
+        {
+          if (lane == 0)
+            atomicOr(&g->error_flags, FPHIP_ERR_RING_TIMEOUT);
+          break;
+        }
+      }
+      FPHIP_REFRESH_BOUND(true);
+    };
+
+    bool done = false;
+    while (!done)
+    {
+      // ================= CHILD chain: descend while the first child survives ====================
+      // (state: a surviving, already counted node at level k with column S = S_k, distance nd)
+      for (;;)
+      {
+        k               = __builtin_amdgcn_readfirstlane(k);
         const int kc    = k - 1;
         const double c1 = rl_f64(S, kc);  // center[kk-1] = center_partsums[kk-1][kk]
         const double x1 = round(c1);      // roundto(): half away from zero, enumerate_base.h:33-34
         const double a1 = x1 - c1;
         const double n1 = nd + a1 * a1 * rl_f64(rd, kc);  // :28-29
         if (!(n1 <= rl_f64(bnd, kc)))
-        {  // :31-32 the child level is empty: next sibling at level k (or done, at the root)
-          child = false;
-          if (k >= Lt)
-            break;
-          continue;
+        {  // :31-32 no surviving child: next sibling at level k (the root has none: task done)
+          done = k >= Lt;
+          break;
         }
         if ((k == stop || k >= donate) && k < Lt)
         {  // hand the subtree below this node to the next launch
@@ -218,8 +256,7 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK)
               out.pd[oi]    = nd;
               out.level[oi] = k;
             }
-            child = false;
-            continue;
+            break;  // → next sibling at level k
           }
           // buffer full: keep walking this subtree inline (results stay exact)
           if (lane == 0)
@@ -243,33 +280,32 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK)
         if (k == 0)
         {
           if (nd > 0.0)
-            goto report_solution;  // process_solution, :42-46
-          child = false;
-          continue;
+            report(nd);  // process_solution, :42-46
+          break;         // level 0 has no children: next sibling
         }
+        const double mk = (lane < k) ? mu_s[tri_off(k) + lane] : 0.0;
+        S               = S - x1 * mk;  // S_k = S_{k+1} - x[k]*mu(k,·), :53-58
+      }
+      if (done)
+        break;
+      // ================= STEP loop: next sibling at level k, climbing while they fail ===========
+      for (;;)
+      {
+        k = __builtin_amdgcn_readfirstlane(k);
+        ++titer;
+        if (((++iter) & 63u) == 0u)
         {
-          const double mk = (lane < k) ? mu_s[tri_off(k) + lane] : 0.0;
-          S               = S - x1 * mk;  // S_k = S_{k+1} - x[k]*mu(k,·), :53-58
+          FPHIP_REFRESH_BOUND((iter & 16383u) == 0u);
+          if (budget != 0u && titer >= 256u)
+          {  // work donation: once the task queue has run dry (other waves are idle), or this task
+             // exceeded its budget, keep only the subtree below the current level and emit every
+             // sibling subtree above it as a task for the next launch
+            const unsigned dr = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(
+                &g->drain[launch_idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            if (dr != 0u || titer >= budget)
+              donate = min(donate, k + 1);
+          }
         }
-        continue;
-      }
-
-      // ---------------- STEP(k): next sibling at level k ---------------------------------------
-      ++titer;
-      if (((++iter) & 63u) == 0u)
-      {
-        FPHIP_REFRESH_BOUND((iter & 16383u) == 0u);
-        if (budget != 0u && titer >= 256u)
-        {  // work donation: once the task queue has run dry (other waves are idle), or this task
-           // exceeded its budget, keep only the subtree below the current level and emit every
-           // sibling subtree above it as a task for the next launch
-          const unsigned dr = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(
-              &g->drain[launch_idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-          if (dr != 0u || titer >= budget)
-            donate = min(donate, k + 1);
-        }
-      }
-      {
         // speculative loads for the surviving case (LDS latency overlaps the test)
         const double par = (lane <= k) ? stk[tri_off(k + 1) + lane] : 0.0;  // S_{k+1}
         const double mk  = (lane < k) ? mu_s[tri_off(k) + lane] : 0.0;
@@ -297,62 +333,22 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK)
         {  // :93-94 → the parent steps to its next sibling
           ++k;
           if (k >= Lt)
+          {
+            done = true;
             break;
+          }
           continue;
         }
         cnt += me ? 1ull : 0ull;  // ++nodes[kk]
         if (k == 0)
         {
           if (nd > 0.0)
-            goto report_solution;  // :97-101
+            report(nd);  // :97-101
           continue;
         }
-        S     = par - xk * mk;  // :104-110
-        child = true;
-        continue;
+        S = par - xk * mk;  // :104-110
+        break;              // → CHILD chain
       }
-
-    report_solution:
-    {
-      unsigned long long idx = 0;
-      if (lane == 0)
-        idx = atomicAdd(&g->sol_head, 1ull);
-      idx = rfl_u64(idx);
-      // flow control against the host consumer
-      for (unsigned spin = 0; idx >= load_sys_u64(&h->consumed) + FPHIP_RING_CAP; ++spin)
-      {
-        __builtin_amdgcn_s_sleep(64);
-        if (spin > (1u << 24))
-        {
-          if (lane == 0)
-            atomicOr(&g->error_flags, FPHIP_ERR_RING_TIMEOUT);
-          break;
-        }
-      }
-      SolRec *r  = &h->ring[idx % FPHIP_RING_CAP];
-      double xf  = (lane < Lt) ? xs : xpre;
-      r->x[lane] = (lane < d) ? xf : 0.0;
-      if (lane == 0)
-        r->dist = nd;
-      __threadfence_system();
-      if (lane == 0)
-        __hip_atomic_store(&r->seq, idx + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-      // wait for the host's verdict (enumlib processes solutions synchronously too,
-      // enumeration.h:286-299) so that this wave continues with the updated bound
-      for (unsigned spin = 0; load_sys_u64(&h->consumed) <= idx; ++spin)
-      {
-        __builtin_amdgcn_s_sleep(32);
-        if (spin > (1u << 24))
-        {
-          if (lane == 0)
-            atomicOr(&g->error_flags, FPHIP_ERR_RING_TIMEOUT);
-          break;
-        }
-      }
-      FPHIP_REFRESH_BOUND(true);
-      child = false;  // level 0 has no children: next sibling
-      continue;
-    }
     }
   }
 #undef FPHIP_REFRESH_BOUND
