@@ -283,7 +283,7 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK)
             report(nd);  // process_solution, :42-46
           break;         // level 0 has no children: next sibling
         }
-        const double mk = (lane < k) ? mu_s[tri_off(k) + lane] : 0.0;
+        const double mk = mu_s[tri_off(k) + min(lane, k - 1)];  // k >= 1 here
         S               = S - x1 * mk;  // S_k = S_{k+1} - x[k]*mu(k,·), :53-58
       }
       if (done)
@@ -306,9 +306,10 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK)
               donate = min(donate, k + 1);
           }
         }
-        // speculative loads for the surviving case (LDS latency overlaps the test)
-        const double par = (lane <= k) ? stk[tri_off(k + 1) + lane] : 0.0;  // S_{k+1}
-        const double mk  = (lane < k) ? mu_s[tri_off(k) + lane] : 0.0;
+        // speculative loads for the surviving case (LDS latency overlaps the test); lanes beyond
+        // the row read a clamped (valid, unused) address so that no exec-mask branch is needed
+        const double par = stk[tri_off(k + 1) + min(lane, k)];              // S_{k+1}
+        const double mk  = mu_s[tri_off(k) + max(min(lane, k - 1), 0)];
         double xk        = rl_f64(xs, k);
         const double ck  = rl_f64(cs, k);
         const double pdk = rl_f64(pds, k);
