@@ -20,8 +20,10 @@
 #include "../../include/fplll_hip.h"
 #include "enum_device.h"
 
+
 namespace fphip
 {
+template <bool MU_LDS>
 __global__ void enum_phase_kernel(DevShared *g, HostCtl *h, TaskBuf in, TaskBuf out, int d,
                                   int Lmax, int stop, unsigned task_lo, unsigned task_hi,
                                   unsigned shard_idx, unsigned shard_cnt, int launch_idx,
@@ -120,7 +122,9 @@ extern "C" int fphip_create(int device, fphip_ctx **out)
     HIPCHK(ctx, hipMalloc((void **)&ctx->buf[b].count, 64));
     ctx->buf[b].cap = ctx->cap;
   }
-  HIPCHK(ctx, hipFuncSetAttribute((const void *)enum_phase_kernel,
+  HIPCHK(ctx, hipFuncSetAttribute((const void *)enum_phase_kernel<true>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(ctx, hipFuncSetAttribute((const void *)enum_phase_kernel<false>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   return FPHIP_OK;
 }
@@ -386,7 +390,12 @@ extern "C" int fphip_enum_run(fphip_ctx *ctx, int dim, double maxdist, const dou
     }
     const int wpb     = (in_final && C >= 1024) ? wpb_final : 1;
     const int triL    = L * (L + 1) / 2;
-    const size_t lds  = (size_t)(wpb + 1) * triL * sizeof(double);
+    // big walk launches read mu through L1 and spend the LDS on more resident waves
+    // (only where the LDS limits residency the most — tall stacks — and the launch is large;
+    // measured +7 % on a 10^9-node tree with L = 49, but -5..10 % on 3 M-node trees with L = 44)
+    const bool mu_lds = C < (unsigned)env_int("FPHIP_MU_GLOBAL_MIN_TASKS", 8192) ||
+                        L < env_int("FPHIP_MU_GLOBAL_MIN_LEVEL", 47);
+    const size_t lds  = (size_t)(wpb + (mu_lds ? 1 : 0)) * triL * sizeof(double);
     if (lds > 160 * 1024)
       return fail(ctx, "LDS request too large (%zu)", lds);
     int blocks_per_cu = (int)std::max<size_t>(1, std::min<size_t>(32 / wpb, (160 * 1024) / lds));
@@ -415,10 +424,15 @@ extern "C" int fphip_enum_run(fphip_ctx *ctx, int dim, double maxdist, const dou
       if (hi > lo)
       {
         HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-        hipLaunchKernelGGL(enum_phase_kernel, dim3(grid), dim3(wpb * 64), lds, ctx->stream, ctx->g,
-                           ctx->h, ctx->buf[cur], ctx->buf[nxt], d, L, stop, lo, hi, sidx, scnt,
-                           launch_idx, count_nodes,
-                           (in_final && round < max_rounds) ? budget : 0u);
+        const unsigned bud = (in_final && round < max_rounds) ? budget : 0u;
+        if (mu_lds)
+          hipLaunchKernelGGL(enum_phase_kernel<true>, dim3(grid), dim3(wpb * 64), lds, ctx->stream,
+                             ctx->g, ctx->h, ctx->buf[cur], ctx->buf[nxt], d, L, stop, lo, hi, sidx,
+                             scnt, launch_idx, count_nodes, bud);
+        else
+          hipLaunchKernelGGL(enum_phase_kernel<false>, dim3(grid), dim3(wpb * 64), lds, ctx->stream,
+                             ctx->g, ctx->h, ctx->buf[cur], ctx->buf[nxt], d, L, stop, lo, hi, sidx,
+                             scnt, launch_idx, count_nodes, bud);
         HIPCHK(ctx, hipGetLastError());
         HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
         ++launch_idx;

@@ -41,6 +41,7 @@
 
 #include "enum_device.h"
 
+
 namespace fphip
 {
 
@@ -84,6 +85,7 @@ __device__ __forceinline__ unsigned long long load_sys_u64(const unsigned long l
 //       loop in CHILD with the child as the current node.
 //   STEP(k): the subtree below the current coefficient x[k] is exhausted — advance x[k] in
 //       zig-zag order (:80-89), test (:91-94): fail → STEP(k+1), survive → CHILD.
+template <bool MU_LDS>
 __global__ void __launch_bounds__(FPHIP_MAX_BLOCK)
     enum_phase_kernel(DevShared *__restrict__ g, HostCtl *__restrict__ h, TaskBuf in, TaskBuf out,
                       int d, int Lmax, int stop, unsigned task_lo, unsigned task_hi,
@@ -94,15 +96,27 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK)
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int triL = (Lmax * (Lmax + 1)) >> 1;  // doubles for slots 1..Lmax
-  double *mu_s   = smem;                       // mu rows 1..Lmax-1, packed like slots
-  double *stk    = smem + triL + wave * triL;
-
+  // mu rows 1..Lmax-1 (packed like the stack slots).  MU_LDS: one copy per workgroup in LDS (lowest
+  // latency: split launches and tails, where few waves run).  !MU_LDS: read straight from global
+  // memory — <= 16 KB, read-only, L1-resident after the first touches — so that the LDS buys
+  // more resident waves (the big walk launch, where throughput matters).
+  const double *mu_s;
+  double *stk;
+  if constexpr (MU_LDS)
   {
+    double *mu_l = smem;
+    stk          = smem + triL + wave * triL;
     const int nmu = (Lmax * (Lmax - 1)) >> 1;
     for (int i = threadIdx.x; i < nmu; i += blockDim.x)
-      mu_s[i] = g->mu_tri[i];
+      mu_l[i] = g->mu_tri[i];
+    __syncthreads();
+    mu_s = mu_l;
   }
-  __syncthreads();
+  else
+  {
+    mu_s = g->mu_tri;
+    stk  = smem + wave * triL;
+  }
 
   const double rd = g->rdiag[lane];
   const double pr = g->pruning[lane];
@@ -359,5 +373,10 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK)
   if (lane == 0)
     atomicAdd(&g->iters, (unsigned long long)iter);
 }
+
+template __global__ void enum_phase_kernel<true>(DevShared *, HostCtl *, TaskBuf, TaskBuf, int, int, int,
+                                                 unsigned, unsigned, unsigned, unsigned, int, int, unsigned);
+template __global__ void enum_phase_kernel<false>(DevShared *, HostCtl *, TaskBuf, TaskBuf, int, int, int,
+                                                  unsigned, unsigned, unsigned, unsigned, int, int, unsigned);
 
 }  // namespace fphip
