@@ -449,9 +449,9 @@ extern "C" int fphip_enum_run(fphip_ctx *ctx, int dim, double maxdist, const dou
           unsigned long long it = 0;
           hipMemcpy(&it, &ctx->g->iters, 8, hipMemcpyDeviceToHost);
           fprintf(stderr,
-                  "[fphip] launch %d %s tasks [%u,%u) L=%d stop=%d budget=%u grid=%u wpb=%d lds=%zu "
+                  "[fphip s%d] launch %d %s tasks [%u,%u) L=%d stop=%d budget=%u grid=%u wpb=%d lds=%zu "
                   "-> %.3f ms, iters so far %llu\n",
-                  launch_idx - 1, in_final ? "walk" : "split", lo, hi, L, stop,
+                  o.shard_index, launch_idx - 1, in_final ? "walk" : "split", lo, hi, L, stop,
                   in_final ? budget : 0u, grid, wpb, lds, ms, it);
         }
       }
@@ -467,7 +467,15 @@ extern "C" int fphip_enum_run(fphip_ctx *ctx, int dim, double maxdist, const dou
     }
     ++launches;
     unsigned cnt = 0;
-    HIPCHK(ctx, hipMemcpy(&cnt, ctx->buf[nxt].count, 4, hipMemcpyDeviceToHost));
+    if (C > 0)
+    {
+      // The count was zeroed with a memset on OUR stream; a plain hipMemcpy runs on the null stream,
+      // which does not order against a non-blocking stream — it is only safe because every launch
+      // above was waited for.  Make that explicit (an idle multi-GPU iteration launches nothing:
+      // reading the count there returned the stale value of two rounds ago and re-ran old tasks).
+      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+      HIPCHK(ctx, hipMemcpy(&cnt, ctx->buf[nxt].count, 4, hipMemcpyDeviceToHost));
+    }
     if (cnt > ctx->cap)
       cnt = ctx->cap;
     if (in_final && o.exchange)

@@ -1,0 +1,71 @@
+"""Two ranks (two processes, gloo collectives) sharing ONE GPU run the sharded enumeration exactly
+as bench.py --gpus 2 does: content-hash partition of the subtree tasks + bound/active all-reduce at
+every chunk and round boundary.  With a radius that never shrinks the ranks' per-level node counts
+must add up to the reference's counts — disjoint and complete — and the collective must terminate
+(same number of exchange calls on every rank)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+import conftest as C
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, fixture, q):
+    import torch.distributed as dist
+    import fplll_amd
+    from fplll_amd.distributed import make_exchange
+    from fplll_amd.enumeration import FastEvaluator, enumerate_block
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    f = C.load_fixture(fixture)
+    ctx = fplll_amd.Context(0)
+    calls = [0]
+    ex0 = make_exchange(dist, "cpu")
+
+    def ex(b, a):
+        calls[0] += 1
+        return ex0(b, a)
+
+    ev = FastEvaluator(f["max_sols"], f["strategy"])
+    res = enumerate_block(ctx, f["mut"], f["rdiag"], f["pruning"], f["maxdist"], ev,
+                          shard_index=rank, shard_count=world, exchange=ex, exchange_chunks=3)
+    q.put((rank, [int(v) for v in res.nodes], calls[0], len(ev.solutions),
+           (res.stats.phases, res.stats.final_tasks, res.stats.final_root_level, res.stats.overflowed)))
+    dist.barrier()
+    ctx.close()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_partition_the_tree():
+    import torch.multiprocessing as mp
+    fixture = os.path.join(C.GOLDEN, "enum_d48_lin30_fixed.json")
+    f = C.load_fixture(fixture)
+    mpctx = mp.get_context("spawn")
+    q = mpctx.Queue()
+    port = _free_port()
+    ps = [mpctx.Process(target=_worker, args=(r, 2, port, fixture, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    out = [q.get(timeout=300) for _ in range(2)]
+    for p in ps:
+        p.join(120)
+        assert p.exitcode == 0
+    out.sort()
+    tot = np.array(out[0][1]) + np.array(out[1][1])
+    diff = [(k, int(a) - b) for k, (a, b) in enumerate(zip(tot, f["nodes"])) if int(a) != b]
+    assert not diff, (str(diff), out[0][2], out[1][2], out[0][4], out[1][4])
+    assert min(sum(out[0][1]), sum(out[1][1])) > 0.2 * f["total_nodes"]  # both ranks did real work
+    assert out[0][2] == out[1][2] >= 3  # identical collective call counts
