@@ -26,8 +26,9 @@ namespace fphip
 template <bool MU_LDS>
 __global__ void enum_phase_kernel(DevShared *g, HostCtl *h, TaskBuf in, TaskBuf out, int d,
                                   int Lmax, int stop, unsigned task_lo, unsigned task_hi,
-                                  unsigned shard_idx, unsigned shard_cnt, int launch_idx,
-                                  int count_nodes, unsigned budget);
+                                  const unsigned *idxlist, int launch_idx, int count_nodes,
+                                  unsigned budget);
+__global__ void task_key_kernel(TaskBuf in, unsigned n, int d, unsigned long long *keys);
 }
 using namespace fphip;
 
@@ -43,6 +44,8 @@ struct fphip_ctx
   TaskBuf buf[2];
   unsigned cap                 = 0;
   unsigned long long ring_next = 0;
+  unsigned long long *keys     = nullptr;  // device: content key per task (multi-GPU partition)
+  unsigned *idxlist            = nullptr;  // device: this rank's task indices, heaviest first
   char err[512]                = {0};
   // GSO state lives in gso_host.hip, linked through this opaque slot
   void *gso = nullptr;
@@ -122,6 +125,8 @@ extern "C" int fphip_create(int device, fphip_ctx **out)
     HIPCHK(ctx, hipMalloc((void **)&ctx->buf[b].count, 64));
     ctx->buf[b].cap = ctx->cap;
   }
+  HIPCHK(ctx, hipMalloc((void **)&ctx->keys, (size_t)ctx->cap * sizeof(unsigned long long)));
+  HIPCHK(ctx, hipMalloc((void **)&ctx->idxlist, (size_t)ctx->cap * sizeof(unsigned)));
   HIPCHK(ctx, hipFuncSetAttribute((const void *)enum_phase_kernel<true>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(ctx, hipFuncSetAttribute((const void *)enum_phase_kernel<false>,
@@ -151,6 +156,10 @@ extern "C" void fphip_destroy(fphip_ctx *ctx)
     if (ctx->buf[b].count)
       hipFree(ctx->buf[b].count);
   }
+  if (ctx->keys)
+    hipFree(ctx->keys);
+  if (ctx->idxlist)
+    hipFree(ctx->idxlist);
   if (ctx->g)
     hipFree(ctx->g);
   if (ctx->stage)
@@ -401,20 +410,60 @@ extern "C" int fphip_enum_run(fphip_ctx *ctx, int dim, double maxdist, const dou
     int blocks_per_cu = (int)std::max<size_t>(1, std::min<size_t>(32 / wpb, (160 * 1024) / lds));
     const int nxt     = cur ^ 1;
     // only the first final round is sharded across GPUs; donated tasks stay on their GPU
-    const bool shard_now  = in_final && round == 0;
-    const int chunks      = shard_now ? o.exchange_chunks : 1;
-    const unsigned sidx   = shard_now ? (unsigned)o.shard_index : 0u;
-    const unsigned scnt   = shard_now ? (unsigned)o.shard_count : 1u;
+    const bool shard_now = in_final && round == 0 && o.shard_count > 1;
+    const int chunks     = (in_final && round == 0) ? o.exchange_chunks : 1;
+    const unsigned *idxl = nullptr;
+    unsigned n_list      = C;  // number of tasks this rank walks in this round
+    if (shard_now)
+    {
+      // Partition by CONTENT, weight-aware: every rank holds the same task set (in its own
+      // order).  Sort by (partial distance of the root, 64-bit key of the coefficient prefix) — a
+      // total order that depends only on content; smaller partial distance = larger remaining
+      // radius = heavier subtree — and deal the sorted list to the ranks in snake order.  The
+      // shares are disjoint, complete and of nearly equal weight, and each rank walks its share
+      // heaviest-first.
+      const unsigned kgrid = std::min<unsigned>((C + 3) / 4, (unsigned)ctx->num_cus * 8u);
+      hipLaunchKernelGGL(task_key_kernel, dim3(kgrid ? kgrid : 1), dim3(256), 0, ctx->stream,
+                         ctx->buf[cur], C, d, ctx->keys);
+      HIPCHK(ctx, hipGetLastError());
+      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+      std::vector<unsigned long long> keys(C);
+      std::vector<double> pds(C);
+      HIPCHK(ctx, hipMemcpy(keys.data(), ctx->keys, (size_t)C * 8, hipMemcpyDeviceToHost));
+      HIPCHK(ctx, hipMemcpy(pds.data(), ctx->buf[cur].pd, (size_t)C * 8, hipMemcpyDeviceToHost));
+      std::vector<unsigned> order(C);
+      for (unsigned i = 0; i < C; ++i)
+        order[i] = i;
+      std::sort(order.begin(), order.end(), [&](unsigned a, unsigned b) {
+        if (pds[a] != pds[b])
+          return pds[a] < pds[b];
+        return keys[a] < keys[b];
+      });
+      std::vector<unsigned> mine;
+      mine.reserve(C / o.shard_count + 2);
+      const unsigned W = (unsigned)o.shard_count;
+      for (unsigned p = 0; p < C; ++p)
+      {
+        const unsigned r = p % (2 * W);
+        const unsigned owner = r < W ? r : 2 * W - 1 - r;  // snake: 0..W-1, W-1..0
+        if (owner == (unsigned)o.shard_index)
+          mine.push_back(order[p]);
+      }
+      n_list = (unsigned)mine.size();
+      if (n_list)
+        HIPCHK(ctx, hipMemcpy(ctx->idxlist, mine.data(), (size_t)n_list * 4, hipMemcpyHostToDevice));
+      idxl = ctx->idxlist;
+    }
     const int count_nodes = (in_final || o.shard_index == 0) ? 1 : 0;
     HIPCHK(ctx, hipMemsetAsync(ctx->buf[nxt].count, 0, 4, ctx->stream));
 
     for (int ch = 0; ch < chunks; ++ch)
     {
-      unsigned lo = (unsigned)(((unsigned long long)C * ch) / chunks);
-      unsigned hi = (unsigned)(((unsigned long long)C * (ch + 1)) / chunks);
+      unsigned lo = (unsigned)(((unsigned long long)n_list * ch) / chunks);
+      unsigned hi = (unsigned)(((unsigned long long)n_list * (ch + 1)) / chunks);
       if (hi <= lo && !(in_final && o.exchange))
         continue;
-      unsigned mine = hi - lo;  // every rank scans the whole list and keeps its residue class
+      unsigned mine = hi - lo;
       unsigned grid = std::min<unsigned>((mine + wpb - 1) / wpb,
                                          (unsigned)(ctx->num_cus * blocks_per_cu));
       if (grid == 0)
@@ -427,12 +476,12 @@ extern "C" int fphip_enum_run(fphip_ctx *ctx, int dim, double maxdist, const dou
         const unsigned bud = (in_final && round < max_rounds) ? budget : 0u;
         if (mu_lds)
           hipLaunchKernelGGL(enum_phase_kernel<true>, dim3(grid), dim3(wpb * 64), lds, ctx->stream,
-                             ctx->g, ctx->h, ctx->buf[cur], ctx->buf[nxt], d, L, stop, lo, hi, sidx,
-                             scnt, launch_idx, count_nodes, bud);
+                             ctx->g, ctx->h, ctx->buf[cur], ctx->buf[nxt], d, L, stop, lo, hi, idxl,
+                             launch_idx, count_nodes, bud);
         else
           hipLaunchKernelGGL(enum_phase_kernel<false>, dim3(grid), dim3(wpb * 64), lds, ctx->stream,
-                             ctx->g, ctx->h, ctx->buf[cur], ctx->buf[nxt], d, L, stop, lo, hi, sidx,
-                             scnt, launch_idx, count_nodes, bud);
+                             ctx->g, ctx->h, ctx->buf[cur], ctx->buf[nxt], d, L, stop, lo, hi, idxl,
+                             launch_idx, count_nodes, bud);
         HIPCHK(ctx, hipGetLastError());
         HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
         ++launch_idx;

@@ -89,7 +89,7 @@ template <bool MU_LDS>
 __global__ void __launch_bounds__(FPHIP_MAX_BLOCK)
     enum_phase_kernel(DevShared *__restrict__ g, HostCtl *__restrict__ h, TaskBuf in, TaskBuf out,
                       int d, int Lmax, int stop, unsigned task_lo, unsigned task_hi,
-                      unsigned shard_idx, unsigned shard_cnt, int launch_idx, int count_nodes,
+                      const unsigned *__restrict__ idxlist, int launch_idx, int count_nodes,
                       unsigned budget)
 {
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -162,30 +162,20 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK)
     if (lane == 0)
       t = atomicAdd(&g->task_head[launch_idx], 1u);
     t = (unsigned)__builtin_amdgcn_readfirstlane((int)t);
-    const unsigned long long ti = (unsigned long long)task_lo + t;
-    if (ti >= task_hi)
+    const unsigned long long pos = (unsigned long long)task_lo + t;
+    if (pos >= task_hi)
     {  // queue empty: tell the waves still walking to shed work for the next launch
       if (budget != 0u && lane == 0)
         __hip_atomic_store(&g->drain[launch_idx], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       break;
     }
 
+    // multi-GPU: this rank's share of the task list is an explicit index list (built on the host
+    // from a content-sorted order, see enum_host.hip), walked heaviest-first
+    const unsigned long long ti =
+        idxlist ? (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)idxlist[pos]) : pos;
     const int Lt      = __builtin_amdgcn_readfirstlane(in.level[ti]);  // root level of this task
     const double xpre = in.x[ti * 64 + lane];                          // coefficients of levels >= Lt
-    if (shard_cnt > 1u)
-    {  // multi-GPU partition by task CONTENT (the order of tasks in the buffer is not
-       // deterministic, their coefficient prefixes are): every rank walks the same task list
-       // and keeps the tasks whose prefix hash falls in its residue class
-      unsigned hsh = (lane >= Lt && lane < d)
-                         ? (unsigned)(int)xpre * (2654435761u * (unsigned)(lane + 1))
-                         : 0u;
-      for (int off = 32; off > 0; off >>= 1)
-        hsh += (unsigned)__shfl_xor((int)hsh, off);
-      hsh = (unsigned)__builtin_amdgcn_readfirstlane((int)hsh);
-      hsh ^= hsh >> 15;
-      if (hsh % shard_cnt != shard_idx)
-        continue;
-    }
     const double col0 = in.col[ti * 64 + lane];  // S_Lt rows (lane < Lt)
     const double pd0  = in.pd[ti];
     int donate        = 1 << 20;
@@ -375,8 +365,33 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK)
 }
 
 template __global__ void enum_phase_kernel<true>(DevShared *, HostCtl *, TaskBuf, TaskBuf, int, int, int,
-                                                 unsigned, unsigned, unsigned, unsigned, int, int, unsigned);
+                                                 unsigned, unsigned, const unsigned *, int, int, unsigned);
 template __global__ void enum_phase_kernel<false>(DevShared *, HostCtl *, TaskBuf, TaskBuf, int, int, int,
-                                                  unsigned, unsigned, unsigned, unsigned, int, int, unsigned);
+                                                  unsigned, unsigned, const unsigned *, int, int, unsigned);
+
+// 64-bit content key of every task (its coefficient prefix x[Lt..d)): the task ORDER in the buffer
+// is not deterministic across ranks, the content is.  One wave per task.
+__global__ void __launch_bounds__(256)
+    task_key_kernel(TaskBuf in, unsigned n, int d, unsigned long long *__restrict__ keys)
+{
+  const int lane = threadIdx.x & 63;
+  const unsigned w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const unsigned nw = (gridDim.x * blockDim.x) >> 6;
+  for (unsigned ti = w; ti < n; ti += nw)
+  {
+    const int Lt      = in.level[ti];
+    const double xpre = in.x[(unsigned long long)ti * 64 + lane];
+    const bool on     = lane >= Lt && lane < d;
+    unsigned h1 = on ? (unsigned)(int)xpre * (2654435761u * (unsigned)(lane + 1)) : 0u;
+    unsigned h2 = on ? ((unsigned)(int)xpre ^ 0x9e3779b9u) * (40503u * (unsigned)(2 * lane + 3) + 2246822519u) : 0u;
+    for (int off = 32; off > 0; off >>= 1)
+    {
+      h1 += (unsigned)__shfl_xor((int)h1, off);
+      h2 += (unsigned)__shfl_xor((int)h2, off);
+    }
+    if (lane == 0)
+      keys[ti] = ((unsigned long long)h1 << 32) | h2;
+  }
+}
 
 }  // namespace fphip

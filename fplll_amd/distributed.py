@@ -26,16 +26,31 @@ def make_exchange(dist, device="cpu"):
     return exchange
 
 
-def task_shard(prefix, root_level, d, shard_count):
-    """The content hash enum_kernel.hip uses to assign a subtree task to a rank: computed from the
-    coefficient prefix x[root_level..d) only, so every rank derives the same owner whatever the
-    order of the task in its buffer.  (Python restatement for the CPU tests.)"""
-    h = 0
+def task_key(prefix, root_level, d):
+    """64-bit content key of a subtree task (task_key_kernel in enum_kernel.hip): computed from the
+    coefficient prefix x[root_level..d) only, so every rank derives the same key whatever the
+    position of the task in its buffer.  (Python restatement for the CPU tests.)"""
+    M = 0xFFFFFFFF
+    h1 = h2 = 0
     for lane in range(root_level, d):
-        x = int(prefix[lane]) & 0xFFFFFFFF
-        h = (h + x * ((2654435761 * (lane + 1)) & 0xFFFFFFFF)) & 0xFFFFFFFF
-    h ^= h >> 15
-    return h % shard_count
+        x = int(prefix[lane]) & M
+        h1 = (h1 + x * ((2654435761 * (lane + 1)) & M)) & M
+        h2 = (h2 + (x ^ 0x9E3779B9) * ((40503 * (2 * lane + 3) + 2246822519) & M)) & M
+    return (h1 << 32) | h2
+
+
+def partition_tasks(partdists, keys, shard_count):
+    """The rule fphip_enum_run uses to deal subtree tasks to ranks (enum_host.hip, first walk
+    round): sort by (partial distance of the root ascending = heaviest subtree first, content key),
+    then deal the sorted list in snake order 0..W-1,W-1..0.  Returns, per rank, the list of task
+    indices in walking order.  Depends on task CONTENT only."""
+    order = sorted(range(len(keys)), key=lambda i: (partdists[i], keys[i]))
+    W = shard_count
+    shares = [[] for _ in range(W)]
+    for p, i in enumerate(order):
+        r = p % (2 * W)
+        shares[r if r < W else 2 * W - 1 - r].append(i)
+    return shares
 
 
 def run_rounds(exchange, rounds_local, bound0):

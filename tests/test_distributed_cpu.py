@@ -1,6 +1,6 @@
 """World-size-2 tests of the multi-GPU glue on CPU (gloo): the bound/active all-reduce, the
 termination consensus of the round protocol (every rank makes the same number of collective
-calls even when their round counts differ) and the content-hash partition (disjoint + complete,
+calls even when their round counts differ) and the content partition (disjoint + complete,
 independent of task order)."""
 import os
 import socket
@@ -54,21 +54,31 @@ def test_exchange_and_round_consensus_world2():
     assert res[0][2] == res[1][2] == 5    # same number of collective calls on every rank
 
 
-def test_content_hash_partition_is_order_independent():
-    from fplll_amd.distributed import task_shard
+def test_content_partition_is_order_independent():
+    from fplll_amd.distributed import task_key, partition_tasks
     rng = np.random.default_rng(0)
     d, L = 60, 35
     tasks = [rng.integers(-3, 4, size=d) for _ in range(5000)]
+    pds = rng.random(5000).round(2)   # many exact ties: the key must break them
+    keys = [task_key(t, L, d) for t in tasks]
+    assert len(set(keys)) == len(keys)
+    # coefficients below the root level do not matter
+    t2 = tasks[0].copy()
+    t2[:L] = 99
+    assert task_key(t2, L, d) == keys[0]
     for world in (2, 4, 8):
-        owner = [task_shard(t, L, d, world) for t in tasks]
-        # complete and disjoint by construction; reasonably balanced
-        counts = np.bincount(owner, minlength=world)
-        assert counts.sum() == len(tasks)
-        assert counts.min() > 0.7 * len(tasks) / world
-        # a permuted task list gives every task the same owner
+        shares = partition_tasks(pds, keys, world)
+        flat = sorted(i for s in shares for i in s)
+        assert flat == list(range(len(tasks)))                   # complete and disjoint
+        assert max(len(s) for s in shares) - min(len(s) for s in shares) <= 1
+        # weight proxy (remaining radius) is balanced to well under 1%
+        w = [sum(1.0 - pds[i] for i in s) for s in shares]
+        assert max(w) / (sum(w) / world) < 1.01
+        # every share is walked heaviest first
+        for s in shares:
+            assert all(pds[s[i]] <= pds[s[i + 1]] for i in range(len(s) - 1))
+        # a permuted task buffer gives every task the same owner
         perm = rng.permutation(len(tasks))
-        assert [task_shard(tasks[i], L, d, world) for i in perm] == [owner[i] for i in perm]
-        # coefficients below the root level do not matter
-        t2 = tasks[0].copy()
-        t2[:L] = 99
-        assert task_shard(t2, L, d, world) == owner[0]
+        shares_p = partition_tasks([pds[i] for i in perm], [keys[i] for i in perm], world)
+        for a, b in zip(shares, shares_p):
+            assert a == [int(perm[j]) for j in b]

@@ -1,5 +1,5 @@
 """Two ranks (two processes, gloo collectives) sharing ONE GPU run the sharded enumeration exactly
-as bench.py --gpus 2 does: content-hash partition of the subtree tasks + bound/active all-reduce at
+as bench.py --gpus 2 does: content-sorted partition of the subtree tasks + bound/active all-reduce at
 every chunk and round boundary.  With a radius that never shrinks the ranks' per-level node counts
 must add up to the reference's counts — disjoint and complete — and the collective must terminate
 (same number of exchange calls on every rank)."""
