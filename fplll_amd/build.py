@@ -12,12 +12,12 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 
-HIP_SOURCES = ["enum_kernel.hip", "enum_host.hip", "gso_kernel.hip", "gso_host.hip"]
-HIP_HEADERS = ["enum_device.h", "gso_device.h", os.path.join(ROOT, "include", "fplll_hip.h")]
+HIP_SOURCES = ["enum_kernel.hip", "enum_host.hip", "gso_kernel.hip", "lll_kernel.hip", "gso_host.hip"]
+HIP_HEADERS = ["enum_device.h", "gso_device.h", "gso_wave.h", os.path.join(ROOT, "include", "fplll_hip.h")]
 HIPCC_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17",
     "-ffp-contract=off",  # fplll's arithmetic is separate mul/add (nr/nr_FP_d.inl:178); no FMA
-    "-fPIC", "-shared", "-Wno-unused-value",
+    "-fPIC", "-Wno-unused-value",
 ]
 
 
@@ -52,8 +52,19 @@ def build_hip(force=False):
     if os.environ.get("FPHIP_GSO_RING"):
         extra.append("-DFPHIP_GSO_RING=" + os.environ["FPHIP_GSO_RING"])
         force = True
-    if force or _newer(out, srcs + hdrs):
-        _run([hipcc()] + HIPCC_FLAGS + extra + ["-o", out] + srcs)
+    # one object per source (objects are scratch: fplll_amd/lib/obj is git-ignored), then link
+    objdir = os.path.join(LIBDIR, "obj")
+    os.makedirs(objdir, exist_ok=True)
+    objs = []
+    relink = force or not os.path.exists(out)
+    for src in srcs:
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        objs.append(obj)
+        if force or _newer(obj, [src] + hdrs):
+            _run([hipcc()] + HIPCC_FLAGS + extra + ["-c", "-o", obj, src])
+            relink = True
+    if relink:
+        _run([hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared", "-o", out] + objs)
     return out
 
 

@@ -31,6 +31,12 @@ struct GsoBatch
   double *rdg;
   long long *rexp;
   int *status;
+  // LLL kernel only (allocated on first use): symmetric Gram cache [batch][d][ldd], valid-column
+  // counts [batch][d], output basis in position order [batch][d][ldn], info [batch][4]
+  double *gf;
+  int *vc;
+  long long *b2;
+  int *lll_info;
 };
 // Batched Householder state (MatHouseholder<Z_NR<long>, FP_NR<double>>): b, V, R are [batch][d][ldn]
 // row-major (lane = column), sigma / rexp [batch][d].

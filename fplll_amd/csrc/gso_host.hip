@@ -7,7 +7,9 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
+#include <utility>
 #include <vector>
 
 #include "../../include/fplll_hip.h"
@@ -20,6 +22,9 @@
 namespace fphip
 {
 template <int NQ> __global__ void gso_sweep_kernel(GsoBatch P, int kmin, int kend, double eta, int mode);
+template <int NQ>
+__global__ void lll_kernel(GsoBatch P, int kmin, int kstart, int kend, double delta, double eta,
+                           double logdelta);
 }
 using namespace fphip;
 
@@ -128,12 +133,26 @@ extern "C" void fphip_gso_destroy(fphip_gso *g)
   hipFree(g->P.rdg);
   hipFree(g->P.rexp);
   hipFree(g->P.status);
+  if (g->P.gf)
+    hipFree(g->P.gf);
+  if (g->P.vc)
+    hipFree(g->P.vc);
+  if (g->P.b2)
+    hipFree(g->P.b2);
+  if (g->P.lll_info)
+    hipFree(g->P.lll_info);
   hipEventDestroy(g->ev[0]);
   hipEventDestroy(g->ev[1]);
   delete g;
 }
 
-static int launch(fphip_gso *g, int kmin, int kend, double eta, int mode)
+struct LllArgs
+{
+  int kstart;
+  double delta, logdelta;
+};
+
+static int launch(fphip_gso *g, int kmin, int kend, double eta, int mode, const LllArgs *la = nullptr)
 {
   const int need = (g->P.d > g->P.n ? g->P.d : g->P.n);
   const int nq   = (need + 63) / 64;
@@ -154,6 +173,25 @@ static int launch(fphip_gso *g, int kmin, int kend, double eta, int mode)
     return FPHIP_ERROR;
   }
   GCHK(hipEventRecord(g->ev[0], s));
+  if (la)
+  {
+    switch (nq)
+    {
+    case 1:
+      hipLaunchKernelGGL(lll_kernel<1>, dim3(grid), dim3(wpb * 64), lds, s, g->P, kmin, la->kstart, kend, la->delta, eta, la->logdelta);
+      break;
+    case 2:
+      hipLaunchKernelGGL(lll_kernel<2>, dim3(grid), dim3(wpb * 64), lds, s, g->P, kmin, la->kstart, kend, la->delta, eta, la->logdelta);
+      break;
+    case 3:
+      hipLaunchKernelGGL(lll_kernel<3>, dim3(grid), dim3(wpb * 64), lds, s, g->P, kmin, la->kstart, kend, la->delta, eta, la->logdelta);
+      break;
+    default:
+      hipLaunchKernelGGL(lll_kernel<4>, dim3(grid), dim3(wpb * 64), lds, s, g->P, kmin, la->kstart, kend, la->delta, eta, la->logdelta);
+      break;
+    }
+  }
+  else
   switch (nq)
   {
   case 1:
@@ -251,6 +289,54 @@ extern "C" int fphip_gso_size_reduce(fphip_gso *g, int kappa_min, int kappa_end,
   if (rc != FPHIP_OK)
     return rc;
   return fetch_status(g, status);
+}
+
+// LLLReduction<Z_NR<long>, FP_NR<double>>(m, delta, eta, LLL_DEFAULT).lll(kappa_min, kappa_start,
+// kappa_end, 0) on a fresh MatGSO(b, GSO_ROW_EXPO) of every lattice (lll.cpp:44-164,
+// wrapper.cpp lll_reduction_zf with LM_FAST), then update_gso() so that mu / r are readable in
+// place.  info (nullable): 4 ints per lattice — final_kappa, n_swaps, zeros, loop iterations.
+extern "C" int fphip_gso_lll(fphip_gso *g, int kappa_min, int kappa_start, int kappa_end,
+                             double delta, double eta, int *status, int *info)
+{
+  if (!g)
+    return FPHIP_ERROR;
+  if (kappa_end < 0)
+    kappa_end = g->P.d;
+  if (kappa_min < 0 || kappa_min > kappa_start || kappa_start >= kappa_end || kappa_end > g->P.d)
+  {
+    snprintf(fphip_ctx_errbuf(g->ctx), 512, "fphip_gso_lll: need 0 <= kappa_min <= kappa_start < kappa_end <= d");
+    return FPHIP_ERROR;
+  }
+  const size_t B = (size_t)g->P.batch, d = g->P.d, ldd = g->P.ldd, ldn = g->P.ldn;
+  if (!g->P.gf)
+  {
+    GCHK(hipMalloc((void **)&g->P.gf, B * d * ldd * sizeof(double) + 4096));
+    GCHK(hipMalloc((void **)&g->P.vc, B * d * sizeof(int)));
+    GCHK(hipMalloc((void **)&g->P.b2, B * d * ldn * sizeof(long long) + 4096));
+    GCHK(hipMalloc((void **)&g->P.lll_info, B * 4 * sizeof(int)));
+    GCHK(hipMemset(g->P.b2, 0, B * d * ldn * sizeof(long long) + 4096));
+  }
+  int rc = launch(g, 0, g->P.d, 0.0, 2);  // bf / row_expo of every row from b
+  if (rc != FPHIP_OK)
+    return rc;
+  LllArgs la{kappa_start, delta, std::log(delta)};
+  rc = launch(g, kappa_min, kappa_end, eta, 3, &la);
+  if (rc != FPHIP_OK)
+    return rc;
+  const float lll_ms = g->last_ms;
+  std::swap(g->P.b, g->P.b2);  // the kernel wrote the rows in position order into b2
+  std::vector<int> st(B);
+  GCHK(hipMemcpy(st.data(), g->P.status, sizeof(int) * B, hipMemcpyDeviceToHost));
+  if (info)
+    GCHK(hipMemcpy(info, g->P.lll_info, sizeof(int) * 4 * B, hipMemcpyDeviceToHost));
+  // identity-layout GSO of the reduced bases (same values: every entry is a function of b)
+  rc = launch(g, 0, g->P.d, 0.0, 2);
+  if (rc == FPHIP_OK)
+    rc = launch(g, 0, g->P.d, 0.0, 0);
+  g->last_ms = lll_ms;
+  if (status)
+    memcpy(status, st.data(), sizeof(int) * B);
+  return rc;
 }
 
 extern "C" int fphip_gso_get_mu(fphip_gso *g, int lattice, double *mu)

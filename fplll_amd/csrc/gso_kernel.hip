@@ -27,562 +27,10 @@
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (no FMA contraction).
 
-#include <hip/hip_runtime.h>
-#include <limits.h>
-#include <stdint.h>
-
-#include "gso_device.h"
+#include "gso_wave.h"
 
 namespace fphip
 {
-
-__device__ __forceinline__ double g_rl_f64(double v, int lane)
-{
-  int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
-  int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
-  return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ long long g_rl_i64(long long v, int lane)
-{
-  unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, lane);
-  unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)v >> 32), lane);
-  return (long long)(((unsigned long long)hi << 32) | lo);
-}
-__device__ __forceinline__ int wave_max_i32(int v)
-{
-  for (int off = 32; off > 0; off >>= 1)
-    v = max(v, __shfl_xor(v, off));
-  return __builtin_amdgcn_readfirstlane(v);
-}
-// FP_NR<double>::exponent(), nr_FP_d.inl:44 (glibc: ilogb(0) = INT_MIN)
-__device__ __forceinline__ long long fexponent(double x)
-{
-  return (x == 0.0) ? ((long long)INT_MIN + 1) : ((long long)ilogb(x) + 1);
-}
-
-template <int NQ> struct Lattice
-{
-  int d, n, ldd, ldn, row_expo_on;
-  long long *b;
-  double *bfT, *mu, *muT, *r, *rdg;
-  long long *rexp;
-  int lane;
-  double murow[NQ];  // mu(kappa, j) of the row last updated (lane j)
-  double rrow[NQ];   // r(kappa, j)  of the row last updated (lane j)
-  double bfk[NQ];    // bf(kappa, c) of the row last updated (lane c)
-};
-
-// ---------------------------------------------------------------------------------------------
-// LDS-DMA ring ("chain" loops).  Every hot loop of this kernel has the shape
-//     for step s (in a fixed order):  v[q] = ROW_s[lane + 64 q];  state[q] = f(state[q], v[q], scalar_s)
-// where ROW_s is a contiguous row in HBM whose address does not depend on the state, while scalar_s
-// does (it is read from a lane of the state with v_readlane).  The rows are streamed into a per-wave
-// ring in LDS with global_load_lds_dwordx4 (16 B per lane, 1 KiB per instruction, no VGPRs), R-1
-// steps ahead of the consumer; the consumer waits with a COUNTED s_waitcnt vmcnt(pending·IPS) — loads
-// retire in order — and reads its 8 bytes with ds_read_b64.  A wave therefore keeps up to
-// (R-1)·IPS KiB of HBM reads in flight; that, times the waves per CU, is what hides HBM latency
-// (a register-buffered version of the same loops reached 24 % of the HBM roofline; the chain
-// itself is a handful of VALU ops per step).
-//   * hipcc neither counts nor orders these instructions (cdna_hip_programming.md §5.7): the ring
-//     code owns every vmcnt wait, and NO other vector-memory instruction (including scratch spills)
-//     may be issued between ring_begin() and ring_end() — ScratchSize must stay 0 for this kernel.
-//   * rows start 16-byte aligned: leading dimensions are padded to even (ldd, ldn).
-// ---------------------------------------------------------------------------------------------
-#ifndef FPHIP_GSO_RING
-#define FPHIP_GSO_RING 6
-#endif
-
-__device__ __forceinline__ void glds16(const void *gsrc, unsigned lds_dst)
-{
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
-               "s_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "v"(gsrc), "s"(lds_dst)
-               : "memory");
-}
-
-// Make the compiler finish (wait for) an ordinary load NOW: an empty asm that reads and writes the
-// value.  hipcc places its own s_waitcnt vmcnt(0) at the FIRST USE of a loaded value; if that first
-// use sits inside a ring loop the wait would drain the DMA pipe on every iteration.
-__device__ __forceinline__ void settle(double &x) { asm volatile("" : "+v"(x)); }
-__device__ __forceinline__ void settle(long long &x) { asm volatile("" : "+v"(x)); }
-__device__ __forceinline__ void settle(int &x) { asm volatile("" : "+v"(x)); }
-
-template <int N> __device__ __forceinline__ void wait_vmcnt()
-{
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
-struct RowDesc
-{
-  const void *ptr;  // wave-uniform, 16-byte aligned start of the row
-  int lo, hi;       // bytes [lo, hi) of the row are needed
-};
-
-template <int Q> struct IC
-{
-  static constexpr int value = Q;
-};
-
-// f(IC<q>, idx - 64 q) for the (wave-uniform) chunk q = idx >> 6: gives loop bodies a COMPILE-TIME
-// register index for the chunk that owns step idx.
-template <int NQ, class F> __device__ __forceinline__ void dispatch_chunk(int idx, F f)
-{
-  if constexpr (NQ == 1)
-  {
-    f(IC<0>{}, idx);
-  }
-  else
-  {
-    const int q = idx >> 6;
-    if (q == 0)
-      f(IC<0>{}, idx);
-    else if (q == 1)
-      f(IC<1>{}, idx - 64);
-    else if constexpr (NQ >= 3)
-    {
-      if (q == 2)
-        f(IC<2>{}, idx - 128);
-      else if constexpr (NQ >= 4)
-        f(IC<3>{}, idx - 192);
-    }
-  }
-}
-
-template <int NQ, int IPS> struct Ring
-{
-  static constexpr int R     = FPHIP_GSO_RING;
-  static constexpr int SLOT  = IPS * 1024;
-  static constexpr int AHEAD = (R - 1 < 7 ? R - 1 : 7);  // rows kept in flight behind the consumer
-  unsigned base;  // LDS byte address of this wave's ring (wave-uniform)
-  int lane;
-  int head, tail;
-  int ahead;  // rows issued and not yet consumed
-
-  // Start a new stream: nothing of ours is in flight; also retires every older vector-memory
-  // operation (stores of the previous phase) so that the counted waits below only see ring loads.
-  __device__ __forceinline__ void reset()
-  {
-    wait_vmcnt<0>();
-    head = tail = 0;
-    ahead       = 0;
-  }
-
-  // stream bytes [lo, hi) of one row.  Every one of the IPS instructions is issued (lane 0 stays
-  // active) so that the vmcnt arithmetic of fetch() holds; lanes outside the window move no data.
-  __device__ __forceinline__ void issue(const RowDesc &r)
-  {
-    const char *g      = (const char *)r.ptr + lane * 16;
-    const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(base + head * SLOT));
-#pragma unroll
-    for (int i = 0; i < IPS; ++i)
-    {
-      const int off = lane * 16 + i * 1024;
-      // lane 0 is always active: an instruction none of whose lanes meets the window must still be
-      // issued, otherwise the consumer's vmcnt arithmetic is off by one (a ballot per instruction
-      // to find that case costs more than the occasional extra 16 bytes)
-      if (lane == 0 || (off + 16 > r.lo && off < r.hi))
-        glds16(g + i * 1024, dst + i * 1024);
-    }
-    head = (head + 1 == R) ? 0 : head + 1;
-    ++ahead;
-  }
-
-  template <int P> __device__ __forceinline__ void read(double (&v)[NQ], unsigned addr)
-  {
-    // wait until at most P newer rows are outstanding, then fetch this lane's elements
-    if constexpr (NQ == 1)
-      asm volatile("s_waitcnt vmcnt(%2)\n\tds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)"
-                   : "=&v"(v[0])
-                   : "v"(addr), "n"(P * IPS)
-                   : "memory");
-    else if constexpr (NQ == 2)
-      asm volatile("s_waitcnt vmcnt(%3)\n\tds_read_b64 %0, %2\n\tds_read_b64 %1, %2 offset:512\n\t"
-                   "s_waitcnt lgkmcnt(0)"
-                   : "=&v"(v[0]), "=&v"(v[1])
-                   : "v"(addr), "n"(P * IPS)
-                   : "memory");
-    else if constexpr (NQ == 3)
-      asm volatile("s_waitcnt vmcnt(%4)\n\tds_read_b64 %0, %3\n\tds_read_b64 %1, %3 offset:512\n\t"
-                   "ds_read_b64 %2, %3 offset:1024\n\ts_waitcnt lgkmcnt(0)"
-                   : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2])
-                   : "v"(addr), "n"(P * IPS)
-                   : "memory");
-    else
-      asm volatile("s_waitcnt vmcnt(%5)\n\tds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:512\n\t"
-                   "ds_read_b64 %2, %4 offset:1024\n\tds_read_b64 %3, %4 offset:1536\n\t"
-                   "s_waitcnt lgkmcnt(0)"
-                   : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
-                   : "v"(addr), "n"(P * IPS)
-                   : "memory");
-  }
-
-  // consume the oldest row in flight (ahead - 1 newer rows are behind it)
-  __device__ __forceinline__ void fetch(double (&v)[NQ])
-  {
-    const unsigned addr = base + tail * SLOT + lane * 8;
-    tail                = (tail + 1 == R) ? 0 : tail + 1;
-    const int pending   = ahead - 1;
-    --ahead;
-    if (pending == AHEAD)
-    {
-      read<AHEAD>(v, addr);
-      return;
-    }
-    switch (pending)
-    {
-    case 0: read<0>(v, addr); break;
-    case 1: read<1>(v, addr); break;
-    case 2: read<2>(v, addr); break;
-    case 3: read<3>(v, addr); break;
-    case 4: read<4>(v, addr); break;
-    case 5: read<5>(v, addr); break;
-    default: read<6>(v, addr); break;
-    }
-  }
-
-  // One phase of `cnt` steps.  Rows [0, ahead) of it may already be in flight (prefetched by the
-  // previous phase).  While consuming, keep the pipe full: first with this phase's remaining rows,
-  // then with the first rows of the NEXT phase (ncnt rows, nrow(s)) — phases are chained without
-  // draining the pipe whenever no other vector-memory instruction separates them.
-  template <class RowA, class BodyF, class RowB>
-  __device__ __forceinline__ void run(int cnt, RowA row, BodyF body, int ncnt, RowB nrow)
-  {
-    int issued  = ahead;  // rows of this phase issued so far
-    int nissued = 0;      // rows of the next phase issued so far
-#pragma unroll 1
-    for (int s = 0; s < cnt; ++s)
-    {
-      while (ahead <= AHEAD)
-      {
-        if (issued < cnt)
-          issue(row(issued++));
-        else if (nissued < ncnt)
-          issue(nrow(nissued++));
-        else
-          break;
-      }
-      double v[NQ];
-      fetch(v);
-      body(s, v);
-    }
-  }
-  template <class RowA, class BodyF> __device__ __forceinline__ void run(int cnt, RowA row, BodyF body)
-  {
-    run(cnt, row, body, 0, row);
-  }
-};
-
-// update_gso_row(kappa, last) recomputed from column 0 (identical values: every input is unchanged
-// since the row was invalidated).  Returns false on a non-finite mu (RED_GSO_FAILURE).
-template <int NQ, int IPS>
-__device__ bool update_row(Lattice<NQ> &T, Ring<NQ, IPS> &ring, int kappa, int last)
-{
-  const int n = T.n, lane = T.lane, ldd = T.ldd;
-  const int qact = (last >> 6) + 1;  // chunks holding a lane j <= last
-  double bk[NQ], acc[NQ], rd[NQ];
-  bool inrow[NQ];
-#pragma unroll
-  for (int q = 0; q < NQ; ++q)
-  {
-    const int c = lane + 64 * q;
-    bk[q]       = (c < n) ? T.bfT[(size_t)c * ldd + kappa] : 0.0;
-    acc[q]      = 0.0;
-    rd[q]       = (c < kappa) ? T.rdg[c] : 1.0;
-    inrow[q]    = c <= last;
-  }
-  const int need_bytes = (last + 1) * 8;  // lanes j <= last of a row
-  auto gram_row = [&](int c) { return RowDesc{T.bfT + (size_t)c * ldd, 0, need_bytes}; };
-  auto rec_row  = [&](int k) { return RowDesc{T.muT + (size_t)k * ldd, (k + 1) * 8, need_bytes}; };
-  bool ok       = true;
-#pragma unroll
-  for (int q = 0; q < NQ; ++q)
-  {
-    settle(bk[q]);
-    settle(rd[q]);
-  }
-  ring.reset();
-  // ---- Gram row: g(kappa,j) = bf_kappa . bf_j, columns in ascending order (numvect.h:386-396);
-  //      the recurrence's first mu columns are prefetched behind it
-  ring.run(
-      n, gram_row,
-      [&](int c, const double(&v)[NQ])
-      {
-        dispatch_chunk<NQ>(c,
-                           [&](auto cq, int cc)
-                           {
-                             const double bkc = g_rl_f64(bk[decltype(cq)::value], cc);
-#pragma unroll
-                             for (int q = 0; q < NQ; ++q)
-                               if (q < qact)
-                               {
-                                 const double p = bkc * v[q];
-                                 acc[q]         = (c == 0) ? p : acc[q] + p;
-                               }
-                           });
-      },
-      last + 1, rec_row);
-  // ---- recurrence, gso_interface.cpp:143-158, column-oriented
-  ring.run(last + 1, rec_row,
-           [&](int k, const double(&v)[NQ])
-           {
-             dispatch_chunk<NQ>(
-                 k,
-                 [&](auto kq_, int kk)
-                 {
-                   constexpr int kq = decltype(kq_)::value;
-                   const double rk  = g_rl_f64(acc[kq], kk);  // r(kappa,k) is final
-                   double muk       = 0.0;
-                   if (last == kappa && k < kappa)  // only the diagonal lane j == kappa needs it
-                     muk = rk / g_rl_f64(rd[kq], kk);  // mu(kappa,k) = r(kappa,k) / r(k,k)
-#pragma unroll
-                   for (int q = kq; q < NQ; ++q)
-                     if (q < qact)
-                     {
-                       const int j = lane + 64 * q;
-                       // chunks above kq hold only rows j > k; the diagonal chunk needs the test
-                       const bool on = inrow[q] && (q > kq || lane > kk);
-                       if (on)
-                       {
-                         const double m = (j == kappa) ? muk : v[q];
-                         acc[q]         = acc[q] - m * rk;
-                       }
-                     }
-                 });
-           });
-  // ---- store the row
-#pragma unroll
-  for (int q = 0; q < NQ; ++q)
-  {
-    const int j = lane + 64 * q;
-    T.murow[q]  = 0.0;
-    T.rrow[q]   = acc[q];
-    T.bfk[q]    = bk[q];
-    if (j <= last)
-    {
-      T.r[(size_t)kappa * ldd + j] = acc[q];
-      if (j < kappa)
-      {
-        const double m = acc[q] / rd[q];  // mu(kappa,j) = r(kappa,j) / r(j,j), gso_interface.cpp:154
-        if (!isfinite(m))
-          ok = false;
-        T.murow[q]                     = m;
-        T.mu[(size_t)kappa * ldd + j]  = m;
-        T.muT[(size_t)j * ldd + kappa] = m;
-      }
-      else
-      {
-        T.rdg[kappa] = acc[q];
-      }
-    }
-  }
-  return __all(ok);
-}
-
-// update_gso_row(kappa, kappa) right after update_gso_row(kappa, kappa-1): gso_valid_cols = kappa,
-// so the reference computes ONLY column j = kappa (gso_interface.cpp:141-152):
-//   g(kappa,kappa) = bf_kappa . bf_kappa (columns ascending), r(kappa,kappa) = g - sum_k mu(kappa,k) r(kappa,k)
-// (k ascending).  Both operands are still in registers (lane-distributed), so this is two short
-// v_readlane chains and no memory traffic.
-template <int NQ> __device__ void finish_diag(Lattice<NQ> &T, int kappa)
-{
-  const int n = T.n, ldd = T.ldd;
-  double g = 0.0;
-  for (int c = 0; c < n; ++c)
-  {
-    double a = 0.0;
-    dispatch_chunk<NQ>(c, [&](auto cq, int cc) { a = g_rl_f64(T.bfk[decltype(cq)::value], cc); });
-    const double p = a * a;
-    g              = (c == 0) ? p : g + p;
-  }
-  for (int k = 0; k < kappa; ++k)
-  {
-    double m = 0.0, r = 0.0;
-    dispatch_chunk<NQ>(k,
-                       [&](auto kq, int kk)
-                       {
-                         m = g_rl_f64(T.murow[decltype(kq)::value], kk);
-                         r = g_rl_f64(T.rrow[decltype(kq)::value], kk);
-                       });
-    g = g - m * r;
-  }
-  if (T.lane == 0)
-  {
-    T.r[(size_t)kappa * ldd + kappa] = g;
-    T.rdg[kappa]                     = g;
-  }
-}
-
-// LLLReduction::babai(kappa, kappa, 0).  1 ok, 0 GSO failure, -1 babai failure, -2 multiplier.
-template <int NQ, int IPS>
-__device__ int babai(Lattice<NQ> &T, Ring<NQ, IPS> &ring, int kappa, double eta)
-{
-  const int n = T.n, lane = T.lane, ldd = T.ldd, ldn = T.ldn;
-  long long max_expo = LLONG_MAX;
-  for (int iter = 0;; ++iter)
-  {
-    if (!update_row<NQ, IPS>(T, ring, kappa, kappa - 1))
-      return 0;
-    const long long rexpk = T.rexp[kappa];
-    int e[NQ];
-    bool need = false;
-    int mexp  = INT_MIN;
-#pragma unroll
-    for (int q = 0; q < NQ; ++q)
-    {
-      const int j = lane + 64 * q;
-      e[q]        = 0;
-      if (j < kappa)
-      {
-        e[q]           = (int)(rexpk - T.rexp[j]);
-        const double f = fabs(ldexp(T.murow[q], e[q]));  // get_mu, gso_interface.h:694-702
-        need |= (f > eta);
-        const long long ex = (long long)e[q] + fexponent(T.murow[q]);
-        mexp               = max(mexp, (int)max(ex, (long long)INT_MIN + 2));
-      }
-    }
-    if (!__any(need))
-      break;
-    if (iter >= 2)
-    {  // lll.cpp:187-195
-      const long long new_max = (long long)wave_max_i32(mexp);
-      if (new_max > max_expo - 5)
-        return -1;
-      max_expo = new_max;
-    }
-    double bm[NQ];
-    long long xl[NQ], bv[NQ];
-#pragma unroll
-    for (int q = 0; q < NQ; ++q)
-    {
-      const int c = lane + 64 * q;
-      bm[q]       = T.murow[q];
-      xl[q]       = 0;
-      bv[q]       = (c < n) ? T.b[(size_t)kappa * ldn + c] : 0;
-    }
-    bool too_big = false;
-    // step s of both loops handles row j = kappa-1-s (descending, lll.cpp:202)
-    auto mu_row = [&](int s)
-    {
-      const int j = kappa - 1 - s;
-      return RowDesc{T.mu + (size_t)j * ldd, 0, j * 8};  // mu(j,k) is needed for k < j
-    };
-    auto b_row = [&](int s) { return RowDesc{T.b + (size_t)(kappa - 1 - s) * ldn, 0, n * 8}; };
-#pragma unroll
-    for (int q = 0; q < NQ; ++q)
-    {
-      settle(e[q]);
-      settle(bv[q]);
-      settle(bm[q]);
-    }
-    ring.reset();
-    // ---- lll.cpp:202-220: lane k owns babai_mu[k]; the basis rows of the integer AXPY are
-    //      prefetched behind the sweep
-    ring.run(
-        kappa, mu_row,
-        [&](int s, const double(&v)[NQ])
-        {
-          const int j = kappa - 1 - s;
-          dispatch_chunk<NQ>(
-              j,
-              [&](auto jq_, int jj)
-              {
-                constexpr int jq = decltype(jq_)::value;
-                const double bmj = g_rl_f64(bm[jq], jj);
-                const int ej     = __builtin_amdgcn_readlane(e[jq], jj);
-                double X;  // rnd_we, nr_FP_d.inl:226-233
-                if (fexponent(bmj) + ej >= 53)
-                  X = bmj;
-                else
-                  X = ldexp(rint(ldexp(bmj, ej)), -ej);
-                if (X != 0.0)
-                {
-                  {  // row_addmul_we(kappa, j, -X, ej): get_si_exp_we, nr_FP_d.inl:46-53
-                    const long long ex = fexponent(-X) + ej - 63;
-                    if (ex > 0)
-                      too_big = true;
-                    const long long lx = (long long)ldexp(-X, ej);
-                    xl[jq]             = (lane == jj) ? lx : xl[jq];
-                  }
-#pragma unroll
-                  for (int q = 0; q <= jq; ++q)
-                  {
-                    // chunks below jq hold only k < j; the chunk of j itself needs the test
-                    if (q < jq || lane < jj)
-                    {
-                      const double t = X * v[q];
-                      bm[q]          = bm[q] - t;
-                    }
-                  }
-                }
-              });
-        },
-        kappa, b_row);
-    // ---- integer AXPY on row kappa (row_add / row_sub / row_addmul_si, gso.cpp:84-158)
-    ring.run(kappa, b_row,
-             [&](int s, const double(&v)[NQ])
-             {
-               const int j = kappa - 1 - s;
-               dispatch_chunk<NQ>(j,
-                                  [&](auto jq_, int jj)
-                                  {
-                                    const long long lx = g_rl_i64(xl[decltype(jq_)::value], jj);
-                                    if (lx != 0)
-                                    {
-#pragma unroll
-                                      for (int q = 0; q < NQ; ++q)
-                                        bv[q] = (long long)((unsigned long long)bv[q] +
-                                                            (unsigned long long)__double_as_longlong(v[q]) *
-                                                                (unsigned long long)lx);
-                                    }
-                                  });
-             });
-    if (too_big)
-      return -2;  // nothing has been stored yet: the basis is unchanged
-    // ---- row_op_end: update_bf(kappa), gso.cpp:24-48
-    int ce[NQ];
-    double cm[NQ];
-    int emax = INT_MIN;
-#pragma unroll
-    for (int q = 0; q < NQ; ++q)
-    {
-      const int c = lane + 64 * q;
-      ce[q]       = INT_MIN;
-      cm[q]       = 0.0;
-      if (c < n)
-      {
-        T.b[(size_t)kappa * ldn + c] = bv[q];
-        if (T.row_expo_on)
-        {
-          int ex;
-          cm[q] = frexp((double)bv[q], &ex);
-          ce[q] = ex;
-          emax  = max(emax, ex);
-        }
-        else
-        {
-          cm[q] = (double)bv[q];
-          ce[q] = 0;
-          emax  = 0;
-        }
-      }
-    }
-    emax = wave_max_i32(emax);
-#pragma unroll
-    for (int q = 0; q < NQ; ++q)
-    {
-      const int c = lane + 64 * q;
-      if (c < n)
-        T.bfT[(size_t)c * ldd + kappa] = T.row_expo_on ? ldexp(cm[q], ce[q] - emax) : cm[q];
-    }
-    if (lane == 0)
-      T.rexp[kappa] = T.row_expo_on ? (long long)emax : 0;
-    // later reads of b / bfT / rexp in this wave must see these stores
-    __threadfence_block();
-  }
-  return 1;
-}
 
 // mode 0: update_gso() (every row, no size reduction); mode 1: size_reduction(kmin,kend);
 // mode 2: (re)build bfT / row_expo from b for every row (after a basis upload)

@@ -10,7 +10,8 @@ import numpy as np
 
 from . import _lib
 
-LLL_DEF_ETA = 0.51  # fplll/defs.h:143-151
+LLL_DEF_ETA = 0.51
+LLL_DEF_DELTA = 0.99  # fplll/defs.h:143-151
 
 
 def _bind(lib):
@@ -33,6 +34,9 @@ def _bind(lib):
     lib.fphip_gso_update.restype = ctypes.c_int
     lib.fphip_gso_size_reduce.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_double, vp]
     lib.fphip_gso_size_reduce.restype = ctypes.c_int
+    lib.fphip_gso_lll.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double,
+                                  ctypes.c_double, vp, vp]
+    lib.fphip_gso_lll.restype = ctypes.c_int
     for name in ("fphip_gso_get_mu", "fphip_gso_get_r", "fphip_gso_get_row_expo"):
         getattr(lib, name).argtypes = [vp, ctypes.c_int, vp]
         getattr(lib, name).restype = ctypes.c_int
@@ -91,6 +95,16 @@ class MatGSOBatch:
         self._chk(self.lib.fphip_gso_size_reduce(self.h, kappa_min, kappa_end, eta,
                                                  st.ctypes.data_as(ctypes.c_void_p)), "size_reduction")
         return st
+
+    def lll(self, kappa_min=0, kappa_start=0, kappa_end=-1, delta=LLL_DEF_DELTA, eta=LLL_DEF_ETA):
+        """LLLReduction::lll(kappa_min, kappa_start, kappa_end) on every lattice (lll.cpp:44-164).
+        Returns (status[batch], info[batch][4] = final_kappa, n_swaps, zeros, iterations)."""
+        st = np.zeros(self.batch, dtype=np.int32)
+        info = np.zeros((self.batch, 4), dtype=np.int32)
+        self._chk(self.lib.fphip_gso_lll(self.h, kappa_min, kappa_start, kappa_end, delta, eta,
+                                         st.ctypes.data_as(ctypes.c_void_p),
+                                         info.ctypes.data_as(ctypes.c_void_p)), "lll")
+        return st, info
 
     def get_mu_matrix(self, lattice=0):
         m = np.empty((self.d, self.d), dtype=np.float64)

@@ -16,6 +16,8 @@
  *       fphip_gso_update        ← MatGSOInterface::update_gso_row / update_gso
  *                                 gso_interface.cpp:131-164, gso_interface.h:767-775
  *       fphip_gso_size_reduce   ← LLLReduction::size_reduction → babai   lll.h:107-122, lll.cpp:166-224
+ *       fphip_gso_lll           ← LLLReduction::lll (+ MatGSO::move_row)   lll.cpp:44-164, gso.cpp:289-366
+ *                                 (what lll_reduction_zf<long,double> runs with LM_FAST, wrapper.cpp)
  *       fphip_gso_get_*         ← get_mu_exp/get_r_exp/row_expo accessors gso_interface.h:675-732
  *
  * Error convention: 0 = FPHIP_OK; FPHIP_UNSUPPORTED = instance declined, the caller must fall
@@ -139,6 +141,15 @@ int fphip_gso_update(fphip_gso *g, int *status);
  * row_op_end bookkeeping; kappa_end = -1 means d.  status: 1 ok, 0 RED_GSO_FAILURE,
  * -1 RED_BABAI_FAILURE (lll.cpp:187-195), -2 multiplier beyond 63 bits (caller falls back) */
 int fphip_gso_size_reduce(fphip_gso *g, int kappa_min, int kappa_end, double eta, int *status);
+/* LLLReduction<Z_NR<long>,FP_NR<double>>(m, delta, eta, LLL_DEFAULT).lll(kappa_min, kappa_start,
+ * kappa_end, 0) (lll.cpp:44-164) on a fresh MatGSO(b, GSO_ROW_EXPO) of every lattice, rows below
+ * kappa_start brought up to date first; move_row (gso.cpp:289-366) included.  kappa_end = -1 means
+ * d.  The basis is reduced in place (fphip_gso_get_basis), mu / r hold update_gso() of the result.
+ * status[batch]: 1 RED_SUCCESS, 0 RED_GSO_FAILURE, -1 RED_BABAI_FAILURE, -2 multiplier beyond 63
+ * bits, -3 RED_LLL_FAILURE (iteration limit).  info (nullable) [batch][4]: final_kappa, n_swaps,
+ * zeros (rows moved to the end as linearly dependent), loop iterations. */
+int fphip_gso_lll(fphip_gso *g, int kappa_min, int kappa_start, int kappa_end, double delta,
+                  double eta, int *status, int *info);
 /* raw stored values, d×d row-major; true values carry the row exponents exactly as
  * get_mu/get_r do (gso_interface.h:694-732): mu·2^(e_i-e_j), r·2^(e_i+e_j) */
 int fphip_gso_get_mu(fphip_gso *g, int lattice, double *mu);

@@ -295,6 +295,193 @@ int oracle_gso_size_reduction(oracle_gso *g, int kappa_min, int kappa_end, doubl
   return 1;
 }
 
+/* ------------------------------------------------------------------------------------------
+ * LLL driver (pinned by tests/test_lll_oracle_vs_ref.py against `lllfix` fixtures)
+ * ------------------------------------------------------------------------------------------ */
+
+/* MatGSO::move_row, gso.cpp:289-366 (no transforms, float Gram).  Rows of b, bf, mu, r, row_expo and
+ * gso_valid_cols rotate with the row; the lower-triangular Gram cache is permuted symmetrically
+ * (what rotate_gram_left/right, nr/matrix.cpp:65-92, do by element swaps). */
+static void move_row(oracle_gso *g, int old_r, int new_r)
+{
+  const int d = g->d, n = g->n;
+  if (old_r == new_r)
+    return;
+  const int lo = old_r < new_r ? old_r : new_r, hi = old_r < new_r ? new_r : old_r;
+  for (int i = lo; i < d; i++) /* invalidate_gso_row(i, lo) */
+    if (g->valid_cols[i] > lo)
+      g->valid_cols[i] = lo;
+  int *src = (int *)malloc(sizeof(int) * d); /* new position p holds the old row src[p] */
+  for (int p = 0; p < d; p++)
+    src[p] = p;
+  if (new_r < old_r)
+  {
+    src[new_r] = old_r;
+    for (int p = new_r + 1; p <= old_r; p++)
+      src[p] = p - 1;
+  }
+  else
+  {
+    src[new_r] = old_r;
+    for (int p = old_r; p < new_r; p++)
+      src[p] = p + 1;
+  }
+#define PERMUTE_ROWS(type, arr, width)                                           \
+  do                                                                             \
+  {                                                                              \
+    type *tmp_ = (type *)malloc(sizeof(type) * (size_t)(hi - lo + 1) * (width)); \
+    for (int p = lo; p <= hi; p++)                                               \
+      memcpy(tmp_ + (size_t)(p - lo) * (width), (arr) + (size_t)src[p] * (width), \
+             sizeof(type) * (width));                                            \
+    memcpy((arr) + (size_t)lo * (width), tmp_, sizeof(type) * (size_t)(hi - lo + 1) * (width)); \
+    free(tmp_);                                                                  \
+  } while (0)
+  PERMUTE_ROWS(int64_t, g->b, n);
+  PERMUTE_ROWS(double, g->bf, n);
+  PERMUTE_ROWS(double, g->mu, d);
+  PERMUTE_ROWS(double, g->r, d);
+  PERMUTE_ROWS(int64_t, g->row_expo, 1);
+  PERMUTE_ROWS(int, g->valid_cols, 1);
+#undef PERMUTE_ROWS
+  double *ng = (double *)malloc(sizeof(double) * d * d);
+  for (int i = 0; i < d; i++)
+    for (int j = 0; j <= i; j++)
+    {
+      int a = src[i], b = src[j];
+      ng[(size_t)i * d + j] = a >= b ? GF(g, a, b) : GF(g, b, a);
+    }
+  for (int i = 0; i < d; i++)
+    for (int j = 0; j <= i; j++)
+      GF(g, i, j) = ng[(size_t)i * d + j];
+  free(ng);
+  free(src);
+}
+
+/* Z_NR<long>::exponent, nr/nr_Z_l.inl:30-48 */
+static long zexponent(int64_t v)
+{
+  int e;
+  double f = frexp((double)v, &e);
+  if ((double)v > 0x1p53 && fabs(f) == 0.5)
+  {
+    uint64_t y = (uint64_t)(v < 0 ? -v : v);
+    long k     = 0;
+    for (; y; k++, y >>= 1)
+      ;
+    return k;
+  }
+  return e;
+}
+
+/* LLLReduction::lll(kappa_min, kappa_start, kappa_end, 0), lll.cpp:44-164 (no early reduction, no
+ * Siegel).  Returns 1 RED_SUCCESS, 0 RED_GSO_FAILURE, -1 RED_BABAI_FAILURE, -2 multiplier beyond 63
+ * bits, -3 RED_LLL_FAILURE.  info[0..3] = final_kappa, n_swaps, zeros, iterations. */
+int oracle_gso_lll(oracle_gso *g, int kappa_min, int kappa_start, int kappa_end, double delta,
+                   double eta, int *info)
+{
+  const int n = g->n;
+  if (kappa_end == -1)
+    kappa_end = g->d;
+  int kappa = kappa_start + 1;
+  int d     = kappa_end - kappa_min;
+  int zeros = 0, n_swaps = 0, final_kappa = 0;
+  double *lovasz = (double *)calloc(g->d + 1, sizeof(double));
+  int status     = 1;
+  long long iter = 0;
+  for (; zeros < d; zeros++)
+  { /* b_row_is_zero(0) */
+    int z = 1;
+    for (int c = 0; c < n; c++)
+      if (B(g, 0, c) != 0)
+        z = 0;
+    if (!z)
+      break;
+    move_row(g, kappa_min, kappa_end - 1 - zeros);
+  }
+  if (zeros < d)
+  {
+    int rc = 1;
+    if (kappa_start > 0)
+      rc = oracle_gso_babai(g, kappa_start, kappa_start, 0, eta);
+    if (rc == 1 && !oracle_gso_update_row(g, kappa_start, kappa_start))
+      rc = 0;
+    if (rc != 1)
+    {
+      status      = rc;
+      final_kappa = kappa_start;
+      goto done;
+    }
+  }
+  {
+    long max_exp = 0;
+    for (int i = 0; i < g->d; i++)
+      for (int c = 0; c < n; c++)
+      {
+        long e = zexponent(B(g, i, c));
+        if (e > max_exp)
+          max_exp = e;
+      }
+    long long max_iter = (long long)(d - 2 * d * (d + 1) * ((max_exp + 3) / log(delta)));
+    for (iter = 0; iter < max_iter && kappa < kappa_end - zeros; iter++)
+    {
+      int rc = oracle_gso_babai(g, kappa, kappa, 0, eta);
+      if (rc != 1)
+      {
+        status      = rc;
+        final_kappa = kappa;
+        goto done;
+      }
+      lovasz[0] = get_gram(g, kappa, kappa);
+      for (int i = 1; i <= kappa; i++)
+      {
+        double t  = MU(g, kappa, i - 1) * R(g, kappa, i - 1);
+        lovasz[i] = lovasz[i - 1] - t;
+      }
+      double f = R(g, kappa - 1, kappa - 1) * delta;
+      if (g->row_expo_on)
+        f = ldexp(f, (int)(2 * (g->row_expo[kappa - 1] - g->row_expo[kappa])));
+      if (f > lovasz[kappa - 1])
+      {
+        n_swaps++;
+        int old_k = kappa;
+        for (kappa--; kappa > kappa_min; kappa--)
+        {
+          f = R(g, kappa - 1, kappa - 1) * delta;
+          if (g->row_expo_on)
+            f = ldexp(f, (int)(2 * (g->row_expo[kappa - 1] - g->row_expo[old_k])));
+          if (f < lovasz[kappa - 1])
+            break;
+        }
+        if (lovasz[kappa] > 0)
+          move_row(g, old_k, kappa);
+        else
+        {
+          zeros++;
+          move_row(g, old_k, kappa_end - zeros);
+          kappa = old_k;
+          continue;
+        }
+      }
+      /* set_r(kappa, kappa, lovasz[kappa]), gso_interface.h:742-749 */
+      R(g, kappa, kappa) = lovasz[kappa];
+      if (g->valid_cols[kappa] == kappa)
+        g->valid_cols[kappa]++;
+      kappa++;
+    }
+    status = (kappa < kappa_end - zeros) ? -3 : 1;
+  }
+done:
+  free(lovasz);
+  if (info)
+  {
+    info[0] = final_kappa;
+    info[1] = n_swaps;
+    info[2] = zeros;
+    info[3] = (int)(iter & 0x7fffffff);
+  }
+  return status;
+}
+
 const double *oracle_gso_mu(const oracle_gso *g) { return g->mu; }
 const double *oracle_gso_r(const oracle_gso *g) { return g->r; }
 const double *oracle_gso_bf(const oracle_gso *g) { return g->bf; }

@@ -63,6 +63,12 @@ int oracle_gso_update_all(oracle_gso *g);
 int oracle_gso_babai(oracle_gso *g, int kappa, int sr_end, int sr_start, double eta);
 /* LLLReduction::size_reduction(kappa_min,kappa_end)      lll.h:107-122 */
 int oracle_gso_size_reduction(oracle_gso *g, int kappa_min, int kappa_end, double eta);
+/* LLLReduction::lll(kappa_min, kappa_start, kappa_end, 0)  lll.cpp:44-164 + MatGSO::move_row
+ * gso.cpp:289-366.  1 success, 0 GSO failure, -1 babai failure, -2 multiplier, -3 LLL failure.
+ * Rows below kappa_start must have been updated by the caller (as in the reference).
+ * info[4] (nullable): final_kappa, n_swaps, zeros, iterations. */
+int oracle_gso_lll(oracle_gso *g, int kappa_min, int kappa_start, int kappa_end, double delta,
+                   double eta, int *info);
 /* raw (scaled) state access; true values need the row exponents (gso_interface.h:694-732) */
 const double *oracle_gso_mu(const oracle_gso *g);      /* d×d */
 const double *oracle_gso_r(const oracle_gso *g);       /* d×d */

@@ -419,6 +419,94 @@ static int cmd_gsofix(int argc, char **argv)
 }
 
 // ---------------------------------------------------------------------------------------------
+// lllfix: LLLReduction<Z_NR<long>,FP_NR<double>>::lll on MatGSO(GSO_ROW_EXPO) golden vectors
+// ---------------------------------------------------------------------------------------------
+/* lllfix type d k bits seed kmin kstart kend zero_rows dup_rows [reps]
+ *   type q: gen_qary_prime(k,bits) d x d (raw, unreduced);  r: gen_intrel(bits) d x (d+1);
+ *        u: gen_uniform(bits) d x d
+ *   zero_rows: that many leading rows are zeroed;  dup_rows: row d-1-t is replaced by a copy of
+ *   row t+zero_rows + row t+zero_rows+1 (linear dependencies: the "zeros" path of lll.cpp:144-150)
+ *   reps > 1: also time `reps` reductions of the same input (cpu baseline)            */
+static int cmd_lllfix(int argc, char **argv)
+{
+  if (argc < 12)
+    return 2;
+  std::string type = argv[2];
+  int d = atoi(argv[3]), k = atoi(argv[4]), bits = atoi(argv[5]), seed = atoi(argv[6]);
+  int kmin = atoi(argv[7]), kstart = atoi(argv[8]), kend = atoi(argv[9]);
+  int zero_rows = atoi(argv[10]), dup_rows = atoi(argv[11]);
+  int reps = argc > 12 ? atoi(argv[12]) : 1;
+  RandGen::init_with_seed(seed);
+  ZZ_mat<mpz_t> A;
+  if (type == "q")
+  {
+    A.resize(d, d);
+    A.gen_qary_prime(k, bits);
+  }
+  else if (type == "r")
+  {
+    A.resize(d, d + 1);
+    A.gen_intrel(bits);
+  }
+  else
+  {
+    A.resize(d, d);
+    A.gen_uniform(bits);
+  }
+  const int n = A.get_cols();
+  ZZ_mat<long> b0(d, n), u, ut;
+  for (int i = 0; i < d; ++i)
+    for (int j = 0; j < n; ++j)
+      b0(i, j) = A(i, j).get_si();
+  for (int t = 0; t < zero_rows && t < d; ++t)
+    for (int j = 0; j < n; ++j)
+      b0(t, j) = 0;
+  for (int t = 0; t < dup_rows; ++t)
+    for (int j = 0; j < n; ++j)
+      b0(d - 1 - t, j) = b0(zero_rows + t, j).get_si() + b0(zero_rows + t + 1, j).get_si();
+  if (kend < 0)
+    kend = d;
+  std::ostringstream os;
+  os << "{\n\"desc\":\"lll type=" << type << " d=" << d << " k=" << k << " bits=" << bits
+     << " seed=" << seed << " zero_rows=" << zero_rows << " dup_rows=" << dup_rows
+     << "\",\n\"d\":" << d << ",\n\"n\":" << n << ",\n\"kmin\":" << kmin << ",\n\"kstart\":"
+     << kstart << ",\n\"kend\":" << kend << ",\n\"delta\":" << hexd(LLL_DEF_DELTA) << ",\n\"eta\":"
+     << hexd(LLL_DEF_ETA) << ",\n\"b_in\":[";
+  for (int i = 0; i < d; ++i)
+    for (int j = 0; j < n; ++j)
+      os << ((i || j) ? "," : "") << b0(i, j).get_si();
+  os << "],\n";
+  ZZ_mat<long> b = b0;
+  double secs = 0;
+  int status = 0, final_kappa = 0, n_swaps = 0, zeros = 0;
+  for (int rep = 0; rep < reps; ++rep)
+  {
+    b = b0;
+    auto t0 = std::chrono::steady_clock::now();
+    MatGSO<Z_NR<long>, FP_NR<double>> M(b, u, ut, GSO_ROW_EXPO);
+    LLLReduction<Z_NR<long>, FP_NR<double>> L(M, LLL_DEF_DELTA, LLL_DEF_ETA, LLL_DEFAULT);
+    if (kstart > 0)
+    {  // the caller's precondition: rows below kappa_start are known to the GSO
+      for (int i = 0; i < kstart; ++i)
+        M.update_gso_row(i);
+    }
+    L.lll(kmin, kstart, kend, 0);
+    secs += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    status = L.status; final_kappa = L.final_kappa; n_swaps = L.n_swaps; zeros = L.zeros;
+  }
+  os << "\"ref_status\":" << status << ",\n\"final_kappa\":" << final_kappa << ",\n\"n_swaps\":"
+     << n_swaps << ",\n\"zeros\":" << zeros << ",\n\"reps\":" << reps << ",\n\"ref_seconds\":"
+     << secs << ",\n\"b_out\":[";
+  for (int i = 0; i < d; ++i)
+    for (int j = 0; j < n; ++j)
+      os << ((i || j) ? "," : "") << b(i, j).get_si();
+  os << "]\n}\n";
+  std::cout << os.str();
+  return 0;
+}
+
+
+// ---------------------------------------------------------------------------------------------
 // BKZ tour axis (SURVEY.md §8(d) metric (ii)): the reference's bkz_reduction, unchanged, with its
 // internal enumerator or with OUR plugin installed through set_external_enumerator.
 // ---------------------------------------------------------------------------------------------
@@ -612,6 +700,8 @@ int main(int argc, char **argv)
     return cmd_gsofix(argc, argv);
   if (cmd == "hhfix")
     return cmd_hhfix(argc, argv);
+  if (cmd == "lllfix")
+    return cmd_lllfix(argc, argv);
   if (cmd == "genstrat")
     return cmd_genstrat(argc, argv);
   if (cmd == "bkztour")

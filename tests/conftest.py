@@ -163,6 +163,22 @@ class OracleGSO:
     def size_reduction(self, kmin, kend, eta=0.51):
         return self.lib.oracle_gso_size_reduction(self.h, kmin, kend, eta)
 
+    def update_row(self, i, last=None):
+        self.lib.oracle_gso_update_row.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+        return self.lib.oracle_gso_update_row(self.h, i, i if last is None else last)
+
+    def lll(self, kmin=0, kstart=0, kend=-1, delta=0.99, eta=0.51):
+        """LLLReduction::lll (oracle/gso_oracle.c).  Returns (status, info[4])."""
+        self.lib.oracle_gso_lll.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                            ctypes.c_int, ctypes.c_double, ctypes.c_double,
+                                            ctypes.c_void_p]
+        info = np.zeros(4, dtype=np.int32)
+        for i in range(kstart):  # the caller's precondition in the reference
+            self.update_row(i)
+        st = self.lib.oracle_gso_lll(self.h, kmin, kstart, kend, delta, eta,
+                                     info.ctypes.data_as(ctypes.c_void_p))
+        return st, info
+
     def _arr(self, fn, shape, dtype):
         p = getattr(self.lib, fn)(self.h)
         return np.ctypeslib.as_array(p, shape=shape).astype(dtype).copy()
@@ -197,6 +213,28 @@ class OracleGSO:
             self.close()
         except Exception:
             pass
+
+
+# ---- LLL fixtures ---------------------------------------------------------------------------------
+REF_STATUS_TO_OURS = {0: 1, 2: 0, 3: -1, 4: -3}  # RedStatus (defs.h:153-169) -> kernel / oracle code
+
+
+def lll_fixtures():
+    return sorted(glob.glob(os.path.join(GOLDEN, "lll_*.json")))
+
+
+def load_lll_fixture(path):
+    with open(path) as f:
+        j = json.load(f)
+    d, n = j["d"], j["n"]
+    out = {k: j[k] for k in ("d", "n", "kmin", "kstart", "kend", "final_kappa", "n_swaps", "zeros")}
+    out["name"] = os.path.basename(path)[:-5]
+    out["status"] = REF_STATUS_TO_OURS[j["ref_status"]]
+    out["delta"] = float.fromhex(j["delta"])
+    out["eta"] = float.fromhex(j["eta"])
+    out["b_in"] = np.array(j["b_in"], dtype=np.int64).reshape(d, n)
+    out["b_out"] = np.array(j["b_out"], dtype=np.int64).reshape(d, n)
+    return out
 
 
 # ---- Householder oracle wrappers ----------------------------------------------------------------

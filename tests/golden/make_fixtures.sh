@@ -21,4 +21,31 @@ $D enumfix 100 50 14  2  20   0   40 linear:20  100000000 0 0.99 > $G/enum_d40_l
 $D enumfix 100 50 14  2  20   0   40 linear:20  1         0 0.99 > $G/enum_d40_lin20_best1.json
 $D enumfix 120 60 16  5  20  10   48 linear:30  100000000 0 0.99 > $G/enum_d48_lin30_fixed.json
 $D enumfix 120 60 16  5  20  10   48 linear:30  1         0 0.99 > $G/enum_d48_lin30_best1.json
+
+# --- GSO / size-reduction (MatGSO<long,double>, GSO_ROW_EXPO): n k bits seed perturb
+$D gsofix 30 15 10 1 0 > $G/gso_q30_p0.json
+$D gsofix 48 24 12 2 3 > $G/gso_q48_p3.json
+$D gsofix 64 32 14 3 5 > $G/gso_q64_p5.json
+# --- Householder R factor: n k bits seed perturb row_expo
+$D hhfix 40 20 11 4 2 0 > $G/hh_q40_p2_e0.json
+$D hhfix 64 32 14 3 3 1 > $G/hh_q64_p3_e1.json
+# --- LLL (LLLReduction<long,double>::lll): type d k bits seed kmin kstart kend zero_rows dup_rows
+$D lllfix q  40 20 20 1  0  0 -1 0 0 > $G/lll_q40.json
+$D lllfix q  72 36 16 2  0  0 -1 0 0 > $G/lll_q72.json
+$D lllfix q 130 65 12 3  0  0 -1 0 0 > $G/lll_q130.json
+$D lllfix r  30  0 40 4  0  0 -1 0 0 > $G/lll_r30.json
+$D lllfix u  24  0 30 5  0  0 -1 0 0 > $G/lll_u24.json
+$D lllfix q  40 20 20 6  0  0 -1 2 0 > $G/lll_q40_zero2.json
+$D lllfix q  40 20 20 7  0  0 -1 0 2 > $G/lll_q40_dup2.json
+$D lllfix q  40 20 20 8  0 10 30 0 0 > $G/lll_q40_range10_30.json
+$D lllfix q  40 20 20 9  5  5 35 0 0 > $G/lll_q40_kmin5.json
+# --- C3 (BASELINE configs[2]): the 180-dim q-ary lattice, LLL + BKZ-20 by the reference, its
+#     beta=60 blocks as the plugin sees them, and pruner-generated strategies for the tour bench
+$D dumpbasis 180 90 20 0 20 > $G/basis_q180_seed0_lll_bkz20.txt
+for k in 0 1 2; do
+  f=$((k*1))
+  REFDRV_INPUT_ONLY=1 $D enumfix 0 $G/basis_q180_seed0_lll_bkz20.txt 0 0 0 $f 60 linear:30 1 0 0.99 > $G/c3_b60_k${k}_linear30_input.json
+  $D enumfix 0 $G/basis_q180_seed0_lll_bkz20.txt 0 0 0 $f 60 prune:0.5 1 0 0.99 > $G/c3_b60_k${k}_pruner.json
+done
+$D genstrat $G/basis_q180_seed0_lll_bkz20.txt 60 > $G/strategies_q180_b60.json
 md5sum $G/enum_*.json > $G/MD5SUMS

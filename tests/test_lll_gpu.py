@@ -1,0 +1,133 @@
+"""GPU parity tests for the batched LLL kernel (fphip_gso_lll through the C ABI): the reduced
+basis, the swap count, the number of zero rows and the status must equal the real reference's
+(tests/golden/lll_*.json) and the C oracle's on seeded inputs — LLL is a chain of floating-point
+DECISIONS, so equality of the output basis means every Lovasz test, insertion index and rounded
+multiplier along the way was the reference's.  After the call mu / r must be update_gso() of the
+reduced basis."""
+import os
+
+import numpy as np
+import pytest
+
+import conftest as C
+
+pytestmark = pytest.mark.gpu
+
+
+def _qary(rng, d, k, q):
+    """[[I_k H],[0 q I_(d-k)]] like gen_qary (nr/matrix.cpp:407-433), raw."""
+    b = np.zeros((d, d), dtype=np.int64)
+    b[:k, :k] = np.eye(k, dtype=np.int64)
+    b[:k, k:] = rng.integers(0, q, size=(k, d - k))
+    b[k:, k:] = q * np.eye(d - k, dtype=np.int64)
+    return b
+
+
+@pytest.mark.parametrize("path", C.lll_fixtures(), ids=lambda p: os.path.basename(p)[:-5])
+def test_reference_fixture_parity(ctx, path):
+    from fplll_amd.gso import MatGSOBatch
+    f = C.load_lll_fixture(path)
+    g = MatGSOBatch(ctx, 3, f["d"], f["n"])
+    g.set_basis(np.stack([f["b_in"]] * 3))
+    st, info = g.lll(f["kmin"], f["kstart"], f["kend"], f["delta"], f["eta"])
+    assert list(st) == [f["status"]] * 3
+    for L in range(3):
+        assert info[L][1] == f["n_swaps"]
+        assert info[L][2] == f["zeros"]
+        assert info[L][0] == f["final_kappa"]
+        assert np.array_equal(g.get_basis(L, 1)[0], f["b_out"])
+    # mu / r after the call = update_gso() of the reduced basis (only meaningful without zero rows)
+    if f["zeros"] == 0:
+        o = C.OracleGSO(f["b_out"])
+        assert o.update_all() == 1
+        assert np.array_equal(g.row_expo(0), o.row_expo)
+        assert np.array_equal(g.get_mu_matrix(0), o.mu)
+        assert np.array_equal(g.get_r_matrix(0), o.r)
+        o.close()
+    g.close()
+
+
+@pytest.mark.parametrize("d,n_extra", [(2, 0), (3, 0), (17, 0), (33, 1), (64, 0), (65, 0), (96, 2)])
+def test_seeded_vs_oracle_heterogeneous_batch(ctx, d, n_extra):
+    """A batch of DIFFERENT lattices (every wave takes its own decision path), incl. shapes at the
+    chunk boundaries (64/65) and n > d."""
+    from fplll_amd.gso import MatGSOBatch
+    rng = np.random.default_rng(1000 + d)
+    B = 6
+    n = d + n_extra
+    bs = []
+    for L in range(B):
+        if n_extra == 0 and d >= 4:
+            b = _qary(rng, d, d // 2, int(rng.integers(50, 5000)))
+        else:
+            b = np.zeros((d, n), dtype=np.int64)
+            b[:, :d] = np.eye(d, dtype=np.int64)
+            b[:, d - 1 if n_extra == 0 else d:] += rng.integers(-10**6, 10**6,
+                                                               size=(d, n - (d - 1 if n_extra == 0 else d)))
+        bs.append(b)
+    g = MatGSOBatch(ctx, B, d, n)
+    g.set_basis(np.stack(bs))
+    st, info = g.lll()
+    for L in range(B):
+        o = C.OracleGSO(bs[L])
+        ost, oinfo = o.lll()
+        assert st[L] == ost == 1
+        assert list(info[L][:3]) == list(oinfo[:3])
+        assert np.array_equal(g.get_basis(L, 1)[0], o.b)
+        o.close()
+    g.close()
+
+
+def test_lll_is_idempotent_and_reduced(ctx):
+    """size-independent properties: an LLL-reduced basis is a fixed point (0 swaps), it is
+    size-reduced (|mu| <= eta) and satisfies Lovasz (delta r_{i-1} <= r_i + mu^2 r_{i-1})."""
+    from fplll_amd.gso import MatGSOBatch
+    rng = np.random.default_rng(7)
+    d = 80
+    bs = np.stack([_qary(rng, d, d // 2, 3001 + 2 * i) for i in range(4)])
+    g = MatGSOBatch(ctx, 4, d, d)
+    g.set_basis(bs)
+    st, info = g.lll()
+    assert list(st) == [1] * 4 and all(info[:, 1] > 0)
+    out = g.get_basis(0, 4)
+    for L in range(4):
+        mu = g.get_mu_matrix(L)
+        r = g.get_r_matrix(L)
+        e = g.row_expo(L).astype(np.float64)
+        mu_t = mu * np.exp2(e[:, None] - e[None, :])
+        rd = np.diag(r) * np.exp2(2 * e)
+        assert np.abs(mu_t).max() <= 0.51 + 1e-9
+        lhs = 0.99 * rd[:-1]
+        rhs = rd[1:] + np.diag(mu_t, -1) ** 2 * rd[:-1]
+        assert np.all(lhs <= rhs * (1 + 1e-9))
+        # same lattice: |det| of the q-ary basis is q^(d-k)
+        assert abs(np.sum(np.log(rd)) / 2 - (d - d // 2) * np.log(3001 + 2 * L)) < 1e-6
+    g.set_basis(out)
+    st2, info2 = g.lll()
+    assert list(st2) == [1] * 4
+    assert list(info2[:, 1]) == [0] * 4
+    assert np.array_equal(g.get_basis(0, 4), out)
+    g.close()
+
+
+def test_lll_large_batch_stress(ctx):
+    """Many waves in flight (the DMA ring's vmcnt arithmetic only breaks under load)."""
+    from fplll_amd.gso import MatGSOBatch
+    rng = np.random.default_rng(11)
+    d, B = 40, 1536
+    base = [_qary(rng, d, d // 2, 1009 + 2 * i) for i in range(8)]
+    bs = np.stack([base[i % 8] for i in range(B)])
+    g = MatGSOBatch(ctx, B, d, d)
+    g.set_basis(bs)
+    st, info = g.lll()
+    assert np.all(st == 1)
+    out = g.get_basis(0, B)
+    for i in range(8):
+        o = C.OracleGSO(base[i])
+        ost, oinfo = o.lll()
+        assert ost == 1
+        for L in range(i, B, 8):
+            assert info[L][1] == oinfo[1]
+            assert np.array_equal(out[L], o.b), (i, L)
+        o.close()
+    g.close()

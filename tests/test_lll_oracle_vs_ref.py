@@ -1,0 +1,26 @@
+"""Pins oracle/gso_oracle.c::oracle_gso_lll against the REAL reference:
+LLLReduction<Z_NR<long>,FP_NR<double>>::lll on MatGSO(GSO_ROW_EXPO) (fplll/lll.cpp:44-164,
+gso.cpp:289-366) — tests/golden/lll_*.json from oracle/ref_driver.cpp `lllfix`: raw q-ary, knapsack
+(intrel) and uniform bases, leading zero rows and linearly dependent rows (the "zeros" path), a
+sub-range (kappa_start > 0) and kappa_min > 0.  The output basis, the swap count, the number of
+zero rows and the status must be identical."""
+import os
+
+import numpy as np
+import pytest
+
+import conftest as C
+
+
+@pytest.mark.parametrize("path", C.lll_fixtures(), ids=lambda p: os.path.basename(p)[:-5])
+def test_lll_oracle_matches_reference(path):
+    f = C.load_lll_fixture(path)
+    g = C.OracleGSO(f["b_in"])
+    st, info = g.lll(f["kmin"], f["kstart"], f["kend"], f["delta"], f["eta"])
+    assert st == f["status"]
+    assert info[1] == f["n_swaps"]
+    assert info[2] == f["zeros"]
+    assert info[0] == f["final_kappa"]
+    assert np.array_equal(g.b, f["b_out"])
+    assert not np.array_equal(f["b_in"], f["b_out"])
+    g.close()
