@@ -421,9 +421,57 @@ static int cmd_gsofix(int argc, char **argv)
 // ---------------------------------------------------------------------------------------------
 // lllfix: LLLReduction<Z_NR<long>,FP_NR<double>>::lll on MatGSO(GSO_ROW_EXPO) golden vectors
 // ---------------------------------------------------------------------------------------------
+// test bases for lllfix / hlllfix (see cmd_lllfix for the meaning of the arguments)
+static bool gen_long_basis(const std::string &type, int &d, int k, int bits, int seed, int zero_rows,
+                           int dup_rows, ZZ_mat<long> &b0)
+{
+  RandGen::init_with_seed(seed);
+  ZZ_mat<mpz_t> A;
+  if (type.rfind("f:", 0) == 0)
+  {  // basis from a file in fplll's matrix format (d is taken from the file)
+    std::ifstream in(type.substr(2));
+    in >> A;
+    if (A.get_rows() == 0)
+      return false;
+    d = A.get_rows();
+  }
+  else if (type == "q")
+  {
+    A.resize(d, d);
+    A.gen_qary_prime(k, bits);
+  }
+  else if (type == "r")
+  {
+    A.resize(d, d + 1);
+    A.gen_intrel(bits);
+  }
+  else if (type == "n")
+  {  // NTRU-like [[I, Rot(h)],[0, qI]], d must be even (latticegen n, matrix.cpp:288-352)
+    A.resize(d, d);
+    A.gen_ntrulike_bits(bits);
+  }
+  else
+  {
+    A.resize(d, d);
+    A.gen_uniform(bits);
+  }
+  const int n = A.get_cols();
+  b0.resize(d, n);
+  for (int i = 0; i < d; ++i)
+    for (int j = 0; j < n; ++j)
+      b0(i, j) = A(i, j).get_si();
+  for (int t = 0; t < zero_rows && t < d; ++t)
+    for (int j = 0; j < n; ++j)
+      b0(t, j) = 0;
+  for (int t = 0; t < dup_rows; ++t)
+    for (int j = 0; j < n; ++j)
+      b0(d - 1 - t, j) = b0(zero_rows + t, j).get_si() + b0(zero_rows + t + 1, j).get_si();
+  return true;
+}
+
 /* lllfix type d k bits seed kmin kstart kend zero_rows dup_rows [reps]
  *   type q: gen_qary_prime(k,bits) d x d (raw, unreduced);  r: gen_intrel(bits) d x (d+1);
- *        u: gen_uniform(bits) d x d
+ *        u: gen_uniform(bits) d x d;  f:<path>: read the basis from a file
  *   zero_rows: that many leading rows are zeroed;  dup_rows: row d-1-t is replaced by a copy of
  *   row t+zero_rows + row t+zero_rows+1 (linear dependencies: the "zeros" path of lll.cpp:144-150)
  *   reps > 1: also time `reps` reductions of the same input (cpu baseline)            */
@@ -436,34 +484,10 @@ static int cmd_lllfix(int argc, char **argv)
   int kmin = atoi(argv[7]), kstart = atoi(argv[8]), kend = atoi(argv[9]);
   int zero_rows = atoi(argv[10]), dup_rows = atoi(argv[11]);
   int reps = argc > 12 ? atoi(argv[12]) : 1;
-  RandGen::init_with_seed(seed);
-  ZZ_mat<mpz_t> A;
-  if (type == "q")
-  {
-    A.resize(d, d);
-    A.gen_qary_prime(k, bits);
-  }
-  else if (type == "r")
-  {
-    A.resize(d, d + 1);
-    A.gen_intrel(bits);
-  }
-  else
-  {
-    A.resize(d, d);
-    A.gen_uniform(bits);
-  }
-  const int n = A.get_cols();
-  ZZ_mat<long> b0(d, n), u, ut;
-  for (int i = 0; i < d; ++i)
-    for (int j = 0; j < n; ++j)
-      b0(i, j) = A(i, j).get_si();
-  for (int t = 0; t < zero_rows && t < d; ++t)
-    for (int j = 0; j < n; ++j)
-      b0(t, j) = 0;
-  for (int t = 0; t < dup_rows; ++t)
-    for (int j = 0; j < n; ++j)
-      b0(d - 1 - t, j) = b0(zero_rows + t, j).get_si() + b0(zero_rows + t + 1, j).get_si();
+  ZZ_mat<long> b0, u, ut;
+  if (!gen_long_basis(type, d, k, bits, seed, zero_rows, dup_rows, b0))
+    return 3;
+  const int n = b0.get_cols();
   if (kend < 0)
     kend = d;
   std::ostringstream os;
@@ -497,6 +521,54 @@ static int cmd_lllfix(int argc, char **argv)
   os << "\"ref_status\":" << status << ",\n\"final_kappa\":" << final_kappa << ",\n\"n_swaps\":"
      << n_swaps << ",\n\"zeros\":" << zeros << ",\n\"reps\":" << reps << ",\n\"ref_seconds\":"
      << secs << ",\n\"b_out\":[";
+  for (int i = 0; i < d; ++i)
+    for (int j = 0; j < n; ++j)
+      os << ((i || j) ? "," : "") << b(i, j).get_si();
+  os << "]\n}\n";
+  std::cout << os.str();
+  return 0;
+}
+
+
+/* hlllfix type d k bits seed [reps]: HLLLReduction<Z_NR<long>,FP_NR<double>>::hlll() with the
+ * LM_FAST Householder flags (wrapper.cpp:790-806), default delta/eta/theta/c */
+static int cmd_hlllfix(int argc, char **argv)
+{
+  if (argc < 7)
+    return 2;
+  std::string type = argv[2];
+  int d = atoi(argv[3]), k = atoi(argv[4]), bits = atoi(argv[5]), seed = atoi(argv[6]);
+  int reps = argc > 7 ? atoi(argv[7]) : 1;
+  ZZ_mat<long> b0, u, ut;
+  if (!gen_long_basis(type, d, k, bits, seed, 0, 0, b0))
+    return 3;
+  const int n = b0.get_cols();
+  std::ostringstream os;
+  os << "{\n\"desc\":\"hlll type=" << type << " d=" << d << " k=" << k << " bits=" << bits
+     << " seed=" << seed << "\",\n\"d\":" << d << ",\n\"n\":" << n << ",\n\"delta\":"
+     << hexd(LLL_DEF_DELTA) << ",\n\"eta\":" << hexd(LLL_DEF_ETA) << ",\n\"theta\":"
+     << hexd(HLLL_DEF_THETA) << ",\n\"c\":" << hexd(HLLL_DEF_C) << ",\n\"b_in\":[";
+  for (int i = 0; i < d; ++i)
+    for (int j = 0; j < n; ++j)
+      os << ((i || j) ? "," : "") << b0(i, j).get_si();
+  os << "],\n";
+  ZZ_mat<long> b = b0;
+  double secs = 0;
+  int status = 0;
+  for (int rep = 0; rep < reps; ++rep)
+  {
+    b = b0;
+    auto t0 = std::chrono::steady_clock::now();
+    MatHouseholder<Z_NR<long>, FP_NR<double>> M(b, u, ut,
+                                                HOUSEHOLDER_ROW_EXPO | HOUSEHOLDER_OP_FORCE_LONG);
+    HLLLReduction<Z_NR<long>, FP_NR<double>> H(M, LLL_DEF_DELTA, LLL_DEF_ETA, HLLL_DEF_THETA,
+                                               HLLL_DEF_C, LLL_DEFAULT);
+    H.hlll();
+    secs += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    status = H.get_status();
+  }
+  os << "\"ref_status\":" << status << ",\n\"reps\":" << reps << ",\n\"ref_seconds\":" << secs
+     << ",\n\"b_out\":[";
   for (int i = 0; i < d; ++i)
     for (int j = 0; j < n; ++j)
       os << ((i || j) ? "," : "") << b(i, j).get_si();
@@ -702,6 +774,8 @@ int main(int argc, char **argv)
     return cmd_hhfix(argc, argv);
   if (cmd == "lllfix")
     return cmd_lllfix(argc, argv);
+  if (cmd == "hlllfix")
+    return cmd_hlllfix(argc, argv);
   if (cmd == "genstrat")
     return cmd_genstrat(argc, argv);
   if (cmd == "bkztour")

@@ -237,6 +237,41 @@ def load_lll_fixture(path):
     return out
 
 
+# ---- HLLL fixtures / oracle -----------------------------------------------------------------------
+HLLL_REF_STATUS_TO_OURS = {0: 1, 11: -4, 10: -5}  # RED_HLLL_SR_FAILURE=11, RED_HLLL_NORM_FAILURE=10
+
+
+def hlll_fixtures():
+    return sorted(glob.glob(os.path.join(GOLDEN, "hlll_*.json")))
+
+
+def load_hlll_fixture(path):
+    with open(path) as f:
+        j = json.load(f)
+    d, n = j["d"], j["n"]
+    out = {"d": d, "n": n, "name": os.path.basename(path)[:-5],
+           "status": HLLL_REF_STATUS_TO_OURS[j["ref_status"]]}
+    for k in ("delta", "eta", "theta", "c"):
+        out[k] = float.fromhex(j[k])
+    out["b_in"] = np.array(j["b_in"], dtype=np.int64).reshape(d, n)
+    out["b_out"] = np.array(j["b_out"], dtype=np.int64).reshape(d, n)
+    return out
+
+
+def oracle_hlll(b, delta=0.99, eta=0.51, theta=0.001, c=0.1, row_expo=True):
+    """HLLLReduction::hlll (oracle/hh_oracle.c).  Returns (status, reduced basis, info[2])."""
+    lib = oracle_lib()
+    lib.oracle_hlll.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+                                ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                ctypes.c_void_p]
+    out = np.ascontiguousarray(b, dtype=np.int64).copy()
+    info = np.zeros(2, dtype=np.int32)
+    st = lib.oracle_hlll(out.shape[0], out.shape[1], out.ctypes.data_as(ctypes.c_void_p),
+                         1 if row_expo else 0, delta, eta, theta, c,
+                         info.ctypes.data_as(ctypes.c_void_p))
+    return st, out, info
+
+
 # ---- Householder oracle wrappers ----------------------------------------------------------------
 def hh_fixtures():
     return sorted(glob.glob(os.path.join(GOLDEN, "hh_*.json")))
