@@ -50,6 +50,9 @@ struct HhBatch
   double *sigma;
   long long *rexp;
   int *status;
+  // HLLL kernel only (allocated on first use): float basis [batch][d][ldn], info [batch][2]
+  double *bf;
+  int *info;
 };
 }  // namespace fphip
 #endif

@@ -22,6 +22,7 @@
 namespace fphip
 {
 template <int NQ> __global__ void gso_sweep_kernel(GsoBatch P, int kmin, int kend, double eta, int mode);
+template <int NQ> __global__ void hlll_kernel(HhBatch P, double delta, double theta, long long iter_cap);
 template <int NQ>
 __global__ void lll_kernel(GsoBatch P, int kmin, int kstart, int kend, double delta, double eta,
                            double logdelta);
@@ -475,6 +476,10 @@ extern "C" void fphip_hh_destroy(fphip_hh *h)
   hipFree(h->P.sigma);
   hipFree(h->P.rexp);
   hipFree(h->P.status);
+  if (h->P.bf)
+    hipFree(h->P.bf);
+  if (h->P.info)
+    hipFree(h->P.info);
   hipEventDestroy(h->ev[0]);
   hipEventDestroy(h->ev[1]);
   delete h;
@@ -532,6 +537,66 @@ extern "C" int fphip_hh_update_R(fphip_hh *h, int *status)
   HCHK(hipEventElapsedTime(&h->last_ms, h->ev[0], h->ev[1]));
   if (status)
     HCHK(hipMemcpy(status, h->P.status, sizeof(int) * h->P.batch, hipMemcpyDeviceToHost));
+  return FPHIP_OK;
+}
+
+extern "C" int fphip_hh_get_basis(fphip_hh *h, int first, int count, int64_t *b)
+{
+  if (!h || !b || first < 0 || count <= 0 || first + count > h->P.batch)
+    return FPHIP_ERROR;
+  HCHK(hipMemcpy2D(b, (size_t)h->P.n * 8, h->P.b + (size_t)first * h->P.d * h->P.ldn,
+                   (size_t)h->P.ldn * 8, (size_t)h->P.n * 8, (size_t)h->P.d * count,
+                   hipMemcpyDeviceToHost));
+  return FPHIP_OK;
+}
+
+// HLLLReduction<Z_NR<long>, FP_NR<double>>(m, delta, eta, theta, c, LLL_DEFAULT).hlll() on a fresh
+// MatHouseholder of every lattice (hlll.cpp:26-169).  eta and c are accepted for interface parity:
+// the default build of the reference uses neither (eR is delta*R(k,k), hlll.h:155-159; the size
+// reduction stop rule uses the constant 0.1, hlll.cpp:297).  info (nullable) [batch][2]: swaps,
+// loop iterations.
+extern "C" int fphip_hh_hlll(fphip_hh *h, double delta, double eta, double theta, double c,
+                             int *status, int *info)
+{
+  (void)eta;
+  (void)c;
+  if (!h)
+    return FPHIP_ERROR;
+  const size_t B = (size_t)h->P.batch, d = h->P.d, ld = h->P.ldn;
+  if (!h->P.bf)
+  {
+    HCHK(hipMalloc((void **)&h->P.bf, B * d * ld * 8 + 4096));
+    HCHK(hipMalloc((void **)&h->P.info, B * 2 * sizeof(int)));
+    HCHK(hipMemset(h->P.bf, 0, B * d * ld * 8 + 4096));
+    HCHK(hipDeviceSynchronize());
+  }
+  const int nq  = (h->P.n + 63) / 64;
+  const int wpb = 4;
+  const size_t lds = (size_t)wpb * FPHIP_GSO_RING * (size_t)((nq + 1) / 2) * 1024;
+  int bpc          = (int)((160 * 1024) / lds);
+  if (bpc * wpb > 32)
+    bpc = 32 / wpb;
+  int grid = (h->P.batch + wpb - 1) / wpb;
+  if (grid > fphip_ctx_num_cus(h->ctx) * bpc)
+    grid = fphip_ctx_num_cus(h->ctx) * bpc;
+  const long long cap = 1LL << 40;
+  hipStream_t s = fphip_ctx_stream(h->ctx);
+  HCHK(hipEventRecord(h->ev[0], s));
+  switch (nq)
+  {
+  case 1: hipLaunchKernelGGL(hlll_kernel<1>, dim3(grid), dim3(wpb * 64), lds, s, h->P, delta, theta, cap); break;
+  case 2: hipLaunchKernelGGL(hlll_kernel<2>, dim3(grid), dim3(wpb * 64), lds, s, h->P, delta, theta, cap); break;
+  case 3: hipLaunchKernelGGL(hlll_kernel<3>, dim3(grid), dim3(wpb * 64), lds, s, h->P, delta, theta, cap); break;
+  default: hipLaunchKernelGGL(hlll_kernel<4>, dim3(grid), dim3(wpb * 64), lds, s, h->P, delta, theta, cap); break;
+  }
+  HCHK(hipGetLastError());
+  HCHK(hipEventRecord(h->ev[1], s));
+  HCHK(hipStreamSynchronize(s));
+  HCHK(hipEventElapsedTime(&h->last_ms, h->ev[0], h->ev[1]));
+  if (status)
+    HCHK(hipMemcpy(status, h->P.status, sizeof(int) * B, hipMemcpyDeviceToHost));
+  if (info)
+    HCHK(hipMemcpy(info, h->P.info, sizeof(int) * 2 * B, hipMemcpyDeviceToHost));
   return FPHIP_OK;
 }
 

@@ -158,27 +158,6 @@ template __global__ void gso_sweep_kernel<4>(GsoBatch, int, int, double, int);
 namespace fphip
 {
 
-// sum of p[c] for c in [from, to), ascending, starting from `init` if has_init, else from p[from]
-template <int NQ>
-__device__ __forceinline__ double seq_sum(const double (&p)[NQ], int from, int to)
-{
-  double s   = 0.0;
-  bool first = true;
-#pragma unroll
-  for (int q = 0; q < NQ; ++q)
-  {
-    const int lo = max(from, 64 * q) - 64 * q;
-    const int hi = min(to, 64 * q + 64) - 64 * q;
-    for (int cc = lo; cc < hi; ++cc)
-    {
-      const double v = g_rl_f64(p[q], cc);
-      s              = first ? v : s + v;
-      first          = false;
-    }
-  }
-  return s;
-}
-
 template <int NQ>
 __global__ void __launch_bounds__(256) hh_update_kernel(HhBatch P)
 {

@@ -680,6 +680,27 @@ __device__ int babai(Lattice<NQ> &T, Ring<NQ, IPS> &ring, int kappa, double eta)
       [&](int k, int last) { return update_row<NQ, IPS>(T, ring, k, last); }, [](int) {});
 }
 
+// sum of p[c] for c in [from, to), ascending, starting from `init` if has_init, else from p[from]
+template <int NQ>
+__device__ __forceinline__ double seq_sum(const double (&p)[NQ], int from, int to)
+{
+  double s   = 0.0;
+  bool first = true;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+  {
+    const int lo = max(from, 64 * q) - 64 * q;
+    const int hi = min(to, 64 * q + 64) - 64 * q;
+    for (int cc = lo; cc < hi; ++cc)
+    {
+      const double v = g_rl_f64(p[q], cc);
+      s              = first ? v : s + v;
+      first          = false;
+    }
+  }
+  return s;
+}
+
 }  // namespace fphip
 #endif
 

@@ -19,6 +19,9 @@ def _bind(lib):
     lib.fphip_hh_set_basis.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp]
     lib.fphip_hh_broadcast_basis.argtypes = [vp, ctypes.c_int]
     lib.fphip_hh_update_R.argtypes = [vp, vp]
+    lib.fphip_hh_get_basis.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp]
+    lib.fphip_hh_hlll.argtypes = [vp, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                  ctypes.c_double, vp, vp]
     lib.fphip_hh_get_R.argtypes = [vp, ctypes.c_int, vp]
     lib.fphip_hh_get_row_expo.argtypes = [vp, ctypes.c_int, vp]
     lib.fphip_hh_last_kernel_ms.argtypes = [vp]
@@ -59,6 +62,22 @@ class MatHouseholderBatch:
         st = np.zeros(self.batch, dtype=np.int32)
         self._chk(self.lib.fphip_hh_update_R(self.h, st.ctypes.data_as(ctypes.c_void_p)), "update_R")
         return st
+
+    def get_basis(self, first=0, count=1):
+        b = np.empty((count, self.d, self.n), dtype=np.int64)
+        self._chk(self.lib.fphip_hh_get_basis(self.h, first, count,
+                                              b.ctypes.data_as(ctypes.c_void_p)), "get_basis")
+        return b
+
+    def hlll(self, delta=0.99, eta=0.51, theta=0.001, c=0.1):
+        """HLLLReduction::hlll() on every lattice (fplll/hlll.cpp:26-169).
+        Returns (status[batch], info[batch][2] = swaps, iterations)."""
+        st = np.zeros(self.batch, dtype=np.int32)
+        info = np.zeros((self.batch, 2), dtype=np.int32)
+        self._chk(self.lib.fphip_hh_hlll(self.h, delta, eta, theta, c,
+                                         st.ctypes.data_as(ctypes.c_void_p),
+                                         info.ctypes.data_as(ctypes.c_void_p)), "hlll")
+        return st, info
 
     def get_R(self, lattice=0):
         R = np.empty((self.d, self.n))

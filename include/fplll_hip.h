@@ -170,6 +170,17 @@ void fphip_hh_destroy(fphip_hh *h);
 int fphip_hh_set_basis(fphip_hh *h, int first_lattice, int count, const int64_t *b);
 int fphip_hh_broadcast_basis(fphip_hh *h, int src);
 int fphip_hh_update_R(fphip_hh *h, int *status);
+int fphip_hh_get_basis(fphip_hh *h, int first_lattice, int count, int64_t *b);
+/* HLLLReduction<Z_NR<long>,FP_NR<double>>(m, delta, eta, theta, c, LLL_DEFAULT).hlll()
+ * (hlll.cpp:26-169; size_reduction :262-351, lovasz_test :171-224, verify_size_reduction :455-496)
+ * over a fresh MatHouseholder (update_R / update_R_last / refresh_R_bf / swap / size_reduce,
+ * householder.cpp:27-451) of every lattice — what hlll_reduction_zf<long,double> runs with LM_FAST
+ * (wrapper.cpp:790-806).  The basis is reduced in place (fphip_hh_get_basis); R / row_expo hold the
+ * R factor of the result.  status[batch]: 1 RED_SUCCESS, -2 multiplier beyond 63 bits (redo on the
+ * CPU), -4 RED_HLLL_SR_FAILURE, -5 RED_HLLL_NORM_FAILURE.  info (nullable) [batch][2]: swaps, loop
+ * iterations. */
+int fphip_hh_hlll(fphip_hh *h, double delta, double eta, double theta, double c, int *status,
+                  int *info);
 /* R as d×n row-major: MatHouseholder::get_R(expo) (householder.h:179); entries right of the
  * diagonal are scratch, exactly as in the reference */
 int fphip_hh_get_R(fphip_hh *h, int lattice, double *R);

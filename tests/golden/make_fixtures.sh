@@ -39,6 +39,12 @@ $D lllfix q  40 20 20 6  0  0 -1 2 0 > $G/lll_q40_zero2.json
 $D lllfix q  40 20 20 7  0  0 -1 0 2 > $G/lll_q40_dup2.json
 $D lllfix q  40 20 20 8  0 10 30 0 0 > $G/lll_q40_range10_30.json
 $D lllfix q  40 20 20 9  5  5 35 0 0 > $G/lll_q40_kmin5.json
+# --- HLLL (HLLLReduction<long,double>::hlll, LM_FAST Householder flags): type d k bits seed
+$D hlllfix q 40 20 20 1 > $G/hlll_q40.json
+$D hlllfix q 72 36 16 2 > $G/hlll_q72.json
+$D hlllfix r 30  0 40 4 > $G/hlll_r30.json
+$D hlllfix u 24  0 30 5 > $G/hlll_u24.json
+$D hlllfix n 64  0 10 6 > $G/hlll_n64.json
 # --- C3 (BASELINE configs[2]): the 180-dim q-ary lattice, LLL + BKZ-20 by the reference, its
 #     beta=60 blocks as the plugin sees them, and pruner-generated strategies for the tour bench
 $D dumpbasis 180 90 20 0 20 > $G/basis_q180_seed0_lll_bkz20.txt
