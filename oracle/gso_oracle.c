@@ -16,6 +16,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <stdio.h>
 
 struct oracle_gso
 {
@@ -40,6 +41,7 @@ struct oracle_gso
 #define R(g, i, j) ((g)->r[(size_t)(i) * (g)->d + (j)])
 
 static long fexponent(double x) { return (long)ilogb(x) + 1; } /* nr_FP_d.inl:44 */
+static long fexponent_l(double x) { return (x == 0.0) ? (long)INT_MIN + 1 : (long)ilogb(x) + 1; }
 
 /* MatGSO::update_bf, gso.cpp:24-48 */
 static void update_bf(oracle_gso *g, int i)
@@ -478,6 +480,272 @@ done:
     info[1] = n_swaps;
     info[2] = zeros;
     info[3] = (int)(iter & 0x7fffffff);
+  }
+  return status;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * BKZ driver (pinned by tests/test_bkz_oracle_vs_ref.py against `bkzfix` fixtures):
+ * BKZReduction<Z_NR<long>, FP_NR<double>>::bkz() with BKZ_DEFAULT or BKZ_MAX_LOOPS flags and no
+ * strategies (BKZParam fills Strategy::EmptyStrategy for every block size, bkz_param.h:124-132: no
+ * pruning, no preprocessing, expectation 1 — BASELINE config 2), primal only.  Restates
+ *   bkz()              bkz.cpp:522-668     tour / trunc_tour / hkz   bkz.cpp:360-441
+ *   svp_reduction      bkz.cpp:274-358     svp_preprocessing (its lll call)  bkz.cpp:100-124
+ *   svp_postprocessing / _generic          bkz.cpp:126-272
+ *   EnumerationDyn::enumerate (normalisation)  enum/enumerate.cpp:58-159
+ *   MatGSOInterface::row_op_end(first,last)    gso_interface.cpp:32-53
+ * ------------------------------------------------------------------------------------------ */
+static void row_op_end_range(oracle_gso *g, int first, int last)
+{
+  for (int i = first; i < last; i++)
+  {
+    update_bf(g, i);
+    for (int j = 0; j <= i; j++)
+      GF(g, i, j) = NAN;
+    for (int j = i + 1; j < g->d; j++)
+      GF(g, j, i) = NAN;
+    g->valid_cols[i] = 0;
+  }
+  for (int i = last; i < g->d; i++)
+    if (g->valid_cols[i] > first)
+      g->valid_cols[i] = first;
+}
+
+static void swap_b_rows(oracle_gso *g, int i, int j)
+{
+  for (int c = 0; c < g->n; c++)
+  {
+    int64_t t  = B(g, i, c);
+    B(g, i, c) = B(g, j, c);
+    B(g, j, c) = t;
+  }
+}
+
+/* 1 ok, else the failing status of babai / update_gso_row */
+static int lll_size_reduction(oracle_gso *g, int kappa_min, int kappa_end, int sr_start, double eta)
+{
+  for (int k = kappa_min; k < kappa_end; k++)
+  {
+    if (k > 0)
+    {
+      int rc = oracle_gso_babai(g, k, k, sr_start, eta);
+      if (rc != 1)
+        return rc;
+    }
+    if (!oracle_gso_update_row(g, k, k))
+      return 0;
+  }
+  return 1;
+}
+
+static int svp_postprocessing(oracle_gso *g, int kappa, int bs, const double *sol)
+{
+  int nz_vectors = 0, i_vector = -1;
+  for (int i = bs - 1; i >= 0; i--)
+    if (sol[i] != 0.0)
+    {
+      nz_vectors++;
+      if (i_vector == -1 && fabs(sol[i]) == 1)
+        i_vector = i;
+    }
+  if (nz_vectors == 1)
+  {
+    move_row(g, kappa + i_vector, kappa);
+  }
+  else if (i_vector != -1)
+  {
+    int sol_i = (int)sol[i_vector];
+    for (int i = 0; i < bs; ++i)
+      if (sol[i] != 0.0 && i != i_vector)
+        if (!row_addmul_we(g, kappa + i_vector, kappa + i, sol_i * sol[i], 0))
+          return -2;
+    row_op_end_range(g, kappa + i_vector, kappa + i_vector + 1);
+    move_row(g, kappa + i_vector, kappa);
+  }
+  else
+  { /* svp_postprocessing_generic, bkz.cpp:205-272 */
+    double *x = (double *)malloc(sizeof(double) * bs);
+    for (int i = 0; i < bs; i++)
+    {
+      x[i] = sol[i];
+      if (x[i] < 0)
+      {
+        x[i] = -x[i];
+        for (int c = 0; c < g->n; c++) /* negate_row_of_b */
+          B(g, i + kappa, c) = -B(g, i + kappa, c);
+      }
+    }
+    int off = 1;
+    while (off < bs)
+    {
+      int k = bs - 1;
+      while (k - off >= 0)
+      {
+        if (!(x[k] == 0.0 && x[k - off] == 0.0))
+        {
+          if (x[k] < x[k - off])
+          {
+            double t = x[k]; x[k] = x[k - off]; x[k - off] = t;
+            swap_b_rows(g, kappa + k - off, kappa + k);
+          }
+          while (x[k - off] != 0.0)
+          {
+            while (x[k - off] <= x[k])
+            {
+              x[k] = x[k] - x[k - off];
+              if (!row_addmul_we(g, kappa + k - off, kappa + k, 1.0, 0)) /* row_add */
+              {
+                free(x);
+                return -2;
+              }
+            }
+            double t = x[k]; x[k] = x[k - off]; x[k - off] = t;
+            swap_b_rows(g, kappa + k - off, kappa + k);
+          }
+        }
+        k -= 2 * off;
+      }
+      off *= 2;
+    }
+    free(x);
+    row_op_end_range(g, kappa, kappa + bs);
+    move_row(g, kappa + bs - 1, kappa);
+  }
+  return 1;
+}
+
+/* returns 1 ok (clean flag in *clean), else a failure status */
+static int svp_reduction(oracle_gso *g, int kappa, int bs, double delta, double eta, int *clean,
+                         uint64_t *total_nodes)
+{
+  int rc = lll_size_reduction(g, 0, kappa + 1, 0, eta);
+  if (rc != 1)
+    return rc;
+  double old_first   = R(g, kappa, kappa);
+  long old_first_expo = (long)(2 * g->row_expo[kappa]);
+  /* svp_preprocessing: lll(0, 0, kappa + bs) (no recursive preprocessing in the empty strategy) */
+  rc = oracle_gso_lll(g, 0, 0, kappa + bs, delta, eta, NULL);
+  if (rc != 1)
+    return rc;
+  /* radius, bkz.cpp:311-317 */
+  double max_dist    = R(g, kappa, kappa);
+  long max_dist_expo = (long)(2 * g->row_expo[kappa]);
+  max_dist           = max_dist * delta;
+  /* EnumerationDyn::enumerate, enumerate.cpp:88-141 */
+  long normexp = -1;
+  for (int i = 0; i < bs; ++i)
+  {
+    long rexpo = (long)(2 * g->row_expo[i + kappa]);
+    long e     = rexpo + fexponent_l(R(g, i + kappa, i + kappa));
+    if (e > normexp)
+      normexp = e;
+  }
+  double maxdist = ldexp(max_dist, (int)(max_dist_expo - normexp));
+  double *rdiag  = (double *)calloc(bs, sizeof(double));
+  double *mut    = (double *)calloc((size_t)bs * bs, sizeof(double));
+  double *sol    = (double *)calloc(bs, sizeof(double));
+  uint64_t *nodes = (uint64_t *)calloc(bs + 1, sizeof(uint64_t));
+  for (int i = 0; i < bs; ++i)
+  {
+    long rexpo = (long)(2 * g->row_expo[i + kappa]);
+    rdiag[i]   = ldexp(R(g, i + kappa, i + kappa), (int)(rexpo - normexp));
+    for (int j = i + 1; j < bs; ++j)
+      mut[(size_t)i * bs + j] =
+          ldexp(MU(g, j + kappa, i + kappa), (int)(g->row_expo[j + kappa] - g->row_expo[i + kappa]));
+  }
+  double best_dist = 0.0;
+  if (getenv("ORACLE_BKZ_DEBUG"))
+    fprintf(stderr, "call dim %d maxdist %a r0 %a\n", bs, maxdist, rdiag[0]);
+  int64_t nsol = oracle_enumerate(bs, mut, rdiag, NULL, maxdist, 0, NULL, NULL, NULL, nodes, sol,
+                                  &best_dist);
+  if (total_nodes)
+    for (int i = 0; i <= bs; ++i)
+      *total_nodes += nodes[i];
+  if (getenv("ORACLE_BKZ_DEBUG"))
+  {
+    uint64_t t = 0;
+    for (int i = 0; i <= bs; ++i)
+      t += nodes[i];
+    fprintf(stderr, "   nodes %llu nsol %lld\n", (unsigned long long)t, (long long)nsol);
+  }
+  rc = 1;
+  if (nsol > 0)
+    rc = svp_postprocessing(g, kappa, bs, sol);
+  free(rdiag); free(mut); free(sol); free(nodes);
+  if (rc != 1)
+    return rc;
+  rc = lll_size_reduction(g, 0, kappa + 1, 0, eta);
+  if (rc != 1)
+    return rc;
+  double new_first    = R(g, kappa, kappa);
+  long new_first_expo = (long)(2 * g->row_expo[kappa]);
+  new_first           = ldexp(new_first, (int)(new_first_expo - old_first_expo));
+  *clean              = (old_first <= new_first);
+  return 1;
+}
+
+/* BKZReduction::bkz().  flags: 0 = BKZ_DEFAULT, 1 = BKZ_MAX_LOOPS (with max_loops).
+ * returns 1 RED_SUCCESS, 8 RED_BKZ_LOOPS_LIMIT, else a failure status (<= 0).
+ * info[0] = tours executed, info[1..2] = enumeration nodes (lo, hi 32 bits). */
+int oracle_gso_bkz(oracle_gso *g, int block_size, double delta, double eta, int use_max_loops,
+                   int max_loops, int *info)
+{
+  int num_rows = g->d;
+  for (; num_rows > 0; num_rows--)
+  { /* trailing zero rows are not part of the lattice, bkz.cpp:35-37 */
+    int z = 1;
+    for (int c = 0; c < g->n; c++)
+      if (B(g, num_rows - 1, c) != 0)
+        z = 0;
+    if (!z)
+      break;
+  }
+  uint64_t nodes = 0;
+  int status = 1, tours = 0;
+  if (block_size < 2)
+    goto done;
+  for (int i = 0;; ++i)
+  {
+    if (use_max_loops && i >= max_loops)
+    {
+      status = 8;
+      break;
+    }
+    int clean = 1, c1 = 1, rc;
+    /* trunc_tour */
+    for (int kappa = 0; kappa < num_rows - block_size; ++kappa)
+    {
+      rc = svp_reduction(g, kappa, block_size, delta, eta, &c1, &nodes);
+      if (rc != 1)
+      {
+        status = rc;
+        goto done;
+      }
+      clean &= c1;
+    }
+    /* hkz */
+    int min_row = num_rows - block_size > 0 ? num_rows - block_size : 0;
+    for (int kappa = min_row; kappa < num_rows - 1; ++kappa)
+    {
+      rc = svp_reduction(g, kappa, num_rows - kappa, delta, eta, &c1, &nodes);
+      if (rc != 1)
+      {
+        status = rc;
+        goto done;
+      }
+      clean &= c1;
+    }
+    lll_size_reduction(g, num_rows - 1, num_rows, num_rows - 2, eta); /* bkz.cpp:437 */
+    ++tours;
+    if (clean || block_size >= num_rows)
+      break;
+  }
+done:
+  if (info)
+  {
+    info[0] = tours;
+    info[1] = (int)(nodes & 0xffffffffu);
+    info[2] = (int)(nodes >> 32);
   }
   return status;
 }

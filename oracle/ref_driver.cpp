@@ -53,6 +53,8 @@ recording_enumerator(const int dim, double maxdist, std::function<extenum_cb_set
   g_rec.pruning.assign(dim, 0.0);
   cbfunc(g_rec.mut.data(), dim, true, g_rec.rdiag.data(), g_rec.pruning.data());
   g_rec.calls++;
+  if (getenv("REFDRV_RECORD") && getenv("REFDRV_RECORD")[0] == '2')
+    fprintf(stderr, "call %d dim %d maxdist %a r0 %a\n", g_rec.calls, dim, maxdist, g_rec.rdiag[0]);
   std::array<uint64_t, FPLLL_EXTENUM_MAX_EXTENUM_DIM> out{};
   if (getenv("REFDRV_INPUT_ONLY"))
     return out;           // pretend "done, nothing found": only the plugin inputs are wanted
@@ -578,6 +580,86 @@ static int cmd_hlllfix(int argc, char **argv)
 }
 
 
+/* bkzfix type d k bits seed block_size max_loops [reps]:
+ * BKZReduction<Z_NR<long>,FP_NR<double>>::bkz() on MatGSO(GSO_ROW_EXPO) exactly as bkz_reduction_f
+ * sets it up after convert<long> (bkz.cpp:813-845), empty strategies (no pruning / preprocessing),
+ * flags BKZ_DEFAULT (max_loops = 0) or BKZ_MAX_LOOPS.  The input is LLL-reduced first, as
+ * bkz_reduction does (bkz.cpp:870-885). */
+static int cmd_bkzfix(int argc, char **argv)
+{
+  if (argc < 9)
+    return 2;
+  std::string type = argv[2];
+  int d = atoi(argv[3]), k = atoi(argv[4]), bits = atoi(argv[5]), seed = atoi(argv[6]);
+  int block_size = atoi(argv[7]), max_loops = atoi(argv[8]);
+  int reps = argc > 9 ? atoi(argv[9]) : 1;
+  ZZ_mat<long> b0, u, ut;
+  if (!gen_long_basis(type, d, k, bits, seed, 0, 0, b0))
+    return 3;
+  const int n = b0.get_cols();
+  {  // LLL first (long/double, the same reduction the device LLL kernel reproduces)
+    MatGSO<Z_NR<long>, FP_NR<double>> M(b0, u, ut, GSO_ROW_EXPO);
+    LLLReduction<Z_NR<long>, FP_NR<double>> L(M, LLL_DEF_DELTA, LLL_DEF_ETA, LLL_DEFAULT);
+    L.lll();
+  }
+  std::ostringstream os;
+  os << "{\n\"desc\":\"bkz type=" << type << " d=" << d << " k=" << k << " bits=" << bits
+     << " seed=" << seed << " LLL-reduced, then BKZ-" << block_size << " max_loops=" << max_loops
+     << "\",\n\"d\":" << d << ",\n\"n\":" << n << ",\n\"block_size\":" << block_size
+     << ",\n\"max_loops\":" << max_loops << ",\n\"delta\":" << hexd(LLL_DEF_DELTA) << ",\n\"eta\":"
+     << hexd(LLL_DEF_ETA) << ",\n\"b_in\":[";
+  for (int i = 0; i < d; ++i)
+    for (int j = 0; j < n; ++j)
+      os << ((i || j) ? "," : "") << b0(i, j).get_si();
+  os << "],\n";
+  ZZ_mat<long> b = b0;
+  double secs = 0;
+  int status = 0;
+  long nodes = 0;
+  for (int rep = 0; rep < reps; ++rep)
+  {
+    b = b0;
+    vector<Strategy> strategies;
+    BKZParam par(block_size, strategies, LLL_DEF_DELTA, max_loops > 0 ? BKZ_MAX_LOOPS : BKZ_DEFAULT,
+                 max_loops);
+    auto t0 = std::chrono::steady_clock::now();
+    MatGSO<Z_NR<long>, FP_NR<double>> M(b, u, ut, GSO_ROW_EXPO);
+    LLLReduction<Z_NR<long>, FP_NR<double>> L(M, LLL_DEF_DELTA, LLL_DEF_ETA, LLL_DEFAULT);
+    BKZReduction<Z_NR<long>, FP_NR<double>> B(M, L, par);
+    // fplll's own enumerator (node counts by the fplll rule); the build's default external
+    // enumerator is enumlib, which counts before the bound test
+    set_external_enumerator(nullptr);
+    if (getenv("REFDRV_RECORD"))
+      set_external_enumerator(recording_enumerator);
+    if (getenv("REFDRV_RECORD") && getenv("REFDRV_RECORD")[0] == '3')
+    {  // debugging aid: one hkz pass by hand, node count after every svp_reduction
+      set_external_enumerator(nullptr);
+      for (int kappa = 0; kappa < d - 1; ++kappa)
+      {
+        long before = B.nodes;
+        B.svp_reduction(kappa, std::min(block_size, d - kappa), par);
+        fprintf(stderr, "kappa %d nodes %ld\n", kappa, B.nodes - before);
+      }
+    }
+    else
+    B.bkz();
+    if (getenv("REFDRV_RECORD"))
+      fprintf(stderr, "enumeration calls: %d\n", g_rec.calls);
+    secs += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    status = B.status;
+    nodes  = B.nodes;
+  }
+  os << "\"ref_status\":" << status << ",\n\"nodes\":" << nodes << ",\n\"reps\":" << reps
+     << ",\n\"ref_seconds\":" << secs << ",\n\"b_out\":[";
+  for (int i = 0; i < d; ++i)
+    for (int j = 0; j < n; ++j)
+      os << ((i || j) ? "," : "") << b(i, j).get_si();
+  os << "]\n}\n";
+  std::cout << os.str();
+  return 0;
+}
+
+
 // ---------------------------------------------------------------------------------------------
 // BKZ tour axis (SURVEY.md §8(d) metric (ii)): the reference's bkz_reduction, unchanged, with its
 // internal enumerator or with OUR plugin installed through set_external_enumerator.
@@ -776,6 +858,8 @@ int main(int argc, char **argv)
     return cmd_lllfix(argc, argv);
   if (cmd == "hlllfix")
     return cmd_hlllfix(argc, argv);
+  if (cmd == "bkzfix")
+    return cmd_bkzfix(argc, argv);
   if (cmd == "genstrat")
     return cmd_genstrat(argc, argv);
   if (cmd == "bkztour")

@@ -179,6 +179,16 @@ class OracleGSO:
                                      info.ctypes.data_as(ctypes.c_void_p))
         return st, info
 
+    def bkz(self, block_size, delta=0.99, eta=0.51, max_loops=0):
+        """BKZReduction::bkz, empty strategies (oracle/gso_oracle.c).  Returns (status, info[3])."""
+        self.lib.oracle_gso_bkz.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_double,
+                                            ctypes.c_double, ctypes.c_int, ctypes.c_int,
+                                            ctypes.c_void_p]
+        info = np.zeros(3, dtype=np.int32)
+        st = self.lib.oracle_gso_bkz(self.h, block_size, delta, eta, 1 if max_loops > 0 else 0,
+                                     max_loops, info.ctypes.data_as(ctypes.c_void_p))
+        return st, info
+
     def _arr(self, fn, shape, dtype):
         p = getattr(self.lib, fn)(self.h)
         return np.ctypeslib.as_array(p, shape=shape).astype(dtype).copy()
@@ -230,6 +240,28 @@ def load_lll_fixture(path):
     out = {k: j[k] for k in ("d", "n", "kmin", "kstart", "kend", "final_kappa", "n_swaps", "zeros")}
     out["name"] = os.path.basename(path)[:-5]
     out["status"] = REF_STATUS_TO_OURS[j["ref_status"]]
+    out["delta"] = float.fromhex(j["delta"])
+    out["eta"] = float.fromhex(j["eta"])
+    out["b_in"] = np.array(j["b_in"], dtype=np.int64).reshape(d, n)
+    out["b_out"] = np.array(j["b_out"], dtype=np.int64).reshape(d, n)
+    return out
+
+
+# ---- BKZ fixtures ---------------------------------------------------------------------------------
+BKZ_REF_STATUS_TO_OURS = {0: 1, 8: 8}  # RED_SUCCESS, RED_BKZ_LOOPS_LIMIT
+
+
+def bkz_fixtures():
+    return sorted(glob.glob(os.path.join(GOLDEN, "bkz_*.json")))
+
+
+def load_bkz_fixture(path):
+    with open(path) as f:
+        j = json.load(f)
+    d, n = j["d"], j["n"]
+    out = {k: j[k] for k in ("d", "n", "block_size", "max_loops", "nodes")}
+    out["name"] = os.path.basename(path)[:-5]
+    out["status"] = BKZ_REF_STATUS_TO_OURS[j["ref_status"]]
     out["delta"] = float.fromhex(j["delta"])
     out["eta"] = float.fromhex(j["eta"])
     out["b_in"] = np.array(j["b_in"], dtype=np.int64).reshape(d, n)

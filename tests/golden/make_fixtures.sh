@@ -45,6 +45,13 @@ $D hlllfix q 72 36 16 2 > $G/hlll_q72.json
 $D hlllfix r 30  0 40 4 > $G/hlll_r30.json
 $D hlllfix u 24  0 30 5 > $G/hlll_u24.json
 $D hlllfix n 64  0 10 6 > $G/hlll_n64.json
+# --- BKZ (BKZReduction<long,double>::bkz, empty strategies): type d k bits seed block_size max_loops
+$D bkzfix q 40 20 20 1 10 0 > $G/bkz_q40_b10.json
+$D bkzfix q 40 20 20 1 20 0 > $G/bkz_q40_b20.json
+$D bkzfix q 72 36 16 2 12 2 > $G/bkz_q72_b12_loops2.json
+$D bkzfix r 30  0 40 4  8 0 > $G/bkz_r30_b8.json
+$D bkzfix u 24  0 30 5 24 0 > $G/bkz_u24_hkz.json
+$D bkzfix q 60 30 12 7 16 0 > $G/bkz_q60_b16.json
 # --- C3 (BASELINE configs[2]): the 180-dim q-ary lattice, LLL + BKZ-20 by the reference, its
 #     beta=60 blocks as the plugin sees them, and pruner-generated strategies for the tour bench
 $D dumpbasis 180 90 20 0 20 > $G/basis_q180_seed0_lll_bkz20.txt
