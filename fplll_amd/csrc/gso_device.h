@@ -37,6 +37,7 @@ struct GsoBatch
   int *vc;
   long long *b2;
   int *lll_info;
+  double *enum_mu;  // BKZ kernel: [batch][64*63/2] scaled mu rows of the block being enumerated
 };
 // Batched Householder state (MatHouseholder<Z_NR<long>, FP_NR<double>>): b, V, R are [batch][d][ldn]
 // row-major (lane = column), sigma / rexp [batch][d].

@@ -22,6 +22,9 @@
 namespace fphip
 {
 template <int NQ> __global__ void gso_sweep_kernel(GsoBatch P, int kmin, int kend, double eta, int mode);
+template <int NQ>
+__global__ void bkz_kernel(GsoBatch P, int block_size, double delta, double eta, double logdelta,
+                           int use_max_loops, int max_loops, int stack_doubles);
 template <int NQ> __global__ void hlll_kernel(HhBatch P, double delta, double theta, long long iter_cap);
 template <int NQ>
 __global__ void lll_kernel(GsoBatch P, int kmin, int kstart, int kend, double delta, double eta,
@@ -142,6 +145,8 @@ extern "C" void fphip_gso_destroy(fphip_gso *g)
     hipFree(g->P.b2);
   if (g->P.lll_info)
     hipFree(g->P.lll_info);
+  if (g->P.enum_mu)
+    hipFree(g->P.enum_mu);
   hipEventDestroy(g->ev[0]);
   hipEventDestroy(g->ev[1]);
   delete g;
@@ -292,6 +297,8 @@ extern "C" int fphip_gso_size_reduce(fphip_gso *g, int kappa_min, int kappa_end,
   return fetch_status(g, status);
 }
 
+static int ensure_lll_buffers(fphip_gso *g);
+
 // LLLReduction<Z_NR<long>, FP_NR<double>>(m, delta, eta, LLL_DEFAULT).lll(kappa_min, kappa_start,
 // kappa_end, 0) on a fresh MatGSO(b, GSO_ROW_EXPO) of every lattice (lll.cpp:44-164,
 // wrapper.cpp lll_reduction_zf with LM_FAST), then update_gso() so that mu / r are readable in
@@ -308,14 +315,11 @@ extern "C" int fphip_gso_lll(fphip_gso *g, int kappa_min, int kappa_start, int k
     snprintf(fphip_ctx_errbuf(g->ctx), 512, "fphip_gso_lll: need 0 <= kappa_min <= kappa_start < kappa_end <= d");
     return FPHIP_ERROR;
   }
-  const size_t B = (size_t)g->P.batch, d = g->P.d, ldd = g->P.ldd, ldn = g->P.ldn;
-  if (!g->P.gf)
+  const size_t B = (size_t)g->P.batch;
   {
-    GCHK(hipMalloc((void **)&g->P.gf, B * d * ldd * sizeof(double) + 4096));
-    GCHK(hipMalloc((void **)&g->P.vc, B * d * sizeof(int)));
-    GCHK(hipMalloc((void **)&g->P.b2, B * d * ldn * sizeof(long long) + 4096));
-    GCHK(hipMalloc((void **)&g->P.lll_info, B * 4 * sizeof(int)));
-    GCHK(hipMemset(g->P.b2, 0, B * d * ldn * sizeof(long long) + 4096));
+    const int rc0 = ensure_lll_buffers(g);
+    if (rc0 != FPHIP_OK)
+      return rc0;
   }
   int rc = launch(g, 0, g->P.d, 0.0, 2);  // bf / row_expo of every row from b
   if (rc != FPHIP_OK)
@@ -335,6 +339,104 @@ extern "C" int fphip_gso_lll(fphip_gso *g, int kappa_min, int kappa_start, int k
   if (rc == FPHIP_OK)
     rc = launch(g, 0, g->P.d, 0.0, 0);
   g->last_ms = lll_ms;
+  if (status)
+    memcpy(status, st.data(), sizeof(int) * B);
+  return rc;
+}
+
+static int ensure_lll_buffers(fphip_gso *g)
+{
+  const size_t B = (size_t)g->P.batch, d = g->P.d, ldd = g->P.ldd, ldn = g->P.ldn;
+  if (!g->P.gf)
+  {
+    GCHK(hipMalloc((void **)&g->P.gf, B * d * ldd * sizeof(double) + 4096));
+    GCHK(hipMalloc((void **)&g->P.vc, B * d * sizeof(int)));
+    GCHK(hipMalloc((void **)&g->P.b2, B * d * ldn * sizeof(long long) + 4096));
+    GCHK(hipMalloc((void **)&g->P.lll_info, B * 4 * sizeof(int)));
+    GCHK(hipMemset(g->P.b2, 0, B * d * ldn * sizeof(long long) + 4096));
+    GCHK(hipDeviceSynchronize());
+  }
+  return FPHIP_OK;
+}
+
+// BKZReduction<Z_NR<long>, FP_NR<double>>(m, lll_obj, BKZParam(block_size, {}, delta, flags,
+// max_loops)).bkz() (bkz.cpp:522-668) on every lattice: primal BKZ with empty strategies (no
+// pruning, no preprocessing — what bkz_reduction(b, beta, BKZ_DEFAULT, FT_DOUBLE) runs without a
+// strategies file, BASELINE config 2), the whole reduction in one launch.  flags: 0 = BKZ_DEFAULT,
+// FPHIP_BKZ_MAX_LOOPS (0x4, fplll's value) with max_loops.  The input is expected LLL-reduced, as
+// bkz_reduction guarantees (bkz.cpp:870-885): call fphip_gso_lll first.
+// status[batch]: 1 RED_SUCCESS, 8 RED_BKZ_LOOPS_LIMIT, <= 0 the failing LLL status.
+// info (nullable) [batch][4]: tours, enumeration nodes (low, high 32 bits; fplll rule), enumeration calls.
+extern "C" int fphip_gso_bkz(fphip_gso *g, int block_size, double delta, double eta, int flags,
+                             int max_loops, int *status, int *info)
+{
+  if (!g)
+    return FPHIP_ERROR;
+  if (block_size > 64 || (flags & ~0x4))
+    return FPHIP_UNSUPPORTED;  // blocks beyond one wavefront / other BKZ variants: fplll's CPU code
+  int rc = ensure_lll_buffers(g);
+  if (rc != FPHIP_OK)
+    return rc;
+  const size_t B = (size_t)g->P.batch;
+  if (!g->P.enum_mu)
+    GCHK(hipMalloc((void **)&g->P.enum_mu, B * (64 * 63 / 2) * sizeof(double)));
+  rc = launch(g, 0, g->P.d, 0.0, 2);  // bf / row_expo of every row from b
+  if (rc != FPHIP_OK)
+    return rc;
+  const int need = (g->P.d > g->P.n ? g->P.d : g->P.n);
+  const int nq   = (need + 63) / 64;
+  const int wpb  = g->waves_per_block;
+  const int bs   = block_size < 2 ? 2 : (block_size < g->P.d ? block_size : g->P.d);
+  const int stack_doubles = (bs * (bs + 1)) / 2 + 2;
+  const size_t ring_bytes = (size_t)wpb * FPHIP_GSO_RING * (size_t)((nq + 1) / 2) * 1024;
+  const size_t lds        = ring_bytes + (size_t)wpb * stack_doubles * sizeof(double);
+  if (ring_bytes > 64 * 1024 || lds > 160 * 1024)
+  {
+    snprintf(fphip_ctx_errbuf(g->ctx), 512, "bkz: %zu bytes of LDS per workgroup do not fit", lds);
+    return FPHIP_ERROR;
+  }
+  int bpc = (int)((160 * 1024) / lds);
+  if (bpc * wpb > 32)
+    bpc = 32 / wpb;
+  int grid      = (g->P.batch + wpb - 1) / wpb;
+  const int cap = fphip_ctx_num_cus(g->ctx) * (bpc > 0 ? bpc : 1);
+  if (grid > cap)
+    grid = cap;
+  hipStream_t s        = fphip_ctx_stream(g->ctx);
+  const double logd    = std::log(delta);
+  const int use_loops  = (flags & 0x4) ? 1 : 0;
+  if (lds > 64 * 1024)
+  {
+    switch (nq)
+    {
+    case 1: GCHK(hipFuncSetAttribute((const void *)bkz_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); break;
+    case 2: GCHK(hipFuncSetAttribute((const void *)bkz_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); break;
+    case 3: GCHK(hipFuncSetAttribute((const void *)bkz_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); break;
+    default: GCHK(hipFuncSetAttribute((const void *)bkz_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); break;
+    }
+  }
+  GCHK(hipEventRecord(g->ev[0], s));
+  switch (nq)
+  {
+  case 1: hipLaunchKernelGGL(bkz_kernel<1>, dim3(grid), dim3(wpb * 64), lds, s, g->P, block_size, delta, eta, logd, use_loops, max_loops, stack_doubles); break;
+  case 2: hipLaunchKernelGGL(bkz_kernel<2>, dim3(grid), dim3(wpb * 64), lds, s, g->P, block_size, delta, eta, logd, use_loops, max_loops, stack_doubles); break;
+  case 3: hipLaunchKernelGGL(bkz_kernel<3>, dim3(grid), dim3(wpb * 64), lds, s, g->P, block_size, delta, eta, logd, use_loops, max_loops, stack_doubles); break;
+  default: hipLaunchKernelGGL(bkz_kernel<4>, dim3(grid), dim3(wpb * 64), lds, s, g->P, block_size, delta, eta, logd, use_loops, max_loops, stack_doubles); break;
+  }
+  GCHK(hipGetLastError());
+  GCHK(hipEventRecord(g->ev[1], s));
+  GCHK(hipStreamSynchronize(s));
+  float bkz_ms = 0;
+  GCHK(hipEventElapsedTime(&bkz_ms, g->ev[0], g->ev[1]));
+  std::swap(g->P.b, g->P.b2);  // the kernel wrote the rows in position order into b2
+  std::vector<int> st(B);
+  GCHK(hipMemcpy(st.data(), g->P.status, sizeof(int) * B, hipMemcpyDeviceToHost));
+  if (info)
+    GCHK(hipMemcpy(info, g->P.lll_info, sizeof(int) * 4 * B, hipMemcpyDeviceToHost));
+  rc = launch(g, 0, g->P.d, 0.0, 2);
+  if (rc == FPHIP_OK)
+    rc = launch(g, 0, g->P.d, 0.0, 0);
+  g->last_ms = bkz_ms;
   if (status)
     memcpy(status, st.data(), sizeof(int) * B);
   return rc;

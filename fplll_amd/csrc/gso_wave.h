@@ -496,13 +496,59 @@ template <int NQ> __device__ void finish_diag(Lattice<NQ> &T, int kappa)
   }
 }
 
+// Store the integer row held in registers into slot pk and re-float it: MatGSO::update_bf,
+// gso.cpp:24-48 (mantissa/exponent per entry, renormalised to the row maximum).
+template <int NQ>
+__device__ __forceinline__ void store_row_and_refloat(Lattice<NQ> &T, int pk, const long long (&bv)[NQ])
+{
+  const int n = T.n, lane = T.lane, ldd = T.ldd, ldn = T.ldn;
+  int ce[NQ];
+  double cm[NQ];
+  int emax = INT_MIN;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+  {
+    const int c = lane + 64 * q;
+    ce[q]       = INT_MIN;
+    cm[q]       = 0.0;
+    if (c < n)
+    {
+      T.b[(size_t)pk * ldn + c] = bv[q];
+      if (T.row_expo_on)
+      {
+        int ex;
+        cm[q] = frexp((double)bv[q], &ex);
+        ce[q] = ex;
+        emax  = max(emax, ex);
+      }
+      else
+      {
+        cm[q] = (double)bv[q];
+        ce[q] = 0;
+        emax  = 0;
+      }
+    }
+  }
+  emax = wave_max_i32(emax);
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+  {
+    const int c = lane + 64 * q;
+    if (c < n)
+      T.bfT[(size_t)c * ldd + pk] = T.row_expo_on ? ldexp(cm[q], ce[q] - emax) : cm[q];
+  }
+  if (lane == 0)
+    T.rexp[pk] = T.row_expo_on ? (long long)emax : 0;
+}
+
 // LLLReduction::babai(kappa, kappa, 0).  1 ok, 0 GSO failure, -1 babai failure, -2 multiplier.
 // `upd(kappa, last)` brings row kappa of the GSO up to column `last` (and leaves mu/r of the row in
 // T.murow / T.rrow); `after(kappa)` runs after b_kappa changed (row_op_end's invalidations).
 template <int NQ, int IPS, class Map, class Upd, class After>
 __device__ __forceinline__ int babai_impl(Lattice<NQ> &T, Ring<NQ, IPS> &ring, int kappa, double eta,
-                                          const Map &map, Upd upd, After after)
+                                          const Map &map, Upd upd, After after, int sr_start = 0)
 {
+  // sr_start = size_reduction_start (lll.cpp:167): only columns j in [sr_start, kappa) are reduced
   const int pk = map.phys(kappa);  // physical slot of row kappa
   const int n = T.n, lane = T.lane, ldd = T.ldd, ldn = T.ldn;
   long long max_expo = LLONG_MAX;
@@ -524,7 +570,7 @@ __device__ __forceinline__ int babai_impl(Lattice<NQ> &T, Ring<NQ, IPS> &ring, i
       {
         e[q]           = (int)(rexpk - T.rexp[lphys[q]]);
         const double f = fabs(ldexp(T.murow[q], e[q]));  // get_mu, gso_interface.h:694-702
-        need |= (f > eta);
+        need |= (j >= sr_start) && (f > eta);
         const long long ex = (long long)e[q] + fexponent(T.murow[q]);
         mexp               = max(mexp, (int)max(ex, (long long)INT_MIN + 2));
       }
@@ -566,8 +612,9 @@ __device__ __forceinline__ int babai_impl(Lattice<NQ> &T, Ring<NQ, IPS> &ring, i
     ring.reset();
     // ---- lll.cpp:202-220: lane k owns babai_mu[k]; the basis rows of the integer AXPY are
     //      prefetched behind the sweep
+    const int nsteps = kappa - sr_start;  // rows j = kappa-1 … sr_start
     ring.run(
-        kappa, mu_row,
+        nsteps, mu_row,
         [&](int s, const double(&v)[NQ])
         {
           const int j = kappa - 1 - s;
@@ -596,7 +643,7 @@ __device__ __forceinline__ int babai_impl(Lattice<NQ> &T, Ring<NQ, IPS> &ring, i
                   for (int q = 0; q <= jq; ++q)
                   {
                     // chunks below jq hold only k < j; the chunk of j itself needs the test
-                    if (q < jq || lane < jj)
+                    if ((q < jq || lane < jj) && lane + 64 * q >= sr_start)
                     {
                       const double t = X * v[q];
                       bm[q]          = bm[q] - t;
@@ -605,9 +652,9 @@ __device__ __forceinline__ int babai_impl(Lattice<NQ> &T, Ring<NQ, IPS> &ring, i
                 }
               });
         },
-        kappa, b_row);
+        nsteps, b_row);
     // ---- integer AXPY on row kappa (row_add / row_sub / row_addmul_si, gso.cpp:84-158)
-    ring.run(kappa, b_row,
+    ring.run(nsteps, b_row,
              [&](int s, const double(&v)[NQ])
              {
                const int j = kappa - 1 - s;
@@ -628,43 +675,7 @@ __device__ __forceinline__ int babai_impl(Lattice<NQ> &T, Ring<NQ, IPS> &ring, i
     if (too_big)
       return -2;  // nothing has been stored yet: the basis is unchanged
     // ---- row_op_end: update_bf(kappa), gso.cpp:24-48
-    int ce[NQ];
-    double cm[NQ];
-    int emax = INT_MIN;
-#pragma unroll
-    for (int q = 0; q < NQ; ++q)
-    {
-      const int c = lane + 64 * q;
-      ce[q]       = INT_MIN;
-      cm[q]       = 0.0;
-      if (c < n)
-      {
-        T.b[(size_t)pk * ldn + c] = bv[q];
-        if (T.row_expo_on)
-        {
-          int ex;
-          cm[q] = frexp((double)bv[q], &ex);
-          ce[q] = ex;
-          emax  = max(emax, ex);
-        }
-        else
-        {
-          cm[q] = (double)bv[q];
-          ce[q] = 0;
-          emax  = 0;
-        }
-      }
-    }
-    emax = wave_max_i32(emax);
-#pragma unroll
-    for (int q = 0; q < NQ; ++q)
-    {
-      const int c = lane + 64 * q;
-      if (c < n)
-        T.bfT[(size_t)c * ldd + pk] = T.row_expo_on ? ldexp(cm[q], ce[q] - emax) : cm[q];
-    }
-    if (lane == 0)
-      T.rexp[pk] = T.row_expo_on ? (long long)emax : 0;
+    store_row_and_refloat<NQ>(T, pk, bv);
     after(kappa);
     // later reads of b / bfT / rexp in this wave must see these stores
     __threadfence_block();

@@ -1,0 +1,596 @@
+// lll_wave.h — the LLL machinery of one lattice owned by one wavefront, shared by lll_kernel.hip and
+// bkz_kernel.hip (device code only; the design notes are in lll_kernel.hip).
+#ifndef FPHIP_LLL_WAVE_H
+#define FPHIP_LLL_WAVE_H
+
+#include "gso_wave.h"
+
+namespace fphip
+{
+
+struct LllCtx
+{
+  double *gf;  // [d][ldd] symmetric Gram cache indexed by slots, NaN = unknown
+  int *vc;     // [d] valid columns of the row in each slot
+};
+
+__device__ __forceinline__ double make_nan() { return __longlong_as_double(0x7ff8000000000000LL); }
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+template <int NQ> __device__ __forceinline__ double lane_get(const double (&v)[NQ], int idx)
+{
+  double r = 0.0;
+  dispatch_chunk<NQ>(idx, [&](auto q, int ii) { r = g_rl_f64(v[decltype(q)::value], ii); });
+  return r;
+}
+
+// Z_NR<long>::exponent(), nr/nr_Z_l.inl:30-48 (MAX_LONG_FAST = 2^53 on LP64, defs.h:134)
+__device__ __forceinline__ int zexponent(long long v)
+{
+  int e;
+  const double f = frexp((double)v, &e);
+  if ((double)v > 0x1p53 && fabs(f) == 0.5)
+  {
+    const unsigned long long y = (unsigned long long)(v < 0 ? -v : v);
+    return 64 - __clzll((long long)y);
+  }
+  return e;
+}
+
+// update_gso_row(kappa, last) from the first invalid column of the row (gso_interface.cpp:131-164).
+// Leaves mu(kappa, .) / r(kappa, .) of columns <= last in T.murow / T.rrow (lane = column).
+template <int NQ, int IPS>
+__device__ __forceinline__ bool update_row_cached(Lattice<NQ> &T, LllCtx &C, const SlotMap<NQ> &M,
+                                  Ring<NQ, IPS> &ring, int kappa, int last)
+{
+  const int n = T.n, lane = T.lane, ldd = T.ldd;
+  const int sk    = M.phys(kappa);
+  const int start = uni(C.vc[sk]);
+  double *rrowp   = T.r + (size_t)sk * ldd;
+  double *murowp  = T.mu + (size_t)sk * ldd;
+  double *gfrow   = C.gf + (size_t)sk * ldd;
+  if (start > last)
+  {  // nothing to compute: bring the row into registers
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+    {
+      const int j = lane + 64 * q;
+      T.rrow[q]   = (j < start && j <= kappa) ? rrowp[j] : 0.0;
+      T.murow[q]  = (j < start && j < kappa) ? murowp[j] : 0.0;
+    }
+    return true;
+  }
+  double acc[NQ], rd[NQ], mold[NQ];
+  unsigned off[NQ];
+  bool miss = false;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+  {
+    const int j = lane + 64 * q;
+    acc[q]      = 0.0;
+    rd[q]       = 1.0;
+    mold[q]     = 0.0;
+    off[q]      = (unsigned)M.sl[q] * 8u;
+    if (j < start)
+    {
+      acc[q]  = rrowp[j];  // final r(kappa,j)
+      mold[q] = (j < kappa) ? murowp[j] : 0.0;
+    }
+    else if (j <= last)
+    {
+      acc[q] = gfrow[M.sl[q]];  // cached g(kappa,j)
+      miss |= (acc[q] != acc[q]);
+    }
+    if (j < kappa && j <= last)
+      rd[q] = T.rdg[M.sl[q]];
+  }
+  if (__any(miss))
+  {
+    // ---- Gram row: g(kappa,j) = bf_kappa . bf_j, columns ascending (numvect.h:386-396)
+    double bk[NQ], g[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+    {
+      const int c = lane + 64 * q;
+      bk[q]       = (c < n) ? T.bfT[(size_t)c * ldd + sk] : 0.0;
+      g[q]        = 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+    {
+      settle(bk[q]);
+      settle(acc[q]);
+      settle(rd[q]);
+      settle(mold[q]);
+    }
+    auto gram_row = [&](int c) { return RowDesc{T.bfT + (size_t)c * ldd, 0, ldd * 8}; };
+    ring.reset();
+    ring.run_with(
+        n, gram_row,
+        [&](int c, const double(&v)[NQ])
+        {
+          const double bkc = lane_get<NQ>(bk, c);
+#pragma unroll
+          for (int q = 0; q < NQ; ++q)
+          {
+            const double p = bkc * v[q];
+            g[q]           = (c == 0) ? p : g[q] + p;
+          }
+        },
+        0, gram_row, [&](double(&v)[NQ]) { ring.fetch_gather(v, off); });
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+    {
+      const int j = lane + 64 * q;
+      if (j >= start && j <= last && acc[q] != acc[q])
+      {
+        acc[q]                                = g[q];
+        gfrow[M.sl[q]]                        = g[q];
+        C.gf[(size_t)M.sl[q] * ldd + sk]      = g[q];
+      }
+    }
+  }
+  if (start == 0 || last - start >= 3)
+  {
+    // ---- column-oriented recurrence over k = 0..last-1 (gso_interface.cpp:143-158): lanes
+    //      j >= max(start, k+1) subtract mu(j,k) r(kappa,k); columns of muT are gathered by slot
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+    {
+      settle(acc[q]);
+      settle(rd[q]);
+      settle(mold[q]);
+    }
+    auto rec_row = [&](int k) { return RowDesc{T.muT + (size_t)k * ldd, 0, ldd * 8}; };
+    ring.reset();
+    ring.run_with(
+        last, rec_row,
+        [&](int k, const double(&v)[NQ])
+        {
+          dispatch_chunk<NQ>(k,
+                             [&](auto kq_, int kk)
+                             {
+                               constexpr int kq = decltype(kq_)::value;
+                               const double rk  = g_rl_f64(acc[kq], kk);  // r(kappa,k) is final
+                               double muk       = 0.0;
+                               if (last == kappa)
+                                 muk = rk / g_rl_f64(rd[kq], kk);  // mu(kappa,k)
+#pragma unroll
+                               for (int q = kq; q < NQ; ++q)
+                               {
+                                 const int j   = lane + 64 * q;
+                                 const bool on = j <= last && j >= start && (q > kq || lane > kk);
+                                 if (on)
+                                 {
+                                   const double m = (j == kappa) ? muk : v[q];
+                                   acc[q]         = acc[q] - m * rk;
+                                 }
+                               }
+                             });
+        },
+        0, rec_row, [&](double(&v)[NQ]) { ring.fetch_gather(v, off); });
+  }
+  else
+  {
+    // ---- a few new columns: row-oriented, the reference's own loop order.  r(kappa,j) =
+    //      g(kappa,j) - sum_{k<j} mu(j,k) r(kappa,k), k ascending: products are formed in parallel
+    //      (lane k), the subtraction chain runs over v_readlane
+    for (int j = start; j <= last; ++j)
+    {
+      const double *mj = T.mu + (size_t)M.phys(j) * ldd;
+      double p[NQ];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+      {
+        const int k = lane + 64 * q;
+        double mm   = 0.0;
+        if (k < j)
+          mm = (j == kappa) ? acc[q] / rd[q] : mj[k];
+        p[q] = mm * acc[q];
+      }
+      double s = lane_get<NQ>(acc, j);
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+      {
+        const int hi = min(j - 64 * q, 64);
+        for (int kk = 0; kk < hi; ++kk)
+          s = s - g_rl_f64(p[q], kk);
+      }
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+        acc[q] = (lane + 64 * q == j) ? s : acc[q];
+    }
+  }
+  // ---- store the new columns
+  bool ok = true;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+  {
+    const int j = lane + 64 * q;
+    T.murow[q]  = 0.0;
+    T.rrow[q]   = (j <= last) ? acc[q] : 0.0;
+    if (j <= last)
+    {
+      if (j < start)
+      {
+        T.murow[q] = mold[q];
+      }
+      else if (j < kappa)
+      {
+        const double m = acc[q] / rd[q];  // mu(kappa,j) = r(kappa,j) / r(j,j)
+        if (!isfinite(m))
+          ok = false;
+        T.murow[q]                  = m;
+        rrowp[j]                    = acc[q];
+        murowp[j]                   = m;
+        T.muT[(size_t)j * ldd + sk] = m;
+      }
+      else
+      {  // j == kappa
+        rrowp[j]  = acc[q];
+        T.rdg[sk] = acc[q];
+      }
+    }
+  }
+  if (lane == 0)
+    C.vc[sk] = last + 1;
+  return __all(ok);
+}
+
+// row_op_end(kappa, kappa+1) after b_kappa changed (gso_interface.cpp:32-53): the vector's Gram row
+// and column, its own GSO row, and columns >= kappa of every later row become invalid
+template <int NQ>
+__device__ __forceinline__ void after_rowop(Lattice<NQ> &T, LllCtx &C, const SlotMap<NQ> &M, int kappa)
+{
+  const int lane = T.lane, ldd = T.ldd, d = T.d;
+  const int sk     = M.phys(kappa);
+  const double nan = make_nan();
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+  {
+    const int t = lane + 64 * q;
+    if (t < ldd)
+      C.gf[(size_t)sk * ldd + t] = nan;
+    if (t < d)
+      C.gf[(size_t)t * ldd + sk] = nan;
+  }
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+  {
+    const int p = lane + 64 * q;
+    if (p == kappa)
+      C.vc[sk] = 0;
+    else if (p > kappa && p < d)
+    {
+      const int s = M.sl[q];
+      if (C.vc[s] > kappa)
+        C.vc[s] = kappa;
+    }
+  }
+}
+
+// rows at positions >= from keep only their columns < from (invalidate_gso_row(i, from) for all i)
+template <int NQ> __device__ __forceinline__ void clamp_valid(Lattice<NQ> &T, LllCtx &C, const SlotMap<NQ> &M, int from)
+{
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+  {
+    const int p = T.lane + 64 * q;
+    if (p >= from && p < T.d)
+    {
+      const int s = M.sl[q];
+      if (C.vc[s] > from)
+        C.vc[s] = from;
+    }
+  }
+}
+
+// move_row(kold, knew), knew < kold: the row at kold goes to knew, rows knew..kold-1 shift up by one
+template <int NQ> __device__ __forceinline__ void rotate_right(SlotMap<NQ> &M, int knew, int kold, int lane)
+{
+  const int skold = M.phys(kold);
+  int up[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+  {
+    up[q] = __shfl_up(M.sl[q], 1);
+    if (q > 0)
+    {
+      const int carry = __builtin_amdgcn_readlane(M.sl[q > 0 ? q - 1 : 0], 63);
+      up[q]           = (lane == 0) ? carry : up[q];
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+  {
+    const int p = lane + 64 * q;
+    if (p == knew)
+      M.sl[q] = skold;
+    else if (p > knew && p <= kold)
+      M.sl[q] = up[q];
+  }
+}
+
+// move_row(a, b), a < b: the row at a goes to b, rows a+1..b shift down by one
+template <int NQ> __device__ __forceinline__ void rotate_left(SlotMap<NQ> &M, int a, int b, int lane)
+{
+  const int sa = M.phys(a);
+  int dn[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+  {
+    dn[q] = __shfl_down(M.sl[q], 1);
+    if (q + 1 < NQ)
+    {
+      const int carry = __builtin_amdgcn_readlane(M.sl[q + 1 < NQ ? q + 1 : q], 0);
+      dn[q]           = (lane == 63) ? carry : dn[q];
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+  {
+    const int p = lane + 64 * q;
+    if (p == b)
+      M.sl[q] = sa;
+    else if (p >= a && p < b)
+      M.sl[q] = dn[q];
+  }
+}
+
+// A fresh MatGSO: nothing known (gso.h:33 ctor + size_increased); rows sit in their own slots.
+template <int NQ>
+__device__ __forceinline__ void lll_init_state(Lattice<NQ> &T, LllCtx &C, SlotMap<NQ> &M)
+{
+  const int lane = T.lane, d = T.d, ldd = T.ldd;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+    M.sl[q] = lane + 64 * q;
+  const double nan = make_nan();
+  for (int i = 0; i < d; ++i)
+  {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+      if (lane + 64 * q < ldd)
+        C.gf[(size_t)i * ldd + lane + 64 * q] = nan;
+  }
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+    if (lane + 64 * q < d)
+      C.vc[lane + 64 * q] = 0;
+  __threadfence_block();
+}
+
+// LLLReduction::lll(kmin, kstart, kend, 0), lll.cpp:44-164, on the cached state (T, C, M).
+// status: 1 RED_SUCCESS, 0 RED_GSO_FAILURE, -1 RED_BABAI_FAILURE, -2 multiplier beyond 63 bits,
+//         -3 RED_LLL_FAILURE (iteration limit, lll.cpp:159-160)
+template <int NQ, int IPS>
+__device__ __forceinline__ int lll_run(Lattice<NQ> &T, LllCtx &C, SlotMap<NQ> &M, Ring<NQ, IPS> &ring,
+                                       int kmin, int kstart, int kend, double delta, double eta,
+                                       double logdelta, int &final_kappa, int &nswaps, int &zeros,
+                                       long long &iter)
+{
+  const int lane = T.lane, d = T.d, n = T.n, ldd = T.ldd, ldn = T.ldn;
+  // ---- iteration limit, lll.cpp:79-80
+  int mexp = 0;
+  for (int i = 0; i < d; ++i)
+  {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+    {
+      const int c = lane + 64 * q;
+      if (c < n)
+        mexp = max(mexp, zexponent(T.b[(size_t)i * ldn + c]));
+    }
+  }
+  mexp         = wave_max_i32(mexp);
+  const int dd = kend - kmin;
+  const long long max_iter =
+      (long long)((double)dd - (double)(2 * dd * (dd + 1)) * ((double)(mexp + 3) / logdelta));
+  __threadfence_block();
+
+  auto upd = [&](int k, int last) { return update_row_cached<NQ, IPS>(T, C, M, ring, k, last); };
+  auto after = [&](int k) { after_rowop<NQ>(T, C, M, k); };
+  auto row_is_zero = [&](int s)
+  {
+    bool nz = false;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+    {
+      const int c = lane + 64 * q;
+      if (c < n)
+        nz |= (T.b[(size_t)s * ldn + c] != 0);
+    }
+    return !__any(nz);
+  };
+
+  int status = 1;
+  final_kappa = 0;
+  zeros       = 0;
+  nswaps      = 0;
+  iter        = 0;
+  bool ok     = true;
+  // zero rows go to the end, lll.cpp:68-71
+  for (; zeros < dd && row_is_zero(M.phys(0)); ++zeros)
+    rotate_left<NQ>(M, kmin, kend - 1 - zeros, lane);
+  if (zeros < dd)
+  {
+    // the reference expects rows below kappa_start to be valid already; on a fresh GSO that is
+    // update_gso_row(i) for each of them (a no-op for rows whose cache is valid)
+    for (int i = 0; i < kstart && ok; ++i)
+    {
+      ok = upd(i, i);
+      __threadfence_block();
+    }
+    if (!ok)
+      status = 0;
+    if (ok && kstart > 0)
+    {
+      const int rc = babai_impl<NQ, IPS>(T, ring, kstart, eta, M, upd, after);
+      if (rc != 1)
+      {
+        status = rc;
+        ok     = false;
+      }
+    }
+    if (ok && !upd(kstart, kstart))
+    {
+      status = 0;
+      ok     = false;
+    }
+    if (!ok)
+      final_kappa = kstart;
+    __threadfence_block();
+  }
+  int kappa = kstart + 1;
+  for (; ok && iter < max_iter && kappa < kend - zeros; ++iter)
+  {
+    // ---- lazy size reduction, lll.cpp:103-108
+    const int rc = babai_impl<NQ, IPS>(T, ring, kappa, eta, M, upd, after);
+    if (rc != 1)
+    {
+      status      = rc;
+      final_kappa = kappa;
+      ok          = false;
+      break;
+    }
+    const int sk = M.phys(kappa);
+    // ---- Lovasz prefix values, lll.cpp:110-116: lt[0] = g(kappa,kappa),
+    //      lt[i] = lt[i-1] - mu(kappa,i-1) r(kappa,i-1); lane i keeps lt[i] for i < kappa
+    double lt0 = C.gf[(size_t)sk * ldd + sk];
+    if (lt0 != lt0)
+    {
+      double p[NQ];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+      {
+        const int c    = lane + 64 * q;
+        const double a = (c < n) ? T.bfT[(size_t)c * ldd + sk] : 0.0;
+        p[q]           = a * a;
+      }
+      double s = 0.0;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+      {
+        const int hi = min(n - 64 * q, 64);
+        for (int cc = 0; cc < hi; ++cc)
+        {
+          const double v = g_rl_f64(p[q], cc);
+          s              = (q == 0 && cc == 0) ? v : s + v;
+        }
+      }
+      lt0 = s;
+      if (lane == 0)
+        C.gf[(size_t)sk * ldd + sk] = s;
+    }
+    double prod[NQ], ltv[NQ], f[NQ];
+    const long long rexpk = T.rexp[sk];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+    {
+      const int t = lane + 64 * q;
+      prod[q]     = T.murow[q] * T.rrow[q];
+      ltv[q]      = 0.0;
+      f[q]        = 0.0;
+      if (t < kappa)
+      {
+        // delta * r(t,t) * 2^(2 (row_expo[t] - row_expo[kappa])), lll.cpp:117-121,131-135
+        const int s = M.sl[q];
+        double x    = T.rdg[s] * delta;
+        if (T.row_expo_on)
+        {
+          long long e2 = 2 * (T.rexp[s] - rexpk);
+          e2           = e2 > 100000 ? 100000 : (e2 < -100000 ? -100000 : e2);
+          x            = ldexp(x, (int)e2);
+        }
+        f[q] = x;
+      }
+    }
+    double g = lt0;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+    {
+      const int hi = min(kappa - 64 * q, 64);
+      for (int kk = 0; kk < hi; ++kk)
+      {
+        ltv[q] = (lane == kk) ? g : ltv[q];
+        g      = g - g_rl_f64(prod[q], kk);
+      }
+    }
+    // g = lt[kappa]
+    bool swp = false;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+      swp |= (lane + 64 * q == kappa - 1) && (f[q] > ltv[q]);
+    double ltk = g;
+    if (__any(swp))
+    {
+      ++nswaps;
+      const int old_k = kappa;
+      // insertion index: largest kappa' in (kmin, old_k) with delta r(kappa'-1) < lt[kappa'-1]
+      int knew = kmin;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+      {
+        const int t      = lane + 64 * q;
+        const bool cand  = t >= kmin && t <= old_k - 2 && f[q] < ltv[q];
+        const uint64_t m = __ballot(cand);
+        if (m)
+          knew = max(knew, 64 * q + (63 - __clzll((long long)m)) + 1);
+      }
+      knew = uni(knew);
+      ltk  = lane_get<NQ>(ltv, knew);
+      if (ltk > 0.0)
+      {
+        rotate_right<NQ>(M, knew, old_k, lane);
+        clamp_valid<NQ>(T, C, M, knew);
+        kappa = knew;
+      }
+      else
+      {  // linearly dependent row: to the end, lll.cpp:144-150
+        ++zeros;
+        rotate_left<NQ>(M, old_k, kend - zeros, lane);
+        clamp_valid<NQ>(T, C, M, old_k);
+        kappa = old_k;
+        __threadfence_block();
+        continue;
+      }
+    }
+    // ---- set_r(kappa, kappa, lt[kappa]), lll.cpp:153
+    {
+      const int s = M.phys(kappa);
+      if (lane == 0)
+      {
+        T.r[(size_t)s * ldd + kappa] = ltk;
+        T.rdg[s]                     = ltk;
+        if (C.vc[s] == kappa)
+          C.vc[s] = kappa + 1;
+      }
+    }
+    ++kappa;
+    __threadfence_block();
+  }
+  if (ok)
+    status = (kappa < kend - zeros) ? -3 : 1;
+  return status;
+}
+
+// the rows in position order (b2), after which the host rebuilds the identity-layout GSO
+template <int NQ>
+__device__ __forceinline__ void lll_write_ordered(const Lattice<NQ> &T, const SlotMap<NQ> &M, long long *bo)
+{
+  const int lane = T.lane, d = T.d, ldn = T.ldn;
+  for (int p = 0; p < d; ++p)
+  {
+    const int s = M.phys(p);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+    {
+      const int c = lane + 64 * q;
+      if (c < ldn)
+        bo[(size_t)p * ldn + c] = T.b[(size_t)s * ldn + c];
+    }
+  }
+}
+
+}  // namespace fphip
+#endif

@@ -37,6 +37,9 @@ def _bind(lib):
     lib.fphip_gso_lll.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double,
                                   ctypes.c_double, vp, vp]
     lib.fphip_gso_lll.restype = ctypes.c_int
+    lib.fphip_gso_bkz.argtypes = [vp, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_int,
+                                  ctypes.c_int, vp, vp]
+    lib.fphip_gso_bkz.restype = ctypes.c_int
     for name in ("fphip_gso_get_mu", "fphip_gso_get_r", "fphip_gso_get_row_expo"):
         getattr(lib, name).argtypes = [vp, ctypes.c_int, vp]
         getattr(lib, name).restype = ctypes.c_int
@@ -104,6 +107,20 @@ class MatGSOBatch:
         self._chk(self.lib.fphip_gso_lll(self.h, kappa_min, kappa_start, kappa_end, delta, eta,
                                          st.ctypes.data_as(ctypes.c_void_p),
                                          info.ctypes.data_as(ctypes.c_void_p)), "lll")
+        return st, info
+
+    def bkz(self, block_size, delta=LLL_DEF_DELTA, eta=LLL_DEF_ETA, max_loops=0):
+        """BKZReduction::bkz() with empty strategies on every (LLL-reduced) lattice
+        (bkz.cpp:522-668).  Returns (status[batch], info[batch][4] = tours, nodes lo, nodes hi,
+        enumeration calls)."""
+        st = np.zeros(self.batch, dtype=np.int32)
+        info = np.zeros((self.batch, 4), dtype=np.int32)
+        rc = self.lib.fphip_gso_bkz(self.h, block_size, delta, eta, 0x4 if max_loops > 0 else 0,
+                                    max_loops, st.ctypes.data_as(ctypes.c_void_p),
+                                    info.ctypes.data_as(ctypes.c_void_p))
+        if rc == _lib.FPHIP_UNSUPPORTED:
+            raise NotImplementedError("block sizes above 64 / other BKZ variants stay on the CPU")
+        self._chk(rc, "bkz")
         return st, info
 
     def get_mu_matrix(self, lattice=0):

@@ -18,6 +18,7 @@
  *       fphip_gso_size_reduce   ← LLLReduction::size_reduction → babai   lll.h:107-122, lll.cpp:166-224
  *       fphip_gso_lll           ← LLLReduction::lll (+ MatGSO::move_row)   lll.cpp:44-164, gso.cpp:289-366
  *                                 (what lll_reduction_zf<long,double> runs with LM_FAST, wrapper.cpp)
+ *       fphip_gso_bkz           ← BKZReduction::bkz (empty strategies)      bkz.cpp:274-358,360-441,522-668
  *       fphip_gso_get_*         ← get_mu_exp/get_r_exp/row_expo accessors gso_interface.h:675-732
  *
  * Error convention: 0 = FPHIP_OK; FPHIP_UNSUPPORTED = instance declined, the caller must fall
@@ -150,6 +151,22 @@ int fphip_gso_size_reduce(fphip_gso *g, int kappa_min, int kappa_end, double eta
  * zeros (rows moved to the end as linearly dependent), loop iterations. */
 int fphip_gso_lll(fphip_gso *g, int kappa_min, int kappa_start, int kappa_end, double delta,
                   double eta, int *status, int *info);
+/* BKZReduction<Z_NR<long>,FP_NR<double>>(m, lll_obj, BKZParam(block_size, {}, delta, flags,
+ * max_loops)).bkz() (bkz.cpp:522-668: tour / trunc_tour / hkz :360-441, svp_reduction :274-358,
+ * svp_preprocessing's lll :107-113, svp_postprocessing :126-272, the block enumeration with
+ * FastEvaluator(1)) on every lattice — primal BKZ with EMPTY strategies (no pruning, no
+ * preprocessing: what bkz_reduction(b, beta, BKZ_DEFAULT, FT_DOUBLE) runs without a strategies
+ * file, bkz_param.h:124-132), the whole reduction in one launch on device-resident GSO state.
+ * flags: 0 (BKZ_DEFAULT) or FPHIP_BKZ_MAX_LOOPS with max_loops; block_size <= 64; anything else
+ * returns FPHIP_UNSUPPORTED (the caller keeps fplll's CPU path).  The input must be LLL-reduced, as
+ * bkz_reduction guarantees (bkz.cpp:870-885) — call fphip_gso_lll first.
+ * status[batch]: 1 RED_SUCCESS, 8 RED_BKZ_LOOPS_LIMIT, <= 0 the failing LLL status.
+ * info (nullable) [batch][4]: tours, enumeration nodes low / high 32 bits (fplll rule), enumeration
+ * calls. */
+#define FPHIP_BKZ_DEFAULT 0
+#define FPHIP_BKZ_MAX_LOOPS 0x4 /* fplll's BKZ_MAX_LOOPS, defs.h */
+int fphip_gso_bkz(fphip_gso *g, int block_size, double delta, double eta, int flags, int max_loops,
+                  int *status, int *info);
 /* raw stored values, d×d row-major; true values carry the row exponents exactly as
  * get_mu/get_r do (gso_interface.h:694-732): mu·2^(e_i-e_j), r·2^(e_i+e_j) */
 int fphip_gso_get_mu(fphip_gso *g, int lattice, double *mu);
