@@ -102,8 +102,13 @@ __global__ void __launch_bounds__(256)
     SlotMap<NQ> M;
     lll_init_state<NQ>(T, C, M);
 
+    int vp = 0;  // verified prefix of the LLL loop (lll_wave.h), kept across every call of the run
     auto upd   = [&](int k, int last) { return update_row_cached<NQ, IPS>(T, C, M, ring, k, last); };
-    auto after = [&](int k) { after_rowop<NQ>(T, C, M, k); };
+    auto after = [&](int k)
+    {
+      after_rowop<NQ>(T, C, M, k);
+      vp = min(vp, k);
+    };
 
     // trailing zero rows are not part of the lattice, bkz.cpp:35-37
     int num_rows = d;
@@ -165,7 +170,9 @@ __global__ void __launch_bounds__(256)
             if (pass == 1 || num_rows < 2)
               break;
           }
-          for (int k = kmin; k < kend && status == 1; ++k)
+          // rows below the verified prefix are size-reduced with r(k,k) in place: babai and
+          // update_gso_row are no-ops on them
+          for (int k = max(kmin, min(vp, kend)); k < kend && status == 1; ++k)
           {
             if (k > 0)
             {
@@ -197,7 +204,7 @@ __global__ void __launch_bounds__(256)
             int fk, ns, zs;
             long long it;
             const int rc = lll_run<NQ, IPS>(T, C, M, ring, 0, 0, kappa + bs, delta, eta, logdelta,
-                                            fk, ns, zs, it);
+                                            fk, ns, zs, it, vp);
             if (rc != 1)
             {
               status = rc;
@@ -372,6 +379,7 @@ __global__ void __launch_bounds__(256)
               {
                 rotate_right<NQ>(M, kappa, kappa + iv, lane);
                 clamp_valid<NQ>(T, C, M, kappa);
+                vp = min(vp, kappa);
               }
             }
             else if (iv != -1)
@@ -404,6 +412,7 @@ __global__ void __launch_bounds__(256)
               }
               store_row_and_refloat<NQ>(T, st, bv);
               after_rowop<NQ>(T, C, M, kappa + iv);
+              vp = min(vp, kappa);
               __threadfence_block();
               if (iv > 0)
               {
@@ -485,6 +494,7 @@ __global__ void __launch_bounds__(256)
                 }
               }
               refloat_and_invalidate<NQ>(T, C, M, kappa, kappa + bs);
+              vp = min(vp, kappa);
               clamp_valid<NQ>(T, C, M, kappa);
               rotate_right<NQ>(M, kappa, kappa + bs - 1, lane);
               clamp_valid<NQ>(T, C, M, kappa);

@@ -70,10 +70,10 @@ __global__ void __launch_bounds__(256)
     LllCtx C{P.gf + (size_t)L * d * ldd, P.vc + (size_t)L * d};
     SlotMap<NQ> M;
     lll_init_state<NQ>(T, C, M);
-    int final_kappa, nswaps, zeros;
+    int final_kappa, nswaps, zeros, vp = 0;
     long long iter;
     const int status = lll_run<NQ, IPS>(T, C, M, ring, kmin, kstart, kend, delta, eta, logdelta,
-                                        final_kappa, nswaps, zeros, iter);
+                                        final_kappa, nswaps, zeros, iter, vp);
     lll_write_ordered<NQ>(T, M, P.b2 + (size_t)L * d * ldn);
     if (lane == 0)
     {

@@ -367,29 +367,53 @@ template <int NQ, int IPS>
 __device__ __forceinline__ int lll_run(Lattice<NQ> &T, LllCtx &C, SlotMap<NQ> &M, Ring<NQ, IPS> &ring,
                                        int kmin, int kstart, int kend, double delta, double eta,
                                        double logdelta, int &final_kappa, int &nswaps, int &zeros,
-                                       long long &iter)
+                                       long long &iter, int &vp)
 {
+  // vp ("verified prefix"): rows 0..vp-1 are known to be a fixed point of this loop — babai is a
+  // no-op on each, Lovasz holds between neighbours, r(k,k) is set — and nothing they depend on has
+  // changed since.  The reference would walk them again without effect (lll.cpp:82-155 with
+  // kappa_start = 0, as BKZ calls it for every block); the walk resumes behind them instead and
+  // the skipped iterations are added to the iteration count.  Any change at row position p lowers
+  // vp to p.  A caller that keeps no state across calls passes vp = 0.
   const int lane = T.lane, d = T.d, n = T.n, ldd = T.ldd, ldn = T.ldn;
-  // ---- iteration limit, lll.cpp:79-80
+  // ---- iteration limit, lll.cpp:79-80: Matrix::get_max_exp over b.  With row exponents every
+  //      row's maximum is its row_expo (MatGSO::update_bf), except for |entries| >= 2^53 where
+  //      Z_NR<long>::exponent() can be one less than frexp's: scan the matrix only then
   int mexp = 0;
-  for (int i = 0; i < d; ++i)
   {
+    int rmax = 0;
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
-    {
-      const int c = lane + 64 * q;
-      if (c < n)
-        mexp = max(mexp, zexponent(T.b[(size_t)i * ldn + c]));
-    }
+      if (lane + 64 * q < d)
+        rmax = max(rmax, (int)T.rexp[lane + 64 * q]);
+    mexp = wave_max_i32(rmax);
   }
-  mexp         = wave_max_i32(mexp);
+  if (!T.row_expo_on || mexp >= 53)
+  {
+    mexp = 0;
+    for (int i = 0; i < d; ++i)
+    {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+      {
+        const int c = lane + 64 * q;
+        if (c < n)
+          mexp = max(mexp, zexponent(T.b[(size_t)i * ldn + c]));
+      }
+    }
+    mexp = wave_max_i32(mexp);
+  }
   const int dd = kend - kmin;
   const long long max_iter =
       (long long)((double)dd - (double)(2 * dd * (dd + 1)) * ((double)(mexp + 3) / logdelta));
   __threadfence_block();
 
   auto upd = [&](int k, int last) { return update_row_cached<NQ, IPS>(T, C, M, ring, k, last); };
-  auto after = [&](int k) { after_rowop<NQ>(T, C, M, k); };
+  auto after = [&](int k)
+  {
+    after_rowop<NQ>(T, C, M, k);
+    vp = min(vp, k);
+  };
   auto row_is_zero = [&](int s)
   {
     bool nz = false;
@@ -411,8 +435,12 @@ __device__ __forceinline__ int lll_run(Lattice<NQ> &T, LllCtx &C, SlotMap<NQ> &M
   bool ok     = true;
   // zero rows go to the end, lll.cpp:68-71
   for (; zeros < dd && row_is_zero(M.phys(0)); ++zeros)
+  {
     rotate_left<NQ>(M, kmin, kend - 1 - zeros, lane);
-  if (zeros < dd)
+    vp = min(vp, kmin);
+  }
+  const bool resume = kmin == 0 && vp > kstart + 1;  // rows <= kstart are verified: nothing to do
+  if (zeros < dd && !resume)
   {
     // the reference expects rows below kappa_start to be valid already; on a fresh GSO that is
     // update_gso_row(i) for each of them (a no-op for rows whose cache is valid)
@@ -442,6 +470,11 @@ __device__ __forceinline__ int lll_run(Lattice<NQ> &T, LllCtx &C, SlotMap<NQ> &M
     __threadfence_block();
   }
   int kappa = kstart + 1;
+  if (resume && ok)
+  {
+    kappa = max(kappa, min(vp, kend - zeros));
+    iter  = kappa - (kstart + 1);  // the no-op iterations the reference spends on rows < kappa
+  }
   for (; ok && iter < max_iter && kappa < kend - zeros; ++iter)
   {
     // ---- lazy size reduction, lll.cpp:103-108
@@ -544,6 +577,7 @@ __device__ __forceinline__ int lll_run(Lattice<NQ> &T, LllCtx &C, SlotMap<NQ> &M
         rotate_right<NQ>(M, knew, old_k, lane);
         clamp_valid<NQ>(T, C, M, knew);
         kappa = knew;
+        vp    = min(vp, knew);
       }
       else
       {  // linearly dependent row: to the end, lll.cpp:144-150
@@ -551,6 +585,7 @@ __device__ __forceinline__ int lll_run(Lattice<NQ> &T, LllCtx &C, SlotMap<NQ> &M
         rotate_left<NQ>(M, old_k, kend - zeros, lane);
         clamp_valid<NQ>(T, C, M, old_k);
         kappa = old_k;
+        vp    = min(vp, old_k);
         __threadfence_block();
         continue;
       }
@@ -566,6 +601,10 @@ __device__ __forceinline__ int lll_run(Lattice<NQ> &T, LllCtx &C, SlotMap<NQ> &M
           C.vc[s] = kappa + 1;
       }
     }
+    // rows 0..kappa are now a fixed point of this loop (see vp above); an insertion at kmin > 0
+    // has not been tested against row kmin-1 and does not extend the prefix
+    if (vp >= kappa && (kappa > kmin || kmin == 0))
+      vp = max(vp, kappa + 1);
     ++kappa;
     __threadfence_block();
   }
