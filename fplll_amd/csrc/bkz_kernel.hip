@@ -72,13 +72,13 @@ __global__ void __launch_bounds__(256)
   const int lane = threadIdx.x & 63;
   const int wpb  = blockDim.x >> 6;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  Ring<NQ, IPS> ring;
-  ring.base = (unsigned)(wave * Ring<NQ, IPS>::R * Ring<NQ, IPS>::SLOT);
+  Ring<NQ, IPS, FPHIP_RING_REDUCE> ring;
+  ring.base = (unsigned)(wave * Ring<NQ, IPS, FPHIP_RING_REDUCE>::R * Ring<NQ, IPS, FPHIP_RING_REDUCE>::SLOT);
   ring.lane = lane;
   ring.head = ring.tail = 0;
   ring.ahead            = 0;
   // enumeration stack (triangular column stack of the walk) behind the rings
-  double *stk = (double *)(bkz_smem + (size_t)wpb * Ring<NQ, IPS>::R * Ring<NQ, IPS>::SLOT) +
+  double *stk = (double *)(bkz_smem + (size_t)wpb * Ring<NQ, IPS, FPHIP_RING_REDUCE>::R * Ring<NQ, IPS, FPHIP_RING_REDUCE>::SLOT) +
                 (size_t)wave * stack_doubles;
   const int d = P.d, n = P.n, ldd = P.ldd, ldn = P.ldn;
   for (int L = blockIdx.x * wpb + wave; L < P.batch; L += gridDim.x * wpb)
@@ -103,7 +103,7 @@ __global__ void __launch_bounds__(256)
     lll_init_state<NQ>(T, C, M);
 
     int vp = 0;  // verified prefix of the LLL loop (lll_wave.h), kept across every call of the run
-    auto upd   = [&](int k, int last) { return update_row_cached<NQ, IPS>(T, C, M, ring, k, last); };
+    auto upd   = [&](int k, int last) { return update_row_cached(T, C, M, ring, k, last); };
     auto after = [&](int k)
     {
       after_rowop<NQ>(T, C, M, k);
@@ -176,7 +176,7 @@ __global__ void __launch_bounds__(256)
           {
             if (k > 0)
             {
-              const int rc = babai_impl<NQ, IPS>(T, ring, k, eta, M, upd, after, sr0);
+              const int rc = babai_impl(T, ring, k, eta, M, upd, after, sr0);
               if (rc != 1)
               {
                 status = rc;
@@ -203,7 +203,7 @@ __global__ void __launch_bounds__(256)
           {
             int fk, ns, zs;
             long long it;
-            const int rc = lll_run<NQ, IPS>(T, C, M, ring, 0, 0, kappa + bs, delta, eta, logdelta,
+            const int rc = lll_run(T, C, M, ring, 0, 0, kappa + bs, delta, eta, logdelta,
                                             fk, ns, zs, it, vp);
             if (rc != 1)
             {

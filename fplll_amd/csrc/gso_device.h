@@ -16,6 +16,14 @@
 
 #include <stdint.h>
 
+// LDS-DMA ring depths (slots per wave): sweep kernels / reduction drivers (see gso_wave.h)
+#ifndef FPHIP_GSO_RING
+#define FPHIP_GSO_RING 6
+#endif
+#ifndef FPHIP_RING_REDUCE
+#define FPHIP_RING_REDUCE 8
+#endif
+
 namespace fphip
 {
 struct GsoBatch

@@ -166,7 +166,7 @@ static int launch(fphip_gso *g, int kmin, int kend, double eta, int mode, const 
   int grid       = (g->P.batch + wpb - 1) / wpb;
   hipStream_t s = fphip_ctx_stream(g->ctx);
   // per-wave LDS-DMA ring: FPHIP_GSO_RING slots of IPS KiB (IPS = ceil(NQ/2))
-  const size_t lds = (size_t)wpb * FPHIP_GSO_RING * (size_t)((nq + 1) / 2) * 1024;
+  const size_t lds = (size_t)wpb * (la ? FPHIP_RING_REDUCE : FPHIP_GSO_RING) * (size_t)((nq + 1) / 2) * 1024;
   int bpc          = g->blocks_per_cu > 0 ? g->blocks_per_cu : (int)((160 * 1024) / lds);
   if (bpc * wpb > 32)
     bpc = 32 / wpb;
@@ -388,7 +388,7 @@ extern "C" int fphip_gso_bkz(fphip_gso *g, int block_size, double delta, double 
   const int wpb  = g->waves_per_block;
   const int bs   = block_size < 2 ? 2 : (block_size < g->P.d ? block_size : g->P.d);
   const int stack_doubles = (bs * (bs + 1)) / 2 + 2;
-  const size_t ring_bytes = (size_t)wpb * FPHIP_GSO_RING * (size_t)((nq + 1) / 2) * 1024;
+  const size_t ring_bytes = (size_t)wpb * FPHIP_RING_REDUCE * (size_t)((nq + 1) / 2) * 1024;
   const size_t lds        = ring_bytes + (size_t)wpb * stack_doubles * sizeof(double);
   if (ring_bytes > 64 * 1024 || lds > 160 * 1024)
   {
@@ -674,7 +674,7 @@ extern "C" int fphip_hh_hlll(fphip_hh *h, double delta, double eta, double theta
   }
   const int nq  = (h->P.n + 63) / 64;
   const int wpb = 4;
-  const size_t lds = (size_t)wpb * FPHIP_GSO_RING * (size_t)((nq + 1) / 2) * 1024;
+  const size_t lds = (size_t)wpb * FPHIP_RING_REDUCE * (size_t)((nq + 1) / 2) * 1024;
   int bpc          = (int)((160 * 1024) / lds);
   if (bpc * wpb > 32)
     bpc = 32 / wpb;

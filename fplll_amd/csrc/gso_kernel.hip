@@ -115,7 +115,7 @@ __global__ void __launch_bounds__(256)
       {
         if (mode == 1 && kappa > 0)
         {
-          const int rc = babai<NQ, IPS>(T, ring, kappa, eta);
+          const int rc = babai(T, ring, kappa, eta);
           if (rc != 1)
           {
             status = rc;
@@ -126,7 +126,7 @@ __global__ void __launch_bounds__(256)
         {
           finish_diag<NQ>(T, kappa);  // babai left the row valid up to column kappa-1
         }
-        else if (!update_row<NQ, IPS>(T, ring, kappa, kappa))
+        else if (!update_row(T, ring, kappa, kappa))
         {
           status = 0;
           break;

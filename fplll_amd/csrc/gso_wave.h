@@ -168,9 +168,12 @@ template <int NQ, class F> __device__ __forceinline__ void dispatch_chunk(int id
   }
 }
 
-template <int NQ, int IPS> struct Ring
+// RR = ring depth: FPHIP_GSO_RING for the HBM-bound sweep kernels (more waves per CU matter more
+// than depth), FPHIP_RING_REDUCE for the reduction drivers (LLL / BKZ / HLLL), which run few waves
+// per CU for a long time and are bound by the latency of each streamed row.
+template <int NQ, int IPS, int RR = FPHIP_GSO_RING> struct Ring
 {
-  static constexpr int R     = FPHIP_GSO_RING;
+  static constexpr int R     = RR;
   static constexpr int SLOT  = IPS * 1024;
   static constexpr int AHEAD = (R - 1 < 7 ? R - 1 : 7);  // rows kept in flight behind the consumer
   unsigned base;  // LDS byte address of this wave's ring (wave-uniform)
@@ -322,31 +325,90 @@ template <int NQ, int IPS> struct Ring
   // previous phase).  While consuming, keep the pipe full: first with this phase's remaining rows,
   // then with the first rows of the NEXT phase (ncnt rows, nrow(s)) — phases are chained without
   // draining the pipe whenever no other vector-memory instruction separates them.
+  //
+  // The loop is split by pipeline state so that the steady state is branch-free: while a row can
+  // be issued for every row consumed, exactly AHEAD newer rows are behind the one being read and
+  // the wait is the compile-time s_waitcnt vmcnt(AHEAD*IPS); only the last <= AHEAD steps of an
+  // unchained phase take the dynamic wait.
   template <class RowA, class BodyF, class RowB>
   __device__ __forceinline__ void run(int cnt, RowA row, BodyF body, int ncnt, RowB nrow)
   {
-    run_with(cnt, row, body, ncnt, nrow, [&](double(&v)[NQ]) { fetch(v); });
+    run_with(cnt, row, body, ncnt, nrow, PlainFetch{});
   }
-  template <class RowA, class BodyF, class RowB, class FetchF>
+  struct PlainFetch
+  {
+  };
+  struct GatherFetch
+  {
+    const unsigned (&off)[NQ];
+  };
+  template <int P> __device__ __forceinline__ void consume(double (&v)[NQ], const PlainFetch &)
+  {
+    const unsigned addr = base + tail * SLOT + lane * 8;
+    tail                = (tail + 1 == R) ? 0 : tail + 1;
+    --ahead;
+    read<P>(v, addr);
+  }
+  template <int P> __device__ __forceinline__ void consume(double (&v)[NQ], const GatherFetch &g)
+  {
+    unsigned a[NQ];
+    const unsigned sb = base + tail * SLOT;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+      a[q] = sb + g.off[q];
+    tail = (tail + 1 == R) ? 0 : tail + 1;
+    --ahead;
+    readg<P>(v, a);
+  }
+  __device__ __forceinline__ void consume_dyn(double (&v)[NQ], const PlainFetch &) { fetch(v); }
+  __device__ __forceinline__ void consume_dyn(double (&v)[NQ], const GatherFetch &g)
+  {
+    fetch_gather(v, g.off);
+  }
+  template <class RowA, class BodyF, class RowB, class FetchP>
   __device__ __forceinline__ void run_with(int cnt, RowA row, BodyF body, int ncnt, RowB nrow,
-                                           FetchF fetchf)
+                                           const FetchP &fp)
   {
     int issued  = ahead;  // rows of this phase issued so far
     int nissued = 0;      // rows of the next phase issued so far
-#pragma unroll 1
-    for (int s = 0; s < cnt; ++s)
+    // fill the pipe
+    while (ahead <= AHEAD)
     {
-      while (ahead <= AHEAD)
+      if (issued < cnt)
+        issue(row(issued++));
+      else if (nissued < ncnt)
+        issue(nrow(nissued++));
+      else
+        break;
+    }
+    int s = 0;
+    if (ahead == AHEAD + 1)
+    {
+      // steady state, refilled from this phase
+#pragma unroll 1
+      for (; s < cnt && issued < cnt; ++s)
       {
-        if (issued < cnt)
-          issue(row(issued++));
-        else if (nissued < ncnt)
-          issue(nrow(nissued++));
-        else
-          break;
+        double v[NQ];
+        consume<AHEAD>(v, fp);
+        issue(row(issued++));
+        body(s, v);
       }
+      // steady state, refilled from the next phase
+#pragma unroll 1
+      for (; s < cnt && nissued < ncnt; ++s)
+      {
+        double v[NQ];
+        consume<AHEAD>(v, fp);
+        issue(nrow(nissued++));
+        body(s, v);
+      }
+    }
+    // drain (nothing left to issue, or the phase is shorter than the pipe)
+#pragma unroll 1
+    for (; s < cnt; ++s)
+    {
       double v[NQ];
-      fetchf(v);
+      consume_dyn(v, fp);
       body(s, v);
     }
   }
@@ -358,8 +420,8 @@ template <int NQ, int IPS> struct Ring
 
 // update_gso_row(kappa, last) recomputed from column 0 (identical values: every input is unchanged
 // since the row was invalidated).  Returns false on a non-finite mu (RED_GSO_FAILURE).
-template <int NQ, int IPS>
-__device__ bool update_row(Lattice<NQ> &T, Ring<NQ, IPS> &ring, int kappa, int last)
+template <int NQ, int IPS, int RR>
+__device__ bool update_row(Lattice<NQ> &T, Ring<NQ, IPS, RR> &ring, int kappa, int last)
 {
   const int n = T.n, lane = T.lane, ldd = T.ldd;
   const int qact = (last >> 6) + 1;  // chunks holding a lane j <= last
@@ -544,8 +606,8 @@ __device__ __forceinline__ void store_row_and_refloat(Lattice<NQ> &T, int pk, co
 // LLLReduction::babai(kappa, kappa, 0).  1 ok, 0 GSO failure, -1 babai failure, -2 multiplier.
 // `upd(kappa, last)` brings row kappa of the GSO up to column `last` (and leaves mu/r of the row in
 // T.murow / T.rrow); `after(kappa)` runs after b_kappa changed (row_op_end's invalidations).
-template <int NQ, int IPS, class Map, class Upd, class After>
-__device__ __forceinline__ int babai_impl(Lattice<NQ> &T, Ring<NQ, IPS> &ring, int kappa, double eta,
+template <int NQ, int IPS, int RR, class Map, class Upd, class After>
+__device__ __forceinline__ int babai_impl(Lattice<NQ> &T, Ring<NQ, IPS, RR> &ring, int kappa, double eta,
                                           const Map &map, Upd upd, After after, int sr_start = 0)
 {
   // sr_start = size_reduction_start (lll.cpp:167): only columns j in [sr_start, kappa) are reduced
@@ -683,12 +745,12 @@ __device__ __forceinline__ int babai_impl(Lattice<NQ> &T, Ring<NQ, IPS> &ring, i
   return 1;
 }
 
-template <int NQ, int IPS>
-__device__ int babai(Lattice<NQ> &T, Ring<NQ, IPS> &ring, int kappa, double eta)
+template <int NQ, int IPS, int RR>
+__device__ int babai(Lattice<NQ> &T, Ring<NQ, IPS, RR> &ring, int kappa, double eta)
 {
-  return babai_impl<NQ, IPS>(
+  return babai_impl(
       T, ring, kappa, eta, IdentityMap{},
-      [&](int k, int last) { return update_row<NQ, IPS>(T, ring, k, last); }, [](int) {});
+      [&](int k, int last) { return update_row(T, ring, k, last); }, [](int) {});
 }
 
 // sum of p[c] for c in [from, to), ascending, starting from `init` if has_init, else from p[from]

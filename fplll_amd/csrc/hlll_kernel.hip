@@ -67,8 +67,8 @@ __global__ void __launch_bounds__(256)
   const int lane = threadIdx.x & 63;
   const int wpb  = blockDim.x >> 6;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  Ring<NQ, IPS> ring;
-  ring.base = (unsigned)(wave * Ring<NQ, IPS>::R * Ring<NQ, IPS>::SLOT);
+  Ring<NQ, IPS, FPHIP_RING_REDUCE> ring;
+  ring.base = (unsigned)(wave * Ring<NQ, IPS, FPHIP_RING_REDUCE>::R * Ring<NQ, IPS, FPHIP_RING_REDUCE>::SLOT);
   ring.lane = lane;
   ring.head = ring.tail = 0;
   ring.ahead            = 0;

@@ -45,8 +45,8 @@ __global__ void __launch_bounds__(256)
   const int lane = threadIdx.x & 63;
   const int wpb  = blockDim.x >> 6;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  Ring<NQ, IPS> ring;
-  ring.base = (unsigned)(wave * Ring<NQ, IPS>::R * Ring<NQ, IPS>::SLOT);
+  Ring<NQ, IPS, FPHIP_RING_REDUCE> ring;
+  ring.base = (unsigned)(wave * Ring<NQ, IPS, FPHIP_RING_REDUCE>::R * Ring<NQ, IPS, FPHIP_RING_REDUCE>::SLOT);
   ring.lane = lane;
   ring.head = ring.tail = 0;
   ring.ahead            = 0;
@@ -72,7 +72,7 @@ __global__ void __launch_bounds__(256)
     lll_init_state<NQ>(T, C, M);
     int final_kappa, nswaps, zeros, vp = 0;
     long long iter;
-    const int status = lll_run<NQ, IPS>(T, C, M, ring, kmin, kstart, kend, delta, eta, logdelta,
+    const int status = lll_run(T, C, M, ring, kmin, kstart, kend, delta, eta, logdelta,
                                         final_kappa, nswaps, zeros, iter, vp);
     lll_write_ordered<NQ>(T, M, P.b2 + (size_t)L * d * ldn);
     if (lane == 0)

@@ -39,9 +39,9 @@ __device__ __forceinline__ int zexponent(long long v)
 
 // update_gso_row(kappa, last) from the first invalid column of the row (gso_interface.cpp:131-164).
 // Leaves mu(kappa, .) / r(kappa, .) of columns <= last in T.murow / T.rrow (lane = column).
-template <int NQ, int IPS>
+template <int NQ, int IPS, int RR>
 __device__ __forceinline__ bool update_row_cached(Lattice<NQ> &T, LllCtx &C, const SlotMap<NQ> &M,
-                                  Ring<NQ, IPS> &ring, int kappa, int last)
+                                  Ring<NQ, IPS, RR> &ring, int kappa, int last)
 {
   const int n = T.n, lane = T.lane, ldd = T.ldd;
   const int sk    = M.phys(kappa);
@@ -117,7 +117,7 @@ __device__ __forceinline__ bool update_row_cached(Lattice<NQ> &T, LllCtx &C, con
             g[q]           = (c == 0) ? p : g[q] + p;
           }
         },
-        0, gram_row, [&](double(&v)[NQ]) { ring.fetch_gather(v, off); });
+        0, gram_row, typename Ring<NQ, IPS, RR>::GatherFetch{off});
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
     {
@@ -168,7 +168,7 @@ __device__ __forceinline__ bool update_row_cached(Lattice<NQ> &T, LllCtx &C, con
                                }
                              });
         },
-        0, rec_row, [&](double(&v)[NQ]) { ring.fetch_gather(v, off); });
+        0, rec_row, typename Ring<NQ, IPS, RR>::GatherFetch{off});
   }
   else
   {
@@ -363,8 +363,8 @@ __device__ __forceinline__ void lll_init_state(Lattice<NQ> &T, LllCtx &C, SlotMa
 // LLLReduction::lll(kmin, kstart, kend, 0), lll.cpp:44-164, on the cached state (T, C, M).
 // status: 1 RED_SUCCESS, 0 RED_GSO_FAILURE, -1 RED_BABAI_FAILURE, -2 multiplier beyond 63 bits,
 //         -3 RED_LLL_FAILURE (iteration limit, lll.cpp:159-160)
-template <int NQ, int IPS>
-__device__ __forceinline__ int lll_run(Lattice<NQ> &T, LllCtx &C, SlotMap<NQ> &M, Ring<NQ, IPS> &ring,
+template <int NQ, int IPS, int RR>
+__device__ __forceinline__ int lll_run(Lattice<NQ> &T, LllCtx &C, SlotMap<NQ> &M, Ring<NQ, IPS, RR> &ring,
                                        int kmin, int kstart, int kend, double delta, double eta,
                                        double logdelta, int &final_kappa, int &nswaps, int &zeros,
                                        long long &iter, int &vp)
@@ -408,7 +408,7 @@ __device__ __forceinline__ int lll_run(Lattice<NQ> &T, LllCtx &C, SlotMap<NQ> &M
       (long long)((double)dd - (double)(2 * dd * (dd + 1)) * ((double)(mexp + 3) / logdelta));
   __threadfence_block();
 
-  auto upd = [&](int k, int last) { return update_row_cached<NQ, IPS>(T, C, M, ring, k, last); };
+  auto upd = [&](int k, int last) { return update_row_cached(T, C, M, ring, k, last); };
   auto after = [&](int k)
   {
     after_rowop<NQ>(T, C, M, k);
@@ -453,7 +453,7 @@ __device__ __forceinline__ int lll_run(Lattice<NQ> &T, LllCtx &C, SlotMap<NQ> &M
       status = 0;
     if (ok && kstart > 0)
     {
-      const int rc = babai_impl<NQ, IPS>(T, ring, kstart, eta, M, upd, after);
+      const int rc = babai_impl(T, ring, kstart, eta, M, upd, after);
       if (rc != 1)
       {
         status = rc;
@@ -478,7 +478,7 @@ __device__ __forceinline__ int lll_run(Lattice<NQ> &T, LllCtx &C, SlotMap<NQ> &M
   for (; ok && iter < max_iter && kappa < kend - zeros; ++iter)
   {
     // ---- lazy size reduction, lll.cpp:103-108
-    const int rc = babai_impl<NQ, IPS>(T, ring, kappa, eta, M, upd, after);
+    const int rc = babai_impl(T, ring, kappa, eta, M, upd, after);
     if (rc != 1)
     {
       status      = rc;
