@@ -235,7 +235,10 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK)
       {
         k               = __builtin_amdgcn_readfirstlane(k);
         const int kc    = k - 1;
-        const double c1 = rl_f64(S, kc);  // center[kk-1] = center_partsums[kk-1][kk]
+        // speculative load for the descending case: row kc of mu is needed right after the test
+        // (its latency overlaps the test); clamped (valid, unused) address when kc == 0
+        const double mk1 = mu_s[tri_off(max(kc, 1)) + min(lane, max(kc, 1) - 1)];
+        const double c1  = rl_f64(S, kc);  // center[kk-1] = center_partsums[kk-1][kk]
         const double x1 = round(c1);      // roundto(): half away from zero, enumerate_base.h:33-34
         const double a1 = x1 - c1;
         const double n1 = nd + a1 * a1 * rl_f64(rd, kc);  // :28-29
@@ -287,8 +290,7 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK)
             report(nd);  // process_solution, :42-46
           break;         // level 0 has no children: next sibling
         }
-        const double mk = mu_s[tri_off(k) + min(lane, k - 1)];  // k >= 1 here
-        S               = S - x1 * mk;  // S_k = S_{k+1} - x[k]*mu(k,·), :53-58
+        S = S - x1 * mk1;  // S_k = S_{k+1} - x[k]*mu(k,·), :53-58 (k >= 1 here: mk1 is row k)
       }
       if (done)
         break;
