@@ -227,10 +227,15 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK)
     };
 
     bool done = false;
+    bool rep  = false;  // a candidate (level 0, nd > 0) is waiting to be reported
+    bool at0  = false;  // ... and it was found by the STEP loop: resume there, not in CHILD
     while (!done)
     {
       // ================= CHILD chain: descend while the first child survives ====================
       // (state: a surviving, already counted node at level k with column S = S_k, distance nd)
+      // Candidates are reported OUTSIDE the two hot loops (one copy of the slow path, no live
+      // ranges of it inside them).
+      if (!at0)
       for (;;)
       {
         k               = __builtin_amdgcn_readfirstlane(k);
@@ -286,14 +291,19 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK)
         nd = n1;
         if (k == 0)
         {
-          if (nd > 0.0)
-            report(nd);  // process_solution, :42-46
-          break;         // level 0 has no children: next sibling
+          rep = nd > 0.0;  // process_solution, :42-46
+          break;           // level 0 has no children: next sibling
         }
         S = S - x1 * mk1;  // S_k = S_{k+1} - x[k]*mu(k,·), :53-58 (k >= 1 here: mk1 is row k)
       }
       if (done)
         break;
+      if (rep)
+      {
+        report(nd);
+        rep = false;
+      }
+      at0 = false;
       // ================= STEP loop: next sibling at level k, climbing while they fail ===========
       for (;;)
       {
@@ -350,7 +360,11 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK)
         if (k == 0)
         {
           if (nd > 0.0)
-            report(nd);  // :97-101
+          {  // :97-101: report outside the loop, then come back to the next sibling of level 0
+            rep = true;
+            at0 = true;
+            break;
+          }
           continue;
         }
         S = par - xk * mk;  // :104-110
