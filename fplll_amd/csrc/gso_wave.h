@@ -190,8 +190,11 @@ template <int NQ, int IPS, int RR = FPHIP_GSO_RING> struct Ring
     ahead       = 0;
   }
 
-  // stream bytes [lo, hi) of one row.  Every one of the IPS instructions is issued (lane 0 stays
-  // active) so that the vmcnt arithmetic of fetch() holds; lanes outside the window move no data.
+  // stream bytes [lo, hi) of one row.  Every one of the IPS instructions is issued, so that the
+  // vmcnt arithmetic of the consumer holds; lanes outside the window move no data.  An instruction
+  // whose whole 1 KiB span lies outside the window is issued by lane 0 alone, re-reading the first
+  // 16 bytes of the window (a line the other instruction fetches anyway — no extra HBM traffic)
+  // into its own, unused, part of the slot.
   __device__ __forceinline__ void issue(const RowDesc &r)
   {
     const char *g      = (const char *)r.ptr + lane * 16;
@@ -199,12 +202,17 @@ template <int NQ, int IPS, int RR = FPHIP_GSO_RING> struct Ring
 #pragma unroll
     for (int i = 0; i < IPS; ++i)
     {
-      const int off = lane * 16 + i * 1024;
-      // lane 0 is always active: an instruction none of whose lanes meets the window must still be
-      // issued, otherwise the consumer's vmcnt arithmetic is off by one (a ballot per instruction
-      // to find that case costs more than the occasional extra 16 bytes)
-      if (lane == 0 || (off + 16 > r.lo && off < r.hi))
-        glds16(g + i * 1024, dst + i * 1024);
+      const int off  = lane * 16 + i * 1024;
+      const bool any = r.hi > r.lo && r.hi > i * 1024 && r.lo < (i + 1) * 1024;  // wave-uniform
+      if (any)
+      {
+        if (off + 16 > r.lo && off < r.hi)
+          glds16(g + i * 1024, dst + i * 1024);
+      }
+      else if (lane == 0)
+      {
+        glds16((const char *)r.ptr + (r.lo & ~15), dst + i * 1024);
+      }
     }
     head = (head + 1 == R) ? 0 : head + 1;
     ++ahead;
