@@ -84,6 +84,15 @@ __device__ __forceinline__ bool update_row_cached(Lattice<NQ> &T, LllCtx &C, con
     if (j < kappa && j <= last)
       rd[q] = T.rdg[M.sl[q]];
   }
+  // rows are gathered by slot: only slots up to the largest one among positions <= last are needed
+  // (the slots of positions 0..kappa_max are a permutation of 0..kappa_max: moves stay inside the
+  // processed prefix), so the DMA window of a streamed row ends there
+  int hi_slot = 0;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+    if (lane + 64 * q <= last)
+      hi_slot = max(hi_slot, M.sl[q]);
+  const int row_bytes = min((wave_max_i32(hi_slot) + 1) * 8, ldd * 8);
   if (__any(miss))
   {
     // ---- Gram row: g(kappa,j) = bf_kappa . bf_j, columns ascending (numvect.h:386-396)
@@ -103,7 +112,7 @@ __device__ __forceinline__ bool update_row_cached(Lattice<NQ> &T, LllCtx &C, con
       settle(rd[q]);
       settle(mold[q]);
     }
-    auto gram_row = [&](int c) { return RowDesc{T.bfT + (size_t)c * ldd, 0, ldd * 8}; };
+    auto gram_row = [&](int c) { return RowDesc{T.bfT + (size_t)c * ldd, 0, row_bytes}; };
     ring.reset();
     ring.run_with(
         n, gram_row,
@@ -141,7 +150,7 @@ __device__ __forceinline__ bool update_row_cached(Lattice<NQ> &T, LllCtx &C, con
       settle(rd[q]);
       settle(mold[q]);
     }
-    auto rec_row = [&](int k) { return RowDesc{T.muT + (size_t)k * ldd, 0, ldd * 8}; };
+    auto rec_row = [&](int k) { return RowDesc{T.muT + (size_t)k * ldd, 0, row_bytes}; };
     ring.reset();
     ring.run_with(
         last, rec_row,
