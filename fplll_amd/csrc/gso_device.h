@@ -39,6 +39,13 @@ struct GsoBatch
   double *rdg;
   long long *rexp;
   int *status;
+  // narrow mirrors of the sweep kernels: bf as float [batch][n][ldd], b as int32 [batch][d][ldn],
+  // per-row flag [batch][d] "every entry of the row is below 2^24 in magnitude" (its mirrors are
+  // then exact); a pass that reads rows 0..k streams the 4-byte mirrors when all of them are narrow
+  float *bfT32;
+  int *b32;
+  int *narrow;
+  int use_narrow;
   // LLL kernel only (allocated on first use): symmetric Gram cache [batch][d][ldd], valid-column
   // counts [batch][d], output basis in position order [batch][d][ldn], info [batch][4]
   double *gf;

@@ -107,7 +107,17 @@ extern "C" int fphip_gso_create(fphip_ctx *ctx, int batch, int d, int n, int row
   GCHK(hipMalloc((void **)&g->P.rdg, B * d * sizeof(double)));
   GCHK(hipMalloc((void **)&g->P.rexp, B * d * sizeof(long long)));
   GCHK(hipMalloc((void **)&g->P.status, B * sizeof(int)));
+  GCHK(hipMalloc((void **)&g->P.bfT32, B * n * ldd * sizeof(float) + pad));
+  GCHK(hipMalloc((void **)&g->P.b32, B * d * ldn * sizeof(int) + pad));
+  GCHK(hipMalloc((void **)&g->P.narrow, B * d * sizeof(int)));
   hipStream_t s0 = fphip_ctx_stream(ctx);
+  GCHK(hipMemsetAsync(g->P.bfT32, 0, B * n * ldd * sizeof(float) + pad, s0));
+  GCHK(hipMemsetAsync(g->P.b32, 0, B * d * ldn * sizeof(int) + pad, s0));
+  GCHK(hipMemsetAsync(g->P.narrow, 0, B * d * sizeof(int), s0));
+  {
+    const char *nv = getenv("FPHIP_GSO_NARROW");  // 0 keeps every pass on the 8-byte rows (A/B runs)
+    g->P.use_narrow = (nv && atoi(nv) == 0) ? 0 : 1;
+  }
   GCHK(hipMemsetAsync(g->P.b, 0, B * d * ldn * sizeof(long long) + pad, s0));
   GCHK(hipMemsetAsync(g->P.bfT, 0, B * n * ldd * sizeof(double) + pad, s0));
   GCHK(hipMemsetAsync(g->P.mu, 0, B * d * ldd * sizeof(double) + pad, s0));
@@ -137,6 +147,9 @@ extern "C" void fphip_gso_destroy(fphip_gso *g)
   hipFree(g->P.rdg);
   hipFree(g->P.rexp);
   hipFree(g->P.status);
+  hipFree(g->P.bfT32);
+  hipFree(g->P.b32);
+  hipFree(g->P.narrow);
   if (g->P.gf)
     hipFree(g->P.gf);
   if (g->P.vc)

@@ -65,48 +65,32 @@ __global__ void __launch_bounds__(256)
     T.r           = P.r + (size_t)L * P.d * P.ldd;
     T.rdg         = P.rdg + (size_t)L * P.d;
     T.rexp        = P.rexp + (size_t)L * P.d;
+    T.bfT32       = P.bfT32 + (size_t)L * P.n * P.ldd;
+    T.b32         = P.b32 + (size_t)L * P.d * P.ldn;
+    T.narrow_flag = P.narrow + (size_t)L * P.d;
+    T.np          = 0;
+    if (mode != 2)
+    {  // narrow prefix from the per-row flags (FPHIP_GSO_NARROW=0: P.use_narrow == 0)
+      int p = 0;
+      while (P.use_narrow && p < P.d && __builtin_amdgcn_readfirstlane(T.narrow_flag[p]) != 0)
+        ++p;
+      T.np = p;
+    }
     int status    = 1;
     if (mode == 2)
     {
+      // (re)float every row from b (MatGSO::update_bf, gso.cpp:24-48) and rebuild the narrow
+      // mirrors; the lattice streams 4-byte rows while all its entries stay below 2^24
       for (int i = 0; i < P.d; ++i)
       {
-        int ce[NQ];
-        double cm[NQ];
-        int emax = INT_MIN;
+        long long bv[NQ];
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
         {
           const int c = lane + 64 * q;
-          ce[q]       = INT_MIN;
-          cm[q]       = 0.0;
-          if (c < P.n)
-          {
-            const long long v = T.b[(size_t)i * P.ldn + c];
-            if (P.row_expo)
-            {
-              int ex;
-              cm[q] = frexp((double)v, &ex);
-              ce[q] = ex;
-              emax  = max(emax, ex);
-            }
-            else
-            {
-              cm[q] = (double)v;
-              ce[q] = 0;
-              emax  = 0;
-            }
-          }
+          bv[q]       = (c < P.n) ? T.b[(size_t)i * P.ldn + c] : 0;
         }
-        emax = wave_max_i32(emax);
-#pragma unroll
-        for (int q = 0; q < NQ; ++q)
-        {
-          const int c = lane + 64 * q;
-          if (c < P.n)
-            T.bfT[(size_t)c * P.ldd + i] = P.row_expo ? ldexp(cm[q], ce[q] - emax) : cm[q];
-        }
-        if (lane == 0)
-          T.rexp[i] = P.row_expo ? (long long)emax : 0;
+        store_row_and_refloat<NQ, true>(T, i, bv);
       }
     }
     else

@@ -45,6 +45,13 @@ template <int NQ> struct Lattice
   long long *b;
   double *bfT, *mu, *muT, *r, *rdg;
   long long *rexp;
+  // narrow mirrors (sweep kernels only; nullptr elsewhere): while every entry of the lattice is
+  // below 2^24 in magnitude, bf fits a float exactly and b an int32 — the Gram pass and the
+  // integer AXPY then stream 4-byte rows (half the HBM bytes) and widen in registers, bit-exactly
+  float *bfT32;      // [n][ldd]
+  int *b32;          // [d][ldn]
+  int *narrow_flag;  // [d] per row: every entry of the row is below 2^24 in magnitude
+  int np;            // narrow prefix: rows 0..np-1 are all narrow (wave-uniform)
   int lane;
   double murow[NQ];  // mu(kappa, j) of the row last updated (lane j)
   double rrow[NQ];   // r(kappa, j)  of the row last updated (lane j)
@@ -56,11 +63,13 @@ template <int NQ> struct Lattice
 // fplll/gso.cpp:289-366, nr/matrix.h rotate_left/right).
 struct IdentityMap
 {
+  static constexpr bool kNarrowMirrors = true;  // the sweep kernels keep the 4-byte mirrors
   __device__ __forceinline__ int phys(int j) const { return j; }
   template <int Q> __device__ __forceinline__ int lane_phys(int lane) const { return lane + 64 * Q; }
 };
 template <int NQ> struct SlotMap
 {
+  static constexpr bool kNarrowMirrors = false;
   int sl[NQ];  // lane j of chunk q holds the slot of row position j + 64 q
   __device__ __forceinline__ int phys(int j) const
   {
@@ -247,6 +256,35 @@ template <int NQ, int IPS, int RR = FPHIP_GSO_RING> struct Ring
                    : "memory");
   }
 
+  // 4-byte elements (narrow rows): this lane's element of each chunk, raw bits
+  template <int P> __device__ __forceinline__ void read32(unsigned (&w)[NQ], unsigned addr)
+  {
+    if constexpr (NQ == 1)
+      asm volatile("s_waitcnt vmcnt(%2)\n\tds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)"
+                   : "=&v"(w[0])
+                   : "v"(addr), "n"(P * IPS)
+                   : "memory");
+    else if constexpr (NQ == 2)
+      asm volatile("s_waitcnt vmcnt(%3)\n\tds_read_b32 %0, %2\n\tds_read_b32 %1, %2 offset:256\n\t"
+                   "s_waitcnt lgkmcnt(0)"
+                   : "=&v"(w[0]), "=&v"(w[1])
+                   : "v"(addr), "n"(P * IPS)
+                   : "memory");
+    else if constexpr (NQ == 3)
+      asm volatile("s_waitcnt vmcnt(%4)\n\tds_read_b32 %0, %3\n\tds_read_b32 %1, %3 offset:256\n\t"
+                   "ds_read_b32 %2, %3 offset:512\n\ts_waitcnt lgkmcnt(0)"
+                   : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2])
+                   : "v"(addr), "n"(P * IPS)
+                   : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(%5)\n\tds_read_b32 %0, %4\n\tds_read_b32 %1, %4 offset:256\n\t"
+                   "ds_read_b32 %2, %4 offset:512\n\tds_read_b32 %3, %4 offset:768\n\t"
+                   "s_waitcnt lgkmcnt(0)"
+                   : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3])
+                   : "v"(addr), "n"(P * IPS)
+                   : "memory");
+  }
+
   // gather variant of read(): chunk q of this lane takes the element at byte offset a[q] of the slot
   template <int P> __device__ __forceinline__ void readg(double (&v)[NQ], const unsigned (&a)[NQ])
   {
@@ -350,6 +388,57 @@ template <int NQ, int IPS, int RR = FPHIP_GSO_RING> struct Ring
   {
     const unsigned (&off)[NQ];
   };
+  struct F32Fetch  // rows of float, widened to double (exact)
+  {
+  };
+  struct I32Fetch  // rows of int32, delivered as the bit pattern of the sign-extended int64
+  {
+  };
+  // chosen at run time (wave-uniform): 8-byte rows, or 4-byte rows widened in registers
+  struct AutoF32Fetch
+  {
+    bool narrow;
+  };
+  struct AutoI32Fetch
+  {
+    bool narrow;
+  };
+  template <int P> __device__ __forceinline__ void consume(double (&v)[NQ], const AutoF32Fetch &f)
+  {
+    if (f.narrow)
+      consume<P>(v, F32Fetch{});
+    else
+      consume<P>(v, PlainFetch{});
+  }
+  template <int P> __device__ __forceinline__ void consume(double (&v)[NQ], const AutoI32Fetch &f)
+  {
+    if (f.narrow)
+      consume<P>(v, I32Fetch{});
+    else
+      consume<P>(v, PlainFetch{});
+  }
+  template <int P> __device__ __forceinline__ void consume(double (&v)[NQ], const F32Fetch &)
+  {
+    const unsigned addr = base + tail * SLOT + lane * 4;
+    tail                = (tail + 1 == R) ? 0 : tail + 1;
+    --ahead;
+    unsigned w[NQ];
+    read32<P>(w, addr);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+      v[q] = (double)__uint_as_float(w[q]);
+  }
+  template <int P> __device__ __forceinline__ void consume(double (&v)[NQ], const I32Fetch &)
+  {
+    const unsigned addr = base + tail * SLOT + lane * 4;
+    tail                = (tail + 1 == R) ? 0 : tail + 1;
+    --ahead;
+    unsigned w[NQ];
+    read32<P>(w, addr);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+      v[q] = __longlong_as_double((long long)(int)w[q]);
+  }
   template <int P> __device__ __forceinline__ void consume(double (&v)[NQ], const PlainFetch &)
   {
     const unsigned addr = base + tail * SLOT + lane * 8;
@@ -368,10 +457,20 @@ template <int NQ, int IPS, int RR = FPHIP_GSO_RING> struct Ring
     --ahead;
     readg<P>(v, a);
   }
-  __device__ __forceinline__ void consume_dyn(double (&v)[NQ], const PlainFetch &) { fetch(v); }
-  __device__ __forceinline__ void consume_dyn(double (&v)[NQ], const GatherFetch &g)
+  // dynamic number of newer rows in flight (the drain of a phase)
+  template <class FetchP> __device__ __forceinline__ void consume_dyn(double (&v)[NQ], const FetchP &fp)
   {
-    fetch_gather(v, g.off);
+    switch (ahead - 1)
+    {
+    case 0: consume<0>(v, fp); break;
+    case 1: consume<1>(v, fp); break;
+    case 2: consume<2>(v, fp); break;
+    case 3: consume<3>(v, fp); break;
+    case 4: consume<4>(v, fp); break;
+    case 5: consume<5>(v, fp); break;
+    case 6: consume<6>(v, fp); break;
+    default: consume<7>(v, fp); break;
+    }
   }
   template <class RowA, class BodyF, class RowB, class FetchP>
   __device__ __forceinline__ void run_with(int cnt, RowA row, BodyF body, int ncnt, RowB nrow,
@@ -445,7 +544,12 @@ __device__ bool update_row(Lattice<NQ> &T, Ring<NQ, IPS, RR> &ring, int kappa, i
     inrow[q]    = c <= last;
   }
   const int need_bytes = (last + 1) * 8;  // lanes j <= last of a row
-  auto gram_row = [&](int c) { return RowDesc{T.bfT + (size_t)c * ldd, 0, need_bytes}; };
+  const bool narrow    = T.np > last;     // rows 0..last are read: wave-uniform
+  auto gram_row        = [&](int c)
+  {
+    return narrow ? RowDesc{T.bfT32 + (size_t)c * ldd, 0, (last + 1) * 4}
+                  : RowDesc{T.bfT + (size_t)c * ldd, 0, need_bytes};
+  };
   auto rec_row  = [&](int k) { return RowDesc{T.muT + (size_t)k * ldd, (k + 1) * 8, need_bytes}; };
   bool ok       = true;
 #pragma unroll
@@ -457,24 +561,22 @@ __device__ bool update_row(Lattice<NQ> &T, Ring<NQ, IPS, RR> &ring, int kappa, i
   ring.reset();
   // ---- Gram row: g(kappa,j) = bf_kappa . bf_j, columns in ascending order (numvect.h:386-396);
   //      the recurrence's first mu columns are prefetched behind it
-  ring.run(
-      n, gram_row,
-      [&](int c, const double(&v)[NQ])
-      {
-        dispatch_chunk<NQ>(c,
-                           [&](auto cq, int cc)
-                           {
-                             const double bkc = g_rl_f64(bk[decltype(cq)::value], cc);
+  auto gram_body = [&](int c, const double(&v)[NQ])
+  {
+    dispatch_chunk<NQ>(c,
+                       [&](auto cq, int cc)
+                       {
+                         const double bkc = g_rl_f64(bk[decltype(cq)::value], cc);
 #pragma unroll
-                             for (int q = 0; q < NQ; ++q)
-                               if (q < qact)
-                               {
-                                 const double p = bkc * v[q];
-                                 acc[q]         = (c == 0) ? p : acc[q] + p;
-                               }
-                           });
-      },
-      last + 1, rec_row);
+                         for (int q = 0; q < NQ; ++q)
+                           if (q < qact)
+                           {
+                             const double p = bkc * v[q];
+                             acc[q]         = (c == 0) ? p : acc[q] + p;
+                           }
+                       });
+  };
+  ring.run_with(n, gram_row, gram_body, last + 1, rec_row, typename Ring<NQ, IPS, RR>::AutoF32Fetch{narrow});
   // ---- recurrence, gso_interface.cpp:143-158, column-oriented
   ring.run(last + 1, rec_row,
            [&](int k, const double(&v)[NQ])
@@ -568,7 +670,7 @@ template <int NQ> __device__ void finish_diag(Lattice<NQ> &T, int kappa)
 
 // Store the integer row held in registers into slot pk and re-float it: MatGSO::update_bf,
 // gso.cpp:24-48 (mantissa/exponent per entry, renormalised to the row maximum).
-template <int NQ>
+template <int NQ, bool MIRRORS = false>
 __device__ __forceinline__ void store_row_and_refloat(Lattice<NQ> &T, int pk, const long long (&bv)[NQ])
 {
   const int n = T.n, lane = T.lane, ldd = T.ldd, ldn = T.ldn;
@@ -600,12 +702,37 @@ __device__ __forceinline__ void store_row_and_refloat(Lattice<NQ> &T, int pk, co
     }
   }
   emax = wave_max_i32(emax);
+  bool wide = false;
 #pragma unroll
   for (int q = 0; q < NQ; ++q)
   {
     const int c = lane + 64 * q;
     if (c < n)
-      T.bfT[(size_t)c * ldd + pk] = T.row_expo_on ? ldexp(cm[q], ce[q] - emax) : cm[q];
+    {
+      const double f              = T.row_expo_on ? ldexp(cm[q], ce[q] - emax) : cm[q];
+      T.bfT[(size_t)c * ldd + pk] = f;
+      if constexpr (MIRRORS)
+      {  // narrow mirrors (exact while |entry| < 2^24)
+        T.bfT32[(size_t)c * ldd + pk] = (float)f;
+        T.b32[(size_t)pk * ldn + c]   = (int)bv[q];
+        wide |= (bv[q] >= (1ll << 24) || bv[q] <= -(1ll << 24));
+      }
+    }
+  }
+  if constexpr (MIRRORS)
+  {  // keep the row's flag and the narrow prefix (identity layout: slot pk = position pk)
+    const bool w = __any(wide);
+    if (lane == 0)
+      T.narrow_flag[pk] = w ? 0 : 1;
+    if (w)
+      T.np = min(T.np, pk);
+    else if (pk == T.np)
+    {
+      int p = pk + 1;
+      while (p < T.d && __builtin_amdgcn_readfirstlane(T.narrow_flag[p]) != 0)
+        ++p;
+      T.np = p;
+    }
   }
   if (lane == 0)
     T.rexp[pk] = T.row_expo_on ? (long long)emax : 0;
@@ -671,7 +798,12 @@ __device__ __forceinline__ int babai_impl(Lattice<NQ> &T, Ring<NQ, IPS, RR> &rin
       const int j = kappa - 1 - s;
       return RowDesc{T.mu + (size_t)map.phys(j) * ldd, 0, j * 8};  // mu(j,k) is needed for k < j
     };
-    auto b_row = [&](int s) { return RowDesc{T.b + (size_t)map.phys(kappa - 1 - s) * ldn, 0, n * 8}; };
+    const bool narrow = T.np >= kappa;  // rows below kappa are read: wave-uniform
+    auto b_row        = [&](int s)
+    {
+      const size_t ro = (size_t)map.phys(kappa - 1 - s) * ldn;
+      return narrow ? RowDesc{T.b32 + ro, 0, n * 4} : RowDesc{T.b + ro, 0, n * 8};
+    };
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
     {
@@ -724,28 +856,28 @@ __device__ __forceinline__ int babai_impl(Lattice<NQ> &T, Ring<NQ, IPS, RR> &rin
         },
         nsteps, b_row);
     // ---- integer AXPY on row kappa (row_add / row_sub / row_addmul_si, gso.cpp:84-158)
-    ring.run(nsteps, b_row,
-             [&](int s, const double(&v)[NQ])
-             {
-               const int j = kappa - 1 - s;
-               dispatch_chunk<NQ>(j,
-                                  [&](auto jq_, int jj)
-                                  {
-                                    const long long lx = g_rl_i64(xl[decltype(jq_)::value], jj);
-                                    if (lx != 0)
-                                    {
+    auto axpy_body = [&](int s, const double(&v)[NQ])
+    {
+      const int j = kappa - 1 - s;
+      dispatch_chunk<NQ>(j,
+                         [&](auto jq_, int jj)
+                         {
+                           const long long lx = g_rl_i64(xl[decltype(jq_)::value], jj);
+                           if (lx != 0)
+                           {
 #pragma unroll
-                                      for (int q = 0; q < NQ; ++q)
-                                        bv[q] = (long long)((unsigned long long)bv[q] +
-                                                            (unsigned long long)__double_as_longlong(v[q]) *
-                                                                (unsigned long long)lx);
-                                    }
-                                  });
-             });
+                             for (int q = 0; q < NQ; ++q)
+                               bv[q] = (long long)((unsigned long long)bv[q] +
+                                                   (unsigned long long)__double_as_longlong(v[q]) *
+                                                       (unsigned long long)lx);
+                           }
+                         });
+    };
+    ring.run_with(nsteps, b_row, axpy_body, 0, b_row, typename Ring<NQ, IPS, RR>::AutoI32Fetch{narrow});
     if (too_big)
       return -2;  // nothing has been stored yet: the basis is unchanged
     // ---- row_op_end: update_bf(kappa), gso.cpp:24-48
-    store_row_and_refloat<NQ>(T, pk, bv);
+    store_row_and_refloat<NQ, Map::kNarrowMirrors>(T, pk, bv);
     after(kappa);
     // later reads of b / bfT / rexp in this wave must see these stores
     __threadfence_block();

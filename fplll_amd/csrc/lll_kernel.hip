@@ -67,6 +67,12 @@ __global__ void __launch_bounds__(256)
     T.r           = P.r + (size_t)L * d * ldd;
     T.rdg         = P.rdg + (size_t)L * d;
     T.rexp        = P.rexp + (size_t)L * d;
+    // no narrow mirrors here (the host re-floats every row afterwards): np = 0 keeps every pass
+    // on the 8-byte rows; the pointers only have to be valid
+    T.bfT32       = (float *)T.bfT;
+    T.b32         = (int *)T.b;
+    T.narrow_flag = (int *)T.rexp;
+    T.np          = 0;
     LllCtx C{P.gf + (size_t)L * d * ldd, P.vc + (size_t)L * d};
     SlotMap<NQ> M;
     lll_init_state<NQ>(T, C, M);
