@@ -167,7 +167,7 @@ class MatGSOBatch:
 # ---------------------------------------------------------------------------------------------
 # (2*FETCH_SIZE + WRITE_SIZE)*1024 / lattices, measured with rocprofv3 --pmc on the shipped kernel
 # (separate passes), 180x180 benchmark input: see profiles/r01_gso_traffic.md
-TRAFFIC_BYTES_PER_LATTICE_180 = 126992659
+TRAFFIC_BYTES_PER_LATTICE_180 = 80463991
 
 
 def sweep_bytes(d, n):
