@@ -7,7 +7,8 @@
 #define FPHIP_MAX_BLOCK 512
 #define FPHIP_RING_CAP 1024u
 #define FPHIP_MAX_LAUNCHES 256
-#define FPHIP_TRI64 2016 /* 64*63/2 mu entries */
+#define FPHIP_TRI64 2016   /* 64*63/2 mu entries: rows below 64 (the wave-per-subtree walk) */
+#define FPHIP_TRI128 8128 /* 128*127/2: rows up to 127 (the top walk of blocks larger than 64) */
 
 #define FPHIP_ERR_RING_TIMEOUT 1u
 #define FPHIP_FLAG_TASK_OVERFLOW 2u
@@ -20,7 +21,7 @@ struct __attribute__((aligned(16))) SolRec
 {
   unsigned long long seq;  // == global index + 1 once the record is complete
   double dist;
-  double x[64];
+  double x[128];  // coefficients of levels 0..127
 };
 
 // Pinned, host-coherent control block (hipHostMallocCoherent).
@@ -35,9 +36,9 @@ struct HostCtl
 // Device-resident per-enumeration state.
 struct DevShared
 {
-  double rdiag[64];
-  double pruning[64];
-  unsigned long long nodes[64];
+  double rdiag[128];
+  double pruning[128];
+  unsigned long long nodes[128];
   unsigned long long sol_head;  // monotonically increasing across calls (ring sequence)
   unsigned long long iters;     // walk-loop iterations (diagnostics)
   unsigned long long bound_bits;  // device mirror of HostCtl::bound_bits (only ever lowered)
@@ -45,7 +46,7 @@ struct DevShared
   unsigned int pad;
   unsigned int task_head[FPHIP_MAX_LAUNCHES];
   unsigned int drain[FPHIP_MAX_LAUNCHES];  // set when a launch's task queue ran dry
-  double mu_tri[FPHIP_TRI64];  // mu_tri[k(k-1)/2 + i] = mu(k,i), i<k
+  double mu_tri[FPHIP_TRI128];  // mu_tri[k(k-1)/2 + i] = mu(k,i), i<k
 };
 
 // Subtree tasks (structure of arrays; col/x rows are 64 doubles so that a wave loads them coalesced).
@@ -55,6 +56,8 @@ struct TaskBuf
   double *x;            // [cap][64]  coefficients of levels >= L
   double *pd;           // [cap]      partial distance of the root node
   int *level;           // [cap]      root level L of the task (it walks levels < L)
+  int *root;            // [cap]      index of the level-64 ancestor (blocks larger than 64): its
+                        //            coefficients of levels 64..127 are kept once, in xhi_root
   unsigned int *count;  // number of tasks written (may exceed cap: overflow handled inline)
   unsigned int cap;
 };

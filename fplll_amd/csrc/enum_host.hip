@@ -27,7 +27,9 @@ template <bool MU_LDS>
 __global__ void enum_phase_kernel(DevShared *g, HostCtl *h, TaskBuf in, TaskBuf out, int d,
                                   int Lmax, int stop, unsigned task_lo, unsigned task_hi,
                                   const unsigned *idxlist, int launch_idx, int count_nodes,
-                                  unsigned budget);
+                                  unsigned budget, const double *xhi_root);
+__global__ void enum_top_kernel(DevShared *g, TaskBuf out, double *xhi_root, int d, double maxdist,
+                                int count_nodes);
 __global__ void task_key_kernel(TaskBuf in, unsigned n, int d, unsigned long long *keys);
 }
 using namespace fphip;
@@ -46,6 +48,8 @@ struct fphip_ctx
   unsigned long long ring_next = 0;
   unsigned long long *keys     = nullptr;  // device: content key per task (multi-GPU partition)
   unsigned *idxlist            = nullptr;  // device: this rank's task indices, heaviest first
+  double *xhi_root             = nullptr;  // device: [cap][64] coefficients of levels 64..127 per
+                                           // level-64 ancestor (blocks larger than 64)
   char err[512]                = {0};
   // GSO state lives in gso_host.hip, linked through this opaque slot
   void *gso = nullptr;
@@ -122,11 +126,14 @@ extern "C" int fphip_create(int device, fphip_ctx **out)
     HIPCHK(ctx, hipMalloc((void **)&ctx->buf[b].x, (size_t)ctx->cap * 64 * sizeof(double)));
     HIPCHK(ctx, hipMalloc((void **)&ctx->buf[b].pd, (size_t)ctx->cap * sizeof(double)));
     HIPCHK(ctx, hipMalloc((void **)&ctx->buf[b].level, (size_t)ctx->cap * sizeof(int)));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->buf[b].root, (size_t)ctx->cap * sizeof(int)));
     HIPCHK(ctx, hipMalloc((void **)&ctx->buf[b].count, 64));
     ctx->buf[b].cap = ctx->cap;
   }
   HIPCHK(ctx, hipMalloc((void **)&ctx->keys, (size_t)ctx->cap * sizeof(unsigned long long)));
   HIPCHK(ctx, hipMalloc((void **)&ctx->idxlist, (size_t)ctx->cap * sizeof(unsigned)));
+  HIPCHK(ctx, hipMalloc((void **)&ctx->xhi_root, (size_t)ctx->cap * 64 * sizeof(double)));
+  HIPCHK(ctx, hipMemset(ctx->xhi_root, 0, 64 * sizeof(double)));
   HIPCHK(ctx, hipFuncSetAttribute((const void *)enum_phase_kernel<true>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(ctx, hipFuncSetAttribute((const void *)enum_phase_kernel<false>,
@@ -153,9 +160,13 @@ extern "C" void fphip_destroy(fphip_ctx *ctx)
       hipFree(ctx->buf[b].pd);
     if (ctx->buf[b].level)
       hipFree(ctx->buf[b].level);
+    if (ctx->buf[b].root)
+      hipFree(ctx->buf[b].root);
     if (ctx->buf[b].count)
       hipFree(ctx->buf[b].count);
   }
+  if (ctx->xhi_root)
+    hipFree(ctx->xhi_root);
   if (ctx->keys)
     hipFree(ctx->keys);
   if (ctx->idxlist)
@@ -207,9 +218,9 @@ static void drain(fphip_ctx *ctx, int dim, fphip_sol_cb cb, void *user, uint64_t
     unsigned long long s = __atomic_load_n(&r->seq, __ATOMIC_ACQUIRE);
     if (s != ctx->ring_next + 1)
       return;
-    double x[64];
+    double x[128];
     double dist = r->dist;
-    memcpy(x, (const void *)r->x, sizeof(double) * 64);
+    memcpy(x, (const void *)r->x, sizeof(double) * 128);
     double nb = cb(user, dist, x);  // extenum_cb_process_sol: returns the new bound
     if (!(nb >= 0.0))
       nb = 0.0;
@@ -355,13 +366,41 @@ extern "C" int fphip_enum_run(fphip_ctx *ctx, int dim, double maxdist, const dou
   HIPCHK(ctx, hipMemsetAsync(ctx->buf[cur].pd, 0, sizeof(double), ctx->stream));
   HIPCHK(ctx, hipMemcpyAsync(ctx->buf[cur].level, &d, sizeof(int), hipMemcpyHostToDevice,
                              ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(ctx->buf[cur].root, 0, sizeof(int), ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(ctx->xhi_root, 0, 64 * sizeof(double), ctx->stream));
+  // Blocks larger than 64: one wave walks levels 64..d-1 and leaves the surviving level-64 nodes
+  // as the initial tasks (enum_top_kernel).  Nothing can have been reported yet, so an overfull
+  // task buffer is still a clean decline.
+  unsigned top_tasks = 0;
+  double top_ms      = 0.0;
+  if (d > 64)
+  {
+    const size_t tlds = (size_t)((d + 1) * d / 2 - 65 * 64 / 2) * sizeof(double);
+    HIPCHK(ctx, hipMemsetAsync(ctx->buf[cur].count, 0, 4, ctx->stream));
+    HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    hipLaunchKernelGGL(enum_top_kernel, dim3(1), dim3(64), tlds, ctx->stream, ctx->g, ctx->buf[cur],
+                       ctx->xhi_root, d, maxdist, 1);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    float tms = 0;
+    HIPCHK(ctx, hipEventElapsedTime(&tms, ctx->ev[0], ctx->ev[1]));
+    top_ms = tms;
+    HIPCHK(ctx, hipMemcpy(&top_tasks, ctx->buf[cur].count, 4, hipMemcpyDeviceToHost));
+    if (top_tasks > ctx->cap)
+    {
+      snprintf(ctx->err, sizeof ctx->err,
+               "more than %u surviving nodes at level 64: the block stays on the CPU enumerator", ctx->cap);
+      return FPHIP_UNSUPPORTED;
+    }
+  }
 
   const int debug     = env_int("FPHIP_DEBUG", 0);
   uint64_t nsol       = 0;
-  double kernel_ms    = 0.0, final_ms = 0.0;
+  double kernel_ms    = top_ms, final_ms = 0.0;
   int launches        = 0, launch_idx = 0;
-  int L               = d;  // highest root level among the current tasks (LDS geometry)
-  unsigned C          = 1;  // number of current tasks
+  int L               = d > 64 ? 64 : d;  // highest root level among the current tasks (LDS geometry)
+  unsigned C          = d > 64 ? top_tasks : 1;  // number of current tasks
   int final_tasks     = 0, final_L = d;
   const int max_split = env_int("FPHIP_MAX_SPLIT_PHASES", 6);
   // Work-donation budget (loop iterations a task may run before it sheds its upper subtrees).
@@ -477,11 +516,11 @@ extern "C" int fphip_enum_run(fphip_ctx *ctx, int dim, double maxdist, const dou
         if (mu_lds)
           hipLaunchKernelGGL(enum_phase_kernel<true>, dim3(grid), dim3(wpb * 64), lds, ctx->stream,
                              ctx->g, ctx->h, ctx->buf[cur], ctx->buf[nxt], d, L, stop, lo, hi, idxl,
-                             launch_idx, count_nodes, bud);
+                             launch_idx, count_nodes, bud, ctx->xhi_root);
         else
           hipLaunchKernelGGL(enum_phase_kernel<false>, dim3(grid), dim3(wpb * 64), lds, ctx->stream,
                              ctx->g, ctx->h, ctx->buf[cur], ctx->buf[nxt], d, L, stop, lo, hi, idxl,
-                             launch_idx, count_nodes, bud);
+                             launch_idx, count_nodes, bud, ctx->xhi_root);
         HIPCHK(ctx, hipGetLastError());
         HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
         ++launch_idx;

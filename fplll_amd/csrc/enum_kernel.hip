@@ -90,7 +90,7 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK)
     enum_phase_kernel(DevShared *__restrict__ g, HostCtl *__restrict__ h, TaskBuf in, TaskBuf out,
                       int d, int Lmax, int stop, unsigned task_lo, unsigned task_hi,
                       const unsigned *__restrict__ idxlist, int launch_idx, int count_nodes,
-                      unsigned budget)
+                      unsigned budget, const double *__restrict__ xhi_root)
 {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x & 63;
@@ -175,6 +175,7 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK)
     const unsigned long long ti =
         idxlist ? (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)idxlist[pos]) : pos;
     const int Lt      = __builtin_amdgcn_readfirstlane(in.level[ti]);  // root level of this task
+    const int rid     = __builtin_amdgcn_readfirstlane(in.root[ti]);   // level-64 ancestor (d > 64)
     const double xpre = in.x[ti * 64 + lane];                          // coefficients of levels >= Lt
     const double col0 = in.col[ti * 64 + lane];  // S_Lt rows (lane < Lt)
     const double pd0  = in.pd[ti];
@@ -208,6 +209,8 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK)
       SolRec *r  = &h->ring[idx % FPHIP_RING_CAP];
       double xf  = (lane < Lt) ? xs : xpre;
       r->x[lane] = (lane < d) ? xf : 0.0;
+      // levels 64..127: the coefficients chosen by the top walk, stored once per level-64 ancestor
+      r->x[64 + lane] = (64 + lane < d) ? xhi_root[(size_t)rid * 64 + lane] : 0.0;
       if (lane == 0)
         r->dist = dist;
       __threadfence_system();
@@ -267,6 +270,7 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK)
             {
               out.pd[oi]    = nd;
               out.level[oi] = k;
+              out.root[oi]  = rid;
             }
             break;  // → next sibling at level k
           }
@@ -381,9 +385,188 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK)
 }
 
 template __global__ void enum_phase_kernel<true>(DevShared *, HostCtl *, TaskBuf, TaskBuf, int, int, int,
-                                                 unsigned, unsigned, const unsigned *, int, int, unsigned);
+                                                 unsigned, unsigned, const unsigned *, int, int, unsigned,
+                                                 const double *);
 template __global__ void enum_phase_kernel<false>(DevShared *, HostCtl *, TaskBuf, TaskBuf, int, int, int,
-                                                  unsigned, unsigned, const unsigned *, int, int, unsigned);
+                                                  unsigned, unsigned, const unsigned *, int, int, unsigned,
+                                                  const double *);
+
+
+// ---------------------------------------------------------------------------------------------
+// Blocks larger than 64 (up to 128): the levels 64..d-1.  One wavefront walks the TOP of the tree
+// depth-first with two registers per lane (rows / levels 0..127) — the same CHILD / STEP walk and
+// the same arithmetic as enum_phase_kernel — and emits every surviving node at level 64 as a task
+// (column of the rows below 64, partial distance) for the wave-per-subtree kernel; the
+// coefficients of levels 64..d-1 are stored once per task in xhi_root.  With pruning the top of
+// the tree is a small fraction of the nodes; it is walked once, before any candidate can be
+// reported, under the initial radius (tasks that a later, smaller radius cuts die at their first
+// test in the next launch: the visited set is the reference's).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double rl2(const double (&v)[2], int idx)
+{
+  return idx < 64 ? rl_f64(v[0], idx) : rl_f64(v[1], idx - 64);
+}
+__device__ __forceinline__ int rl2i(const int (&v)[2], int idx)
+{
+  return idx < 64 ? rl_i32(v[0], idx) : rl_i32(v[1], idx - 64);
+}
+
+__global__ void __launch_bounds__(64)
+    enum_top_kernel(DevShared *__restrict__ g, TaskBuf out, double *__restrict__ xhi_root, int d,
+                    double maxdist, int count_nodes)
+{
+  extern __shared__ __attribute__((aligned(16))) double stk2[];  // slots 65..d (slot k: k doubles)
+  const int lane   = threadIdx.x & 63;
+  const int off65  = tri_off(65);
+  const double *mu = g->mu_tri;
+  double rd[2], bnd[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+  {
+    rd[q]  = g->rdiag[lane + 64 * q];
+    bnd[q] = g->pruning[lane + 64 * q] * maxdist;
+  }
+  double xs[2] = {0.0, 0.0}, cs[2] = {0.0, 0.0}, pds[2] = {0.0, 0.0};
+  int dxs[2] = {0, 0}, ddxs[2] = {0, 0};
+  unsigned long long cnt[2] = {0, 0};
+  double S[2] = {0.0, 0.0};
+  unsigned emitted = 0;
+  bool overflow    = false;
+  int k      = d;
+  double nd  = 0.0;
+  bool done  = false;
+  while (!done)
+  {
+    // ---- CHILD chain
+    for (;;)
+    {
+      k               = __builtin_amdgcn_readfirstlane(k);
+      const int kc    = k - 1;
+      const double c1 = rl2(S, kc);
+      const double x1 = round(c1);
+      const double a1 = x1 - c1;
+      const double n1 = nd + a1 * a1 * rl2(rd, kc);
+      if (!(n1 <= rl2(bnd, kc)))
+      {
+        done = k >= d;
+        break;
+      }
+      if (k == 64)
+      {  // hand the subtree below this node to the wave-per-subtree kernel
+        const unsigned oi = emitted++;
+        if (oi < out.cap)
+        {
+          out.col[(unsigned long long)oi * 64 + lane]  = S[0];
+          out.x[(unsigned long long)oi * 64 + lane]    = 0.0;
+          xhi_root[(unsigned long long)oi * 64 + lane] = xs[1];
+          if (lane == 0)
+          {
+            out.pd[oi]    = nd;
+            out.level[oi] = 64;
+            out.root[oi]  = (int)oi;
+          }
+        }
+        else
+          overflow = true;
+        break;
+      }
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+        if (lane + 64 * q < k)
+          stk2[tri_off(k) - off65 + lane + 64 * q] = S[q];
+      {
+        const int s1 = (c1 >= x1) ? 1 : -1;
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+        {
+          const bool me = lane + 64 * q == kc;
+          cs[q]         = me ? c1 : cs[q];
+          xs[q]         = me ? x1 : xs[q];
+          pds[q]        = me ? nd : pds[q];
+          dxs[q]        = me ? s1 : dxs[q];
+          ddxs[q]       = me ? s1 : ddxs[q];
+          cnt[q] += me ? 1ull : 0ull;
+        }
+      }
+      k  = kc;
+      nd = n1;  // k >= 64 here
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+      {
+        const double mk = mu[tri_off(k) + min(lane + 64 * q, k - 1)];
+        S[q]            = S[q] - x1 * mk;
+      }
+    }
+    if (done)
+      break;
+    // ---- STEP loop
+    for (;;)
+    {
+      k = __builtin_amdgcn_readfirstlane(k);
+      double par[2], mk[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+      {
+        par[q] = stk2[tri_off(k + 1) - off65 + min(lane + 64 * q, k)];
+        mk[q]  = mu[tri_off(k) + min(lane + 64 * q, k - 1)];
+      }
+      double xk        = rl2(xs, k);
+      const double ck  = rl2(cs, k);
+      const double pdk = rl2(pds, k);
+      int dxk = rl2i(dxs, k), ddxk = rl2i(ddxs, k);
+      if (pdk != 0.0)
+      {
+        xk += (double)dxk;
+        ddxk = -ddxk;
+        dxk  = ddxk - dxk;
+      }
+      else
+      {
+        xk += 1.0;
+      }
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+      {
+        const bool me = lane + 64 * q == k;
+        xs[q]         = me ? xk : xs[q];
+        dxs[q]        = me ? dxk : dxs[q];
+        ddxs[q]       = me ? ddxk : ddxs[q];
+      }
+      const double a = xk - ck;
+      nd             = pdk + a * a * rl2(rd, k);
+      if (!(nd <= rl2(bnd, k)))
+      {
+        ++k;
+        if (k >= d)
+        {
+          done = true;
+          break;
+        }
+        continue;
+      }
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+        cnt[q] += (lane + 64 * q == k) ? 1ull : 0ull;
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+        S[q] = par[q] - xk * mk[q];
+      break;
+    }
+  }
+  if (count_nodes)
+  {
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      if (cnt[q] != 0)
+        atomicAdd(&g->nodes[lane + 64 * q], cnt[q]);
+  }
+  if (lane == 0)
+  {
+    *out.count = emitted;
+    if (overflow)
+      atomicOr(&g->error_flags, FPHIP_FLAG_TASK_OVERFLOW);
+  }
+}
 
 // 64-bit content key of every task (its coefficient prefix x[Lt..d)): the task ORDER in the buffer
 // is not deterministic across ranks, the content is.  One wave per task.
@@ -405,6 +588,11 @@ __global__ void __launch_bounds__(256)
       h1 += (unsigned)__shfl_xor((int)h1, off);
       h2 += (unsigned)__shfl_xor((int)h2, off);
     }
+    // blocks larger than 64: the coefficients of levels >= 64 are identified by the level-64
+    // ancestor's index (the top walk is sequential: the same index on every rank)
+    const unsigned rid = (unsigned)in.root[ti];
+    h1 += rid * 2246822519u;
+    h2 ^= rid * 3266489917u;
     if (lane == 0)
       keys[ti] = ((unsigned long long)h1 << 32) | h2;
   }

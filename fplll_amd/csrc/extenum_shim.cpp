@@ -11,7 +11,7 @@
 // Protocol implemented (enumerate_ext.cpp:48-167): call cbfunc once with mutranspose=true to
 // receive mu^T / rdiag / pruning; report candidates through cbsol, which returns the new bound;
 // return per-level node counts, or [0] = ~0 to decline so fplll falls back to its own enumerator
-// (dual, sub-solutions, dim > 64, or any device error).
+// (dual, sub-solutions, dim > 128, or any device error).
 
 #include <array>
 #include <cstdint>

@@ -41,9 +41,10 @@ extern "C" {
 #define FPHIP_UNSUPPORTED 1
 #define FPHIP_ERROR (-1)
 
-/* largest enumeration dimension handled on the device (levels are lane-indexed in one wave64);
- * larger blocks are declined (FPHIP_UNSUPPORTED → fplll's own enumerator) */
-#define FPHIP_ENUM_MAX_DIM 64
+/* largest enumeration dimension handled on the device (levels are lane-indexed: 64 per wavefront;
+ * blocks of 65..128 levels are walked in two stages); larger blocks are declined
+ * (FPHIP_UNSUPPORTED → fplll's own enumerator) */
+#define FPHIP_ENUM_MAX_DIM 128
 
 typedef struct fphip_ctx fphip_ctx;
 

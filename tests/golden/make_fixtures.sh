@@ -21,6 +21,11 @@ $D enumfix 100 50 14  2  20   0   40 linear:20  100000000 0 0.99 > $G/enum_d40_l
 $D enumfix 100 50 14  2  20   0   40 linear:20  1         0 0.99 > $G/enum_d40_lin20_best1.json
 $D enumfix 120 60 16  5  20  10   48 linear:30  100000000 0 0.99 > $G/enum_d48_lin30_fixed.json
 $D enumfix 120 60 16  5  20  10   48 linear:30  1         0 0.99 > $G/enum_d48_lin30_best1.json
+# blocks larger than 64 (two-stage walk on the device); REFDRV_RADIUS_SCALE shrinks the radius
+REFDRV_RADIUS_SCALE=0.50 $D enumfix 100 50 14 5 20 0 72 linear:60 100000000 0 0.99 > $G/enum_d72_lin60_fixed.json
+REFDRV_RADIUS_SCALE=0.45 $D enumfix 100 50 14 5 20 0 80 linear:70 100000000 0 0.99 > $G/enum_d80_lin70_fixed.json
+REFDRV_RADIUS_SCALE=0.45 $D enumfix 100 50 14 5 20 0 80 linear:70 1         0 0.99 > $G/enum_d80_lin70_best1.json
+REFDRV_RADIUS_SCALE=0.36 $D enumfix 110 55 14 6 20 0 96 linear:90 100000000 0 0.99 > $G/enum_d96_lin90_fixed.json
 
 # --- GSO / size-reduction (MatGSO<long,double>, GSO_ROW_EXPO): n k bits seed perturb
 $D gsofix 30 15 10 1 0 > $G/gso_q30_p0.json

@@ -159,7 +159,7 @@ def test_edge_cases(ctx):
     res = enumerate_block(ctx, mut, np.array([1.0, 1.0]), None, 0.5, FastEvaluator(1, 0))
     assert [int(v) for v in res.nodes] == [1, 0, 0]
     # declined instances (fplll falls back to its own enumerator)
-    for d in (1, 65, 100):
+    for d in (1, 129, 200):
         with pytest.raises(Unsupported):
             enumerate_block(ctx, np.zeros((d, d)), np.ones(d), None, 1.0, FastEvaluator(1, 0))
     with pytest.raises(Unsupported):
@@ -178,6 +178,32 @@ def test_edge_cases(ctx):
     nodes_o, _ = C.oracle_enumerate(mut, rdiag, None, 4.0, ev_o)
     assert [int(v) for v in res.nodes] == [int(v) for v in nodes_o]
     assert len(ev.solutions) == len(ev_o.solutions)
+
+
+@pytest.mark.parametrize("d,seed,rf", [(65, 21, 0.5), (70, 22, 0.46), (100, 23, 0.22), (128, 24, 0.08)])
+def test_blocks_larger_than_64_vs_oracle(ctx, d, seed, rf):
+    """Two-stage walk (levels >= 64 by one wave, then the wave-per-subtree kernel): per-level counts
+    and the reported candidates are the oracle's, on seeded blocks at the chunk boundary (65), in
+    between and at the maximum (128, where this tree dies above level 64: no task at all).  The
+    radii are far below the Gaussian heuristic so that the oracle finishes in seconds; candidates of
+    large blocks are covered by the reference fixtures enum_d72/d80/d96."""
+    from fplll_amd.enumeration import FastEvaluator, enumerate_block
+    mut, rdiag, maxdist = C.synthetic_block(d, seed, 0.03, rf)
+    pruning = np.clip(np.linspace(1.0, 0.25, d)[::-1].copy(), 0.0, 1.0)[::-1].copy()
+    ev = FastEvaluator(10**9, 0)
+    res = enumerate_block(ctx, mut, rdiag, pruning, maxdist, ev)
+    ev_o = FastEvaluator(10**9, 0)
+    nodes_o, _ = C.oracle_enumerate(mut, rdiag, pruning, maxdist, ev_o)
+    assert [int(v) for v in res.nodes] == [int(v) for v in nodes_o]
+    assert sum(int(v) for v in nodes_o[64:]) > 0
+    so = sorted((s[0], tuple(s[1])) for s in ev_o.solutions)
+    sg = sorted((s[0], tuple(s[1])) for s in ev.solutions)
+    assert sg == so
+    # shrinking radius: same final norm
+    ev1, ev1o = FastEvaluator(1, 0), FastEvaluator(1, 0)
+    enumerate_block(ctx, mut, rdiag, pruning, maxdist, ev1)
+    C.oracle_enumerate(mut, rdiag, pruning, maxdist, ev1o)
+    assert [s[0] for s in ev1.solutions] == [s[0] for s in ev1o.solutions]
 
 
 def test_phase_parameters_do_not_change_results(ctx):
