@@ -22,6 +22,8 @@ struct __attribute__((aligned(16))) SolRec
   unsigned long long seq;  // == global index + 1 once the record is complete
   double dist;
   double x[128];  // coefficients of levels 0..127
+  int kind;       // 0 = candidate solution (process_solution), 1 = sub-solution (process_subsolution)
+  int offset;     // sub-solution: its level (the coefficients below it are zero)
 };
 
 // Pinned, host-coherent control block (hipHostMallocCoherent).
@@ -39,6 +41,8 @@ struct DevShared
   double rdiag[128];
   double pruning[128];
   unsigned long long nodes[128];
+  unsigned long long sub_bits[128];  // findsubsols: best sub-solution distance per level (bit
+                                     // pattern of a positive double; starts at rdiag, only lowered)
   unsigned long long sol_head;  // monotonically increasing across calls (ring sequence)
   unsigned long long iters;     // walk-loop iterations (diagnostics)
   unsigned long long bound_bits;  // device mirror of HostCtl::bound_bits (only ever lowered)

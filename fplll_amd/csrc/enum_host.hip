@@ -23,13 +23,14 @@
 
 namespace fphip
 {
-template <bool MU_LDS>
+template <bool MU_LDS, bool SUBS>
 __global__ void enum_phase_kernel(DevShared *g, HostCtl *h, TaskBuf in, TaskBuf out, int d,
                                   int Lmax, int stop, unsigned task_lo, unsigned task_hi,
                                   const unsigned *idxlist, int launch_idx, int count_nodes,
                                   unsigned budget, const double *xhi_root);
-__global__ void enum_top_kernel(DevShared *g, TaskBuf out, double *xhi_root, int d, double maxdist,
-                                int count_nodes);
+template <bool SUBS>
+__global__ void enum_top_kernel(DevShared *g, HostCtl *h, TaskBuf out, double *xhi_root, int d,
+                                double maxdist, int count_nodes);
 __global__ void task_key_kernel(TaskBuf in, unsigned n, int d, unsigned long long *keys);
 }
 using namespace fphip;
@@ -134,9 +135,13 @@ extern "C" int fphip_create(int device, fphip_ctx **out)
   HIPCHK(ctx, hipMalloc((void **)&ctx->idxlist, (size_t)ctx->cap * sizeof(unsigned)));
   HIPCHK(ctx, hipMalloc((void **)&ctx->xhi_root, (size_t)ctx->cap * 64 * sizeof(double)));
   HIPCHK(ctx, hipMemset(ctx->xhi_root, 0, 64 * sizeof(double)));
-  HIPCHK(ctx, hipFuncSetAttribute((const void *)enum_phase_kernel<true>,
+  HIPCHK(ctx, hipFuncSetAttribute((const void *)enum_phase_kernel<true, false>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  HIPCHK(ctx, hipFuncSetAttribute((const void *)enum_phase_kernel<false>,
+  HIPCHK(ctx, hipFuncSetAttribute((const void *)enum_phase_kernel<false, false>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(ctx, hipFuncSetAttribute((const void *)enum_phase_kernel<true, true>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(ctx, hipFuncSetAttribute((const void *)enum_phase_kernel<false, true>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   return FPHIP_OK;
 }
@@ -210,7 +215,8 @@ static inline double bdbl(unsigned long long b)
   return v;
 }
 
-static void drain(fphip_ctx *ctx, int dim, fphip_sol_cb cb, void *user, uint64_t *nsol)
+static void drain(fphip_ctx *ctx, int dim, fphip_sol_cb cb, fphip_subsol_cb subcb, void *user,
+                  uint64_t *nsol)
 {
   for (;;)
   {
@@ -221,6 +227,14 @@ static void drain(fphip_ctx *ctx, int dim, fphip_sol_cb cb, void *user, uint64_t
     double x[128];
     double dist = r->dist;
     memcpy(x, (const void *)r->x, sizeof(double) * 128);
+    if (r->kind == 1)
+    {  // extenum_cb_process_subsol (enumerate_ext_api.h:70-71): no effect on the radius
+      if (subcb)
+        subcb(user, dist, x, r->offset);
+      ctx->ring_next++;
+      __atomic_store_n(&ctx->h->consumed, ctx->ring_next, __ATOMIC_RELEASE);
+      continue;
+    }
     double nb = cb(user, dist, x);  // extenum_cb_process_sol: returns the new bound
     if (!(nb >= 0.0))
       nb = 0.0;
@@ -233,15 +247,16 @@ static void drain(fphip_ctx *ctx, int dim, fphip_sol_cb cb, void *user, uint64_t
 }
 
 // wait for the stream while serving the ring
-static int wait_serving(fphip_ctx *ctx, int dim, fphip_sol_cb cb, void *user, uint64_t *nsol)
+static int wait_serving(fphip_ctx *ctx, int dim, fphip_sol_cb cb, fphip_subsol_cb subcb, void *user,
+                        uint64_t *nsol)
 {
   for (;;)
   {
-    drain(ctx, dim, cb, user, nsol);
+    drain(ctx, dim, cb, subcb, user, nsol);
     hipError_t q = hipStreamQuery(ctx->stream);
     if (q == hipSuccess)
     {
-      drain(ctx, dim, cb, user, nsol);
+      drain(ctx, dim, cb, subcb, user, nsol);
       return FPHIP_OK;
     }
     if (q != hipErrorNotReady)
@@ -296,7 +311,6 @@ extern "C" int fphip_enum_run(fphip_ctx *ctx, int dim, double maxdist, const dou
                               fphip_subsol_cb subcb, void *user, uint64_t *nodes_out,
                               fphip_enum_stats *stats)
 {
-  (void)subcb;
   if (!ctx)
     return FPHIP_ERROR;
   if (!ctx->g)
@@ -316,8 +330,9 @@ extern "C" int fphip_enum_run(fphip_ctx *ctx, int dim, double maxdist, const dou
   if (o.exchange_chunks <= 0)
     o.exchange_chunks = 1;
   const int d = dim;
-  if (d < 2 || d > FPHIP_ENUM_MAX_DIM || o.dual || o.findsubsols)
+  if (d < 2 || d > FPHIP_ENUM_MAX_DIM || o.dual || (o.findsubsols && !subcb))
     return FPHIP_UNSUPPORTED;  // → ~uint64_t(0): fplll falls back (enumerate_ext.cpp:88)
+  const bool subs = o.findsubsols != 0;
   if (!(maxdist >= 0.0))
     return FPHIP_UNSUPPORTED;
   for (int i = 0; i < d; ++i)
@@ -350,6 +365,7 @@ extern "C" int fphip_enum_run(fphip_ctx *ctx, int dim, double maxdist, const dou
   {
     st->rdiag[i]   = rdiag[i];
     st->pruning[i] = pruning ? pruning[i] : 1.0;
+    st->sub_bits[i] = dbits(rdiag[i]);  // subsoldists = rdiag, enumerate.cpp:143
   }
   for (int k = 1; k < d; ++k)
     for (int i = 0; i < k; ++i)
@@ -378,11 +394,20 @@ extern "C" int fphip_enum_run(fphip_ctx *ctx, int dim, double maxdist, const dou
     const size_t tlds = (size_t)((d + 1) * d / 2 - 65 * 64 / 2) * sizeof(double);
     HIPCHK(ctx, hipMemsetAsync(ctx->buf[cur].count, 0, 4, ctx->stream));
     HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-    hipLaunchKernelGGL(enum_top_kernel, dim3(1), dim3(64), tlds, ctx->stream, ctx->g, ctx->buf[cur],
-                       ctx->xhi_root, d, maxdist, 1);
+    if (subs)
+      hipLaunchKernelGGL(enum_top_kernel<true>, dim3(1), dim3(64), tlds, ctx->stream, ctx->g, ctx->h,
+                         ctx->buf[cur], ctx->xhi_root, d, maxdist, 1);
+    else
+      hipLaunchKernelGGL(enum_top_kernel<false>, dim3(1), dim3(64), tlds, ctx->stream, ctx->g, ctx->h,
+                         ctx->buf[cur], ctx->xhi_root, d, maxdist, 1);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    {  // sub-solutions of the top levels arrive through the ring while the walk runs
+      uint64_t nsub = 0;
+      int rcw       = wait_serving(ctx, d, cb, subcb, user, &nsub);
+      if (rcw != FPHIP_OK)
+        return rcw;
+    }
     float tms = 0;
     HIPCHK(ctx, hipEventElapsedTime(&tms, ctx->ev[0], ctx->ev[1]));
     top_ms = tms;
@@ -513,18 +538,23 @@ extern "C" int fphip_enum_run(fphip_ctx *ctx, int dim, double maxdist, const dou
       {
         HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
         const unsigned bud = (in_final && round < max_rounds) ? budget : 0u;
-        if (mu_lds)
-          hipLaunchKernelGGL(enum_phase_kernel<true>, dim3(grid), dim3(wpb * 64), lds, ctx->stream,
-                             ctx->g, ctx->h, ctx->buf[cur], ctx->buf[nxt], d, L, stop, lo, hi, idxl,
-                             launch_idx, count_nodes, bud, ctx->xhi_root);
+#define FPHIP_LAUNCH(M, S)                                                                          \
+  hipLaunchKernelGGL((enum_phase_kernel<M, S>), dim3(grid), dim3(wpb * 64), lds, ctx->stream, ctx->g, \
+                     ctx->h, ctx->buf[cur], ctx->buf[nxt], d, L, stop, lo, hi, idxl, launch_idx,     \
+                     count_nodes, bud, ctx->xhi_root)
+        if (mu_lds && !subs)
+          FPHIP_LAUNCH(true, false);
+        else if (!mu_lds && !subs)
+          FPHIP_LAUNCH(false, false);
+        else if (mu_lds)
+          FPHIP_LAUNCH(true, true);
         else
-          hipLaunchKernelGGL(enum_phase_kernel<false>, dim3(grid), dim3(wpb * 64), lds, ctx->stream,
-                             ctx->g, ctx->h, ctx->buf[cur], ctx->buf[nxt], d, L, stop, lo, hi, idxl,
-                             launch_idx, count_nodes, bud, ctx->xhi_root);
+          FPHIP_LAUNCH(false, true);
+#undef FPHIP_LAUNCH
         HIPCHK(ctx, hipGetLastError());
         HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
         ++launch_idx;
-        int rc = wait_serving(ctx, d, cb, user, &nsol);
+        int rc = wait_serving(ctx, d, cb, subcb, user, &nsol);
         if (rc != FPHIP_OK)
           return rc;
         float ms = 0.f;

@@ -85,7 +85,7 @@ __device__ __forceinline__ unsigned long long load_sys_u64(const unsigned long l
 //       loop in CHILD with the child as the current node.
 //   STEP(k): the subtree below the current coefficient x[k] is exhausted — advance x[k] in
 //       zig-zag order (:80-89), test (:91-94): fail → STEP(k+1), survive → CHILD.
-template <bool MU_LDS>
+template <bool MU_LDS, bool SUBS>
 __global__ void __launch_bounds__(FPHIP_MAX_BLOCK)
     enum_phase_kernel(DevShared *__restrict__ g, HostCtl *__restrict__ h, TaskBuf in, TaskBuf out,
                       int d, int Lmax, int stop, unsigned task_lo, unsigned task_hi,
@@ -132,6 +132,9 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK)
   int dxs = 0, ddxs = 0;
   unsigned long long cnt = 0;
   unsigned iter          = 0;
+  // findsubsols (enumerate_base.cpp:36-40): lane = level, this wave's view of the best sub-solution
+  // distance per level (subsoldists); the device-wide value in g->sub_bits is authoritative
+  double sb = SUBS ? __longlong_as_double((long long)g->sub_bits[lane]) : 0.0;
 
 #define FPHIP_REFRESH_BOUND(from_host)                                                            \
   do                                                                                              \
@@ -212,7 +215,11 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK)
       // levels 64..127: the coefficients chosen by the top walk, stored once per level-64 ancestor
       r->x[64 + lane] = (64 + lane < d) ? xhi_root[(size_t)rid * 64 + lane] : 0.0;
       if (lane == 0)
-        r->dist = dist;
+      {
+        r->dist   = dist;
+        r->kind   = 0;
+        r->offset = 0;
+      }
       __threadfence_system();
       if (lane == 0)
         __hip_atomic_store(&r->seq, idx + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -227,6 +234,48 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK)
         }
       }
       FPHIP_REFRESH_BOUND(true);
+    };
+
+    // process_subsolution (enumerate.cpp:241-249): a node at level lvl is shorter than every
+    // sub-solution seen at that level.  Only the wave that lowers the device-wide best reports;
+    // no verdict to wait for (sub-solutions never change the radius), only ring space.
+    auto sub_report = [&](int lvl, double dist)
+    {
+      unsigned long long old = 0;
+      if (lane == 0)
+        old = atomicMin(&g->sub_bits[lvl], (unsigned long long)__double_as_longlong(dist));
+      old               = rfl_u64(old);
+      const double oldd = __longlong_as_double((long long)old);
+      sb                = (lane == lvl) ? fmin(oldd, dist) : sb;
+      if (!(dist < oldd))
+        return;
+      unsigned long long idx = 0;
+      if (lane == 0)
+        idx = atomicAdd(&g->sol_head, 1ull);
+      idx = rfl_u64(idx);
+      for (unsigned spin = 0; idx >= load_sys_u64(&h->consumed) + FPHIP_RING_CAP; ++spin)
+      {
+        __builtin_amdgcn_s_sleep(64);
+        if (spin > (1u << 24))
+        {
+          if (lane == 0)
+            atomicOr(&g->error_flags, FPHIP_ERR_RING_TIMEOUT);
+          break;
+        }
+      }
+      SolRec *r       = &h->ring[idx % FPHIP_RING_CAP];
+      const double xf = (lane < Lt) ? xs : xpre;
+      r->x[lane]      = (lane < d && lane >= lvl) ? xf : 0.0;
+      r->x[64 + lane] = (64 + lane < d) ? xhi_root[(size_t)rid * 64 + lane] : 0.0;
+      if (lane == 0)
+      {
+        r->dist   = dist;
+        r->kind   = 1;
+        r->offset = lvl;
+      }
+      __threadfence_system();
+      if (lane == 0)
+        __hip_atomic_store(&r->seq, idx + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     };
 
     bool done = false;
@@ -290,6 +339,11 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK)
           dxs           = me ? s1 : dxs;
           ddxs          = me ? s1 : ddxs;
           cnt += me ? 1ull : 0ull;  // ++nodes[kk-1]
+        }
+        if constexpr (SUBS)
+        {
+          if (n1 < rl_f64(sb, kc) && n1 != 0.0)
+            sub_report(kc, n1);
         }
         k  = kc;
         nd = n1;
@@ -361,6 +415,11 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK)
           continue;
         }
         cnt += me ? 1ull : 0ull;  // ++nodes[kk]
+        if constexpr (SUBS)
+        {
+          if (nd < rl_f64(sb, k) && nd != 0.0)
+            sub_report(k, nd);
+        }
         if (k == 0)
         {
           if (nd > 0.0)
@@ -384,13 +443,15 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK)
     atomicAdd(&g->iters, (unsigned long long)iter);
 }
 
-template __global__ void enum_phase_kernel<true>(DevShared *, HostCtl *, TaskBuf, TaskBuf, int, int, int,
-                                                 unsigned, unsigned, const unsigned *, int, int, unsigned,
-                                                 const double *);
-template __global__ void enum_phase_kernel<false>(DevShared *, HostCtl *, TaskBuf, TaskBuf, int, int, int,
-                                                  unsigned, unsigned, const unsigned *, int, int, unsigned,
-                                                  const double *);
-
+#define FPHIP_INST(M, S)                                                                            \
+  template __global__ void enum_phase_kernel<M, S>(DevShared *, HostCtl *, TaskBuf, TaskBuf, int,  \
+                                                   int, int, unsigned, unsigned, const unsigned *,  \
+                                                   int, int, unsigned, const double *);
+FPHIP_INST(true, false)
+FPHIP_INST(false, false)
+FPHIP_INST(true, true)
+FPHIP_INST(false, true)
+#undef FPHIP_INST
 
 // ---------------------------------------------------------------------------------------------
 // Blocks larger than 64 (up to 128): the levels 64..d-1.  One wavefront walks the TOP of the tree
@@ -411,9 +472,10 @@ __device__ __forceinline__ int rl2i(const int (&v)[2], int idx)
   return idx < 64 ? rl_i32(v[0], idx) : rl_i32(v[1], idx - 64);
 }
 
+template <bool SUBS>
 __global__ void __launch_bounds__(64)
-    enum_top_kernel(DevShared *__restrict__ g, TaskBuf out, double *__restrict__ xhi_root, int d,
-                    double maxdist, int count_nodes)
+    enum_top_kernel(DevShared *__restrict__ g, HostCtl *__restrict__ h, TaskBuf out,
+                    double *__restrict__ xhi_root, int d, double maxdist, int count_nodes)
 {
   extern __shared__ __attribute__((aligned(16))) double stk2[];  // slots 65..d (slot k: k doubles)
   const int lane   = threadIdx.x & 63;
@@ -430,6 +492,47 @@ __global__ void __launch_bounds__(64)
   int dxs[2] = {0, 0}, ddxs[2] = {0, 0};
   unsigned long long cnt[2] = {0, 0};
   double S[2] = {0.0, 0.0};
+  double sb[2] = {0.0, 0.0};  // findsubsols: best sub-solution distance per level (lane = level)
+  if constexpr (SUBS)
+  {
+    sb[0] = __longlong_as_double((long long)g->sub_bits[lane]);
+    sb[1] = __longlong_as_double((long long)g->sub_bits[64 + lane]);
+  }
+  // process_subsolution for a node at level lvl >= 64 (single wave: no competition yet)
+  auto sub_report = [&](int lvl, double dist)
+  {
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      sb[q] = (lane + 64 * q == lvl) ? dist : sb[q];
+    if (lane == 0)
+      g->sub_bits[lvl] = (unsigned long long)__double_as_longlong(dist);
+    unsigned long long idx = 0;
+    if (lane == 0)
+      idx = atomicAdd(&g->sol_head, 1ull);
+    idx = rfl_u64(idx);
+    for (unsigned spin = 0; idx >= load_sys_u64(&h->consumed) + FPHIP_RING_CAP; ++spin)
+    {
+      __builtin_amdgcn_s_sleep(64);
+      if (spin > (1u << 24))
+      {
+        if (lane == 0)
+          atomicOr(&g->error_flags, FPHIP_ERR_RING_TIMEOUT);
+        break;
+      }
+    }
+    SolRec *r       = &h->ring[idx % FPHIP_RING_CAP];
+    r->x[lane]      = 0.0;
+    r->x[64 + lane] = (64 + lane < d && 64 + lane >= lvl) ? xs[1] : 0.0;
+    if (lane == 0)
+    {
+      r->dist   = dist;
+      r->kind   = 1;
+      r->offset = lvl;
+    }
+    __threadfence_system();
+    if (lane == 0)
+      __hip_atomic_store(&r->seq, idx + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  };
   unsigned emitted = 0;
   bool overflow    = false;
   int k      = d;
@@ -487,6 +590,11 @@ __global__ void __launch_bounds__(64)
           ddxs[q]       = me ? s1 : ddxs[q];
           cnt[q] += me ? 1ull : 0ull;
         }
+      }
+      if constexpr (SUBS)
+      {
+        if (n1 < rl2(sb, kc) && n1 != 0.0)
+          sub_report(kc, n1);
       }
       k  = kc;
       nd = n1;  // k >= 64 here
@@ -547,6 +655,11 @@ __global__ void __launch_bounds__(64)
 #pragma unroll
       for (int q = 0; q < 2; ++q)
         cnt[q] += (lane + 64 * q == k) ? 1ull : 0ull;
+      if constexpr (SUBS)
+      {
+        if (nd < rl2(sb, k) && nd != 0.0)
+          sub_report(k, nd);
+      }
 #pragma unroll
       for (int q = 0; q < 2; ++q)
         S[q] = par[q] - xk * mk[q];
@@ -567,6 +680,8 @@ __global__ void __launch_bounds__(64)
       atomicOr(&g->error_flags, FPHIP_FLAG_TASK_OVERFLOW);
   }
 }
+template __global__ void enum_top_kernel<false>(DevShared *, HostCtl *, TaskBuf, double *, int, double, int);
+template __global__ void enum_top_kernel<true>(DevShared *, HostCtl *, TaskBuf, double *, int, double, int);
 
 // 64-bit content key of every task (its coefficient prefix x[Lt..d)): the task ORDER in the buffer
 // is not deterministic across ranks, the content is.  One wave per task.

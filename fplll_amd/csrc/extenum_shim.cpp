@@ -11,7 +11,7 @@
 // Protocol implemented (enumerate_ext.cpp:48-167): call cbfunc once with mutranspose=true to
 // receive mu^T / rdiag / pruning; report candidates through cbsol, which returns the new bound;
 // return per-level node counts, or [0] = ~0 to decline so fplll falls back to its own enumerator
-// (dual, sub-solutions, dim > 128, or any device error).
+// (dual, dim > 128, or any device error).
 
 #include <array>
 #include <cstdint>
@@ -38,8 +38,24 @@ std::mutex g_mutex;  // fplll's global hook is process-wide and unsynchronised (
 struct Trampoline
 {
   std::function<cb_process_sol_t> *cbsol;
+  std::function<cb_process_subsol_t> *cbsubsol;
   int dim;
 };
+
+void subsol_trampoline(void *user, double dist, const double *subsol, int offset)
+{
+  Trampoline *t = static_cast<Trampoline *>(user);
+  double buf[FPHIP_ENUM_MAX_DIM];
+  for (int i = 0; i < t->dim; ++i)
+    buf[i] = subsol[i];
+  try
+  {
+    (*t->cbsubsol)(dist, buf, offset);
+  }
+  catch (...)
+  {
+  }
+}
 
 double sol_trampoline(void *user, double dist, const double *sol)
 {
@@ -77,10 +93,9 @@ nodes_array_t fplll_hip_extenum(const int dim, enumf maxdist, std::function<cb_s
                                 std::function<cb_process_subsol_t> cbsubsol, bool dual,
                                 bool findsubsols)
 {
-  (void)cbsubsol;
   nodes_array_t out{};
   out[0] = ~std::uint64_t(0);
-  if (dim < 2 || dim > FPHIP_ENUM_MAX_DIM || dual || findsubsols)
+  if (dim < 2 || dim > FPHIP_ENUM_MAX_DIM || dual)
     return out;
   std::lock_guard<std::mutex> lock(g_mutex);
   fphip_ctx *ctx = context();
@@ -93,11 +108,13 @@ nodes_array_t fplll_hip_extenum(const int dim, enumf maxdist, std::function<cb_s
   fphip_enum_opts opts{};
   const char *mn         = getenv("FPLLL_HIP_MIN_NODES");
   opts.min_nodes_decline = mn ? atoi(mn) : 0;
-  Trampoline tr{&cbsol, dim};
+  opts.findsubsols       = findsubsols ? 1 : 0;
+  Trampoline tr{&cbsol, &cbsubsol, dim};
   std::vector<std::uint64_t> nodes(dim + 1, 0);
   fphip_enum_stats stats{};
   int rc = fphip_enum_run(ctx, dim, maxdist, mu.data(), rdiag.data(), pruning.data(), &opts,
-                          sol_trampoline, nullptr, &tr, nodes.data(), &stats);
+                          sol_trampoline, findsubsols ? subsol_trampoline : nullptr, &tr,
+                          nodes.data(), &stats);
   if (rc == FPHIP_UNSUPPORTED)
     return out;
   if (rc != FPHIP_OK)

@@ -39,6 +39,7 @@ class FastEvaluator:
         self.strategy = strategy
         self.solutions = []  # list of (dist, tuple(coords)), ascending dist
         self.sol_count = 0
+        self.sub_solutions = {}  # offset -> (dist, tuple(coords)): best per offset (findsubsols)
 
     def empty(self):
         return not self.solutions
@@ -64,6 +65,14 @@ class FastEvaluator:
         if len(self.solutions) < self.max_sols:
             return max_dist
         return 0.0
+
+
+    def eval_sub_sol(self, offset, coord, dist):
+        """FastEvaluator::eval_sub_sol (evaluator.h:185-205): keep the shortest per offset (a later
+        candidate must be STRICTLY shorter)."""
+        cur = self.sub_solutions.get(offset)
+        if cur is None or dist < cur[0]:
+            self.sub_solutions[offset] = (dist, tuple(coord))
 
 
 class EnumResult:
@@ -125,7 +134,14 @@ def enumerate_block(ctx, mut, rdiag, pruning, maxdist, evaluator, shard_index=0,
             any_active[0] = 0
             return 0.0
 
+    def _scb(_user, dist, sub, offset):
+        try:
+            evaluator.eval_sub_sol(offset, [0.0] * offset + [sub[i] for i in range(offset, d)], dist)
+        except BaseException as e:
+            state["exc"] = e
+
     cb = _lib.SOL_CB(_cb)
+    scb = _lib.SUBSOL_CB(_scb) if findsubsols else _lib.SUBSOL_CB()
     opts = _lib.EnumOpts()
     opts.dual = int(bool(dual))
     opts.findsubsols = int(bool(findsubsols))
@@ -142,7 +158,7 @@ def enumerate_block(ctx, mut, rdiag, pruning, maxdist, evaluator, shard_index=0,
     rc = lib.fphip_enum_run(ctx.handle, d, ctypes.c_double(maxdist),
                             mut.ctypes.data_as(ctypes.c_void_p),
                             rdiag.ctypes.data_as(ctypes.c_void_p), pr_ptr, ctypes.byref(opts), cb,
-                            _lib.SUBSOL_CB(), None, nodes.ctypes.data_as(ctypes.c_void_p),
+                            scb, None, nodes.ctypes.data_as(ctypes.c_void_p),
                             ctypes.byref(stats))
     if state["exc"] is not None:
         raise state["exc"]

@@ -66,7 +66,10 @@ recording_enumerator(const int dim, double maxdist, std::function<extenum_cb_set
 struct LoggingEvaluator : public FastEvaluator<FT>
 {
   vector<std::pair<double, vector<double>>> log;
-  LoggingEvaluator(size_t n, EvaluatorStrategy s) : FastEvaluator<FT>(n, s, false) {}
+  LoggingEvaluator(size_t n, EvaluatorStrategy s, bool subsols = false)
+      : FastEvaluator<FT>(n, s, subsols)
+  {
+  }
   void eval_sol(const vector<FT> &c, const enumf &dist, enumf &max_dist) override
   {
     vector<double> x(c.size());
@@ -183,7 +186,8 @@ static int cmd_enumfix(int argc, char **argv)
       make_pruning(prspec, d, &M, first, max_dist.get_d() * std::pow(2.0, (double)expo));
 
   set_external_enumerator(recording_enumerator);
-  LoggingEvaluator ev(max_sols, (EvaluatorStrategy)strategy);
+  // REFDRV_SUBSOLS=1: the evaluator also collects sub-solutions (findsubsols, evaluator.h:185-205)
+  LoggingEvaluator ev(max_sols, (EvaluatorStrategy)strategy, getenv("REFDRV_SUBSOLS") != nullptr);
   Enumeration<ZT, FT> E(M, ev);
   auto t0 = std::chrono::steady_clock::now();
   E.enumerate(first, first + d, max_dist, expo, vector<FT>(), vector<enumxt>(), pruning);
@@ -221,7 +225,27 @@ static int cmd_enumfix(int argc, char **argv)
       os << (i ? "," : "") << (long)ev.log[s].second[i];
     os << "]}";
   }
-  os << "]\n}\n";
+  os << "]";
+  if (getenv("REFDRV_SUBSOLS"))
+  {  // final table: best sub-solution per offset, distance normalised like the plugin sees it
+    os << ",\n\"subsols\":[";
+    bool firsts = true;
+    for (size_t o = 0; o < ev.sub_solutions.size(); ++o)
+    {
+      if (ev.sub_solutions[o].second.empty())
+        continue;
+      FT dn;
+      dn.mul_2si(ev.sub_solutions[o].first, -ev.normExp);
+      os << (firsts ? "\n" : ",\n") << "{\"offset\":" << o << ",\"dist\":" << hexd(dn.get_d())
+         << ",\"x\":[";
+      for (int i = 0; i < d; ++i)
+        os << (i ? "," : "") << (long)ev.sub_solutions[o].second[i].get_d();
+      os << "]}";
+      firsts = false;
+    }
+    os << "]";
+  }
+  os << "\n}\n";
   std::cout << os.str();
   return 0;
 }

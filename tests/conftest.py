@@ -33,6 +33,9 @@ def load_fixture(path):
     j["final_maxdist"] = float.fromhex(j["final_maxdist"])
     j["sol_log"] = [(float.fromhex(s["dist"]), [float(v) for v in s["x"]]) for s in j["sol_log"]]
     j["name"] = os.path.basename(path)[:-5]
+    if "subsols" in j:  # final sub-solution table of the reference's evaluator (findsubsols)
+        j["subsols"] = {s["offset"]: (float.fromhex(s["dist"]), [float(v) for v in s["x"]])
+                        for s in j["subsols"]}
     return j
 
 
@@ -64,7 +67,11 @@ def oracle_lib():
     return _oracle
 
 
-def oracle_enumerate(mut, rdiag, pruning, maxdist, evaluator, log=None):
+SUBSOLCB = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_double, ctypes.POINTER(ctypes.c_double),
+                            ctypes.c_int)
+
+
+def oracle_enumerate(mut, rdiag, pruning, maxdist, evaluator, log=None, findsubsols=False):
     """Run the C oracle with a Python evaluator (same protocol as the device path)."""
     lib = oracle_lib()
     mut = np.ascontiguousarray(mut, dtype=np.float64)
@@ -83,10 +90,14 @@ def oracle_enumerate(mut, rdiag, pruning, maxdist, evaluator, log=None):
         state["m"] = float(evaluator.eval_sol(x, dist, state["m"]))
         return state["m"]
 
+    def subcb(_u, dist, sub, offset):
+        evaluator.eval_sub_sol(offset, [0.0] * offset + [sub[i] for i in range(offset, d)], dist)
+
     c = SOLCB(cb)
+    sc = SUBSOLCB(subcb) if findsubsols else None
     nodes = np.zeros(d + 1, dtype=np.uint64)
     lib.oracle_enumerate(d, mut.ctypes.data_as(ctypes.c_void_p), rdiag.ctypes.data_as(ctypes.c_void_p),
-                         pr, ctypes.c_double(maxdist), 0, c, None, None,
+                         pr, ctypes.c_double(maxdist), 1 if findsubsols else 0, c, sc, None,
                          nodes.ctypes.data_as(ctypes.c_void_p), None, None)
     return nodes, state["m"]
 

@@ -164,9 +164,6 @@ def test_edge_cases(ctx):
             enumerate_block(ctx, np.zeros((d, d)), np.ones(d), None, 1.0, FastEvaluator(1, 0))
     with pytest.raises(Unsupported):
         enumerate_block(ctx, np.zeros((8, 8)), np.ones(8), None, 1.0, FastEvaluator(1, 0), dual=True)
-    with pytest.raises(Unsupported):
-        enumerate_block(ctx, np.zeros((8, 8)), np.ones(8), None, 1.0, FastEvaluator(1, 0),
-                        findsubsols=True)
     # orthogonal basis (mu = 0): the count is the number of half-space lattice points in the ball
     d = 6
     mut, rdiag, _ = C.synthetic_block(d, 1, 0.0, 1.0)
@@ -204,6 +201,44 @@ def test_blocks_larger_than_64_vs_oracle(ctx, d, seed, rf):
     enumerate_block(ctx, mut, rdiag, pruning, maxdist, ev1)
     C.oracle_enumerate(mut, rdiag, pruning, maxdist, ev1o)
     assert [s[0] for s in ev1.solutions] == [s[0] for s in ev1o.solutions]
+
+
+@pytest.mark.parametrize("path", [p for p in C.enum_fixtures() if p.endswith("_subsols.json")],
+                         ids=lambda p: os.path.basename(p)[:-5])
+def test_subsolutions_reference_parity(ctx, path):
+    """findsubsols through the plugin protocol (extenum_cb_process_subsol): the final table of the
+    evaluator — shortest sub-solution per offset — has the reference's distances; where the shortest
+    is unique (no other node of that level at the same distance) also its coefficients.  The main
+    results are unchanged by the option."""
+    from fplll_amd.enumeration import FastEvaluator, enumerate_block
+    f = C.load_fixture(path)
+    ev = FastEvaluator(f["max_sols"], f["strategy"])
+    res = enumerate_block(ctx, f["mut"], f["rdiag"], f["pruning"], f["maxdist"], ev, findsubsols=True)
+    assert sorted(ev.sub_solutions) == sorted(f["subsols"])
+    same = 0
+    for o, (dist, x) in f["subsols"].items():
+        assert ev.sub_solutions[o][0] == dist
+        assert all(v == 0.0 for v in ev.sub_solutions[o][1][:o])
+        same += list(ev.sub_solutions[o][1]) == x
+    assert same >= len(f["subsols"]) - 2  # ties at equal distance may pick another vector
+    if f["max_sols"] > 10**6:
+        assert [int(v) for v in res.nodes] == f["nodes"]
+    assert res.final_maxdist == f["final_maxdist"] or f["strategy"] != 0
+
+
+@pytest.mark.parametrize("d,seed,rf", [(40, 31, 0.95), (70, 22, 0.46)])
+def test_subsolutions_vs_oracle(ctx, d, seed, rf):
+    """Seeded blocks (one larger than 64: the top walk reports sub-solutions of levels >= 64)."""
+    from fplll_amd.enumeration import FastEvaluator, enumerate_block
+    mut, rdiag, maxdist = C.synthetic_block(d, seed, 0.03, rf)
+    pruning = np.linspace(1.0, 0.25, d)
+    ev, ev_o = FastEvaluator(10**9, 0), FastEvaluator(10**9, 0)
+    res = enumerate_block(ctx, mut, rdiag, pruning, maxdist, ev, findsubsols=True)
+    nodes_o, _ = C.oracle_enumerate(mut, rdiag, pruning, maxdist, ev_o, findsubsols=True)
+    assert [int(v) for v in res.nodes] == [int(v) for v in nodes_o]
+    assert sorted(ev.sub_solutions) == sorted(ev_o.sub_solutions)
+    for o in ev_o.sub_solutions:
+        assert ev.sub_solutions[o][0] == ev_o.sub_solutions[o][0]
 
 
 def test_phase_parameters_do_not_change_results(ctx):

@@ -53,3 +53,19 @@ def test_oracle_empty_and_tiny():
     nodes, final = C.oracle_enumerate(mut, rd, None, 0.5, ev)
     assert ev.empty() and final == 0.5
     assert int(nodes[0]) == 1  # the zero vector is counted at level 0 (enumerate_base.cpp:33)
+
+
+@pytest.mark.parametrize("path", [p for p in C.enum_fixtures() if p.endswith("_subsols.json")],
+                         ids=lambda p: os.path.basename(p)[:-5])
+def test_oracle_subsolutions_match_reference(path):
+    """findsubsols (enumerate_base.cpp:36-40, enumerate.cpp:241-249, evaluator.h:185-205): the final
+    table — best sub-solution per offset, distance and coefficients — equals the reference's."""
+    from fplll_amd.enumeration import FastEvaluator
+    f = C.load_fixture(path)
+    ev = FastEvaluator(f["max_sols"], f["strategy"])
+    nodes, _ = C.oracle_enumerate(f["mut"], f["rdiag"], f["pruning"], f["maxdist"], ev, findsubsols=True)
+    assert [int(v) for v in nodes] == f["nodes"]
+    assert sorted(ev.sub_solutions) == sorted(f["subsols"])
+    for o, (dist, x) in f["subsols"].items():
+        assert ev.sub_solutions[o][0] == dist
+        assert list(ev.sub_solutions[o][1]) == x
