@@ -75,7 +75,7 @@ typedef double (*fphip_exchange_cb)(void *user, double local_bound, int local_ac
 typedef struct fphip_enum_opts
 {
   int dual;        /* 1 → declined (the reference adapter does not transform mu/r for dual) */
-  int findsubsols; /* 1 → declined in this round */
+  int findsubsols; /* 1 → sub-solutions are reported through subcb (must be non-NULL) */
   /* subtree sharding across GPUs: this context handles final-phase tasks t with
    * t % shard_count == shard_index; the (cheap) top-of-tree phases are replicated */
   int shard_index;
