@@ -2,7 +2,7 @@
 (a) fplll's internal enumerator, (b) our HIP enumerator installed through set_external_enumerator.
 SURVEY.md §8(d) metric (ii).  Needs oracle/_ref (travels with the tree) and a GPU for (b)."""
 import json, os, subprocess, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 drv = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
 basis = os.path.join(ROOT, "tests", "golden", "basis_q180_seed0_lll_bkz20.txt")
 strat = os.path.join(ROOT, "tests", "golden", "strategies_q180_b60.json")

@@ -1,6 +1,6 @@
 """FETCH_SIZE calibration: stream a known number of bytes with the sweep's load instruction."""
 import ctypes, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import fplll_amd
 ctx = fplll_amd.Context(0)
 lib = ctx.lib

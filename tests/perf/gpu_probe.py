@@ -1,7 +1,7 @@
 """First-contact GPU probe: runs a few fixtures through the C ABI with verbose diagnostics."""
 import os, sys, time, glob
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
 import numpy as np
 import conftest as C
 import fplll_amd

@@ -3,7 +3,7 @@ BASELINE.json: `latticegen q 120 60 20 p`), HLLLReduction::hlll on each.  Prints
 oracle/_ref/ref_driver is present, the real reference's single-core time on the same inputs (and
 checks that the output bases are identical)."""
 import json, os, subprocess, sys, tempfile, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import fplll_amd

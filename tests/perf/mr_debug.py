@@ -1,6 +1,6 @@
 import os, sys, socket
 import multiprocessing as mp
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 def worker(rank, world, port, reps, q):

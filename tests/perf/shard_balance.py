@@ -1,8 +1,8 @@
 """Per-shard work of one C3 enumeration (fixed bound so that the tree is the same for every shard):
 proxy for multi-GPU strong-scaling efficiency = mean/max of per-shard kernel time."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
 import numpy as np
 import conftest as C
 import fplll_amd

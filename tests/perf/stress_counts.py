@@ -2,7 +2,7 @@
 GPU, unsharded, to expose timing-dependent races."""
 import os, sys, time
 import multiprocessing as mp
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 def worker(rank, reps, name, q, mode='plain'):
