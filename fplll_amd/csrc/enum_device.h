@@ -66,5 +66,16 @@ struct TaskBuf
   unsigned int cap;
 };
 
+// Tasks of the top walk of a block larger than 64 (enum_top_kernel): subtree roots at a level > 64.
+struct TopBuf
+{
+  double *col;          // [cap][128] S_L: rows i<L of the centre partial sums at the root
+  double *xhi;          // [cap][64]  coefficients of levels 64..127 chosen so far (lane = level-64)
+  double *pd;           // [cap]
+  int *level;           // [cap]
+  unsigned int *count;  // tasks written (may exceed cap: the host declines the instance)
+  unsigned int cap;
+};
+
 }  // namespace fphip
 #endif

@@ -29,9 +29,11 @@ __global__ void enum_phase_kernel(DevShared *g, HostCtl *h, TaskBuf in, TaskBuf 
                                   const unsigned *idxlist, int launch_idx, int count_nodes,
                                   unsigned budget, const double *xhi_root);
 template <bool SUBS>
-__global__ void enum_top_kernel(DevShared *g, HostCtl *h, TaskBuf out, double *xhi_root, int d,
-                                double maxdist, int count_nodes);
-__global__ void task_key_kernel(TaskBuf in, unsigned n, int d, unsigned long long *keys);
+__global__ void enum_top_kernel(DevShared *g, HostCtl *h, TopBuf in, unsigned n_in, TopBuf out_top,
+                                int stop, TaskBuf out, double *xhi_root, int d, double maxdist,
+                                int count_nodes, int launch_idx);
+__global__ void task_key_kernel(TaskBuf in, unsigned n, int d, unsigned long long *keys,
+                                const double *xhi_root);
 }
 using namespace fphip;
 
@@ -51,6 +53,7 @@ struct fphip_ctx
   unsigned *idxlist            = nullptr;  // device: this rank's task indices, heaviest first
   double *xhi_root             = nullptr;  // device: [cap][64] coefficients of levels 64..127 per
                                            // level-64 ancestor (blocks larger than 64)
+  TopBuf top[2] = {};                           // top tasks of blocks larger than 64 (allocated on demand)
   char err[512]                = {0};
   // GSO state lives in gso_host.hip, linked through this opaque slot
   void *gso = nullptr;
@@ -172,6 +175,19 @@ extern "C" void fphip_destroy(fphip_ctx *ctx)
   }
   if (ctx->xhi_root)
     hipFree(ctx->xhi_root);
+  for (int b = 0; b < 2; ++b)
+  {
+    if (ctx->top[b].col)
+      hipFree(ctx->top[b].col);
+    if (ctx->top[b].xhi)
+      hipFree(ctx->top[b].xhi);
+    if (ctx->top[b].pd)
+      hipFree(ctx->top[b].pd);
+    if (ctx->top[b].level)
+      hipFree(ctx->top[b].level);
+    if (ctx->top[b].count)
+      hipFree(ctx->top[b].count);
+  }
   if (ctx->keys)
     hipFree(ctx->keys);
   if (ctx->idxlist)
@@ -389,28 +405,80 @@ extern "C" int fphip_enum_run(fphip_ctx *ctx, int dim, double maxdist, const dou
   // task buffer is still a clean decline.
   unsigned top_tasks = 0;
   double top_ms      = 0.0;
+  int launch_idx     = 0;
   if (d > 64)
   {
-    const size_t tlds = (size_t)((d + 1) * d / 2 - 65 * 64 / 2) * sizeof(double);
+    const unsigned cap2 = (unsigned)env_int("FPHIP_TOP_TASK_CAP", 32768);
+    for (int b = 0; b < 2 && !ctx->top[1].col; ++b)
+    {
+      HIPCHK(ctx, hipMalloc((void **)&ctx->top[b].col, (size_t)cap2 * 128 * sizeof(double)));
+      HIPCHK(ctx, hipMalloc((void **)&ctx->top[b].xhi, (size_t)cap2 * 64 * sizeof(double)));
+      HIPCHK(ctx, hipMalloc((void **)&ctx->top[b].pd, (size_t)cap2 * sizeof(double)));
+      HIPCHK(ctx, hipMalloc((void **)&ctx->top[b].level, (size_t)cap2 * sizeof(int)));
+      HIPCHK(ctx, hipMalloc((void **)&ctx->top[b].count, 64));
+      ctx->top[b].cap = cap2;
+    }
+    // root top task: level d, zero column, no coefficient chosen, zero partial distance
+    HIPCHK(ctx, hipMemsetAsync(ctx->top[0].col, 0, 128 * sizeof(double), ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(ctx->top[0].xhi, 0, 64 * sizeof(double), ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(ctx->top[0].pd, 0, sizeof(double), ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->top[0].level, &d, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(ctx->top[1].count, 0, 4, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(ctx->buf[cur].count, 0, 4, ctx->stream));
-    HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-    if (subs)
-      hipLaunchKernelGGL(enum_top_kernel<true>, dim3(1), dim3(64), tlds, ctx->stream, ctx->g, ctx->h,
-                         ctx->buf[cur], ctx->xhi_root, d, maxdist, 1);
-    else
-      hipLaunchKernelGGL(enum_top_kernel<false>, dim3(1), dim3(64), tlds, ctx->stream, ctx->g, ctx->h,
-                         ctx->buf[cur], ctx->xhi_root, d, maxdist, 1);
-    HIPCHK(ctx, hipGetLastError());
-    HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
-    {  // sub-solutions of the top levels arrive through the ring while the walk runs
-      uint64_t nsub = 0;
+    const size_t tlds = (size_t)((d + 1) * d / 2 - 65 * 64 / 2) * sizeof(double);
+    // cut level of the first (single-wave) top launch: where the Gaussian heuristic expects a few
+    // thousand nodes; the second launch walks those subtrees in parallel down to level 64
+    int cut = 64;
+    for (int k = d - 1; k > 64; --k)
+      if (logN[k] - logN[d] >= std::log(2048.0))
+      {
+        cut = k;
+        break;
+      }
+    auto top_launch = [&](int in_idx, unsigned n_in, int stop, unsigned grid) -> int
+    {
+      HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+      if (subs)
+        hipLaunchKernelGGL(enum_top_kernel<true>, dim3(grid), dim3(64), tlds, ctx->stream, ctx->g,
+                           ctx->h, ctx->top[in_idx], n_in, ctx->top[in_idx ^ 1], stop, ctx->buf[cur],
+                           ctx->xhi_root, d, maxdist, 1, launch_idx);
+      else
+        hipLaunchKernelGGL(enum_top_kernel<false>, dim3(grid), dim3(64), tlds, ctx->stream, ctx->g,
+                           ctx->h, ctx->top[in_idx], n_in, ctx->top[in_idx ^ 1], stop, ctx->buf[cur],
+                           ctx->xhi_root, d, maxdist, 1, launch_idx);
+      HIPCHK(ctx, hipGetLastError());
+      HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+      uint64_t nsub = 0;  // sub-solutions of the top levels arrive through the ring meanwhile
       int rcw       = wait_serving(ctx, d, cb, subcb, user, &nsub);
       if (rcw != FPHIP_OK)
         return rcw;
+      float tms = 0;
+      HIPCHK(ctx, hipEventElapsedTime(&tms, ctx->ev[0], ctx->ev[1]));
+      top_ms += tms;
+      ++launch_idx;
+      return FPHIP_OK;
+    };
+    int rct = top_launch(0, 1u, cut, 1u);
+    if (rct != FPHIP_OK)
+      return rct;
+    if (cut > 64)
+    {
+      unsigned c1 = 0;
+      HIPCHK(ctx, hipMemcpy(&c1, ctx->top[1].count, 4, hipMemcpyDeviceToHost));
+      if (c1 > cap2)
+      {
+        snprintf(ctx->err, sizeof ctx->err, "more than %u top tasks: the block stays on the CPU enumerator", cap2);
+        return FPHIP_UNSUPPORTED;
+      }
+      if (c1 > 0)
+      {
+        const unsigned per_cu = (unsigned)std::max<size_t>(1, (160 * 1024) / std::max<size_t>(tlds, 1));
+        const unsigned grid   = std::min<unsigned>(c1, (unsigned)ctx->num_cus * std::min(per_cu, 8u));
+        rct                   = top_launch(1, c1, 64, grid);
+        if (rct != FPHIP_OK)
+          return rct;
+      }
     }
-    float tms = 0;
-    HIPCHK(ctx, hipEventElapsedTime(&tms, ctx->ev[0], ctx->ev[1]));
-    top_ms = tms;
     HIPCHK(ctx, hipMemcpy(&top_tasks, ctx->buf[cur].count, 4, hipMemcpyDeviceToHost));
     if (top_tasks > ctx->cap)
     {
@@ -423,7 +491,7 @@ extern "C" int fphip_enum_run(fphip_ctx *ctx, int dim, double maxdist, const dou
   const int debug     = env_int("FPHIP_DEBUG", 0);
   uint64_t nsol       = 0;
   double kernel_ms    = top_ms, final_ms = 0.0;
-  int launches        = 0, launch_idx = 0;
+  int launches        = 0;
   int L               = d > 64 ? 64 : d;  // highest root level among the current tasks (LDS geometry)
   unsigned C          = d > 64 ? top_tasks : 1;  // number of current tasks
   int final_tasks     = 0, final_L = d;
@@ -488,7 +556,7 @@ extern "C" int fphip_enum_run(fphip_ctx *ctx, int dim, double maxdist, const dou
       // heaviest-first.
       const unsigned kgrid = std::min<unsigned>((C + 3) / 4, (unsigned)ctx->num_cus * 8u);
       hipLaunchKernelGGL(task_key_kernel, dim3(kgrid ? kgrid : 1), dim3(256), 0, ctx->stream,
-                         ctx->buf[cur], C, d, ctx->keys);
+                         ctx->buf[cur], C, d, ctx->keys, ctx->xhi_root);
       HIPCHK(ctx, hipGetLastError());
       HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
       std::vector<unsigned long long> keys(C);

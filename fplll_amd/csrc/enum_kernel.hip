@@ -454,14 +454,16 @@ FPHIP_INST(false, true)
 #undef FPHIP_INST
 
 // ---------------------------------------------------------------------------------------------
-// Blocks larger than 64 (up to 128): the levels 64..d-1.  One wavefront walks the TOP of the tree
-// depth-first with two registers per lane (rows / levels 0..127) — the same CHILD / STEP walk and
-// the same arithmetic as enum_phase_kernel — and emits every surviving node at level 64 as a task
-// (column of the rows below 64, partial distance) for the wave-per-subtree kernel; the
-// coefficients of levels 64..d-1 are stored once per task in xhi_root.  With pruning the top of
-// the tree is a small fraction of the nodes; it is walked once, before any candidate can be
-// reported, under the initial radius (tasks that a later, smaller radius cuts die at their first
-// test in the next launch: the visited set is the reference's).
+// Blocks larger than 64 (up to 128): the levels 64..d-1.  The TOP of the tree is walked with two
+// registers per lane (rows / levels 0..127) — the same CHILD / STEP walk and the same arithmetic as
+// enum_phase_kernel — in one or two launches of one-wave workgroups pulling "top tasks" (column of
+// all rows, coefficients of the levels >= 64 chosen so far, partial distance, root level): the
+// first launch walks the root down to a cut level and emits the survivors as top tasks, the second
+// walks those in parallel down to level 64, where every surviving node becomes a task for the
+// wave-per-subtree kernel (column of the rows below 64, partial distance; the coefficients of
+// levels >= 64 are stored once per such node in xhi_root).  No candidate can be reported up here,
+// so the top runs under the initial radius (tasks that a later, smaller radius cuts die at their
+// first test in the next launch: the visited set is the reference's).
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ double rl2(const double (&v)[2], int idx)
 {
@@ -474,8 +476,9 @@ __device__ __forceinline__ int rl2i(const int (&v)[2], int idx)
 
 template <bool SUBS>
 __global__ void __launch_bounds__(64)
-    enum_top_kernel(DevShared *__restrict__ g, HostCtl *__restrict__ h, TaskBuf out,
-                    double *__restrict__ xhi_root, int d, double maxdist, int count_nodes)
+    enum_top_kernel(DevShared *__restrict__ g, HostCtl *__restrict__ h, TopBuf in, unsigned n_in,
+                    TopBuf out_top, int stop, TaskBuf out, double *__restrict__ xhi_root, int d,
+                    double maxdist, int count_nodes, int launch_idx)
 {
   extern __shared__ __attribute__((aligned(16))) double stk2[];  // slots 65..d (slot k: k doubles)
   const int lane   = threadIdx.x & 63;
@@ -488,182 +491,218 @@ __global__ void __launch_bounds__(64)
     rd[q]  = g->rdiag[lane + 64 * q];
     bnd[q] = g->pruning[lane + 64 * q] * maxdist;
   }
-  double xs[2] = {0.0, 0.0}, cs[2] = {0.0, 0.0}, pds[2] = {0.0, 0.0};
-  int dxs[2] = {0, 0}, ddxs[2] = {0, 0};
   unsigned long long cnt[2] = {0, 0};
-  double S[2] = {0.0, 0.0};
-  double sb[2] = {0.0, 0.0};  // findsubsols: best sub-solution distance per level (lane = level)
+  double sb[2] = {0.0, 0.0};  // findsubsols: this wave's view of the best distance per level
   if constexpr (SUBS)
   {
     sb[0] = __longlong_as_double((long long)g->sub_bits[lane]);
     sb[1] = __longlong_as_double((long long)g->sub_bits[64 + lane]);
   }
-  // process_subsolution for a node at level lvl >= 64 (single wave: no competition yet)
-  auto sub_report = [&](int lvl, double dist)
+  for (;;)
   {
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-      sb[q] = (lane + 64 * q == lvl) ? dist : sb[q];
+    unsigned t = 0;
     if (lane == 0)
-      g->sub_bits[lvl] = (unsigned long long)__double_as_longlong(dist);
-    unsigned long long idx = 0;
-    if (lane == 0)
-      idx = atomicAdd(&g->sol_head, 1ull);
-    idx = rfl_u64(idx);
-    for (unsigned spin = 0; idx >= load_sys_u64(&h->consumed) + FPHIP_RING_CAP; ++spin)
+      t = atomicAdd(&g->task_head[launch_idx], 1u);
+    t = (unsigned)__builtin_amdgcn_readfirstlane((int)t);
+    if (t >= n_in)
+      break;
+    const int Lt = __builtin_amdgcn_readfirstlane(in.level[t]);
+    double S[2]  = {in.col[(unsigned long long)t * 128 + lane], in.col[(unsigned long long)t * 128 + 64 + lane]};
+    // xs[1]: lane = level - 64; the levels >= Lt come from the task, the walk fills the others
+    double xs[2] = {0.0, in.xhi[(unsigned long long)t * 64 + lane]};
+    double cs[2] = {0.0, 0.0}, pds[2] = {0.0, 0.0};
+    int dxs[2] = {0, 0}, ddxs[2] = {0, 0};
+    // process_subsolution for a node at level lvl >= 64
+    auto sub_report = [&](int lvl, double dist)
     {
-      __builtin_amdgcn_s_sleep(64);
-      if (spin > (1u << 24))
-      {
-        if (lane == 0)
-          atomicOr(&g->error_flags, FPHIP_ERR_RING_TIMEOUT);
-        break;
-      }
-    }
-    SolRec *r       = &h->ring[idx % FPHIP_RING_CAP];
-    r->x[lane]      = 0.0;
-    r->x[64 + lane] = (64 + lane < d && 64 + lane >= lvl) ? xs[1] : 0.0;
-    if (lane == 0)
-    {
-      r->dist   = dist;
-      r->kind   = 1;
-      r->offset = lvl;
-    }
-    __threadfence_system();
-    if (lane == 0)
-      __hip_atomic_store(&r->seq, idx + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  };
-  unsigned emitted = 0;
-  bool overflow    = false;
-  int k      = d;
-  double nd  = 0.0;
-  bool done  = false;
-  while (!done)
-  {
-    // ---- CHILD chain
-    for (;;)
-    {
-      k               = __builtin_amdgcn_readfirstlane(k);
-      const int kc    = k - 1;
-      const double c1 = rl2(S, kc);
-      const double x1 = round(c1);
-      const double a1 = x1 - c1;
-      const double n1 = nd + a1 * a1 * rl2(rd, kc);
-      if (!(n1 <= rl2(bnd, kc)))
-      {
-        done = k >= d;
-        break;
-      }
-      if (k == 64)
-      {  // hand the subtree below this node to the wave-per-subtree kernel
-        const unsigned oi = emitted++;
-        if (oi < out.cap)
-        {
-          out.col[(unsigned long long)oi * 64 + lane]  = S[0];
-          out.x[(unsigned long long)oi * 64 + lane]    = 0.0;
-          xhi_root[(unsigned long long)oi * 64 + lane] = xs[1];
-          if (lane == 0)
-          {
-            out.pd[oi]    = nd;
-            out.level[oi] = 64;
-            out.root[oi]  = (int)oi;
-          }
-        }
-        else
-          overflow = true;
-        break;
-      }
+      unsigned long long old = 0;
+      if (lane == 0)
+        old = atomicMin(&g->sub_bits[lvl], (unsigned long long)__double_as_longlong(dist));
+      old               = rfl_u64(old);
+      const double oldd = __longlong_as_double((long long)old);
 #pragma unroll
       for (int q = 0; q < 2; ++q)
-        if (lane + 64 * q < k)
-          stk2[tri_off(k) - off65 + lane + 64 * q] = S[q];
+        sb[q] = (lane + 64 * q == lvl) ? fmin(oldd, dist) : sb[q];
+      if (!(dist < oldd))
+        return;
+      unsigned long long idx = 0;
+      if (lane == 0)
+        idx = atomicAdd(&g->sol_head, 1ull);
+      idx = rfl_u64(idx);
+      for (unsigned spin = 0; idx >= load_sys_u64(&h->consumed) + FPHIP_RING_CAP; ++spin)
       {
-        const int s1 = (c1 >= x1) ? 1 : -1;
+        __builtin_amdgcn_s_sleep(64);
+        if (spin > (1u << 24))
+        {
+          if (lane == 0)
+            atomicOr(&g->error_flags, FPHIP_ERR_RING_TIMEOUT);
+          break;
+        }
+      }
+      SolRec *r       = &h->ring[idx % FPHIP_RING_CAP];
+      r->x[lane]      = 0.0;
+      r->x[64 + lane] = (64 + lane < d && 64 + lane >= lvl) ? xs[1] : 0.0;
+      if (lane == 0)
+      {
+        r->dist   = dist;
+        r->kind   = 1;
+        r->offset = lvl;
+      }
+      __threadfence_system();
+      if (lane == 0)
+        __hip_atomic_store(&r->seq, idx + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    };
+    int k     = Lt;
+    double nd = in.pd[t];
+    bool done = false;
+    while (!done)
+    {
+      // ---- CHILD chain
+      for (;;)
+      {
+        k               = __builtin_amdgcn_readfirstlane(k);
+        const int kc    = k - 1;
+        const double c1 = rl2(S, kc);
+        const double x1 = round(c1);
+        const double a1 = x1 - c1;
+        const double n1 = nd + a1 * a1 * rl2(rd, kc);
+        if (!(n1 <= rl2(bnd, kc)))
+        {
+          done = k >= Lt;
+          break;
+        }
+        if (k == stop && k < Lt)
+        {
+          unsigned oi = 0;
+          if (stop == 64)
+          {  // hand the subtree below this node to the wave-per-subtree kernel
+            if (lane == 0)
+              oi = atomicAdd(out.count, 1u);
+            oi = (unsigned)__builtin_amdgcn_readfirstlane((int)oi);
+            if (oi < out.cap)
+            {
+              out.col[(unsigned long long)oi * 64 + lane]  = S[0];
+              out.x[(unsigned long long)oi * 64 + lane]    = 0.0;
+              xhi_root[(unsigned long long)oi * 64 + lane] = xs[1];
+              if (lane == 0)
+              {
+                out.pd[oi]    = nd;
+                out.level[oi] = 64;
+                out.root[oi]  = (int)oi;
+              }
+            }
+          }
+          else
+          {  // a top task for the next (parallel) top launch
+            if (lane == 0)
+              oi = atomicAdd(out_top.count, 1u);
+            oi = (unsigned)__builtin_amdgcn_readfirstlane((int)oi);
+            if (oi < out_top.cap)
+            {
+              out_top.col[(unsigned long long)oi * 128 + lane]      = S[0];
+              out_top.col[(unsigned long long)oi * 128 + 64 + lane] = S[1];
+              out_top.xhi[(unsigned long long)oi * 64 + lane]       = xs[1];
+              if (lane == 0)
+              {
+                out_top.pd[oi]    = nd;
+                out_top.level[oi] = k;
+              }
+            }
+          }
+          break;  // → next sibling at level k (an overfull buffer is detected by the host: count > cap)
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+          if (lane + 64 * q < k)
+            stk2[tri_off(k) - off65 + lane + 64 * q] = S[q];
+        {
+          const int s1 = (c1 >= x1) ? 1 : -1;
+#pragma unroll
+          for (int q = 0; q < 2; ++q)
+          {
+            const bool me = lane + 64 * q == kc;
+            cs[q]         = me ? c1 : cs[q];
+            xs[q]         = me ? x1 : xs[q];
+            pds[q]        = me ? nd : pds[q];
+            dxs[q]        = me ? s1 : dxs[q];
+            ddxs[q]       = me ? s1 : ddxs[q];
+            cnt[q] += me ? 1ull : 0ull;
+          }
+        }
+        if constexpr (SUBS)
+        {
+          if (n1 < rl2(sb, kc) && n1 != 0.0)
+            sub_report(kc, n1);
+        }
+        k  = kc;
+        nd = n1;  // k >= 64 here
 #pragma unroll
         for (int q = 0; q < 2; ++q)
         {
-          const bool me = lane + 64 * q == kc;
-          cs[q]         = me ? c1 : cs[q];
-          xs[q]         = me ? x1 : xs[q];
-          pds[q]        = me ? nd : pds[q];
-          dxs[q]        = me ? s1 : dxs[q];
-          ddxs[q]       = me ? s1 : ddxs[q];
-          cnt[q] += me ? 1ull : 0ull;
+          const double mk = mu[tri_off(k) + min(lane + 64 * q, k - 1)];
+          S[q]            = S[q] - x1 * mk;
         }
       }
-      if constexpr (SUBS)
+      if (done)
+        break;
+      // ---- STEP loop
+      for (;;)
       {
-        if (n1 < rl2(sb, kc) && n1 != 0.0)
-          sub_report(kc, n1);
-      }
-      k  = kc;
-      nd = n1;  // k >= 64 here
+        k = __builtin_amdgcn_readfirstlane(k);
+        double par[2], mk[2];
 #pragma unroll
-      for (int q = 0; q < 2; ++q)
-      {
-        const double mk = mu[tri_off(k) + min(lane + 64 * q, k - 1)];
-        S[q]            = S[q] - x1 * mk;
-      }
-    }
-    if (done)
-      break;
-    // ---- STEP loop
-    for (;;)
-    {
-      k = __builtin_amdgcn_readfirstlane(k);
-      double par[2], mk[2];
-#pragma unroll
-      for (int q = 0; q < 2; ++q)
-      {
-        par[q] = stk2[tri_off(k + 1) - off65 + min(lane + 64 * q, k)];
-        mk[q]  = mu[tri_off(k) + min(lane + 64 * q, k - 1)];
-      }
-      double xk        = rl2(xs, k);
-      const double ck  = rl2(cs, k);
-      const double pdk = rl2(pds, k);
-      int dxk = rl2i(dxs, k), ddxk = rl2i(ddxs, k);
-      if (pdk != 0.0)
-      {
-        xk += (double)dxk;
-        ddxk = -ddxk;
-        dxk  = ddxk - dxk;
-      }
-      else
-      {
-        xk += 1.0;
-      }
-#pragma unroll
-      for (int q = 0; q < 2; ++q)
-      {
-        const bool me = lane + 64 * q == k;
-        xs[q]         = me ? xk : xs[q];
-        dxs[q]        = me ? dxk : dxs[q];
-        ddxs[q]       = me ? ddxk : ddxs[q];
-      }
-      const double a = xk - ck;
-      nd             = pdk + a * a * rl2(rd, k);
-      if (!(nd <= rl2(bnd, k)))
-      {
-        ++k;
-        if (k >= d)
+        for (int q = 0; q < 2; ++q)
         {
-          done = true;
-          break;
+          par[q] = stk2[tri_off(k + 1) - off65 + min(lane + 64 * q, k)];
+          mk[q]  = mu[tri_off(k) + min(lane + 64 * q, k - 1)];
         }
-        continue;
-      }
+        double xk        = rl2(xs, k);
+        const double ck  = rl2(cs, k);
+        const double pdk = rl2(pds, k);
+        int dxk = rl2i(dxs, k), ddxk = rl2i(ddxs, k);
+        if (pdk != 0.0)
+        {
+          xk += (double)dxk;
+          ddxk = -ddxk;
+          dxk  = ddxk - dxk;
+        }
+        else
+        {
+          xk += 1.0;
+        }
 #pragma unroll
-      for (int q = 0; q < 2; ++q)
-        cnt[q] += (lane + 64 * q == k) ? 1ull : 0ull;
-      if constexpr (SUBS)
-      {
-        if (nd < rl2(sb, k) && nd != 0.0)
-          sub_report(k, nd);
-      }
+        for (int q = 0; q < 2; ++q)
+        {
+          const bool me = lane + 64 * q == k;
+          xs[q]         = me ? xk : xs[q];
+          dxs[q]        = me ? dxk : dxs[q];
+          ddxs[q]       = me ? ddxk : ddxs[q];
+        }
+        const double a = xk - ck;
+        nd             = pdk + a * a * rl2(rd, k);
+        if (!(nd <= rl2(bnd, k)))
+        {
+          ++k;
+          if (k >= Lt)
+          {
+            done = true;
+            break;
+          }
+          continue;
+        }
 #pragma unroll
-      for (int q = 0; q < 2; ++q)
-        S[q] = par[q] - xk * mk[q];
-      break;
+        for (int q = 0; q < 2; ++q)
+          cnt[q] += (lane + 64 * q == k) ? 1ull : 0ull;
+        if constexpr (SUBS)
+        {
+          if (nd < rl2(sb, k) && nd != 0.0)
+            sub_report(k, nd);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+          S[q] = par[q] - xk * mk[q];
+        break;
+      }
     }
   }
   if (count_nodes)
@@ -673,20 +712,17 @@ __global__ void __launch_bounds__(64)
       if (cnt[q] != 0)
         atomicAdd(&g->nodes[lane + 64 * q], cnt[q]);
   }
-  if (lane == 0)
-  {
-    *out.count = emitted;
-    if (overflow)
-      atomicOr(&g->error_flags, FPHIP_FLAG_TASK_OVERFLOW);
-  }
 }
-template __global__ void enum_top_kernel<false>(DevShared *, HostCtl *, TaskBuf, double *, int, double, int);
-template __global__ void enum_top_kernel<true>(DevShared *, HostCtl *, TaskBuf, double *, int, double, int);
+template __global__ void enum_top_kernel<false>(DevShared *, HostCtl *, TopBuf, unsigned, TopBuf, int,
+                                                TaskBuf, double *, int, double, int, int);
+template __global__ void enum_top_kernel<true>(DevShared *, HostCtl *, TopBuf, unsigned, TopBuf, int,
+                                               TaskBuf, double *, int, double, int, int);
 
 // 64-bit content key of every task (its coefficient prefix x[Lt..d)): the task ORDER in the buffer
 // is not deterministic across ranks, the content is.  One wave per task.
 __global__ void __launch_bounds__(256)
-    task_key_kernel(TaskBuf in, unsigned n, int d, unsigned long long *__restrict__ keys)
+    task_key_kernel(TaskBuf in, unsigned n, int d, unsigned long long *__restrict__ keys,
+                    const double *__restrict__ xhi_root)
 {
   const int lane = threadIdx.x & 63;
   const unsigned w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -698,16 +734,17 @@ __global__ void __launch_bounds__(256)
     const bool on     = lane >= Lt && lane < d;
     unsigned h1 = on ? (unsigned)(int)xpre * (2654435761u * (unsigned)(lane + 1)) : 0u;
     unsigned h2 = on ? ((unsigned)(int)xpre ^ 0x9e3779b9u) * (40503u * (unsigned)(2 * lane + 3) + 2246822519u) : 0u;
+    if (64 + lane < d)
+    {  // blocks larger than 64: the coefficients of levels >= 64 (kept once per level-64 ancestor)
+      const double xh = xhi_root[(unsigned long long)in.root[ti] * 64 + lane];
+      h1 += (unsigned)(int)xh * (2654435761u * (unsigned)(lane + 65));
+      h2 += ((unsigned)(int)xh ^ 0x9e3779b9u) * (40503u * (unsigned)(2 * lane + 131) + 2246822519u);
+    }
     for (int off = 32; off > 0; off >>= 1)
     {
       h1 += (unsigned)__shfl_xor((int)h1, off);
       h2 += (unsigned)__shfl_xor((int)h2, off);
     }
-    // blocks larger than 64: the coefficients of levels >= 64 are identified by the level-64
-    // ancestor's index (the top walk is sequential: the same index on every rank)
-    const unsigned rid = (unsigned)in.root[ti];
-    h1 += rid * 2246822519u;
-    h2 ^= rid * 3266489917u;
     if (lane == 0)
       keys[ti] = ((unsigned long long)h1 << 32) | h2;
   }
