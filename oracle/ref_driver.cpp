@@ -297,6 +297,8 @@ static EnumOut run_enum(MatGSO<ZT, FT> &M, int first, int d, const vector<double
     FT root_det = M.get_root_det(first, first + d);
     adjust_radius_to_gh_bound(max_dist, expo, d, root_det, 1.1);
   }
+  if (getenv("REFDRV_RADIUS_SCALE"))
+    max_dist *= atof(getenv("REFDRV_RADIUS_SCALE"));
   FastEvaluator<FT> ev(max_sols, (EvaluatorStrategy)strategy, false);
   Enumeration<ZT, FT> E(M, ev);
   auto t0 = std::chrono::steady_clock::now();

@@ -302,3 +302,9 @@ def test_plugin_axis_with_reference_build():
         out = subprocess.run([drv, "plugin", so] + c.split(), capture_output=True, text=True,
                              timeout=600)
         assert out.returncode == 0, (c, out.stdout, out.stderr)
+    # a block larger than 64 (two-stage walk), radius scaled like the enum_d80 fixture
+    env = dict(os.environ, REFDRV_RADIUS_SCALE="0.45")
+    for c in ("100 50 14 5 20 0 80 linear:70 100000000 0 0.99", "100 50 14 5 20 0 80 linear:70 1 0 0.99"):
+        out = subprocess.run([drv, "plugin", so] + c.split(), capture_output=True, text=True,
+                             timeout=600, env=env)
+        assert out.returncode == 0, (c, out.stdout, out.stderr)
