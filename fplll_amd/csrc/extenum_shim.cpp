@@ -15,6 +15,7 @@
 
 #include <array>
 #include <cstdint>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <functional>
@@ -33,6 +34,18 @@ typedef std::array<std::uint64_t, 1024> nodes_array_t;  // FPLLL_EXTENUM_MAX_EXT
 namespace
 {
 fphip_ctx *g_ctx = nullptr;
+struct Totals  // FPLLL_HIP_STATS=1: printed when the process exits
+{
+  double secs = 0, kernel_ms = 0;
+  unsigned long long calls = 0, declined = 0, nodes = 0;
+  ~Totals()
+  {
+    if (getenv("FPLLL_HIP_STATS") && (calls || declined))
+      fprintf(stderr, "[fplll_hip] %llu enumerations on the device (%llu declined): %.3f s in the plugin, "
+                      "%.3f s of kernels, %.3e nodes\n",
+              calls, declined, secs, kernel_ms * 1e-3, (double)nodes);
+  }
+} g_totals;
 std::mutex g_mutex;  // fplll's global hook is process-wide and unsynchronised (enumerate_ext.cpp:32-37)
 
 struct Trampoline
@@ -112,11 +125,19 @@ nodes_array_t fplll_hip_extenum(const int dim, enumf maxdist, std::function<cb_s
   Trampoline tr{&cbsol, &cbsubsol, dim};
   std::vector<std::uint64_t> nodes(dim + 1, 0);
   fphip_enum_stats stats{};
+  const auto t0 = std::chrono::steady_clock::now();
   int rc = fphip_enum_run(ctx, dim, maxdist, mu.data(), rdiag.data(), pruning.data(), &opts,
                           sol_trampoline, findsubsols ? subsol_trampoline : nullptr, &tr,
                           nodes.data(), &stats);
   if (rc == FPHIP_UNSUPPORTED)
+  {
+    g_totals.declined++;
     return out;
+  }
+  g_totals.secs += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  g_totals.kernel_ms += stats.kernel_ms;
+  g_totals.calls++;
+  g_totals.nodes += stats.total_nodes;
   if (rc != FPHIP_OK)
   {
     fprintf(stderr, "[fplll_hip] enumeration failed, falling back: %s\n", fphip_last_error(ctx));
