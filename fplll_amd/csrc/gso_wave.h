@@ -314,59 +314,6 @@ template <int NQ, int IPS, int RR = FPHIP_GSO_RING> struct Ring
                    : "memory");
   }
 
-  // consume the oldest row in flight; lane/chunk q reads byte offset off[q] of the row (a row-level
-  // permutation of the lanes: the LLL kernel keeps rows in physical slots)
-  __device__ __forceinline__ void fetch_gather(double (&v)[NQ], const unsigned (&off)[NQ])
-  {
-    unsigned a[NQ];
-    const unsigned sb = base + tail * SLOT;
-#pragma unroll
-    for (int q = 0; q < NQ; ++q)
-      a[q] = sb + off[q];
-    tail              = (tail + 1 == R) ? 0 : tail + 1;
-    const int pending = ahead - 1;
-    --ahead;
-    if (pending == AHEAD)
-    {
-      readg<AHEAD>(v, a);
-      return;
-    }
-    switch (pending)
-    {
-    case 0: readg<0>(v, a); break;
-    case 1: readg<1>(v, a); break;
-    case 2: readg<2>(v, a); break;
-    case 3: readg<3>(v, a); break;
-    case 4: readg<4>(v, a); break;
-    case 5: readg<5>(v, a); break;
-    default: readg<6>(v, a); break;
-    }
-  }
-
-  // consume the oldest row in flight (ahead - 1 newer rows are behind it)
-  __device__ __forceinline__ void fetch(double (&v)[NQ])
-  {
-    const unsigned addr = base + tail * SLOT + lane * 8;
-    tail                = (tail + 1 == R) ? 0 : tail + 1;
-    const int pending   = ahead - 1;
-    --ahead;
-    if (pending == AHEAD)
-    {
-      read<AHEAD>(v, addr);
-      return;
-    }
-    switch (pending)
-    {
-    case 0: read<0>(v, addr); break;
-    case 1: read<1>(v, addr); break;
-    case 2: read<2>(v, addr); break;
-    case 3: read<3>(v, addr); break;
-    case 4: read<4>(v, addr); break;
-    case 5: read<5>(v, addr); break;
-    default: read<6>(v, addr); break;
-    }
-  }
-
   // One phase of `cnt` steps.  Rows [0, ahead) of it may already be in flight (prefetched by the
   // previous phase).  While consuming, keep the pipe full: first with this phase's remaining rows,
   // then with the first rows of the NEXT phase (ncnt rows, nrow(s)) — phases are chained without
