@@ -360,7 +360,7 @@ extern "C" int fphip_enum_run(fphip_ctx *ctx, int dim, double maxdist, const dou
   const double growth = o.phase_growth > 0 ? o.phase_growth : env_int("FPHIP_PHASE_GROWTH", 96);
   const int wpb_final =
       std::max(1, std::min(8, o.waves_per_block > 0 ? o.waves_per_block
-                                                    : env_int("FPHIP_WAVES_PER_BLOCK", 4)));
+                                                    : env_int("FPHIP_WAVES_PER_BLOCK", 2)));
 
   double logN[FPHIP_ENUM_MAX_DIM + 1];
   estimate_levels(d, rdiag, pruning, maxdist, logN);
