@@ -66,4 +66,7 @@ for k in 0 1 2; do
   $D enumfix 0 $G/basis_q180_seed0_lll_bkz20.txt 0 0 0 $f 60 prune:0.5 1 0 0.99 > $G/c3_b60_k${k}_pruner.json
 done
 $D genstrat $G/basis_q180_seed0_lll_bkz20.txt 60 > $G/strategies_q180_b60.json
+# sub-solutions (findsubsols): the evaluator's final table is added to the fixture
+REFDRV_SUBSOLS=1 $D enumfix  80 40 12 1  0 4 32 none      5 0 1.30 > $G/enum_d32_best5_subsols.json
+REFDRV_SUBSOLS=1 $D enumfix 100 50 14 2 20 0 40 linear:20 1 0 0.99 > $G/enum_d40_lin20_best1_subsols.json
 md5sum $G/enum_*.json > $G/MD5SUMS
