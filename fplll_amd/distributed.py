@@ -53,6 +53,32 @@ def partition_tasks(partdists, keys, shard_count):
     return shares
 
 
+def shard_batch(batch, rank, world):
+    """Replicas only: GSO / LLL / HLLL / BKZ of ONE lattice do not shard, a batch
+    of independent lattices does, with no data-path collective — rank r takes the contiguous slice
+    [lo, hi) of the batch (sizes differ by at most one).  Returns (lo, hi)."""
+    base, rem = divmod(int(batch), int(world))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def gather_status(dist, local_status, batch, rank, world):
+    """Collect the per-lattice status words of every rank's slice on all ranks (one all_gather of
+    `batch` int32 at the end of a batched reduction — the only communication of that path)."""
+    import torch
+    lo, hi = shard_batch(batch, rank, world)
+    width = -(-batch // world)
+    buf = torch.full((width,), -99, dtype=torch.int32)
+    buf[: hi - lo] = torch.as_tensor(local_status, dtype=torch.int32)
+    out = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(out, buf)
+    res = []
+    for r in range(world):
+        a, b = shard_batch(batch, r, world)
+        res.extend(out[r][: b - a].tolist())
+    return res
+
+
 def run_rounds(exchange, rounds_local, bound0):
     """Host-side round protocol of fphip_enum_run's walk phase, for the CPU tests: a rank keeps
     calling ``exchange`` once per round until NO rank has tasks, adopting the smallest bound.

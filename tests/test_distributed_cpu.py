@@ -82,3 +82,43 @@ def test_content_partition_is_order_independent():
         shares_p = partition_tasks([pds[i] for i in perm], [keys[i] for i in perm], world)
         for a, b in zip(shares, shares_p):
             assert a == [int(perm[j]) for j in b]
+
+
+def _shard_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from fplll_amd.distributed import gather_status, shard_batch
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    batch = 11
+    lo, hi = shard_batch(batch, rank, world)
+    local = [1000 * rank + i for i in range(lo, hi)]  # stands for the status words of the slice
+    q.put((rank, lo, hi, gather_status(dist, local, batch, rank, world)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_batch_sharding_replicas_world2():
+    """GSO / LLL / HLLL / BKZ of a batch: contiguous slices per rank, one all_gather of statuses."""
+    import torch.multiprocessing as mp
+    from fplll_amd.distributed import shard_batch
+    for batch in (1, 7, 8, 4096):
+        for world in (1, 2, 3, 8):
+            cuts = [shard_batch(batch, r, world) for r in range(world)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == batch
+            assert all(cuts[i][1] == cuts[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in cuts]
+            assert max(sizes) - min(sizes) <= 1
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_shard_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert (res[0][1], res[0][2], res[1][1], res[1][2]) == (0, 6, 6, 11)
+    expect = list(range(0, 6)) + [1000 + i for i in range(6, 11)]
+    assert res[0][3] == expect and res[1][3] == expect
