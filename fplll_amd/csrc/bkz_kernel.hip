@@ -106,6 +106,14 @@ __global__ void __launch_bounds__(256)
     LllCtx C{P.gf + (size_t)L * d * ldd, P.vc + (size_t)L * d};
     double *mu_blk = P.enum_mu + (size_t)L * (64 * 63 / 2);  // scaled mu rows of the current block
     SlotMap<NQ> M;
+    if (P.bkz_active[L] == 0)
+    {  // this lattice's reduction has ended in an earlier launch: keep its basis
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+        M.sl[q] = lane + 64 * q;
+      lll_write_ordered<NQ>(T, M, P.b2 + (size_t)L * d * ldn);
+      continue;
+    }
     lll_init_state<NQ>(T, C, M);
 
     int vp = 0;  // verified prefix of the LLL loop (lll_wave.h), kept across every call of the run
@@ -523,6 +531,7 @@ __global__ void __launch_bounds__(256)
       P.lll_info[4 * L + 1] = (int)(unsigned)(total_nodes & 0xffffffffull);
       P.lll_info[4 * L + 2] = (int)(unsigned)(total_nodes >> 32);
       P.lll_info[4 * L + 3] = ncalls;
+      P.bkz_rows[L]         = num_rows;
     }
     __threadfence_block();
   }

@@ -53,6 +53,8 @@ struct GsoBatch
   long long *b2;
   int *lll_info;
   double *enum_mu;  // BKZ kernel: [batch][64*63/2] scaled mu rows of the block being enumerated
+  int *bkz_active;  // BKZ kernel: [batch] 0 = leave this lattice alone (its reduction has ended)
+  int *bkz_rows;    // BKZ kernel: [batch] number of rows without the trailing zero rows
 };
 // Batched Householder state (MatHouseholder<Z_NR<long>, FP_NR<double>>): b, V, R are [batch][d][ldn]
 // row-major (lane = column), sigma / rexp [batch][d].

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cmath>
+#include <limits>
 #include <cstring>
 #include <utility>
 #include <vector>
@@ -160,6 +161,10 @@ extern "C" void fphip_gso_destroy(fphip_gso *g)
     hipFree(g->P.lll_info);
   if (g->P.enum_mu)
     hipFree(g->P.enum_mu);
+  if (g->P.bkz_active)
+    hipFree(g->P.bkz_active);
+  if (g->P.bkz_rows)
+    hipFree(g->P.bkz_rows);
   hipEventDestroy(g->ev[0]);
   hipEventDestroy(g->ev[1]);
   delete g;
@@ -375,27 +380,17 @@ static int ensure_lll_buffers(fphip_gso *g)
 // BKZReduction<Z_NR<long>, FP_NR<double>>(m, lll_obj, BKZParam(block_size, {}, delta, flags,
 // max_loops)).bkz() (bkz.cpp:522-668) on every lattice: primal BKZ with empty strategies (no
 // pruning, no preprocessing — what bkz_reduction(b, beta, BKZ_DEFAULT, FT_DOUBLE) runs without a
-// strategies file, BASELINE config 2), the whole reduction in one launch.  flags: 0 = BKZ_DEFAULT,
-// FPHIP_BKZ_MAX_LOOPS (0x4, fplll's value) with max_loops.  The input is expected LLL-reduced, as
-// bkz_reduction guarantees (bkz.cpp:870-885): call fphip_gso_lll first.
+// strategies file, BASELINE config 2).  flags: FPHIP_BKZ_MAX_LOOPS (0x4) with max_loops and / or
+// FPHIP_BKZ_AUTO_ABORT (0x20), fplll's values.  Without AUTO_ABORT the whole reduction is one
+// launch; with it the tours are launched one by one and BKZAutoAbort::test_abort (scale 1.0, 5
+// tours, bkz.cpp:800-809) runs on the host between them — the slope needs the host's log(), the
+// reference's — on the r_ii of every lattice that is still active.  The input is expected
+// LLL-reduced, as bkz_reduction guarantees (bkz.cpp:870-885): call fphip_gso_lll first.
 // status[batch]: 1 RED_SUCCESS, 8 RED_BKZ_LOOPS_LIMIT, <= 0 the failing LLL status.
 // info (nullable) [batch][4]: tours, enumeration nodes (low, high 32 bits; fplll rule), enumeration calls.
-extern "C" int fphip_gso_bkz(fphip_gso *g, int block_size, double delta, double eta, int flags,
-                             int max_loops, int *status, int *info)
+static int bkz_launch(fphip_gso *g, int block_size, double delta, double eta, int use_loops,
+                      int max_loops, float *ms, int *st_out, int *info_out)
 {
-  if (!g)
-    return FPHIP_ERROR;
-  if (block_size > 64 || (flags & ~0x4))
-    return FPHIP_UNSUPPORTED;  // blocks beyond one wavefront / other BKZ variants: fplll's CPU code
-  int rc = ensure_lll_buffers(g);
-  if (rc != FPHIP_OK)
-    return rc;
-  const size_t B = (size_t)g->P.batch;
-  if (!g->P.enum_mu)
-    GCHK(hipMalloc((void **)&g->P.enum_mu, B * (64 * 63 / 2) * sizeof(double)));
-  rc = launch(g, 0, g->P.d, 0.0, 2);  // bf / row_expo of every row from b
-  if (rc != FPHIP_OK)
-    return rc;
   const int need = (g->P.d > g->P.n ? g->P.d : g->P.n);
   const int nq   = (need + 63) / 64;
   const int wpb  = g->waves_per_block;
@@ -415,9 +410,8 @@ extern "C" int fphip_gso_bkz(fphip_gso *g, int block_size, double delta, double 
   const int cap = fphip_ctx_num_cus(g->ctx) * (bpc > 0 ? bpc : 1);
   if (grid > cap)
     grid = cap;
-  hipStream_t s        = fphip_ctx_stream(g->ctx);
-  const double logd    = std::log(delta);
-  const int use_loops  = (flags & 0x4) ? 1 : 0;
+  hipStream_t s     = fphip_ctx_stream(g->ctx);
+  const double logd = std::log(delta);
   if (lds > 64 * 1024)
   {
     switch (nq)
@@ -439,20 +433,149 @@ extern "C" int fphip_gso_bkz(fphip_gso *g, int block_size, double delta, double 
   GCHK(hipGetLastError());
   GCHK(hipEventRecord(g->ev[1], s));
   GCHK(hipStreamSynchronize(s));
-  float bkz_ms = 0;
-  GCHK(hipEventElapsedTime(&bkz_ms, g->ev[0], g->ev[1]));
+  GCHK(hipEventElapsedTime(ms, g->ev[0], g->ev[1]));
+  // (the sweep launches below reuse P.status)
+  GCHK(hipMemcpy(st_out, g->P.status, sizeof(int) * g->P.batch, hipMemcpyDeviceToHost));
+  GCHK(hipMemcpy(info_out, g->P.lll_info, sizeof(int) * 4 * g->P.batch, hipMemcpyDeviceToHost));
   std::swap(g->P.b, g->P.b2);  // the kernel wrote the rows in position order into b2
-  std::vector<int> st(B);
-  GCHK(hipMemcpy(st.data(), g->P.status, sizeof(int) * B, hipMemcpyDeviceToHost));
-  if (info)
-    GCHK(hipMemcpy(info, g->P.lll_info, sizeof(int) * 4 * B, hipMemcpyDeviceToHost));
-  rc = launch(g, 0, g->P.d, 0.0, 2);
+  // identity-layout GSO of the current bases (same values: every entry is a function of b)
+  int rc = launch(g, 0, g->P.d, 0.0, 2);
   if (rc == FPHIP_OK)
     rc = launch(g, 0, g->P.d, 0.0, 0);
-  g->last_ms = bkz_ms;
+  return rc;
+}
+
+extern "C" int fphip_gso_bkz(fphip_gso *g, int block_size, double delta, double eta, int flags,
+                             int max_loops, int *status, int *info)
+{
+  if (!g)
+    return FPHIP_ERROR;
+  if (block_size > 64 || (flags & ~(0x4 | 0x20)))
+    return FPHIP_UNSUPPORTED;  // blocks beyond one wavefront / other BKZ variants: fplll's CPU code
+  int rc = ensure_lll_buffers(g);
+  if (rc != FPHIP_OK)
+    return rc;
+  const size_t B = (size_t)g->P.batch, d = g->P.d;
+  if (!g->P.enum_mu)
+  {
+    GCHK(hipMalloc((void **)&g->P.enum_mu, B * (64 * 63 / 2) * sizeof(double)));
+    GCHK(hipMalloc((void **)&g->P.bkz_active, B * sizeof(int)));
+    GCHK(hipMalloc((void **)&g->P.bkz_rows, B * sizeof(int)));
+  }
+  std::vector<int> active(B, 1), st(B, 1), inf(4 * B, 0), one(4 * B), rows(B, (int)d);
+  GCHK(hipMemcpy(g->P.bkz_active, active.data(), sizeof(int) * B, hipMemcpyHostToDevice));
+  rc = launch(g, 0, g->P.d, 0.0, 2);  // bf / row_expo of every row from b
+  if (rc != FPHIP_OK)
+    return rc;
+  const bool use_loops = (flags & 0x4) != 0, auto_abort = (flags & 0x20) != 0;
+  float total_ms = 0, ms = 0;
+  auto accumulate = [&](size_t L)
+  {
+    inf[4 * L + 0] += one[4 * L + 0];
+    const unsigned long long a = ((unsigned long long)(unsigned)inf[4 * L + 2] << 32) | (unsigned)inf[4 * L + 1];
+    const unsigned long long b2 = ((unsigned long long)(unsigned)one[4 * L + 2] << 32) | (unsigned)one[4 * L + 1];
+    const unsigned long long t = a + b2;
+    inf[4 * L + 1] = (int)(unsigned)(t & 0xffffffffull);
+    inf[4 * L + 2] = (int)(unsigned)(t >> 32);
+    inf[4 * L + 3] += one[4 * L + 3];
+  };
+  if (!auto_abort)
+  {
+    rc = bkz_launch(g, block_size, delta, eta, use_loops ? 1 : 0, max_loops, &ms, st.data(), inf.data());
+    if (rc != FPHIP_OK)
+      return rc;
+    total_ms = ms;
+  }
+  else
+  {
+    // one tour per launch; BKZAutoAbort on the host (bkz.cpp:575-625, 800-809)
+    rc = launch(g, 0, g->P.d, 0.0, 0);  // r_ii of the input bases
+    if (rc != FPHIP_OK)
+      return rc;
+    std::vector<double> rdg(B * d), old_slope(B, std::numeric_limits<double>::max());
+    std::vector<long long> rex(B * d);
+    std::vector<int> no_dec(B, -1);
+    bool rows_known = false;
+    for (int loop = 0;; ++loop)
+    {
+      size_t n_active = 0;
+      GCHK(hipMemcpy(rdg.data(), g->P.rdg, sizeof(double) * B * d, hipMemcpyDeviceToHost));
+      GCHK(hipMemcpy(rex.data(), g->P.rexp, sizeof(long long) * B * d, hipMemcpyDeviceToHost));
+      if (!rows_known)
+      {  // trailing zero rows (bkz.cpp:35-37) have r_ii == 0 exactly
+        for (size_t L = 0; L < B; ++L)
+        {
+          int nr = (int)d;
+          while (nr > 0 && rdg[L * d + nr - 1] == 0.0)
+            --nr;
+          rows[L] = nr;
+        }
+        rows_known = true;
+      }
+      for (size_t L = 0; L < B; ++L)
+      {
+        if (!active[L])
+          continue;
+        if (block_size < 2)
+        {
+          active[L] = 0;
+          continue;
+        }
+        if (use_loops && loop >= max_loops)
+        {
+          st[L]     = 8;
+          active[L] = 0;
+          continue;
+        }
+        // MatGSOInterface::get_current_slope(0, num_rows), gso_interface.cpp:198-218
+        const int n = rows[L];
+        double v1 = 0, v2 = (double)(n + 1) * n * (n - 1) / 12.0, weight = (1.0 - n) / 2.0;
+        for (int i = 0; i < n; ++i)
+        {
+          const double logf = std::log(rdg[L * d + i]);
+          const long expo   = (long)(2 * rex[L * d + i]);
+          v1 += weight * (logf + expo * std::log(2.0));
+          weight++;
+        }
+        const double new_slope = -(v1 / v2);
+        if (no_dec[L] == -1 || new_slope < 1.0 * old_slope[L])
+          no_dec[L] = 0;
+        else
+          no_dec[L]++;
+        old_slope[L] = std::min(old_slope[L], new_slope);
+        if (no_dec[L] >= 5)
+        {
+          active[L] = 0;  // abort: status stays RED_SUCCESS
+          continue;
+        }
+        ++n_active;
+      }
+      if (n_active == 0)
+        break;
+      GCHK(hipMemcpy(g->P.bkz_active, active.data(), sizeof(int) * B, hipMemcpyHostToDevice));
+      std::vector<int> s1(B);
+      rc = bkz_launch(g, block_size, delta, eta, 1, 1, &ms, s1.data(), one.data());  // exactly one tour
+      if (rc != FPHIP_OK)
+        return rc;
+      total_ms += ms;
+      for (size_t L = 0; L < B; ++L)
+      {
+        if (!active[L])
+          continue;
+        accumulate(L);
+        if (s1[L] == 8)
+          continue;        // tour done, not clean: next loop
+        st[L]     = s1[L];  // 1: clean (or block_size >= num_rows); <= 0: failure
+        active[L] = 0;
+      }
+    }
+  }
+  g->last_ms = total_ms;
   if (status)
     memcpy(status, st.data(), sizeof(int) * B);
-  return rc;
+  if (info)
+    memcpy(info, inf.data(), sizeof(int) * 4 * B);
+  return FPHIP_OK;
 }
 
 extern "C" int fphip_gso_get_mu(fphip_gso *g, int lattice, double *mu)

@@ -109,13 +109,14 @@ class MatGSOBatch:
                                          info.ctypes.data_as(ctypes.c_void_p)), "lll")
         return st, info
 
-    def bkz(self, block_size, delta=LLL_DEF_DELTA, eta=LLL_DEF_ETA, max_loops=0):
+    def bkz(self, block_size, delta=LLL_DEF_DELTA, eta=LLL_DEF_ETA, max_loops=0, auto_abort=False):
         """BKZReduction::bkz() with empty strategies on every (LLL-reduced) lattice
         (bkz.cpp:522-668).  Returns (status[batch], info[batch][4] = tours, nodes lo, nodes hi,
         enumeration calls)."""
         st = np.zeros(self.batch, dtype=np.int32)
         info = np.zeros((self.batch, 4), dtype=np.int32)
-        rc = self.lib.fphip_gso_bkz(self.h, block_size, delta, eta, 0x4 if max_loops > 0 else 0,
+        flags = (0x4 if max_loops > 0 else 0) | (0x20 if auto_abort else 0)  # fplll's BKZFlags
+        rc = self.lib.fphip_gso_bkz(self.h, block_size, delta, eta, flags,
                                     max_loops, st.ctypes.data_as(ctypes.c_void_p),
                                     info.ctypes.data_as(ctypes.c_void_p))
         if rc == _lib.FPHIP_UNSUPPORTED:

@@ -158,14 +158,18 @@ int fphip_gso_lll(fphip_gso *g, int kappa_min, int kappa_start, int kappa_end, d
  * FastEvaluator(1)) on every lattice — primal BKZ with EMPTY strategies (no pruning, no
  * preprocessing: what bkz_reduction(b, beta, BKZ_DEFAULT, FT_DOUBLE) runs without a strategies
  * file, bkz_param.h:124-132), the whole reduction in one launch on device-resident GSO state.
- * flags: 0 (BKZ_DEFAULT) or FPHIP_BKZ_MAX_LOOPS with max_loops; block_size <= 64; anything else
+ * flags: 0 (BKZ_DEFAULT), FPHIP_BKZ_MAX_LOOPS with max_loops, FPHIP_BKZ_AUTO_ABORT; block_size <= 64;
+ * anything else
  * returns FPHIP_UNSUPPORTED (the caller keeps fplll's CPU path).  The input must be LLL-reduced, as
  * bkz_reduction guarantees (bkz.cpp:870-885) — call fphip_gso_lll first.
  * status[batch]: 1 RED_SUCCESS, 8 RED_BKZ_LOOPS_LIMIT, <= 0 the failing LLL status.
  * info (nullable) [batch][4]: tours, enumeration nodes low / high 32 bits (fplll rule), enumeration
  * calls. */
 #define FPHIP_BKZ_DEFAULT 0
-#define FPHIP_BKZ_MAX_LOOPS 0x4 /* fplll's BKZ_MAX_LOOPS, defs.h */
+#define FPHIP_BKZ_MAX_LOOPS 0x4   /* fplll's BKZ_MAX_LOOPS, defs.h:262-275 */
+#define FPHIP_BKZ_AUTO_ABORT 0x20 /* fplll's BKZ_AUTO_ABORT: BKZAutoAbort::test_abort(1.0, 5) between
+                                     the tours (bkz.cpp:800-809); the tours are then launched one by
+                                     one and the slope test runs on the host */
 int fphip_gso_bkz(fphip_gso *g, int block_size, double delta, double eta, int flags, int max_loops,
                   int *status, int *info);
 /* raw stored values, d×d row-major; true values carry the row exponents exactly as

@@ -12,6 +12,7 @@
  */
 #include "oracle.h"
 
+#include <float.h>
 #include <limits.h>
 #include <math.h>
 #include <stdlib.h>
@@ -684,7 +685,25 @@ static int svp_reduction(oracle_gso *g, int kappa, int bs, double delta, double 
   return 1;
 }
 
-/* BKZReduction::bkz().  flags: 0 = BKZ_DEFAULT, 1 = BKZ_MAX_LOOPS (with max_loops).
+/* MatGSOInterface::get_current_slope(start_row, stop_row), gso_interface.cpp:198-218 */
+static double current_slope(oracle_gso *g, int start_row, int stop_row)
+{
+  int n     = stop_row - start_row;
+  double v1 = 0, v2 = (double)(n + 1) * n * (n - 1) / 12.0, weight = (1.0 - n) / 2.0;
+  for (int i = start_row; i < stop_row; i++)
+  {
+    oracle_gso_update_row(g, i, i);
+    double f    = R(g, i, i);
+    long expo   = (long)(2 * g->row_expo[i]);
+    double logf = log(f);
+    v1 += weight * (logf + expo * log(2.0));
+    weight++;
+  }
+  return v1 / v2;
+}
+
+/* BKZReduction::bkz().  use_max_loops: bit 0 = BKZ_MAX_LOOPS (with max_loops), bit 1 = BKZ_AUTO_ABORT
+ * (BKZAutoAbort::test_abort with scale 1.0 and 5 tours, bkz.cpp:800-809, bkz_param.h defaults).
  * returns 1 RED_SUCCESS, 8 RED_BKZ_LOOPS_LIMIT, else a failure status (<= 0).
  * info[0] = tours executed, info[1..2] = enumeration nodes (lo, hi 32 bits). */
 int oracle_gso_bkz(oracle_gso *g, int block_size, double delta, double eta, int use_max_loops,
@@ -702,6 +721,10 @@ int oracle_gso_bkz(oracle_gso *g, int block_size, double delta, double eta, int 
   }
   uint64_t nodes = 0;
   int status = 1, tours = 0;
+  const int auto_abort = (use_max_loops & 2) != 0;
+  use_max_loops &= 1;
+  int no_dec       = -1;
+  double old_slope = DBL_MAX; /* numeric_limits<double>::max(), bkz.h BKZAutoAbort ctor */
   if (block_size < 2)
     goto done;
   for (int i = 0;; ++i)
@@ -710,6 +733,18 @@ int oracle_gso_bkz(oracle_gso *g, int block_size, double delta, double eta, int 
     {
       status = 8;
       break;
+    }
+    if (auto_abort)
+    { /* BKZAutoAbort::test_abort(1.0, 5) */
+      double new_slope = -current_slope(g, 0, num_rows);
+      if (no_dec == -1 || new_slope < 1.0 * old_slope)
+        no_dec = 0;
+      else
+        no_dec++;
+      if (new_slope < old_slope)
+        old_slope = new_slope;
+      if (no_dec >= 5)
+        break;
     }
     int clean = 1, c1 = 1, rc;
     /* trunc_tour */

@@ -606,7 +606,7 @@ static int cmd_hlllfix(int argc, char **argv)
 }
 
 
-/* bkzfix type d k bits seed block_size max_loops [reps]:
+/* bkzfix type d k bits seed block_size max_loops [reps] ; REFDRV_BKZ_AUTO_ABORT=1 adds BKZ_AUTO_ABORT:
  * BKZReduction<Z_NR<long>,FP_NR<double>>::bkz() on MatGSO(GSO_ROW_EXPO) exactly as bkz_reduction_f
  * sets it up after convert<long> (bkz.cpp:813-845), empty strategies (no pruning / preprocessing),
  * flags BKZ_DEFAULT (max_loops = 0) or BKZ_MAX_LOOPS.  The input is LLL-reduced first, as
@@ -632,7 +632,8 @@ static int cmd_bkzfix(int argc, char **argv)
   os << "{\n\"desc\":\"bkz type=" << type << " d=" << d << " k=" << k << " bits=" << bits
      << " seed=" << seed << " LLL-reduced, then BKZ-" << block_size << " max_loops=" << max_loops
      << "\",\n\"d\":" << d << ",\n\"n\":" << n << ",\n\"block_size\":" << block_size
-     << ",\n\"max_loops\":" << max_loops << ",\n\"delta\":" << hexd(LLL_DEF_DELTA) << ",\n\"eta\":"
+     << ",\n\"max_loops\":" << max_loops << ",\n\"auto_abort\":"
+     << (getenv("REFDRV_BKZ_AUTO_ABORT") ? 1 : 0) << ",\n\"delta\":" << hexd(LLL_DEF_DELTA) << ",\n\"eta\":"
      << hexd(LLL_DEF_ETA) << ",\n\"b_in\":[";
   for (int i = 0; i < d; ++i)
     for (int j = 0; j < n; ++j)
@@ -646,8 +647,10 @@ static int cmd_bkzfix(int argc, char **argv)
   {
     b = b0;
     vector<Strategy> strategies;
-    BKZParam par(block_size, strategies, LLL_DEF_DELTA, max_loops > 0 ? BKZ_MAX_LOOPS : BKZ_DEFAULT,
-                 max_loops);
+    int flags = max_loops > 0 ? BKZ_MAX_LOOPS : BKZ_DEFAULT;
+    if (getenv("REFDRV_BKZ_AUTO_ABORT"))
+      flags |= BKZ_AUTO_ABORT;
+    BKZParam par(block_size, strategies, LLL_DEF_DELTA, flags, max_loops);
     auto t0 = std::chrono::steady_clock::now();
     MatGSO<Z_NR<long>, FP_NR<double>> M(b, u, ut, GSO_ROW_EXPO);
     LLLReduction<Z_NR<long>, FP_NR<double>> L(M, LLL_DEF_DELTA, LLL_DEF_ETA, LLL_DEFAULT);

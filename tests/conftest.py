@@ -190,13 +190,14 @@ class OracleGSO:
                                      info.ctypes.data_as(ctypes.c_void_p))
         return st, info
 
-    def bkz(self, block_size, delta=0.99, eta=0.51, max_loops=0):
+    def bkz(self, block_size, delta=0.99, eta=0.51, max_loops=0, auto_abort=False):
         """BKZReduction::bkz, empty strategies (oracle/gso_oracle.c).  Returns (status, info[3])."""
         self.lib.oracle_gso_bkz.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_double,
                                             ctypes.c_double, ctypes.c_int, ctypes.c_int,
                                             ctypes.c_void_p]
         info = np.zeros(3, dtype=np.int32)
-        st = self.lib.oracle_gso_bkz(self.h, block_size, delta, eta, 1 if max_loops > 0 else 0,
+        st = self.lib.oracle_gso_bkz(self.h, block_size, delta, eta,
+                                     (1 if max_loops > 0 else 0) | (2 if auto_abort else 0),
                                      max_loops, info.ctypes.data_as(ctypes.c_void_p))
         return st, info
 
@@ -271,6 +272,7 @@ def load_bkz_fixture(path):
         j = json.load(f)
     d, n = j["d"], j["n"]
     out = {k: j[k] for k in ("d", "n", "block_size", "max_loops", "nodes")}
+    out["auto_abort"] = bool(j.get("auto_abort", 0))
     out["name"] = os.path.basename(path)[:-5]
     out["status"] = BKZ_REF_STATUS_TO_OURS[j["ref_status"]]
     out["delta"] = float.fromhex(j["delta"])

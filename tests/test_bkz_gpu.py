@@ -30,7 +30,7 @@ def test_reference_fixture_parity(ctx, path):
     f = C.load_bkz_fixture(path)
     g = MatGSOBatch(ctx, 3, f["d"], f["n"])
     g.set_basis(np.stack([f["b_in"]] * 3))
-    st, info = g.bkz(f["block_size"], f["delta"], f["eta"], f["max_loops"])
+    st, info = g.bkz(f["block_size"], f["delta"], f["eta"], f["max_loops"], f["auto_abort"])
     assert list(st) == [f["status"]] * 3
     out = g.get_basis(0, 3)
     for L in range(3):
@@ -64,6 +64,22 @@ def test_seeded_vs_oracle_heterogeneous_batch(ctx, d, beta):
         assert np.array_equal(out[L], o2.b)
         o.close()
         o2.close()
+    g.close()
+
+
+def test_max_loops_status(ctx):
+    """BKZ_MAX_LOOPS: one tour of a basis that needs more returns RED_BKZ_LOOPS_LIMIT (8)."""
+    from fplll_amd.gso import MatGSOBatch
+    f = C.load_bkz_fixture(os.path.join(C.GOLDEN, "bkz_q100_b20_autoabort.json"))
+    g = MatGSOBatch(ctx, 2, f["d"], f["n"])
+    g.set_basis(np.stack([f["b_in"]] * 2))
+    st, info = g.bkz(f["block_size"], max_loops=1)
+    o = C.OracleGSO(f["b_in"])
+    ost, oinfo = o.bkz(f["block_size"], max_loops=1)
+    assert list(st) == [ost, ost] == [8, 8]
+    assert int(info[0][0]) == int(oinfo[0]) == 1
+    assert np.array_equal(g.get_basis(0, 1)[0], o.b)
+    o.close()
     g.close()
 
 

@@ -15,7 +15,7 @@ import conftest as C
 def test_bkz_oracle_matches_reference(path):
     f = C.load_bkz_fixture(path)
     g = C.OracleGSO(f["b_in"])
-    st, info = g.bkz(f["block_size"], f["delta"], f["eta"], f["max_loops"])
+    st, info = g.bkz(f["block_size"], f["delta"], f["eta"], f["max_loops"], f["auto_abort"])
     assert st == f["status"]
     nodes = (int(info[1]) & 0xffffffff) | (int(info[2]) << 32)
     assert nodes == f["nodes"]
