@@ -204,12 +204,14 @@ template <int NQ, int IPS, int RR = FPHIP_GSO_RING> struct Ring
   // whose whole 1 KiB span lies outside the window is issued by lane 0 alone, re-reading the first
   // 16 bytes of the window (a line the other instruction fetches anyway — no extra HBM traffic)
   // into its own, unused, part of the slot.
-  __device__ __forceinline__ void issue(const RowDesc &r)
+  // NI = number of 1 KiB instructions issued for the row (IPS for 8-byte rows, IPS32 for the
+  // 4-byte mirrors; rows prefetched for the NEXT phase always get IPS, see run_with)
+  template <int NI = IPS> __device__ __forceinline__ void issue(const RowDesc &r)
   {
     const char *g      = (const char *)r.ptr + lane * 16;
     const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(base + head * SLOT));
 #pragma unroll
-    for (int i = 0; i < IPS; ++i)
+    for (int i = 0; i < NI; ++i)
     {
       const int off  = lane * 16 + i * 1024;
       const bool any = r.hi > r.lo && r.hi > i * 1024 && r.lo < (i + 1) * 1024;  // wave-uniform
@@ -227,90 +229,90 @@ template <int NQ, int IPS, int RR = FPHIP_GSO_RING> struct Ring
     ++ahead;
   }
 
-  template <int P> __device__ __forceinline__ void read(double (&v)[NQ], unsigned addr)
+  template <int W> __device__ __forceinline__ void read(double (&v)[NQ], unsigned addr)
   {
     // wait until at most P newer rows are outstanding, then fetch this lane's elements
     if constexpr (NQ == 1)
       asm volatile("s_waitcnt vmcnt(%2)\n\tds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)"
                    : "=&v"(v[0])
-                   : "v"(addr), "n"(P * IPS)
+                   : "v"(addr), "n"(W)
                    : "memory");
     else if constexpr (NQ == 2)
       asm volatile("s_waitcnt vmcnt(%3)\n\tds_read_b64 %0, %2\n\tds_read_b64 %1, %2 offset:512\n\t"
                    "s_waitcnt lgkmcnt(0)"
                    : "=&v"(v[0]), "=&v"(v[1])
-                   : "v"(addr), "n"(P * IPS)
+                   : "v"(addr), "n"(W)
                    : "memory");
     else if constexpr (NQ == 3)
       asm volatile("s_waitcnt vmcnt(%4)\n\tds_read_b64 %0, %3\n\tds_read_b64 %1, %3 offset:512\n\t"
                    "ds_read_b64 %2, %3 offset:1024\n\ts_waitcnt lgkmcnt(0)"
                    : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2])
-                   : "v"(addr), "n"(P * IPS)
+                   : "v"(addr), "n"(W)
                    : "memory");
     else
       asm volatile("s_waitcnt vmcnt(%5)\n\tds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:512\n\t"
                    "ds_read_b64 %2, %4 offset:1024\n\tds_read_b64 %3, %4 offset:1536\n\t"
                    "s_waitcnt lgkmcnt(0)"
                    : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
-                   : "v"(addr), "n"(P * IPS)
+                   : "v"(addr), "n"(W)
                    : "memory");
   }
 
   // 4-byte elements (narrow rows): this lane's element of each chunk, raw bits
-  template <int P> __device__ __forceinline__ void read32(unsigned (&w)[NQ], unsigned addr)
+  template <int W> __device__ __forceinline__ void read32(unsigned (&w)[NQ], unsigned addr)
   {
     if constexpr (NQ == 1)
       asm volatile("s_waitcnt vmcnt(%2)\n\tds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)"
                    : "=&v"(w[0])
-                   : "v"(addr), "n"(P * IPS)
+                   : "v"(addr), "n"(W)
                    : "memory");
     else if constexpr (NQ == 2)
       asm volatile("s_waitcnt vmcnt(%3)\n\tds_read_b32 %0, %2\n\tds_read_b32 %1, %2 offset:256\n\t"
                    "s_waitcnt lgkmcnt(0)"
                    : "=&v"(w[0]), "=&v"(w[1])
-                   : "v"(addr), "n"(P * IPS)
+                   : "v"(addr), "n"(W)
                    : "memory");
     else if constexpr (NQ == 3)
       asm volatile("s_waitcnt vmcnt(%4)\n\tds_read_b32 %0, %3\n\tds_read_b32 %1, %3 offset:256\n\t"
                    "ds_read_b32 %2, %3 offset:512\n\ts_waitcnt lgkmcnt(0)"
                    : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2])
-                   : "v"(addr), "n"(P * IPS)
+                   : "v"(addr), "n"(W)
                    : "memory");
     else
       asm volatile("s_waitcnt vmcnt(%5)\n\tds_read_b32 %0, %4\n\tds_read_b32 %1, %4 offset:256\n\t"
                    "ds_read_b32 %2, %4 offset:512\n\tds_read_b32 %3, %4 offset:768\n\t"
                    "s_waitcnt lgkmcnt(0)"
                    : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3])
-                   : "v"(addr), "n"(P * IPS)
+                   : "v"(addr), "n"(W)
                    : "memory");
   }
 
   // gather variant of read(): chunk q of this lane takes the element at byte offset a[q] of the slot
-  template <int P> __device__ __forceinline__ void readg(double (&v)[NQ], const unsigned (&a)[NQ])
+  template <int W> __device__ __forceinline__ void readg(double (&v)[NQ], const unsigned (&a)[NQ])
   {
     if constexpr (NQ == 1)
       asm volatile("s_waitcnt vmcnt(%2)\n\tds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)"
                    : "=&v"(v[0])
-                   : "v"(a[0]), "n"(P * IPS)
+                   : "v"(a[0]), "n"(W)
                    : "memory");
     else if constexpr (NQ == 2)
       asm volatile("s_waitcnt vmcnt(%4)\n\tds_read_b64 %0, %2\n\tds_read_b64 %1, %3\n\t"
                    "s_waitcnt lgkmcnt(0)"
                    : "=&v"(v[0]), "=&v"(v[1])
-                   : "v"(a[0]), "v"(a[1]), "n"(P * IPS)
+                   : "v"(a[0]), "v"(a[1]), "n"(W)
                    : "memory");
     else if constexpr (NQ == 3)
       asm volatile("s_waitcnt vmcnt(%6)\n\tds_read_b64 %0, %3\n\tds_read_b64 %1, %4\n\t"
                    "ds_read_b64 %2, %5\n\ts_waitcnt lgkmcnt(0)"
                    : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2])
-                   : "v"(a[0]), "v"(a[1]), "v"(a[2]), "n"(P * IPS)
+                   : "v"(a[0]), "v"(a[1]), "v"(a[2]), "n"(W)
                    : "memory");
     else
       asm volatile("s_waitcnt vmcnt(%8)\n\tds_read_b64 %0, %4\n\tds_read_b64 %1, %5\n\t"
                    "ds_read_b64 %2, %6\n\tds_read_b64 %3, %7\n\t"
                    "s_waitcnt lgkmcnt(0)"
                    : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
-                   : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "n"(P * IPS)
+                   : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "n"(W)
                    : "memory");
   }
 
@@ -328,49 +330,31 @@ template <int NQ, int IPS, int RR = FPHIP_GSO_RING> struct Ring
   {
     run_with(cnt, row, body, ncnt, nrow, PlainFetch{});
   }
+  static constexpr int IPS32 = (NQ + 3) / 4;  // 1 KiB instructions per 4-byte row (256 elements each)
   struct PlainFetch
   {
+    static constexpr int IPR = IPS;
   };
   struct GatherFetch
   {
+    static constexpr int IPR = IPS;
     const unsigned (&off)[NQ];
   };
   struct F32Fetch  // rows of float, widened to double (exact)
   {
+    static constexpr int IPR = IPS32;
   };
   struct I32Fetch  // rows of int32, delivered as the bit pattern of the sign-extended int64
   {
+    static constexpr int IPR = IPS32;
   };
-  // chosen at run time (wave-uniform): 8-byte rows, or 4-byte rows widened in registers
-  struct AutoF32Fetch
-  {
-    bool narrow;
-  };
-  struct AutoI32Fetch
-  {
-    bool narrow;
-  };
-  template <int P> __device__ __forceinline__ void consume(double (&v)[NQ], const AutoF32Fetch &f)
-  {
-    if (f.narrow)
-      consume<P>(v, F32Fetch{});
-    else
-      consume<P>(v, PlainFetch{});
-  }
-  template <int P> __device__ __forceinline__ void consume(double (&v)[NQ], const AutoI32Fetch &f)
-  {
-    if (f.narrow)
-      consume<P>(v, I32Fetch{});
-    else
-      consume<P>(v, PlainFetch{});
-  }
   template <int P> __device__ __forceinline__ void consume(double (&v)[NQ], const F32Fetch &)
   {
     const unsigned addr = base + tail * SLOT + lane * 4;
     tail                = (tail + 1 == R) ? 0 : tail + 1;
     --ahead;
     unsigned w[NQ];
-    read32<P>(w, addr);
+    read32<P * IPS32>(w, addr);
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
       v[q] = (double)__uint_as_float(w[q]);
@@ -381,7 +365,7 @@ template <int NQ, int IPS, int RR = FPHIP_GSO_RING> struct Ring
     tail                = (tail + 1 == R) ? 0 : tail + 1;
     --ahead;
     unsigned w[NQ];
-    read32<P>(w, addr);
+    read32<P * IPS32>(w, addr);
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
       v[q] = __longlong_as_double((long long)(int)w[q]);
@@ -391,7 +375,7 @@ template <int NQ, int IPS, int RR = FPHIP_GSO_RING> struct Ring
     const unsigned addr = base + tail * SLOT + lane * 8;
     tail                = (tail + 1 == R) ? 0 : tail + 1;
     --ahead;
-    read<P>(v, addr);
+    read<P * IPS>(v, addr);
   }
   template <int P> __device__ __forceinline__ void consume(double (&v)[NQ], const GatherFetch &g)
   {
@@ -402,7 +386,7 @@ template <int NQ, int IPS, int RR = FPHIP_GSO_RING> struct Ring
       a[q] = sb + g.off[q];
     tail = (tail + 1 == R) ? 0 : tail + 1;
     --ahead;
-    readg<P>(v, a);
+    readg<P * IPS>(v, a);
   }
   // dynamic number of newer rows in flight (the drain of a phase)
   template <class FetchP> __device__ __forceinline__ void consume_dyn(double (&v)[NQ], const FetchP &fp)
@@ -423,15 +407,19 @@ template <int NQ, int IPS, int RR = FPHIP_GSO_RING> struct Ring
   __device__ __forceinline__ void run_with(int cnt, RowA row, BodyF body, int ncnt, RowB nrow,
                                            const FetchP &fp)
   {
+    // The waits of this phase count FetchP::IPR instructions per newer row.  That is safe as long
+    // as every row in flight has AT LEAST that many: this phase's own rows are issued with exactly
+    // IPR, rows prefetched for the next phase always with the full IPS (>= any IPR).
+    constexpr int NI = FetchP::IPR;
     int issued  = ahead;  // rows of this phase issued so far
     int nissued = 0;      // rows of the next phase issued so far
     // fill the pipe
     while (ahead <= AHEAD)
     {
       if (issued < cnt)
-        issue(row(issued++));
+        issue<NI>(row(issued++));
       else if (nissued < ncnt)
-        issue(nrow(nissued++));
+        issue<IPS>(nrow(nissued++));
       else
         break;
     }
@@ -444,7 +432,7 @@ template <int NQ, int IPS, int RR = FPHIP_GSO_RING> struct Ring
       {
         double v[NQ];
         consume<AHEAD>(v, fp);
-        issue(row(issued++));
+        issue<NI>(row(issued++));
         body(s, v);
       }
       // steady state, refilled from the next phase
@@ -453,7 +441,7 @@ template <int NQ, int IPS, int RR = FPHIP_GSO_RING> struct Ring
       {
         double v[NQ];
         consume<AHEAD>(v, fp);
-        issue(nrow(nissued++));
+        issue<IPS>(nrow(nissued++));
         body(s, v);
       }
     }
@@ -523,7 +511,10 @@ __device__ bool update_row(Lattice<NQ> &T, Ring<NQ, IPS, RR> &ring, int kappa, i
                            }
                        });
   };
-  ring.run_with(n, gram_row, gram_body, last + 1, rec_row, typename Ring<NQ, IPS, RR>::AutoF32Fetch{narrow});
+  if (narrow)
+    ring.run_with(n, gram_row, gram_body, last + 1, rec_row, typename Ring<NQ, IPS, RR>::F32Fetch{});
+  else
+    ring.run(n, gram_row, gram_body, last + 1, rec_row);
   // ---- recurrence, gso_interface.cpp:143-158, column-oriented
   ring.run(last + 1, rec_row,
            [&](int k, const double(&v)[NQ])
@@ -820,7 +811,10 @@ __device__ __forceinline__ int babai_impl(Lattice<NQ> &T, Ring<NQ, IPS, RR> &rin
                            }
                          });
     };
-    ring.run_with(nsteps, b_row, axpy_body, 0, b_row, typename Ring<NQ, IPS, RR>::AutoI32Fetch{narrow});
+    if (narrow)
+      ring.run_with(nsteps, b_row, axpy_body, 0, b_row, typename Ring<NQ, IPS, RR>::I32Fetch{});
+    else
+      ring.run(nsteps, b_row, axpy_body);
     if (too_big)
       return -2;  // nothing has been stored yet: the basis is unchanged
     // ---- row_op_end: update_bf(kappa), gso.cpp:24-48
