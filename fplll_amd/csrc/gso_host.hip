@@ -45,6 +45,7 @@ struct fphip_gso
   float last_ms;
   int waves_per_block;
   int blocks_per_cu;
+  bool dirty;  // the integer basis was uploaded after the last (re)float of the rows
 };
 
 static int gfail(fphip_ctx *ctx, const char *what, hipError_t e)
@@ -178,6 +179,14 @@ struct LllArgs
 
 static int launch(fphip_gso *g, int kmin, int kend, double eta, int mode, const LllArgs *la = nullptr)
 {
+  if (mode == 2)
+    g->dirty = false;
+  else if (g->dirty)
+  {  // a sweep on a freshly uploaded basis: float the rows first (MatGSO::update_bf for every row)
+    const int rc0 = launch(g, 0, g->P.d, 0.0, 2);
+    if (rc0 != FPHIP_OK)
+      return rc0;
+  }
   const int need = (g->P.d > g->P.n ? g->P.d : g->P.n);
   const int nq   = (need + 63) / 64;
   const int wpb  = g->waves_per_block;
@@ -252,6 +261,7 @@ extern "C" int fphip_gso_set_basis(fphip_gso *g, int first, int count, const int
   const size_t rows = (size_t)g->P.d * count;
   GCHK(hipMemcpy2D(g->P.b + (size_t)first * g->P.d * g->P.ldn, (size_t)g->P.ldn * 8, b,
                    (size_t)g->P.n * 8, (size_t)g->P.n * 8, rows, hipMemcpyHostToDevice));
+  g->dirty = true;
   return FPHIP_OK;
 }
 
@@ -267,6 +277,7 @@ extern "C" int fphip_gso_broadcast_basis(fphip_gso *g, int src)
                           g->P.b + (size_t)src * g->P.d * g->P.ldn, per, hipMemcpyDeviceToDevice,
                           fphip_ctx_stream(g->ctx)));
   GCHK(hipStreamSynchronize(fphip_ctx_stream(g->ctx)));
+  g->dirty = true;
   return FPHIP_OK;
 }
 

@@ -191,3 +191,18 @@ def test_full_size_batch_is_consistent(ctx):
         assert np.array_equal(r0, g.get_r_matrix(L))
     _check_against_oracle(g, B - 1, b)
     g.close()
+
+
+def test_upload_without_explicit_refresh(ctx):
+    """The C ABI floats the rows itself on the first sweep after fphip_gso_set_basis."""
+    import ctypes
+    from fplll_amd.gso import MatGSOBatch
+    f = C.load_gso_fixture(os.path.join(C.GOLDEN, "gso_q48_p3.json"))
+    g = MatGSOBatch(ctx, 2, f["d"], f["n"])
+    b = np.ascontiguousarray(np.stack([f["b_in"]] * 2), dtype=np.int64)
+    assert g.lib.fphip_gso_set_basis(g.h, 0, 2, b.ctypes.data_as(ctypes.c_void_p)) == 0  # no refresh
+    st = g.size_reduction(0, f["d"])
+    assert list(st) == [1, 1]
+    assert np.array_equal(g.get_basis(0, 1)[0], f["b_out"])
+    assert np.array_equal(g.get_mu_matrix(1), f["mu1"])
+    g.close()
