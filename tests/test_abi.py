@@ -68,3 +68,17 @@ def test_product_code_never_touches_oracle():
                         continue  # build_oracle() compiles the checker; it never calls it
                     bad.append(p)
     assert not bad, bad
+
+
+def test_header_is_plain_c(tmp_path):
+    """The boundary is a C ABI: include/fplll_hip.h must compile as C (gcc) and as C++ (g++) with
+    nothing but the standard headers, and every entry point must be declared with C linkage."""
+    import subprocess
+    hdr = os.path.join(C.ROOT, "include", "fplll_hip.h")
+    csrc = tmp_path / "t.c"
+    csrc.write_text('#include "%s"\nint main(void) { return FPHIP_OK + (int)sizeof(fphip_enum_opts) * 0; }\n' % hdr)
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", str(csrc)], check=True)
+    cpp = tmp_path / "t.cpp"
+    cpp.write_text('#include "%s"\nint main() { return FPHIP_OK; }\n' % hdr)
+    subprocess.run(["g++", "-std=c++11", "-Wall", "-Werror", "-fsyntax-only", str(cpp)], check=True)
+    assert 'extern "C"' in open(hdr).read()
