@@ -20,6 +20,9 @@
  *                                 (what lll_reduction_zf<long,double> runs with LM_FAST, wrapper.cpp)
  *       fphip_gso_bkz           ← BKZReduction::bkz (empty strategies)      bkz.cpp:274-358,360-441,522-668
  *       fphip_gso_get_*         ← get_mu_exp/get_r_exp/row_expo accessors gso_interface.h:675-732
+ *   fphip_hh_*            ← MatHouseholder<Z_NR<long>,FP_NR<double>>   householder.h:70
+ *       fphip_hh_update_R       ← refresh_R_bf + update_R               householder.cpp:27-245
+ *       fphip_hh_hlll           ← HLLLReduction::hlll                   hlll.cpp:26-499
  *
  * Error convention: 0 = FPHIP_OK; FPHIP_UNSUPPORTED = instance declined, the caller must fall
  * back exactly as fplll does for a plugin returning ~uint64_t(0) (enum/enumerate_ext.cpp:88,
