@@ -63,6 +63,8 @@ static int gfail(fphip_ctx *ctx, const char *what, hipError_t e)
 
 extern "C" void fphip_gso_release_all(fphip_ctx *ctx) { (void)ctx; }
 
+static int gso_allocate(fphip_gso *g);
+
 extern "C" int fphip_gso_create(fphip_ctx *ctx, int batch, int d, int n, int row_expo,
                                 fphip_gso **out)
 {
@@ -88,6 +90,20 @@ extern "C" int fphip_gso_create(fphip_ctx *ctx, int batch, int d, int n, int row
   g->P.d        = d;
   g->P.n        = n;
   g->P.row_expo = row_expo ? 1 : 0;
+  const int rc  = gso_allocate(g);
+  if (rc != FPHIP_OK)
+  {
+    fphip_gso_destroy(g);  // frees whatever was allocated before the failure
+    return rc;
+  }
+  *out = g;
+  return FPHIP_OK;
+}
+
+static int gso_allocate(fphip_gso *g)
+{
+  fphip_ctx *ctx = g->ctx;
+  const int batch = g->P.batch, d = g->P.d, n = g->P.n;
   // leading dimensions padded to 16 elements: every row starts on a 128-byte line, so the DMA
   // windows that begin at column 0 waste no partial line (FPHIP_GSO_LD_ALIGN=2 keeps them dense)
   const char *la_s = getenv("FPHIP_GSO_LD_ALIGN");
@@ -132,7 +148,6 @@ extern "C" int fphip_gso_create(fphip_ctx *ctx, int batch, int d, int n, int row
   g->waves_per_block = w ? atoi(w) : 4;
   const char *bp     = getenv("FPHIP_GSO_BLOCKS_PER_CU");
   g->blocks_per_cu   = bp ? atoi(bp) : 0;  // 0 = as many as the LDS ring allows
-  *out               = g;
   return FPHIP_OK;
 }
 
@@ -166,8 +181,10 @@ extern "C" void fphip_gso_destroy(fphip_gso *g)
     hipFree(g->P.bkz_active);
   if (g->P.bkz_rows)
     hipFree(g->P.bkz_rows);
-  hipEventDestroy(g->ev[0]);
-  hipEventDestroy(g->ev[1]);
+  if (g->ev[0])
+    hipEventDestroy(g->ev[0]);
+  if (g->ev[1])
+    hipEventDestroy(g->ev[1]);
   delete g;
 }
 
@@ -376,12 +393,16 @@ extern "C" int fphip_gso_lll(fphip_gso *g, int kappa_min, int kappa_start, int k
 static int ensure_lll_buffers(fphip_gso *g)
 {
   const size_t B = (size_t)g->P.batch, d = g->P.d, ldd = g->P.ldd, ldn = g->P.ldn;
+  // (each buffer on its own: a failed allocation must not leave a half-initialised set behind)
   if (!g->P.gf)
-  {
     GCHK(hipMalloc((void **)&g->P.gf, B * d * ldd * sizeof(double) + 4096));
+  if (!g->P.vc)
     GCHK(hipMalloc((void **)&g->P.vc, B * d * sizeof(int)));
-    GCHK(hipMalloc((void **)&g->P.b2, B * d * ldn * sizeof(long long) + 4096));
+  if (!g->P.lll_info)
     GCHK(hipMalloc((void **)&g->P.lll_info, B * 4 * sizeof(int)));
+  if (!g->P.b2)
+  {
+    GCHK(hipMalloc((void **)&g->P.b2, B * d * ldn * sizeof(long long) + 4096));
     GCHK(hipMemset(g->P.b2, 0, B * d * ldn * sizeof(long long) + 4096));
     GCHK(hipDeviceSynchronize());
   }
@@ -468,11 +489,11 @@ extern "C" int fphip_gso_bkz(fphip_gso *g, int block_size, double delta, double 
     return rc;
   const size_t B = (size_t)g->P.batch, d = g->P.d;
   if (!g->P.enum_mu)
-  {
     GCHK(hipMalloc((void **)&g->P.enum_mu, B * (64 * 63 / 2) * sizeof(double)));
+  if (!g->P.bkz_active)
     GCHK(hipMalloc((void **)&g->P.bkz_active, B * sizeof(int)));
+  if (!g->P.bkz_rows)
     GCHK(hipMalloc((void **)&g->P.bkz_rows, B * sizeof(int)));
-  }
   std::vector<int> active(B, 1), st(B, 1), inf(4 * B, 0), one(4 * B), rows(B, (int)d);
   GCHK(hipMemcpy(g->P.bkz_active, active.data(), sizeof(int) * B, hipMemcpyHostToDevice));
   rc = launch(g, 0, g->P.d, 0.0, 2);  // bf / row_expo of every row from b
@@ -618,7 +639,7 @@ extern "C" int fphip_gso_get_row_expo(fphip_gso *g, int lattice, int64_t *row_ex
 
 extern "C" double fphip_gso_last_kernel_ms(const fphip_gso *g) { return g ? g->last_ms : 0.0; }
 
-// FETCH_SIZE calibration (not part of the product ABI; used by scripts/calib_fetch.py only)
+// FETCH_SIZE calibration (not part of the product ABI; used by tests/perf/calib_fetch.py only)
 namespace fphip
 {
 __global__ void gso_calib_kernel(const char *buf, size_t stride, int row_bytes, long long rows);
@@ -676,6 +697,9 @@ struct fphip_hh
       return gfail(h->ctx, #call, e_); \
   } while (0)
 
+static int hh_allocate(fphip_hh *h);
+extern "C" void fphip_hh_destroy(fphip_hh *h);
+
 extern "C" int fphip_hh_create(fphip_ctx *ctx, int batch, int d, int n, int row_expo, fphip_hh **out)
 {
   if (!ctx || !out)
@@ -698,6 +722,19 @@ extern "C" int fphip_hh_create(fphip_ctx *ctx, int batch, int d, int n, int row_
   if (h->P.ldn > 256)
     h->P.ldn = 256;
   h->P.row_expo = row_expo ? 1 : 0;
+  const int rc  = hh_allocate(h);
+  if (rc != FPHIP_OK)
+  {
+    fphip_hh_destroy(h);
+    return rc;
+  }
+  *out = h;
+  return FPHIP_OK;
+}
+
+static int hh_allocate(fphip_hh *h)
+{
+  const int batch = h->P.batch, d = h->P.d;
   const size_t B = (size_t)batch, ld = h->P.ldn, pad = 4096;
   HCHK(hipMalloc((void **)&h->P.b, B * d * ld * 8 + pad));
   HCHK(hipMalloc((void **)&h->P.V, B * d * ld * 8 + pad));
@@ -710,7 +747,6 @@ extern "C" int fphip_hh_create(fphip_ctx *ctx, int batch, int d, int n, int row_
   HCHK(hipMemset(h->P.R, 0, B * d * ld * 8 + pad));
   HCHK(hipEventCreate(&h->ev[0]));
   HCHK(hipEventCreate(&h->ev[1]));
-  *out = h;
   return FPHIP_OK;
 }
 
@@ -729,8 +765,10 @@ extern "C" void fphip_hh_destroy(fphip_hh *h)
     hipFree(h->P.bf);
   if (h->P.info)
     hipFree(h->P.info);
-  hipEventDestroy(h->ev[0]);
-  hipEventDestroy(h->ev[1]);
+  if (h->ev[0])
+    hipEventDestroy(h->ev[0]);
+  if (h->ev[1])
+    hipEventDestroy(h->ev[1]);
   delete h;
 }
 
