@@ -10,6 +10,7 @@
  * Every sum keeps the reference's order and its separate multiply / add roundings
  * (nr/nr_FP_d.inl:178; compile with -ffp-contract=off).
  */
+#define _DEFAULT_SOURCE /* M_E, M_PI, lgamma under -std=c11 */
 #include "oracle.h"
 
 #include <float.h>
@@ -615,63 +616,223 @@ static int svp_postprocessing(oracle_gso *g, int kappa, int bs, const double *so
   return 1;
 }
 
-/* returns 1 ok (clean flag in *clean), else a failure status */
-static int svp_reduction(oracle_gso *g, int kappa, int bs, double delta, double eta, int *clean,
-                         uint64_t *total_nodes)
+/* ---- BKZParam / Strategy (bkz_param.h:22-66,68-170) as the oracle sees them ---------------- */
+typedef struct
 {
-  int rc = lll_size_reduction(g, 0, kappa + 1, 0, eta);
-  if (rc != 1)
-    return rc;
-  double old_first   = R(g, kappa, kappa);
-  long old_first_expo = (long)(2 * g->row_expo[kappa]);
-  /* svp_preprocessing: lll(0, 0, kappa + bs) (no recursive preprocessing in the empty strategy) */
-  rc = oracle_gso_lll(g, 0, 0, kappa + bs, delta, eta, NULL);
-  if (rc != 1)
-    return rc;
-  /* radius, bkz.cpp:311-317 */
-  double max_dist    = R(g, kappa, kappa);
+  int block_size;
+  int flags;                      /* BKZ_GH_BND 0x80, BKZ_BOUNDED_LLL 0x10 (defs.h:262-275) */
+  double gh_factor;               /* BKZ_DEF_GH_FACTOR 1.1 */
+  double min_success_probability; /* BKZ_DEF_MIN_SUCCESS_PROBABILITY 0.5 */
+  int rerandomization_density;    /* BKZ_DEF_RERANDOMIZATION_DENSITY 3 */
+} bkz_par;
+
+typedef struct
+{
+  double delta;                      /* BKZReduction::delta = param.delta (bkz.cpp:38) */
+  double lll_delta, eta;             /* of the LLLReduction object */
+  const oracle_strategies *strat;    /* NULL: empty strategies */
+  oracle_rand_fn rnd;                /* gmp_urandomm_ui(RandGen::get_gmp_state(), n) */
+  void *rnd_user;
+  uint64_t nodes;
+  uint64_t enum_calls, rerandomizations;
+} bkz_ctx;
+
+/* MatGSOInterface::get_root_det / get_log_det, gso_interface.cpp:220-242 */
+static double get_root_det(oracle_gso *g, int start_row, int end_row)
+{
+  if (start_row < 0)
+    start_row = 0;
+  if (end_row > g->d)
+    end_row = g->d;
+  double h       = (double)(end_row - start_row);
+  double log_det = 0.0;
+  for (int i = start_row; i < end_row; ++i)
+  {
+    double r = ldexp(R(g, i, i), (int)(2 * g->row_expo[i])); /* get_r, gso_interface.h:720-732 */
+    log_det += log(r);
+  }
+  double root_det = log_det / h;
+  return exp(root_det);
+}
+
+/* adjust_radius_to_gh_bound, gso_interface.cpp:260-276 */
+static void adjust_radius_to_gh_bound(double *max_dist, long max_dist_expo, int block_size,
+                                      double root_det, double gh_factor)
+{
+  double t = (double)block_size / 2.0 + 1;
+  t        = lgamma(t);
+  t        = pow(M_E, t * 2.0 / (double)block_size);
+  t        = t / M_PI;
+  double f = t;
+  f        = f * root_det;
+  f        = ldexp(f, (int)-max_dist_expo);
+  f        = f * gh_factor;
+  if (f < *max_dist)
+    *max_dist = f;
+}
+
+/* BKZReduction::get_pruning (bkz.cpp:82-98) + Strategy::get_pruning (bkz_param.cpp:64-80):
+ * index into strat->prune_* of the pruning set whose gh_factor is closest, or -1 (no strategies) */
+static int get_pruning(oracle_gso *g, const bkz_ctx *cx, int kappa, int bs)
+{
+  const oracle_strategies *S = cx->strat;
+  if (!S)
+    return -1;
   long max_dist_expo = (long)(2 * g->row_expo[kappa]);
-  max_dist           = max_dist * delta;
-  /* EnumerationDyn::enumerate, enumerate.cpp:88-141 */
-  long normexp = -1;
-  for (int i = 0; i < bs; ++i)
+  double max_dist    = R(g, kappa, kappa);
+  double gh_max_dist = max_dist;
+  double root_det    = get_root_det(g, kappa, kappa + bs);
+  adjust_radius_to_gh_bound(&gh_max_dist, max_dist_expo, bs, root_det, 1.0);
+  double radius    = max_dist * pow(2, max_dist_expo);
+  double gh        = gh_max_dist * pow(2, max_dist_expo);
+  double gh_factor = radius / gh;
+  double closest   = pow(2, 80);
+  int best         = S->prune_off[bs];
+  for (int p = S->prune_off[bs]; p < S->prune_off[bs + 1]; ++p)
+    if (fabs(S->prune_gh[p] - gh_factor) < closest)
+    {
+      closest = fabs(S->prune_gh[p] - gh_factor);
+      best    = p;
+    }
+  return best;
+}
+
+/* BKZReduction::rerandomize_block, bkz.cpp:43-80 */
+static int rerandomize_block(oracle_gso *g, bkz_ctx *cx, int min_row, int max_row, int density)
+{
+  if (max_row - min_row < 2)
+    return 1;
+  cx->rerandomizations++;
+  size_t niter = 4 * (size_t)(max_row - min_row);
+  for (size_t i = 0; i < niter; ++i)
   {
-    long rexpo = (long)(2 * g->row_expo[i + kappa]);
-    long e     = rexpo + fexponent_l(R(g, i + kappa, i + kappa));
-    if (e > normexp)
-      normexp = e;
+    size_t a = cx->rnd(cx->rnd_user, (unsigned long)(max_row - min_row - 1)) + min_row;
+    size_t b = a;
+    while (b == a)
+      b = cx->rnd(cx->rnd_user, (unsigned long)(max_row - min_row - 1)) + min_row;
+    move_row(g, (int)b, (int)a);
   }
-  double maxdist = ldexp(max_dist, (int)(max_dist_expo - normexp));
-  double *rdiag  = (double *)calloc(bs, sizeof(double));
-  double *mut    = (double *)calloc((size_t)bs * bs, sizeof(double));
-  double *sol    = (double *)calloc(bs, sizeof(double));
+  for (long a = min_row; a < max_row - 2; ++a)
+    for (long i = 0; i < density; i++)
+    {
+      size_t b = cx->rnd(cx->rnd_user, (unsigned long)(max_row - (a + 1) - 1)) + a + 1;
+      if (cx->rnd(cx->rnd_user, 2))
+        row_addmul_we(g, (int)a, (int)b, 1.0, 0); /* row_add */
+      else
+        row_addmul_we(g, (int)a, (int)b, -1.0, 0); /* row_sub */
+    }
+  row_op_end_range(g, min_row, max_row);
+  return 1;
+}
+
+static int bkz_tour(oracle_gso *g, bkz_ctx *cx, const bkz_par *par, int min_row, int max_row,
+                    int *clean);
+
+/* BKZReduction::svp_preprocessing, bkz.cpp:100-124 */
+static int svp_preprocessing(oracle_gso *g, bkz_ctx *cx, const bkz_par *par, int kappa, int bs)
+{
+  int lll_start = (par->flags & 0x10) ? kappa : 0;
+  int rc        = oracle_gso_lll(g, lll_start, lll_start, kappa + bs, cx->lll_delta, cx->eta, NULL);
+  if (rc != 1)
+    return rc;
+  const oracle_strategies *S = cx->strat;
+  if (!S)
+    return 1;
+  for (int p = S->pre_off[bs]; p < S->pre_off[bs + 1]; ++p)
+  { /* BKZParam(*it, strategies, LLL_DEF_DELTA, BKZ_GH_BND): every other field at its default */
+    bkz_par prepar = {S->pre[p], 0x80, 1.1, 0.5, 3};
+    int dummy      = 1;
+    rc             = bkz_tour(g, cx, &prepar, kappa, kappa + bs, &dummy);
+    if (rc != 1)
+      return rc;
+  }
+  return 1;
+}
+
+/* BKZReduction::svp_reduction (primal), bkz.cpp:274-358.
+ * returns 1 ok (clean flag in *clean), else a failure status */
+static int svp_reduction(oracle_gso *g, bkz_ctx *cx, const bkz_par *par, int kappa, int bs, int *clean)
+{
+  const double eta = cx->eta;
+  int rc           = lll_size_reduction(g, 0, kappa + 1, 0, eta);
+  if (rc != 1)
+    return rc;
+  double old_first    = R(g, kappa, kappa);
+  long old_first_expo = (long)(2 * g->row_expo[kappa]);
+  int rerandomize     = 0;
+  double remaining_probability = 1.0;
+  double *rdiag   = (double *)calloc(bs, sizeof(double));
+  double *mut     = (double *)calloc((size_t)bs * bs, sizeof(double));
+  double *sol     = (double *)calloc(bs, sizeof(double));
   uint64_t *nodes = (uint64_t *)calloc(bs + 1, sizeof(uint64_t));
-  for (int i = 0; i < bs; ++i)
+  rc              = 1;
+  while (remaining_probability > 1. - par->min_success_probability)
   {
-    long rexpo = (long)(2 * g->row_expo[i + kappa]);
-    rdiag[i]   = ldexp(R(g, i + kappa, i + kappa), (int)(rexpo - normexp));
-    for (int j = i + 1; j < bs; ++j)
-      mut[(size_t)i * bs + j] =
-          ldexp(MU(g, j + kappa, i + kappa), (int)(g->row_expo[j + kappa] - g->row_expo[i + kappa]));
-  }
-  double best_dist = 0.0;
-  if (getenv("ORACLE_BKZ_DEBUG"))
-    fprintf(stderr, "call dim %d maxdist %a r0 %a\n", bs, maxdist, rdiag[0]);
-  int64_t nsol = oracle_enumerate(bs, mut, rdiag, NULL, maxdist, 0, NULL, NULL, NULL, nodes, sol,
-                                  &best_dist);
-  if (total_nodes)
-    for (int i = 0; i <= bs; ++i)
-      *total_nodes += nodes[i];
-  if (getenv("ORACLE_BKZ_DEBUG"))
-  {
+    if (rerandomize)
+      rerandomize_block(g, cx, kappa + 1, kappa + bs, par->rerandomization_density);
+    rc = svp_preprocessing(g, cx, par, kappa, bs);
+    if (rc != 1)
+      break;
+    /* radius, bkz.cpp:309-323 */
+    double max_dist    = R(g, kappa, kappa);
+    long max_dist_expo = (long)(2 * g->row_expo[kappa]);
+    max_dist           = max_dist * cx->delta;
+    if ((par->flags & 0x80) && bs > 30)
+    {
+      double root_det = get_root_det(g, kappa, kappa + bs);
+      adjust_radius_to_gh_bound(&max_dist, max_dist_expo, bs, root_det, par->gh_factor);
+    }
+    const int pr           = get_pruning(g, cx, kappa, bs);
+    const double *pruning  = NULL;
+    double expectation     = 1.0; /* PruningParams(): no pruning, expectation 1 (pruner.h:47) */
+    if (pr >= 0)
+    {
+      expectation = cx->strat->prune_exp[pr];
+      if (cx->strat->coeff_off[pr + 1] > cx->strat->coeff_off[pr])
+        pruning = cx->strat->coeff + cx->strat->coeff_off[pr];
+    }
+    /* EnumerationDyn::enumerate, enumerate.cpp:88-141 */
+    long normexp = -1;
+    for (int i = 0; i < bs; ++i)
+    {
+      long rexpo = (long)(2 * g->row_expo[i + kappa]);
+      long e     = rexpo + fexponent_l(R(g, i + kappa, i + kappa));
+      if (e > normexp)
+        normexp = e;
+    }
+    double maxdist = ldexp(max_dist, (int)(max_dist_expo - normexp));
+    memset(mut, 0, sizeof(double) * (size_t)bs * bs);
+    for (int i = 0; i < bs; ++i)
+    {
+      long rexpo = (long)(2 * g->row_expo[i + kappa]);
+      rdiag[i]   = ldexp(R(g, i + kappa, i + kappa), (int)(rexpo - normexp));
+      for (int j = i + 1; j < bs; ++j)
+        mut[(size_t)i * bs + j] =
+            ldexp(MU(g, j + kappa, i + kappa), (int)(g->row_expo[j + kappa] - g->row_expo[i + kappa]));
+    }
+    double best_dist = 0.0;
+    if (getenv("ORACLE_BKZ_DEBUG"))
+      fprintf(stderr, "call kappa %d dim %d maxdist %a r0 %a pruning %d\n", kappa, bs, maxdist, rdiag[0], pr);
+    int64_t nsol = oracle_enumerate(bs, mut, rdiag, pruning, maxdist, 0, NULL, NULL, NULL, nodes, sol,
+                                    &best_dist);
+    cx->enum_calls++;
     uint64_t t = 0;
     for (int i = 0; i <= bs; ++i)
       t += nodes[i];
-    fprintf(stderr, "   nodes %llu nsol %lld\n", (unsigned long long)t, (long long)nsol);
+    cx->nodes += t;
+    if (getenv("ORACLE_BKZ_DEBUG"))
+      fprintf(stderr, "   nodes %llu nsol %lld\n", (unsigned long long)t, (long long)nsol);
+    if (nsol > 0)
+    {
+      rc = svp_postprocessing(g, kappa, bs, sol);
+      if (rc != 1)
+        break;
+      rerandomize = 0;
+    }
+    else
+      rerandomize = 1;
+    remaining_probability *= (1 - expectation);
   }
-  rc = 1;
-  if (nsol > 0)
-    rc = svp_postprocessing(g, kappa, bs, sol);
   free(rdiag); free(mut); free(sol); free(nodes);
   if (rc != 1)
     return rc;
@@ -682,6 +843,32 @@ static int svp_reduction(oracle_gso *g, int kappa, int bs, double delta, double 
   long new_first_expo = (long)(2 * g->row_expo[kappa]);
   new_first           = ldexp(new_first, (int)(new_first_expo - old_first_expo));
   *clean              = (old_first <= new_first);
+  return 1;
+}
+
+/* BKZReduction::tour = trunc_tour + hkz, bkz.cpp:360-441 */
+static int bkz_tour(oracle_gso *g, bkz_ctx *cx, const bkz_par *par, int min_row, int max_row,
+                    int *clean_out)
+{
+  int clean = 1, c1 = 1, rc;
+  const int block_size = par->block_size;
+  for (int kappa = min_row; kappa < max_row - block_size; ++kappa)
+  { /* trunc_tour */
+    rc = svp_reduction(g, cx, par, kappa, block_size, &c1);
+    if (rc != 1)
+      return rc;
+    clean &= c1;
+  }
+  int hkz_min = max_row - block_size > 0 ? max_row - block_size : 0;
+  for (int kappa = hkz_min; kappa < max_row - 1; ++kappa)
+  { /* hkz */
+    rc = svp_reduction(g, cx, par, kappa, max_row - kappa, &c1);
+    if (rc != 1)
+      return rc;
+    clean &= c1;
+  }
+  lll_size_reduction(g, max_row - 1, max_row, max_row - 2, cx->eta); /* bkz.cpp:437 */
+  *clean_out = clean;
   return 1;
 }
 
@@ -702,12 +889,15 @@ static double current_slope(oracle_gso *g, int start_row, int stop_row)
   return v1 / v2;
 }
 
-/* BKZReduction::bkz().  use_max_loops: bit 0 = BKZ_MAX_LOOPS (with max_loops), bit 1 = BKZ_AUTO_ABORT
- * (BKZAutoAbort::test_abort with scale 1.0 and 5 tours, bkz.cpp:800-809, bkz_param.h defaults).
+/* BKZReduction::bkz() (bkz.cpp:522-668), primal BKZ.  flags: fplll's BKZ_MAX_LOOPS 0x4,
+ * BKZ_BOUNDED_LLL 0x10, BKZ_AUTO_ABORT 0x20 (BKZAutoAbort::test_abort with scale 1.0 and 5 tours,
+ * bkz.cpp:800-809), BKZ_GH_BND 0x80.  strat NULL = empty strategies.
  * returns 1 RED_SUCCESS, 8 RED_BKZ_LOOPS_LIMIT, else a failure status (<= 0).
- * info[0] = tours executed, info[1..2] = enumeration nodes (lo, hi 32 bits). */
-int oracle_gso_bkz(oracle_gso *g, int block_size, double delta, double eta, int use_max_loops,
-                   int max_loops, int *info)
+ * info[0] = tours executed, info[1..2] = enumeration nodes (lo, hi 32 bits), info[3] = enumeration
+ * calls, info[4] = rerandomisations. */
+int oracle_gso_bkz_param(oracle_gso *g, int block_size, double delta, double eta, int flags,
+                         int max_loops, double gh_factor, const oracle_strategies *strat,
+                         oracle_rand_fn rnd, void *rnd_user, int *info)
 {
   int num_rows = g->d;
   for (; num_rows > 0; num_rows--)
@@ -719,10 +909,18 @@ int oracle_gso_bkz(oracle_gso *g, int block_size, double delta, double eta, int 
     if (!z)
       break;
   }
-  uint64_t nodes = 0;
+  bkz_ctx cx;
+  memset(&cx, 0, sizeof cx);
+  cx.delta     = delta;
+  cx.lll_delta = delta;
+  cx.eta       = eta;
+  cx.strat     = strat;
+  cx.rnd       = rnd;
+  cx.rnd_user  = rnd_user;
+  bkz_par par  = {block_size, flags, gh_factor, 0.5, 3};
   int status = 1, tours = 0;
-  const int auto_abort = (use_max_loops & 2) != 0;
-  use_max_loops &= 1;
+  const int auto_abort    = (flags & 0x20) != 0;
+  const int use_max_loops = (flags & 0x4) != 0;
   int no_dec       = -1;
   double old_slope = DBL_MAX; /* numeric_limits<double>::max(), bkz.h BKZAutoAbort ctor */
   if (block_size < 2)
@@ -746,31 +944,13 @@ int oracle_gso_bkz(oracle_gso *g, int block_size, double delta, double eta, int 
       if (no_dec >= 5)
         break;
     }
-    int clean = 1, c1 = 1, rc;
-    /* trunc_tour */
-    for (int kappa = 0; kappa < num_rows - block_size; ++kappa)
+    int clean = 1;
+    int rc    = bkz_tour(g, &cx, &par, 0, num_rows, &clean);
+    if (rc != 1)
     {
-      rc = svp_reduction(g, kappa, block_size, delta, eta, &c1, &nodes);
-      if (rc != 1)
-      {
-        status = rc;
-        goto done;
-      }
-      clean &= c1;
+      status = rc;
+      goto done;
     }
-    /* hkz */
-    int min_row = num_rows - block_size > 0 ? num_rows - block_size : 0;
-    for (int kappa = min_row; kappa < num_rows - 1; ++kappa)
-    {
-      rc = svp_reduction(g, kappa, num_rows - kappa, delta, eta, &c1, &nodes);
-      if (rc != 1)
-      {
-        status = rc;
-        goto done;
-      }
-      clean &= c1;
-    }
-    lll_size_reduction(g, num_rows - 1, num_rows, num_rows - 2, eta); /* bkz.cpp:437 */
     ++tours;
     if (clean || block_size >= num_rows)
       break;
@@ -779,10 +959,29 @@ done:
   if (info)
   {
     info[0] = tours;
-    info[1] = (int)(nodes & 0xffffffffu);
-    info[2] = (int)(nodes >> 32);
+    info[1] = (int)(cx.nodes & 0xffffffffu);
+    info[2] = (int)(cx.nodes >> 32);
+    info[3] = (int)cx.enum_calls;
+    info[4] = (int)cx.rerandomizations;
   }
   return status;
+}
+
+/* the strategy-less form used by the device parity tests: use_max_loops bit 0 = BKZ_MAX_LOOPS,
+ * bit 1 = BKZ_AUTO_ABORT.  info[3]: tours, nodes lo, nodes hi. */
+int oracle_gso_bkz(oracle_gso *g, int block_size, double delta, double eta, int use_max_loops,
+                   int max_loops, int *info)
+{
+  int inf5[5];
+  int flags = ((use_max_loops & 1) ? 0x4 : 0) | ((use_max_loops & 2) ? 0x20 : 0);
+  int st    = oracle_gso_bkz_param(g, block_size, delta, eta, flags, max_loops, 1.1, NULL, NULL, NULL, inf5);
+  if (info)
+  {
+    info[0] = inf5[0];
+    info[1] = inf5[1];
+    info[2] = inf5[2];
+  }
+  return st;
 }
 
 const double *oracle_gso_mu(const oracle_gso *g) { return g->mu; }

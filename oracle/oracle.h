@@ -74,6 +74,33 @@ int oracle_gso_lll(oracle_gso *g, int kappa_min, int kappa_start, int kappa_end,
  * 8 RED_BKZ_LOOPS_LIMIT, <= 0 failure.  info[3] (nullable): tours, nodes lo, nodes hi. */
 int oracle_gso_bkz(oracle_gso *g, int block_size, double delta, double eta, int use_max_loops,
                    int max_loops, int *info);
+/* Strategies (bkz_param.h:22-66; the content of a strategies JSON, bkz_param.cpp:82-157), flattened:
+ * block size b has preprocessing block sizes pre[pre_off[b] .. pre_off[b+1]) and pruning sets
+ * prune_off[b] .. prune_off[b+1]; set p has gh_factor prune_gh[p], expectation prune_exp[p] and the
+ * coefficients coeff[coeff_off[p] .. coeff_off[p+1]) (none = no pruning).  Every block size
+ * 0..max_block_size has at least one pruning set (bkz_param.cpp:150-154). */
+typedef struct
+{
+  int max_block_size;
+  const int *pre_off;      /* [max_block_size + 2] */
+  const int *pre;
+  const int *prune_off;    /* [max_block_size + 2] */
+  const double *prune_gh;
+  const double *prune_exp;
+  const int *coeff_off;    /* [number of pruning sets + 1] */
+  const double *coeff;
+} oracle_strategies;
+/* gmp_urandomm_ui(RandGen::get_gmp_state(), n) of the reference (nr/nr_rand.inl); the tests supply
+ * it from the same libgmp (oracle/gmp_rng.c) so that rerandomize_block (bkz.cpp:43-80) draws the
+ * same numbers. */
+typedef unsigned long (*oracle_rand_fn)(void *user, unsigned long n);
+/* BKZReduction::bkz() with a BKZParam(block_size, strategies, delta, flags, max_loops, ...,
+ * gh_factor): preprocessing tours, pruning selection, GH bound, rerandomisation (bkz.cpp:43-124,
+ * 274-441, 522-668).  flags are fplll's (MAX_LOOPS 0x4, BOUNDED_LLL 0x10, AUTO_ABORT 0x20, GH_BND
+ * 0x80).  info[5]: tours, nodes lo, nodes hi, enumeration calls, rerandomisations. */
+int oracle_gso_bkz_param(oracle_gso *g, int block_size, double delta, double eta, int flags,
+                         int max_loops, double gh_factor, const oracle_strategies *strat,
+                         oracle_rand_fn rnd, void *rnd_user, int *info);
 /* raw (scaled) state access; true values need the row exponents (gso_interface.h:694-732) */
 const double *oracle_gso_mu(const oracle_gso *g);      /* d×d */
 const double *oracle_gso_r(const oracle_gso *g);       /* d×d */

@@ -639,6 +639,50 @@ static int cmd_bkzfix(int argc, char **argv)
     for (int j = 0; j < n; ++j)
       os << ((i || j) ? "," : "") << b0(i, j).get_si();
   os << "],\n";
+  // REFDRV_STRATEGIES=<json>: BKZ with preprocessing / pruning strategies (load_strategies_json);
+  // REFDRV_BKZ_FLAGS: extra BKZFlags (0x80 GH_BND, 0x10 BOUNDED_LLL); REFDRV_RNG_SEED: state of
+  // RandGen (rerandomize_block draws from it) at the start of bkz()
+  vector<Strategy> loaded;
+  if (getenv("REFDRV_STRATEGIES"))
+  {
+    loaded = load_strategies_json(getenv("REFDRV_STRATEGIES"));
+    while ((int)loaded.size() <= block_size)
+    {
+      loaded.emplace_back();
+      loaded.back().pruning_parameters.emplace_back(PruningParams());
+    }
+    // the strategies as the reference holds them, flattened (oracle.h: oracle_strategies)
+    std::ostringstream po, pv, ro, rg, re, co, cv;
+    int np = 0, npr = 0, nc = 0;
+    for (size_t bs = 0; bs < loaded.size(); ++bs)
+    {
+      po << (bs ? "," : "") << np;
+      ro << (bs ? "," : "") << npr;
+      for (int pb : loaded[bs].preprocessing_block_sizes)
+        pv << (np++ ? "," : "") << pb;
+      for (const PruningParams &pp : loaded[bs].pruning_parameters)
+      {
+        rg << (npr ? "," : "") << hexd(pp.gh_factor);
+        re << (npr ? "," : "") << hexd(pp.expectation);
+        co << (npr ? "," : "") << nc;
+        for (double c : pp.coefficients)
+          cv << (nc++ ? "," : "") << hexd(c);
+        ++npr;
+      }
+    }
+    po << "," << np;
+    ro << "," << npr;
+    co << (npr ? "," : "") << nc;
+    os << "\"strategies\":{\"max_block_size\":" << loaded.size() - 1 << ",\"pre_off\":[" << po.str()
+       << "],\"pre\":[" << pv.str() << "],\"prune_off\":[" << ro.str() << "],\"prune_gh\":["
+       << rg.str() << "],\"prune_exp\":[" << re.str() << "],\"coeff_off\":[" << co.str()
+       << "],\"coeff\":[" << cv.str() << "]},\n";
+  }
+  const int extra_flags = getenv("REFDRV_BKZ_FLAGS") ? (int)strtol(getenv("REFDRV_BKZ_FLAGS"), 0, 0) : 0;
+  const long rng_seed   = getenv("REFDRV_RNG_SEED") ? atol(getenv("REFDRV_RNG_SEED")) : 0;
+  os << "\"flags\":" << ((max_loops > 0 ? BKZ_MAX_LOOPS : BKZ_DEFAULT) | extra_flags |
+                         (getenv("REFDRV_BKZ_AUTO_ABORT") ? BKZ_AUTO_ABORT : 0))
+     << ",\n\"gh_factor\":" << hexd(BKZ_DEF_GH_FACTOR) << ",\n\"rng_seed\":" << rng_seed << ",\n";
   ZZ_mat<long> b = b0;
   double secs = 0;
   int status = 0;
@@ -646,11 +690,12 @@ static int cmd_bkzfix(int argc, char **argv)
   for (int rep = 0; rep < reps; ++rep)
   {
     b = b0;
-    vector<Strategy> strategies;
-    int flags = max_loops > 0 ? BKZ_MAX_LOOPS : BKZ_DEFAULT;
+    vector<Strategy> strategies = loaded;
+    int flags = (max_loops > 0 ? BKZ_MAX_LOOPS : BKZ_DEFAULT) | extra_flags;
     if (getenv("REFDRV_BKZ_AUTO_ABORT"))
       flags |= BKZ_AUTO_ABORT;
     BKZParam par(block_size, strategies, LLL_DEF_DELTA, flags, max_loops);
+    RandGen::init_with_seed(rng_seed);
     auto t0 = std::chrono::steady_clock::now();
     MatGSO<Z_NR<long>, FP_NR<double>> M(b, u, ut, GSO_ROW_EXPO);
     LLLReduction<Z_NR<long>, FP_NR<double>> L(M, LLL_DEF_DELTA, LLL_DEF_ETA, LLL_DEFAULT);

@@ -67,6 +67,21 @@ def oracle_lib():
     return _oracle
 
 
+_gmp_rng = None
+
+
+def gmp_rng_lib():
+    """oracle/gmp_rng.c: the reference's RandGen stream (same libgmp) for rerandomize_block."""
+    global _gmp_rng
+    if _gmp_rng is None:
+        so = os.path.join(ROOT, "oracle", "liboracle_gmprng.so")
+        if not os.path.exists(so):
+            subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "port"])
+        _gmp_rng = ctypes.CDLL(so)
+        _gmp_rng.oracle_gmp_rng_next.restype = ctypes.c_ulong
+    return _gmp_rng
+
+
 SUBSOLCB = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_double, ctypes.POINTER(ctypes.c_double),
                             ctypes.c_int)
 
@@ -201,6 +216,45 @@ class OracleGSO:
                                      max_loops, info.ctypes.data_as(ctypes.c_void_p))
         return st, info
 
+    def bkz_param(self, block_size, delta, eta, flags, max_loops, gh_factor, strategies, rng_seed):
+        """BKZReduction::bkz with strategies (oracle_gso_bkz_param).  strategies: the flattened dict
+        of a bkzs_* fixture or None.  Returns (status, info[5])."""
+        lib = self.lib
+
+        class Strat(ctypes.Structure):
+            _fields_ = [("max_block_size", ctypes.c_int), ("pre_off", ctypes.c_void_p),
+                        ("pre", ctypes.c_void_p), ("prune_off", ctypes.c_void_p),
+                        ("prune_gh", ctypes.c_void_p), ("prune_exp", ctypes.c_void_p),
+                        ("coeff_off", ctypes.c_void_p), ("coeff", ctypes.c_void_p)]
+
+        keep = []
+        sp = None
+        if strategies is not None:
+            def arr(key, dt):
+                a = np.ascontiguousarray(strategies[key], dtype=dt)
+                if a.size == 0:
+                    a = np.zeros(1, dtype=dt)
+                keep.append(a)
+                return a.ctypes.data
+            st = Strat(int(strategies["max_block_size"]), arr("pre_off", np.int32), arr("pre", np.int32),
+                       arr("prune_off", np.int32), arr("prune_gh", np.float64),
+                       arr("prune_exp", np.float64), arr("coeff_off", np.int32),
+                       arr("coeff", np.float64))
+            keep.append(st)
+            sp = ctypes.byref(st)
+        rng = gmp_rng_lib()
+        rng.oracle_gmp_rng_seed(ctypes.c_ulong(rng_seed))
+        fn = ctypes.cast(rng.oracle_gmp_rng_next, ctypes.c_void_p)
+        lib.oracle_gso_bkz_param.restype = ctypes.c_int
+        lib.oracle_gso_bkz_param.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_double,
+                                             ctypes.c_double, ctypes.c_int, ctypes.c_int,
+                                             ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p,
+                                             ctypes.c_void_p, ctypes.c_void_p]
+        info = np.zeros(5, dtype=np.int32)
+        status = lib.oracle_gso_bkz_param(self.h, block_size, delta, eta, flags, max_loops, gh_factor,
+                                          sp, fn, None, info.ctypes.data_as(ctypes.c_void_p))
+        return status, info
+
     def _arr(self, fn, shape, dtype):
         p = getattr(self.lib, fn)(self.h)
         return np.ctypeslib.as_array(p, shape=shape).astype(dtype).copy()
@@ -267,11 +321,24 @@ def bkz_fixtures():
     return sorted(glob.glob(os.path.join(GOLDEN, "bkz_*.json")))
 
 
+def bkz_strategy_fixtures():
+    return sorted(glob.glob(os.path.join(GOLDEN, "bkzs_*.json")))
+
+
 def load_bkz_fixture(path):
     with open(path) as f:
         j = json.load(f)
     d, n = j["d"], j["n"]
     out = {k: j[k] for k in ("d", "n", "block_size", "max_loops", "nodes")}
+    if "strategies" in j:
+        S = dict(j["strategies"])
+        for k in ("prune_gh", "prune_exp", "coeff"):
+            S[k] = [float.fromhex(v) for v in S[k]]
+        out["strategies"] = S
+    if "flags" in j:
+        out["flags"] = j["flags"]
+        out["gh_factor"] = float.fromhex(j["gh_factor"])
+        out["rng_seed"] = j["rng_seed"]
     out["auto_abort"] = bool(j.get("auto_abort", 0))
     out["name"] = os.path.basename(path)[:-5]
     out["status"] = BKZ_REF_STATUS_TO_OURS[j["ref_status"]]

@@ -57,6 +57,20 @@ $D bkzfix q 72 36 16 2 12 2 > $G/bkz_q72_b12_loops2.json
 $D bkzfix r 30  0 40 4  8 0 > $G/bkz_r30_b8.json
 $D bkzfix u 24  0 30 5 24 0 > $G/bkz_u24_hkz.json
 $D bkzfix q 60 30 12 7 16 0 > $G/bkz_q60_b16.json
+# --- BKZ with strategies (preprocessing tours, pruning selection, GH bound, rerandomisation):
+#     pruning coefficients from the reference's pruner on an 80-dim q-ary profile (genstrat),
+#     preprocessing / expectations set by make_strategies.py; REFDRV_RNG_SEED fixes RandGen
+T=$(mktemp -d)
+$D dumpbasis 80 40 20 3 20 > $T/b80.txt
+$D genstrat $T/b80.txt 40 > $T/gen.json
+python3 $G/make_strategies.py $T/gen.json $T/stratA.json 40 14 34 1.0
+python3 $G/make_strategies.py $T/gen.json $T/stratB.json 40 14 34 0.6
+REFDRV_STRATEGIES=$T/stratA.json REFDRV_BKZ_FLAGS=0x80 REFDRV_RNG_SEED=5 $D bkzfix q 64 32 14 3 40 2 > $G/bkzs_q64_b40_pre_gh.json
+REFDRV_STRATEGIES=$T/stratB.json REFDRV_BKZ_FLAGS=0x80 REFDRV_RNG_SEED=5 $D bkzfix q 64 32 14 3 40 2 > $G/bkzs_q64_b40_rerand.json
+REFDRV_STRATEGIES=$T/stratA.json REFDRV_BKZ_FLAGS=0x80 REFDRV_BKZ_AUTO_ABORT=1 REFDRV_RNG_SEED=9 $D bkzfix q 56 28 12 4 36 0 > $G/bkzs_q56_b36_autoabort.json
+REFDRV_STRATEGIES=$T/stratB.json REFDRV_BKZ_FLAGS=0x10 REFDRV_RNG_SEED=11 $D bkzfix q 64 32 14 6 34 1 > $G/bkzs_q64_b34_bounded_lll.json
+REFDRV_STRATEGIES=$T/stratB.json REFDRV_BKZ_FLAGS=0x80 REFDRV_RNG_SEED=13 $D bkzfix r 40 0 40 4 32 2 > $G/bkzs_r40_b32_rerand.json
+rm -rf $T
 # --- C3 (BASELINE configs[2]): the 180-dim q-ary lattice, LLL + BKZ-20 by the reference, its
 #     beta=60 blocks as the plugin sees them, and pruner-generated strategies for the tour bench
 $D dumpbasis 180 90 20 0 20 > $G/basis_q180_seed0_lll_bkz20.txt
