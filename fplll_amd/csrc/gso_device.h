@@ -56,6 +56,45 @@ struct GsoBatch
   int *bkz_active;  // BKZ kernel: [batch] 0 = leave this lattice alone (its reduction has ended)
   int *bkz_rows;    // BKZ kernel: [batch] number of rows without the trailing zero rows
 };
+// ---- BKZ with strategies (bkzs_kernel.hip) ------------------------------------------------------
+#define FPHIP_BKZS_MAX_DEPTH 4  /* nested tour() activations: the BKZ tour + 3 levels of preprocessing */
+#define FPHIP_BKZS_PLAN_MAX 448 /* 4*63 row moves + 3*61 row additions of one rerandomize_block */
+// Device copy of the strategies (bkz_param.h:22-66), flattened like fphip_strategies
+// (include/fplll_hip.h); pre_off == nullptr: no strategies (EmptyStrategy for every block size).
+struct BkzStrat
+{
+  int max_block_size;
+  const int *pre_off;    // [max_block_size + 2]
+  const int *pre;
+  const int *coeff_off;  // [number of pruning sets + 1]
+  const double *coeff;
+};
+// One mailbox per lattice in pinned, host-coherent memory: the wave asks the host for the two
+// decisions that need host libraries (see bkzs_kernel.hip).  The wave fills the request, stores
+// req_seq = n (release) and spins until rsp_seq == n.
+struct BkzMail
+{
+  unsigned long long req_seq;  // device -> host
+  unsigned long long rsp_seq;  // host -> device
+  // request
+  int type;     // 1: radius + pruning set of a block; 2: rerandomisation plan for rows [lo, hi)
+  int bs;       // type 1: block size
+  int flags;    // type 1: BKZParam::flags of the tour (GH_BND 0x80); 0x10000 = a preprocessing tour
+  int lo, hi;   // type 2
+  int density;  // type 2
+  int done;     // the lattice's reduction has ended (diagnostics)
+  int pad0;
+  double delta;
+  double r[64];  // type 1: r(kappa+i, kappa+i) as stored (without the row exponents) ...
+  int e2[64];    //         ... and 2 * row_expo[kappa+i]
+  // response
+  double max_dist;     // type 1: enumeration radius, scaled by 2^-e2[0] like r[0]
+  double expectation;  // type 1: success probability of the chosen pruning set
+  int prune;           // type 1: index of the chosen pruning set (into coeff_off), -1 = none
+  int n_moves, n_ops;  // type 2: plan[0..n_moves) = move_row(b, a) as b | a << 8, then n_ops row
+  int pad1;            //         additions row a +/- row b as a | b << 8 | (add ? 1 : 0) << 16
+  unsigned plan[FPHIP_BKZS_PLAN_MAX];
+};
 // Batched Householder state (MatHouseholder<Z_NR<long>, FP_NR<double>>): b, V, R are [batch][d][ldn]
 // row-major (lane = column), sigma / rexp [batch][d].
 struct HhBatch

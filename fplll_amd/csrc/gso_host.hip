@@ -11,6 +11,7 @@
 #include <limits>
 #include <cstring>
 #include <utility>
+#include <algorithm>
 #include <vector>
 
 #include "../../include/fplll_hip.h"
@@ -26,6 +27,10 @@ template <int NQ> __global__ void gso_sweep_kernel(GsoBatch P, int kmin, int ken
 template <int NQ>
 __global__ void bkz_kernel(GsoBatch P, int block_size, double delta, double eta, double logdelta,
                            int use_max_loops, int max_loops, int stack_doubles);
+template <int NQ>
+__global__ void bkzs_kernel(GsoBatch P, BkzStrat S, BkzMail *mailbox, int *abort_flag, int block_size,
+                            int top_flags, double delta, double eta, double logdelta, int max_loops,
+                            int stack_doubles);
 template <int NQ> __global__ void hlll_kernel(HhBatch P, double delta, double theta, long long iter_cap);
 template <int NQ>
 __global__ void lll_kernel(GsoBatch P, int kmin, int kstart, int kend, double delta, double eta,
@@ -608,6 +613,334 @@ extern "C" int fphip_gso_bkz(fphip_gso *g, int block_size, double delta, double 
   if (info)
     memcpy(info, inf.data(), sizeof(int) * 4 * B);
   return FPHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// BKZ with strategies: BKZReduction::bkz() with a BKZParam(block_size, strategies, delta, flags,
+// max_loops, ..., gh_factor) — recursive preprocessing tours, pruning sets chosen by the radius /
+// Gaussian-heuristic ratio, the GH radius bound, the success-probability loop with
+// rerandomize_block (bkz.cpp:43-124, 274-441, 522-668).  The wave of each lattice runs the whole
+// reduction (bkzs_kernel.hip); this thread serves its mailbox requests while the kernel is in
+// flight: the radius / pruning decision (host libm: log, exp, lgamma, pow — the reference's own
+// roundings) and the rerandomisation plan (drawn from the caller's generator, rnd(user, lattice,
+// n) = gmp_urandomm_ui(state of that lattice, n)).
+// ---------------------------------------------------------------------------------------------
+namespace
+{
+// adjust_radius_to_gh_bound, gso_interface.cpp:260-276
+void adjust_radius_to_gh_bound(double &max_dist, long max_dist_expo, int block_size, double root_det,
+                               double gh_factor)
+{
+  double t = (double)block_size / 2.0 + 1;
+  t        = lgamma(t);
+  t        = pow(M_E, t * 2.0 / (double)block_size);
+  t        = t / M_PI;
+  double f = t;
+  f        = f * root_det;
+  f        = std::ldexp(f, (int)-max_dist_expo);
+  f        = f * gh_factor;
+  if (f < max_dist)
+    max_dist = f;
+}
+
+struct BkzsHost
+{
+  const fphip_strategies *S;
+  double gh_factor;
+  fphip_rand_fn rnd;
+  void *rnd_user;
+};
+
+// type 1: radius (bkz.cpp:309-323) and pruning set (get_pruning :82-98, Strategy::get_pruning
+// bkz_param.cpp:64-80) of the block whose r_ii the wave has written
+void serve_radius(const BkzsHost &H, BkzMail *m)
+{
+  const int bs      = m->bs;
+  const long expo   = m->e2[0];
+  const double r0   = m->r[0];
+  double max_dist   = r0 * m->delta;  // max_dist *= delta
+  // MatGSOInterface::get_root_det / get_log_det, gso_interface.cpp:220-242
+  double log_det = 0.0;
+  for (int i = 0; i < bs; ++i)
+  {
+    const double h = std::ldexp(m->r[i], m->e2[i]);  // get_r(h, i, i)
+    log_det += std::log(h);
+  }
+  double root_det = log_det / (double)bs;
+  root_det        = std::exp(root_det);
+  if ((m->flags & 0x80) && bs > 30)
+    adjust_radius_to_gh_bound(max_dist, expo, bs, root_det,
+                              (m->flags & 0x10000) ? 1.1 /* BKZ_DEF_GH_FACTOR of a preprocessing BKZParam */ : H.gh_factor);
+  int best           = -1;
+  double expectation = 1.0;
+  if (H.S)
+  {
+    double gh_max_dist = r0;
+    adjust_radius_to_gh_bound(gh_max_dist, expo, bs, root_det, 1.0);
+    const double radius    = r0 * pow(2, expo);
+    const double gh        = gh_max_dist * pow(2, expo);
+    const double gh_factor = radius / gh;
+    double closest         = pow(2, 80);
+    best                   = H.S->prune_off[bs];
+    for (int p = H.S->prune_off[bs]; p < H.S->prune_off[bs + 1]; ++p)
+      if (fabs(H.S->prune_gh[p] - gh_factor) < closest)
+      {
+        closest = fabs(H.S->prune_gh[p] - gh_factor);
+        best    = p;
+      }
+    expectation = H.S->prune_exp[best];
+  }
+  m->max_dist    = max_dist;
+  m->expectation = expectation;
+  m->prune       = best;
+}
+
+// type 2: the random choices of rerandomize_block(min_row, max_row, density), bkz.cpp:43-80 — they
+// do not depend on the basis, so the whole call is drawn at once, in the reference's order
+int serve_plan(const BkzsHost &H, int lattice, BkzMail *m)
+{
+  const int min_row = m->lo, max_row = m->hi, density = m->density;
+  int np = 0, n_moves = 0, n_ops = 0;
+  if (max_row - min_row >= 2 && H.rnd)
+  {
+    const size_t niter = 4 * (size_t)(max_row - min_row);
+    for (size_t i = 0; i < niter && np < FPHIP_BKZS_PLAN_MAX; ++i)
+    {
+      const size_t a = H.rnd(H.rnd_user, lattice, (unsigned long)(max_row - min_row - 1)) + min_row;
+      size_t b       = a;
+      while (b == a)
+        b = H.rnd(H.rnd_user, lattice, (unsigned long)(max_row - min_row - 1)) + min_row;
+      m->plan[np++] = (unsigned)b | ((unsigned)a << 8);
+      ++n_moves;
+    }
+    for (long a = min_row; a < max_row - 2; ++a)
+      for (long i = 0; i < density && np < FPHIP_BKZS_PLAN_MAX; i++)
+      {
+        const size_t b = H.rnd(H.rnd_user, lattice, (unsigned long)(max_row - (a + 1) - 1)) + a + 1;
+        const unsigned add = H.rnd(H.rnd_user, lattice, 2) ? 1u : 0u;
+        m->plan[np++] = (unsigned)a | ((unsigned)b << 8) | (add << 16);
+        ++n_ops;
+      }
+  }
+  m->n_moves = n_moves;
+  m->n_ops   = n_ops;
+  return np;
+}
+}  // namespace
+
+extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double delta, double eta,
+                                        int flags, int max_loops, double gh_factor,
+                                        const fphip_strategies *S, fphip_rand_fn rnd, void *rnd_user,
+                                        int *status, int *info)
+{
+  if (!g)
+    return FPHIP_ERROR;
+  // one wavefront enumerates a block: sizes up to 64; BKZ_MAX_LOOPS, BKZ_BOUNDED_LLL, BKZ_GH_BND
+  if (block_size > 64 || (flags & ~(0x4 | 0x10 | 0x80)))
+    return FPHIP_UNSUPPORTED;
+  const int bsz = block_size < g->P.d ? block_size : g->P.d;
+  if (S)
+  {
+    if (!rnd)
+    {
+      snprintf(fphip_ctx_errbuf(g->ctx), 512, "fphip_gso_bkz_strategies: strategies need the caller's generator");
+      return FPHIP_ERROR;
+    }
+    if (S->max_block_size < bsz || !S->pre_off || !S->prune_off || !S->coeff_off)
+    {
+      snprintf(fphip_ctx_errbuf(g->ctx), 512, "fphip_gso_bkz_strategies: strategies do not cover block size %d", bsz);
+      return FPHIP_ERROR;
+    }
+    // every block size needs a pruning set whose coefficient vector is empty or of that size;
+    // preprocessing block sizes must be proper (2 <= p < b) and nest at most MAX_DEPTH - 1 deep
+    std::vector<int> depth(bsz + 1, 0);
+    for (int b = 0; b <= bsz; ++b)
+    {
+      if (S->prune_off[b + 1] <= S->prune_off[b])
+        return FPHIP_UNSUPPORTED;
+      for (int p = S->prune_off[b]; p < S->prune_off[b + 1]; ++p)
+      {
+        const int len = S->coeff_off[p + 1] - S->coeff_off[p];
+        if (len != 0 && len != b)
+          return FPHIP_UNSUPPORTED;
+      }
+      for (int p = S->pre_off[b]; p < S->pre_off[b + 1]; ++p)
+      {
+        const int pb = S->pre[p];
+        if (pb < 2 || pb >= b)
+          return FPHIP_UNSUPPORTED;
+        // a tour of block size pb reaches every block size <= pb through hkz
+        int dmax = 0;
+        for (int c = 2; c <= pb; ++c)
+          dmax = std::max(dmax, depth[c]);
+        depth[b] = std::max(depth[b], dmax + 1);
+      }
+    }
+    int dtop = 0;
+    for (int b = 2; b <= bsz; ++b)
+      dtop = std::max(dtop, depth[b]);
+    if (dtop + 1 > FPHIP_BKZS_MAX_DEPTH)
+      return FPHIP_UNSUPPORTED;
+  }
+  int rc = ensure_lll_buffers(g);
+  if (rc != FPHIP_OK)
+    return rc;
+  const size_t B = (size_t)g->P.batch;
+  if (!g->P.enum_mu)
+    GCHK(hipMalloc((void **)&g->P.enum_mu, B * (64 * 63 / 2) * sizeof(double)));
+  if (!g->P.bkz_active)
+    GCHK(hipMalloc((void **)&g->P.bkz_active, B * sizeof(int)));
+  if (!g->P.bkz_rows)
+    GCHK(hipMalloc((void **)&g->P.bkz_rows, B * sizeof(int)));
+
+  // device copy of what the kernel reads of the strategies; mailboxes; abort flag
+  BkzStrat DS;
+  memset(&DS, 0, sizeof DS);
+  int *d_pre_off = nullptr, *d_pre = nullptr, *d_coeff_off = nullptr, *d_abort = nullptr;
+  double *d_coeff = nullptr;
+  BkzMail *mail   = nullptr;
+  auto cleanup = [&]()
+  {
+    hipFree(d_pre_off);
+    hipFree(d_pre);
+    hipFree(d_coeff_off);
+    hipFree(d_coeff);
+    hipFree(d_abort);
+    if (mail)
+      hipHostFree(mail);
+  };
+#define BCHK(call)                         \
+  do                                       \
+  {                                        \
+    hipError_t e_ = (call);                \
+    if (e_ != hipSuccess)                  \
+    {                                      \
+      cleanup();                           \
+      return gfail(g->ctx, #call, e_);     \
+    }                                      \
+  } while (0)
+  if (S)
+  {
+    const int nb   = S->max_block_size + 2;
+    const int npre = S->pre_off[S->max_block_size + 1];
+    const int nset = S->prune_off[S->max_block_size + 1];
+    const int ncoe = S->coeff_off[nset];
+    BCHK(hipMalloc((void **)&d_pre_off, sizeof(int) * nb));
+    BCHK(hipMalloc((void **)&d_pre, sizeof(int) * (npre > 0 ? npre : 1)));
+    BCHK(hipMalloc((void **)&d_coeff_off, sizeof(int) * (nset + 1)));
+    BCHK(hipMalloc((void **)&d_coeff, sizeof(double) * (ncoe > 0 ? ncoe : 1)));
+    BCHK(hipMemcpy(d_pre_off, S->pre_off, sizeof(int) * nb, hipMemcpyHostToDevice));
+    if (npre > 0)
+      BCHK(hipMemcpy(d_pre, S->pre, sizeof(int) * npre, hipMemcpyHostToDevice));
+    BCHK(hipMemcpy(d_coeff_off, S->coeff_off, sizeof(int) * (nset + 1), hipMemcpyHostToDevice));
+    if (ncoe > 0)
+      BCHK(hipMemcpy(d_coeff, S->coeff, sizeof(double) * ncoe, hipMemcpyHostToDevice));
+    DS.max_block_size = S->max_block_size;
+    DS.pre_off        = d_pre_off;
+    DS.pre            = d_pre;
+    DS.coeff_off      = d_coeff_off;
+    DS.coeff          = d_coeff;
+  }
+  BCHK(hipMalloc((void **)&d_abort, sizeof(int)));
+  BCHK(hipMemset(d_abort, 0, sizeof(int)));
+  BCHK(hipHostMalloc((void **)&mail, B * sizeof(BkzMail), hipHostMallocCoherent | hipHostMallocMapped));
+  memset(mail, 0, B * sizeof(BkzMail));
+
+  rc = launch(g, 0, g->P.d, 0.0, 2);  // bf / row_expo of every row from b
+  if (rc != FPHIP_OK)
+  {
+    cleanup();
+    return rc;
+  }
+  const int need = (g->P.d > g->P.n ? g->P.d : g->P.n);
+  const int nq   = (need + 63) / 64;
+  const int wpb  = g->waves_per_block;
+  const int bs   = block_size < 2 ? 2 : bsz;
+  const int stack_doubles = (bs * (bs + 1)) / 2 + 2;
+  const size_t ring_bytes = (size_t)wpb * FPHIP_RING_REDUCE * (size_t)((nq + 1) / 2) * 1024;
+  const size_t lds = ring_bytes + (size_t)wpb * stack_doubles * sizeof(double) +
+                     (size_t)wpb * FPHIP_BKZS_MAX_DEPTH * 64;  // sizeof(BkzsFrame) == 64
+  if (ring_bytes > 64 * 1024 || lds > 160 * 1024)
+  {
+    cleanup();
+    snprintf(fphip_ctx_errbuf(g->ctx), 512, "bkz: %zu bytes of LDS per workgroup do not fit", lds);
+    return FPHIP_ERROR;
+  }
+  int bpc = (int)((160 * 1024) / lds);
+  if (bpc * wpb > 32)
+    bpc = 32 / wpb;
+  int grid      = (g->P.batch + wpb - 1) / wpb;
+  const int cap = fphip_ctx_num_cus(g->ctx) * (bpc > 0 ? bpc : 1);
+  if (grid > cap)
+    grid = cap;
+  hipStream_t s     = fphip_ctx_stream(g->ctx);
+  const double logd = std::log(delta);
+  if (lds > 64 * 1024)
+  {
+    switch (nq)
+    {
+    case 1: BCHK(hipFuncSetAttribute((const void *)bkzs_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); break;
+    case 2: BCHK(hipFuncSetAttribute((const void *)bkzs_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); break;
+    case 3: BCHK(hipFuncSetAttribute((const void *)bkzs_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); break;
+    default: BCHK(hipFuncSetAttribute((const void *)bkzs_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); break;
+    }
+  }
+  BCHK(hipEventRecord(g->ev[0], s));
+  switch (nq)
+  {
+  case 1: hipLaunchKernelGGL(bkzs_kernel<1>, dim3(grid), dim3(wpb * 64), lds, s, g->P, DS, mail, d_abort, block_size, flags, delta, eta, logd, max_loops, stack_doubles); break;
+  case 2: hipLaunchKernelGGL(bkzs_kernel<2>, dim3(grid), dim3(wpb * 64), lds, s, g->P, DS, mail, d_abort, block_size, flags, delta, eta, logd, max_loops, stack_doubles); break;
+  case 3: hipLaunchKernelGGL(bkzs_kernel<3>, dim3(grid), dim3(wpb * 64), lds, s, g->P, DS, mail, d_abort, block_size, flags, delta, eta, logd, max_loops, stack_doubles); break;
+  default: hipLaunchKernelGGL(bkzs_kernel<4>, dim3(grid), dim3(wpb * 64), lds, s, g->P, DS, mail, d_abort, block_size, flags, delta, eta, logd, max_loops, stack_doubles); break;
+  }
+  BCHK(hipGetLastError());
+  BCHK(hipEventRecord(g->ev[1], s));
+  // ---- serve the mailboxes while the kernel runs ------------------------------------------------
+  {
+    BkzsHost H{S, gh_factor, rnd, rnd_user};
+    std::vector<unsigned long long> handled(B, 0);
+    for (;;)
+    {
+      for (size_t L = 0; L < B; ++L)
+      {
+        BkzMail *m = &mail[L];
+        const unsigned long long seq = __atomic_load_n(&m->req_seq, __ATOMIC_ACQUIRE);
+        if (seq == handled[L])
+          continue;
+        if (m->type == 1)
+          serve_radius(H, m);
+        else if (m->type == 2)
+          serve_plan(H, (int)L, m);
+        handled[L] = seq;
+        __atomic_store_n(&m->rsp_seq, seq, __ATOMIC_RELEASE);
+      }
+      const hipError_t q = hipStreamQuery(s);
+      if (q == hipSuccess)
+        break;
+      if (q != hipErrorNotReady)
+      {
+        cleanup();
+        return gfail(g->ctx, "bkzs_kernel", q);
+      }
+    }
+  }
+  float ms = 0;
+  BCHK(hipEventElapsedTime(&ms, g->ev[0], g->ev[1]));
+  std::vector<int> st(B), inf(4 * B);
+  BCHK(hipMemcpy(st.data(), g->P.status, sizeof(int) * B, hipMemcpyDeviceToHost));
+  BCHK(hipMemcpy(inf.data(), g->P.lll_info, sizeof(int) * 4 * B, hipMemcpyDeviceToHost));
+#undef BCHK
+  cleanup();
+  std::swap(g->P.b, g->P.b2);  // the kernel wrote the rows in position order into b2
+  rc = launch(g, 0, g->P.d, 0.0, 2);
+  if (rc == FPHIP_OK)
+    rc = launch(g, 0, g->P.d, 0.0, 0);
+  g->last_ms = ms;
+  if (status)
+    memcpy(status, st.data(), sizeof(int) * B);
+  if (info)
+    memcpy(info, inf.data(), sizeof(int) * 4 * B);
+  return rc;
 }
 
 extern "C" int fphip_gso_get_mu(fphip_gso *g, int lattice, double *mu)

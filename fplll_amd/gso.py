@@ -124,6 +124,52 @@ class MatGSOBatch:
         self._chk(rc, "bkz")
         return st, info
 
+    def bkz_strategies(self, block_size, strategies, rnd, delta=LLL_DEF_DELTA, eta=LLL_DEF_ETA,
+                       max_loops=0, gh_bnd=False, bounded_lll=False, gh_factor=1.1):
+        """BKZReduction::bkz() with a strategies table (preprocessing tours, pruning, GH bound,
+        rerandomisation; bkz.cpp:43-124, 274-441, 522-668) on every (LLL-reduced) lattice.
+        strategies: dict with the flattened arrays of include/fplll_hip.h's fphip_strategies
+        (max_block_size, pre_off, pre, prune_off, prune_gh, prune_exp, coeff_off, coeff) or None.
+        rnd(lattice, n) -> gmp_urandomm_ui of that lattice's generator (fplll: RandGen).
+        Returns (status[batch], info[batch][4])."""
+        class Strat(ctypes.Structure):
+            _fields_ = [("max_block_size", ctypes.c_int), ("pre_off", ctypes.c_void_p),
+                        ("pre", ctypes.c_void_p), ("prune_off", ctypes.c_void_p),
+                        ("prune_gh", ctypes.c_void_p), ("prune_exp", ctypes.c_void_p),
+                        ("coeff_off", ctypes.c_void_p), ("coeff", ctypes.c_void_p)]
+
+        keep = []
+        sp = None
+        if strategies is not None:
+            def arr(key, dt):
+                a = np.ascontiguousarray(strategies[key], dtype=dt)
+                if a.size == 0:
+                    a = np.zeros(1, dtype=dt)
+                keep.append(a)
+                return a.ctypes.data
+            st_ = Strat(int(strategies["max_block_size"]), arr("pre_off", np.int32),
+                        arr("pre", np.int32), arr("prune_off", np.int32),
+                        arr("prune_gh", np.float64), arr("prune_exp", np.float64),
+                        arr("coeff_off", np.int32), arr("coeff", np.float64))
+            keep.append(st_)
+            sp = ctypes.byref(st_)
+        RND = ctypes.CFUNCTYPE(ctypes.c_ulong, ctypes.c_void_p, ctypes.c_int, ctypes.c_ulong)
+        cb = RND(lambda _u, lattice, n: int(rnd(lattice, n))) if rnd is not None else RND(0)
+        fn = self.lib.fphip_gso_bkz_strategies
+        fn.restype = ctypes.c_int
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_int,
+                       ctypes.c_int, ctypes.c_double, ctypes.c_void_p, RND, ctypes.c_void_p,
+                       ctypes.c_void_p, ctypes.c_void_p]
+        st = np.zeros(self.batch, dtype=np.int32)
+        info = np.zeros((self.batch, 4), dtype=np.int32)
+        flags = (0x4 if max_loops > 0 else 0) | (0x80 if gh_bnd else 0) | (0x10 if bounded_lll else 0)
+        rc = fn(self.h, block_size, delta, eta, flags, max_loops, gh_factor, sp, cb, None,
+                st.ctypes.data_as(ctypes.c_void_p), info.ctypes.data_as(ctypes.c_void_p))
+        if rc == _lib.FPHIP_UNSUPPORTED:
+            raise NotImplementedError("block sizes above 64 / deeper preprocessing stay on the CPU")
+        self._chk(rc, "bkz_strategies")
+        return st, info
+
     def get_mu_matrix(self, lattice=0):
         m = np.empty((self.d, self.d), dtype=np.float64)
         self._chk(self.lib.fphip_gso_get_mu(self.h, lattice, m.ctypes.data_as(ctypes.c_void_p)), "get_mu")

@@ -19,6 +19,7 @@
  *       fphip_gso_lll           ← LLLReduction::lll (+ MatGSO::move_row)   lll.cpp:44-164, gso.cpp:289-366
  *                                 (what lll_reduction_zf<long,double> runs with LM_FAST, wrapper.cpp)
  *       fphip_gso_bkz           ← BKZReduction::bkz (empty strategies)      bkz.cpp:274-358,360-441,522-668
+ *       fphip_gso_bkz_strategies ← BKZReduction::bkz with strategies       bkz.cpp:43-124 (+ the above)
  *       fphip_gso_get_*         ← get_mu_exp/get_r_exp/row_expo accessors gso_interface.h:675-732
  *   fphip_hh_*            ← MatHouseholder<Z_NR<long>,FP_NR<double>>   householder.h:70
  *       fphip_hh_update_R       ← refresh_R_bf + update_R               householder.cpp:27-245
@@ -176,6 +177,42 @@ int fphip_gso_lll(fphip_gso *g, int kappa_min, int kappa_start, int kappa_end, d
                                      one and the slope test runs on the host */
 int fphip_gso_bkz(fphip_gso *g, int block_size, double delta, double eta, int flags, int max_loops,
                   int *status, int *info);
+/* BKZ WITH strategies: BKZReduction::bkz() with BKZParam(block_size, strategies, delta, flags,
+ * max_loops, ..., gh_factor) — what bkz_reduction(b, beta, flags, FT_DOUBLE) runs with a strategies
+ * file (BASELINE configs 3-4): recursive preprocessing tours (svp_preprocessing, bkz.cpp:100-124),
+ * the pruning set closest to radius / GH (get_pruning :82-98, bkz_param.cpp:64-80), the
+ * Gaussian-heuristic radius bound (BKZ_GH_BND, gso_interface.cpp:220-276), the
+ * success-probability loop and rerandomize_block (:43-80, 299-345).  One launch for the whole
+ * batch; the calling thread answers the waves' requests for the two decisions that need host
+ * libraries (libm for the radius, the caller's generator for the rerandomisation) until the kernel
+ * has finished.  strategies = the content of a strategies JSON (load_strategies_json,
+ * bkz_param.cpp:82-157), flattened: block size b has preprocessing block sizes
+ * pre[pre_off[b] .. pre_off[b+1]) and pruning sets prune_off[b] .. prune_off[b+1]; set p has
+ * gh_factor prune_gh[p], expectation prune_exp[p] and coefficients
+ * coeff[coeff_off[p] .. coeff_off[p+1]) (empty = no pruning).  NULL = empty strategies.
+ * rnd(user, lattice, n) must return gmp_urandomm_ui(<generator of that lattice>, n): fplll passes
+ * RandGen::get_gmp_state() (nr/nr_rand.inl:38-43); each lattice of a batch has its own stream, the
+ * one a run of the reference on that lattice alone would draw from.
+ * flags: FPHIP_BKZ_MAX_LOOPS, FPHIP_BKZ_BOUNDED_LLL, FPHIP_BKZ_GH_BND (fplll's values).
+ * FPHIP_UNSUPPORTED: block sizes above 64, other flags, preprocessing nested deeper than 3 levels.
+ * status / info as fphip_gso_bkz; status -7 = a mailbox request was not answered in time. */
+#define FPHIP_BKZ_BOUNDED_LLL 0x10
+#define FPHIP_BKZ_GH_BND 0x80
+typedef struct fphip_strategies
+{
+  int max_block_size;
+  const int *pre_off;      /* [max_block_size + 2] */
+  const int *pre;
+  const int *prune_off;    /* [max_block_size + 2] */
+  const double *prune_gh;
+  const double *prune_exp;
+  const int *coeff_off;    /* [number of pruning sets + 1] */
+  const double *coeff;
+} fphip_strategies;
+typedef unsigned long (*fphip_rand_fn)(void *user, int lattice, unsigned long n);
+int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double delta, double eta, int flags,
+                             int max_loops, double gh_factor, const fphip_strategies *strategies,
+                             fphip_rand_fn rnd, void *rnd_user, int *status, int *info);
 /* raw stored values, d×d row-major; true values carry the row exponents exactly as
  * get_mu/get_r do (gso_interface.h:694-732): mu·2^(e_i-e_j), r·2^(e_i+e_j) */
 int fphip_gso_get_mu(fphip_gso *g, int lattice, double *mu);

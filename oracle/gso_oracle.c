@@ -773,6 +773,10 @@ static int svp_reduction(oracle_gso *g, bkz_ctx *cx, const bkz_par *par, int kap
     rc = svp_preprocessing(g, cx, par, kappa, bs);
     if (rc != 1)
       break;
+    if (getenv("ORACLE_BKZ_DEBUG"))
+      for (int i = kappa; i < kappa + bs; ++i)
+        if (g->valid_cols[i] < i + 1) /* the enumeration would read a stale GSO row */
+          fprintf(stderr, "STALE row %d (valid %d) in block kappa %d bs %d\n", i, g->valid_cols[i], kappa, bs);
     /* radius, bkz.cpp:309-323 */
     double max_dist    = R(g, kappa, kappa);
     long max_dist_expo = (long)(2 * g->row_expo[kappa]);

@@ -82,6 +82,35 @@ def gmp_rng_lib():
     return _gmp_rng
 
 
+class GmpStreams:
+    """One GMP generator per lattice, each RandGen::init_with_seed(seed) (nr/nr_rand.inl:20-24):
+    gmp_randinit_default + gmp_randseed_ui; next(lattice, n) = gmp_urandomm_ui.  Straight from the
+    libgmp the reference build links — the product takes the generator from its caller."""
+
+    def __init__(self, batch, seed):
+        import ctypes.util
+        path = "/opt/conda/lib/libgmp.so"
+        if not os.path.exists(path):
+            path = ctypes.util.find_library("gmp")
+        self.g = ctypes.CDLL(path)
+        # (getattr: a name starting with two underscores would be mangled inside a class body)
+        self._init = getattr(self.g, "__gmp_randinit_default")
+        self._seed = getattr(self.g, "__gmp_randseed_ui")
+        self._next = getattr(self.g, "__gmp_urandomm_ui")
+        self._next.restype = ctypes.c_ulong
+        self.states = []
+        for _ in range(batch):
+            buf = ctypes.create_string_buffer(64)  # gmp_randstate_t
+            self._init(buf)
+            self._seed(buf, ctypes.c_ulong(seed))
+            self.states.append(buf)
+        self.draws = 0
+
+    def __call__(self, lattice, n):
+        self.draws += 1
+        return self._next(self.states[lattice], ctypes.c_ulong(n))
+
+
 SUBSOLCB = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_double, ctypes.POINTER(ctypes.c_double),
                             ctypes.c_int)
 
