@@ -130,7 +130,8 @@ class MatGSOBatch:
         rerandomisation; bkz.cpp:43-124, 274-441, 522-668) on every (LLL-reduced) lattice.
         strategies: dict with the flattened arrays of include/fplll_hip.h's fphip_strategies
         (max_block_size, pre_off, pre, prune_off, prune_gh, prune_exp, coeff_off, coeff) or None.
-        rnd(lattice, n) -> gmp_urandomm_ui of that lattice's generator (fplll: RandGen).
+        rnd(lattice, n) -> gmp_urandomm_ui of that lattice's generator (fplll: RandGen); a Python
+        callable or the address (ctypes.c_void_p) of a C function with fphip_rand_fn's signature.
         Returns (status[batch], info[batch][4])."""
         class Strat(ctypes.Structure):
             _fields_ = [("max_block_size", ctypes.c_int), ("pre_off", ctypes.c_void_p),
@@ -154,7 +155,12 @@ class MatGSOBatch:
             keep.append(st_)
             sp = ctypes.byref(st_)
         RND = ctypes.CFUNCTYPE(ctypes.c_ulong, ctypes.c_void_p, ctypes.c_int, ctypes.c_ulong)
-        cb = RND(lambda _u, lattice, n: int(rnd(lattice, n))) if rnd is not None else RND(0)
+        if rnd is None:
+            cb = RND(0)
+        elif callable(rnd):
+            cb = RND(lambda _u, lattice, n: int(rnd(lattice, n)))
+        else:  # the address of a C function with fphip_rand_fn's signature
+            cb = ctypes.cast(rnd, RND)
         fn = self.lib.fphip_gso_bkz_strategies
         fn.restype = ctypes.c_int
         fn.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_int,

@@ -31,3 +31,35 @@ unsigned long oracle_gmp_rng_next(void *user, unsigned long n)
     oracle_gmp_rng_seed(0);
   return gmp_urandomm_ui(state, n);
 }
+
+/* ---- one generator per lattice of a batch (the device strategy-BKZ tests) ------------------------
+ * matches fphip_rand_fn (include/fplll_hip.h): rnd(user, lattice, n).  Each stream is
+ * RandGen::init_with_seed(seed) — what a run of the reference on that lattice alone starts from. */
+#include <stdlib.h>
+static gmp_randstate_t *streams;
+static int n_streams;
+static unsigned long long stream_draws;
+
+void oracle_gmp_streams_init(int batch, unsigned long seed)
+{
+  for (int i = 0; i < n_streams; ++i)
+    gmp_randclear(streams[i]);
+  free(streams);
+  streams      = (gmp_randstate_t *)malloc(sizeof(gmp_randstate_t) * (size_t)batch);
+  n_streams    = batch;
+  stream_draws = 0;
+  for (int i = 0; i < batch; ++i)
+  {
+    gmp_randinit_default(streams[i]);
+    gmp_randseed_ui(streams[i], seed);
+  }
+}
+
+unsigned long oracle_gmp_streams_next(void *user, int lattice, unsigned long n)
+{
+  (void)user;
+  ++stream_draws;
+  return gmp_urandomm_ui(streams[lattice], n);
+}
+
+unsigned long long oracle_gmp_streams_draws(void) { return stream_draws; }

@@ -82,6 +82,16 @@ def gmp_rng_lib():
     return _gmp_rng
 
 
+def gmp_streams_native(batch, seed):
+    """The same streams as GmpStreams, served by C (oracle/gmp_rng.c): returns (address of an
+    fphip_rand_fn, draws()) — a Python callback per random number would dominate the run time of
+    the rerandomisation fixtures."""
+    lib = gmp_rng_lib()
+    lib.oracle_gmp_streams_init(ctypes.c_int(batch), ctypes.c_ulong(seed))
+    lib.oracle_gmp_streams_draws.restype = ctypes.c_ulonglong
+    return ctypes.cast(lib.oracle_gmp_streams_next, ctypes.c_void_p), lib.oracle_gmp_streams_draws
+
+
 class GmpStreams:
     """One GMP generator per lattice, each RandGen::init_with_seed(seed) (nr/nr_rand.inl:20-24):
     gmp_randinit_default + gmp_randseed_ui; next(lattice, n) = gmp_urandomm_ui.  Straight from the

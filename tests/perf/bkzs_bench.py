@@ -32,7 +32,7 @@ cpu_s = time.time() - t
 ctx = fplll_amd.Context(0)
 g = MatGSOBatch(ctx, batch, f["d"], f["n"])
 g.set_basis(np.stack([f["b_in"]] * batch))
-rnd = C.GmpStreams(batch, f["rng_seed"])
+rnd, draws = C.gmp_streams_native(batch, f["rng_seed"])
 t = time.time()
 st, info = g.bkz_strategies(f["block_size"], f["strategies"], rnd, f["delta"], f["eta"],
                             max_loops=f["max_loops"], gh_bnd=bool(f["flags"] & 0x80),
@@ -49,6 +49,6 @@ print(json.dumps({
     "cpu_port_s_per_reduction": cpu_s, "cpu_reductions_per_s_1core": 1.0 / cpu_s,
     "speedup_vs_1core": (batch / wall) * cpu_s,
     "enum_calls_per_lattice": int(info[0][3]), "nodes_per_lattice": nodes[0],
-    "rng_draws": rnd.draws}))
+    "rng_draws": int(draws())}))
 g.close()
 ctx.close()

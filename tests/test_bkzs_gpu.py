@@ -25,17 +25,73 @@ def test_bkz_strategies_matches_reference(ctx, path):
     batch = 3
     g = MatGSOBatch(ctx, batch, f["d"], f["n"])
     g.set_basis(np.stack([f["b_in"]] * batch))
-    rnd = C.GmpStreams(batch, f["rng_seed"])
+    # the caller's generator: natively for the long streams, through a Python callable for one
+    # fixture (both forms of the mirror's `rnd` argument)
+    if "r40" in path:
+        py = C.GmpStreams(batch, f["rng_seed"])
+        rnd, draws = py, (lambda: py.draws)
+    else:
+        rnd, draws = C.gmp_streams_native(batch, f["rng_seed"])
     st, info = g.bkz_strategies(f["block_size"], f["strategies"], rnd, f["delta"], f["eta"],
                                 max_loops=f["max_loops"], gh_bnd=bool(f["flags"] & 0x80),
                                 bounded_lll=bool(f["flags"] & 0x10), gh_factor=f["gh_factor"])
     out = g.get_basis()
     nodes = [(int(i[1]) & 0xffffffff) | (int(i[2]) << 32) for i in info]
     print("status", st, "expected", f["status"], "tours/calls", info[:, 0], info[:, 3], "nodes", nodes,
-          "expected", f["nodes"], "kernel ms", g.last_kernel_ms, "rng draws", rnd.draws)
+          "expected", f["nodes"], "kernel ms", g.last_kernel_ms, "rng draws", draws())
     for L in range(batch):
         bad = np.nonzero((out[L] != f["b_out"]).any(axis=1))[0]
         assert st[L] == f["status"], (L, st, info)
         assert bad.size == 0, ("first differing row", int(bad[0]), "of", f["d"], "nodes", nodes[L], f["nodes"])
         assert nodes[L] == f["nodes"]
+    g.close()
+
+
+def _qary(rng, d, k, q):
+    b = np.zeros((d, d), dtype=np.int64)
+    b[:k, :k] = np.eye(k, dtype=np.int64)
+    b[:k, k:] = rng.integers(0, q, size=(k, d - k))
+    b[k:, k:] = q * np.eye(d - k, dtype=np.int64)
+    return b
+
+
+def oracle_side(bs, beta, S, flags, max_loops, seed):
+    """oracle LLL then oracle BKZ-with-strategies of every lattice (its own generator each)."""
+    res = []
+    for b in bs:
+        o = C.OracleGSO(b)
+        ost, _ = o.lll()
+        assert ost == 1
+        o2 = C.OracleGSO(o.b)
+        st, info = o2.bkz_param(beta, 0.99, 0.51, flags, max_loops, 1.1, S, seed)
+        res.append((st, (int(info[1]) & 0xffffffff) | (int(info[2]) << 32), int(info[4]), o2.b.copy()))
+        o.close()
+        o2.close()
+    return res
+
+
+@pytest.mark.parametrize("d,beta,which", [(44, 34, "rerand"), (52, 36, "pre_gh")])
+def test_heterogeneous_batch_vs_oracle(ctx, d, beta, which):
+    """DIFFERENT lattices in one launch (every wave has its own mailbox, generator and schedule):
+    device LLL + device strategy-BKZ against oracle LLL + oracle strategy-BKZ."""
+    from fplll_amd.gso import MatGSOBatch
+    S = C.load_bkz_fixture([p for p in C.bkz_strategy_fixtures() if which in p][0])["strategies"]
+    rng = np.random.default_rng(4000 + d)
+    B = 4
+    bs = [_qary(rng, d, d // 2, int(rng.integers(500, 20000))) for _ in range(B)]
+    flags, max_loops, seed = 0x4 | 0x80, 1, 17
+    want = oracle_side(bs, beta, S, flags, max_loops, seed)
+    g = MatGSOBatch(ctx, B, d, d)
+    g.set_basis(np.stack(bs))
+    st, _ = g.lll()
+    assert np.all(st == 1)
+    rnd, draws = C.gmp_streams_native(B, seed)
+    st, info = g.bkz_strategies(beta, S, rnd, max_loops=max_loops, gh_bnd=True)
+    out = g.get_basis(0, B)
+    print("rerandomisations (oracle)", [w[2] for w in want], "rng draws", draws(), "kernel ms", g.last_kernel_ms)
+    for L in range(B):
+        nodes = (int(info[L][1]) & 0xffffffff) | (int(info[L][2]) << 32)
+        assert st[L] == want[L][0]
+        assert nodes == want[L][1]
+        assert np.array_equal(out[L], want[L][3])
     g.close()
