@@ -172,6 +172,15 @@ __global__ void __launch_bounds__(256)
     double *mu_blk = P.enum_mu + (size_t)L * (64 * 63 / 2);
     BkzMail *mail  = mailbox + L;
     SlotMap<NQ> M;
+    if (P.bkz_active[L] == 0)
+    {  // this lattice's reduction has ended in an earlier launch (BKZ_AUTO_ABORT runs one tour per
+       // launch): keep its basis
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+        M.sl[q] = lane + 64 * q;
+      lll_write_ordered<NQ>(T, M, P.b2 + (size_t)L * d * ldn);
+      continue;
+    }
     lll_init_state<NQ>(T, C, M);
 
     int vp = 0;

@@ -735,8 +735,9 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
 {
   if (!g)
     return FPHIP_ERROR;
-  // one wavefront enumerates a block: sizes up to 64; BKZ_MAX_LOOPS, BKZ_BOUNDED_LLL, BKZ_GH_BND
-  if (block_size > 64 || (flags & ~(0x4 | 0x10 | 0x80)))
+  // one wavefront enumerates a block: sizes up to 64; BKZ_MAX_LOOPS, BKZ_BOUNDED_LLL, BKZ_AUTO_ABORT,
+  // BKZ_GH_BND
+  if (block_size > 64 || (flags & ~(0x4 | 0x10 | 0x20 | 0x80)))
     return FPHIP_UNSUPPORTED;
   const int bsz = block_size < g->P.d ? block_size : g->P.d;
   if (S)
@@ -846,12 +847,6 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
   BCHK(hipHostMalloc((void **)&mail, B * sizeof(BkzMail), hipHostMallocCoherent | hipHostMallocMapped));
   memset(mail, 0, B * sizeof(BkzMail));
 
-  rc = launch(g, 0, g->P.d, 0.0, 2);  // bf / row_expo of every row from b
-  if (rc != FPHIP_OK)
-  {
-    cleanup();
-    return rc;
-  }
   const int need = (g->P.d > g->P.n ? g->P.d : g->P.n);
   const int nq   = (need + 63) / 64;
   const int wpb  = g->waves_per_block;
@@ -885,22 +880,29 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
     default: BCHK(hipFuncSetAttribute((const void *)bkzs_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); break;
     }
   }
-  BCHK(hipEventRecord(g->ev[0], s));
-  switch (nq)
+  BkzsHost H{S, gh_factor, rnd, rnd_user};
+  std::vector<unsigned long long> handled(B, 0);
+  std::vector<int> active(B, 1);
+  BCHK(hipMemcpy(g->P.bkz_active, active.data(), sizeof(int) * B, hipMemcpyHostToDevice));
+  // one launch (kflags / kloops as the kernel sees them) with the mailbox service; afterwards the
+  // identity-layout GSO of the new bases (same values: every entry is a function of b)
+  auto run_once = [&](int kflags, int kloops, float *ms, int *st_out, int *info_out) -> int
   {
-  case 1: hipLaunchKernelGGL(bkzs_kernel<1>, dim3(grid), dim3(wpb * 64), lds, s, g->P, DS, mail, d_abort, block_size, flags, delta, eta, logd, max_loops, stack_doubles); break;
-  case 2: hipLaunchKernelGGL(bkzs_kernel<2>, dim3(grid), dim3(wpb * 64), lds, s, g->P, DS, mail, d_abort, block_size, flags, delta, eta, logd, max_loops, stack_doubles); break;
-  case 3: hipLaunchKernelGGL(bkzs_kernel<3>, dim3(grid), dim3(wpb * 64), lds, s, g->P, DS, mail, d_abort, block_size, flags, delta, eta, logd, max_loops, stack_doubles); break;
-  default: hipLaunchKernelGGL(bkzs_kernel<4>, dim3(grid), dim3(wpb * 64), lds, s, g->P, DS, mail, d_abort, block_size, flags, delta, eta, logd, max_loops, stack_doubles); break;
-  }
-  BCHK(hipGetLastError());
-  BCHK(hipEventRecord(g->ev[1], s));
-  // ---- serve the mailboxes while the kernel runs ------------------------------------------------
-  {
-    BkzsHost H{S, gh_factor, rnd, rnd_user};
-    std::vector<unsigned long long> handled(B, 0);
-    for (;;)
+    int rc1 = launch(g, 0, g->P.d, 0.0, 2);  // bf / row_expo of every row from b
+    if (rc1 != FPHIP_OK)
+      return rc1;
+    GCHK(hipEventRecord(g->ev[0], s));
+    switch (nq)
     {
+    case 1: hipLaunchKernelGGL(bkzs_kernel<1>, dim3(grid), dim3(wpb * 64), lds, s, g->P, DS, mail, d_abort, block_size, kflags, delta, eta, logd, kloops, stack_doubles); break;
+    case 2: hipLaunchKernelGGL(bkzs_kernel<2>, dim3(grid), dim3(wpb * 64), lds, s, g->P, DS, mail, d_abort, block_size, kflags, delta, eta, logd, kloops, stack_doubles); break;
+    case 3: hipLaunchKernelGGL(bkzs_kernel<3>, dim3(grid), dim3(wpb * 64), lds, s, g->P, DS, mail, d_abort, block_size, kflags, delta, eta, logd, kloops, stack_doubles); break;
+    default: hipLaunchKernelGGL(bkzs_kernel<4>, dim3(grid), dim3(wpb * 64), lds, s, g->P, DS, mail, d_abort, block_size, kflags, delta, eta, logd, kloops, stack_doubles); break;
+    }
+    GCHK(hipGetLastError());
+    GCHK(hipEventRecord(g->ev[1], s));
+    for (;;)
+    {  // serve the mailboxes while the kernel runs
       for (size_t L = 0; L < B; ++L)
       {
         BkzMail *m = &mail[L];
@@ -918,24 +920,119 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
       if (q == hipSuccess)
         break;
       if (q != hipErrorNotReady)
-      {
-        cleanup();
         return gfail(g->ctx, "bkzs_kernel", q);
+    }
+    GCHK(hipEventElapsedTime(ms, g->ev[0], g->ev[1]));
+    GCHK(hipMemcpy(st_out, g->P.status, sizeof(int) * B, hipMemcpyDeviceToHost));
+    GCHK(hipMemcpy(info_out, g->P.lll_info, sizeof(int) * 4 * B, hipMemcpyDeviceToHost));
+    std::swap(g->P.b, g->P.b2);  // the kernel wrote the rows in position order into b2
+    rc1 = launch(g, 0, g->P.d, 0.0, 2);
+    if (rc1 == FPHIP_OK)
+      rc1 = launch(g, 0, g->P.d, 0.0, 0);
+    return rc1;
+  };
+
+  std::vector<int> st(B, 1), inf(4 * B, 0);
+  float total_ms = 0, ms = 0;
+  const bool use_loops = (flags & 0x4) != 0, auto_abort = (flags & 0x20) != 0;
+  const int kbase = flags & (0x10 | 0x80);
+  if (!auto_abort)
+  {
+    rc       = run_once(kbase | (use_loops ? 0x4 : 0), max_loops, &ms, st.data(), inf.data());
+    total_ms = ms;
+  }
+  else
+  {
+    // one tour per launch; BKZAutoAbort::test_abort(1.0, 5) on the host in between (bkz.cpp:575-625,
+    // 800-809), exactly as fphip_gso_bkz does it for the strategy-less kernel
+    const size_t d = g->P.d;
+    rc = launch(g, 0, g->P.d, 0.0, 0);  // r_ii of the input bases
+    std::vector<double> rdg(B * d), old_slope(B, std::numeric_limits<double>::max());
+    std::vector<long long> rex(B * d);
+    std::vector<int> no_dec(B, -1), rows(B, (int)d), one(4 * B), s1(B);
+    bool rows_known = false;
+    for (int loop = 0; rc == FPHIP_OK; ++loop)
+    {
+      size_t n_active = 0;
+      BCHK(hipMemcpy(rdg.data(), g->P.rdg, sizeof(double) * B * d, hipMemcpyDeviceToHost));
+      BCHK(hipMemcpy(rex.data(), g->P.rexp, sizeof(long long) * B * d, hipMemcpyDeviceToHost));
+      if (!rows_known)
+      {  // trailing zero rows (bkz.cpp:35-37) have r_ii == 0 exactly
+        for (size_t L = 0; L < B; ++L)
+        {
+          int nr = (int)d;
+          while (nr > 0 && rdg[L * d + nr - 1] == 0.0)
+            --nr;
+          rows[L] = nr;
+        }
+        rows_known = true;
+      }
+      for (size_t L = 0; L < B; ++L)
+      {
+        if (!active[L])
+          continue;
+        if (block_size < 2)
+        {
+          active[L] = 0;
+          continue;
+        }
+        if (use_loops && loop >= max_loops)
+        {
+          st[L]     = 8;
+          active[L] = 0;
+          continue;
+        }
+        // MatGSOInterface::get_current_slope(0, num_rows), gso_interface.cpp:198-218
+        const int n = rows[L];
+        double v1 = 0, v2 = (double)(n + 1) * n * (n - 1) / 12.0, weight = (1.0 - n) / 2.0;
+        for (int i = 0; i < n; ++i)
+        {
+          const double logf = std::log(rdg[L * d + i]);
+          const long expo   = (long)(2 * rex[L * d + i]);
+          v1 += weight * (logf + expo * std::log(2.0));
+          weight++;
+        }
+        const double new_slope = -(v1 / v2);
+        if (no_dec[L] == -1 || new_slope < 1.0 * old_slope[L])
+          no_dec[L] = 0;
+        else
+          no_dec[L]++;
+        old_slope[L] = std::min(old_slope[L], new_slope);
+        if (no_dec[L] >= 5)
+        {
+          active[L] = 0;  // abort: status stays RED_SUCCESS
+          continue;
+        }
+        ++n_active;
+      }
+      if (n_active == 0)
+        break;
+      BCHK(hipMemcpy(g->P.bkz_active, active.data(), sizeof(int) * B, hipMemcpyHostToDevice));
+      rc = run_once(kbase | 0x4, 1, &ms, s1.data(), one.data());  // exactly one tour
+      if (rc != FPHIP_OK)
+        break;
+      total_ms += ms;
+      for (size_t L = 0; L < B; ++L)
+      {
+        if (!active[L])
+          continue;
+        inf[4 * L + 0] += one[4 * L + 0];
+        const unsigned long long a0 = ((unsigned long long)(unsigned)inf[4 * L + 2] << 32) | (unsigned)inf[4 * L + 1];
+        const unsigned long long a1 = ((unsigned long long)(unsigned)one[4 * L + 2] << 32) | (unsigned)one[4 * L + 1];
+        const unsigned long long t  = a0 + a1;
+        inf[4 * L + 1] = (int)(unsigned)(t & 0xffffffffull);
+        inf[4 * L + 2] = (int)(unsigned)(t >> 32);
+        inf[4 * L + 3] += one[4 * L + 3];
+        if (s1[L] == 8)
+          continue;        // tour done, not clean: next loop
+        st[L]     = s1[L];  // 1: clean (or block_size >= num_rows); <= 0: failure
+        active[L] = 0;
       }
     }
   }
-  float ms = 0;
-  BCHK(hipEventElapsedTime(&ms, g->ev[0], g->ev[1]));
-  std::vector<int> st(B), inf(4 * B);
-  BCHK(hipMemcpy(st.data(), g->P.status, sizeof(int) * B, hipMemcpyDeviceToHost));
-  BCHK(hipMemcpy(inf.data(), g->P.lll_info, sizeof(int) * 4 * B, hipMemcpyDeviceToHost));
 #undef BCHK
   cleanup();
-  std::swap(g->P.b, g->P.b2);  // the kernel wrote the rows in position order into b2
-  rc = launch(g, 0, g->P.d, 0.0, 2);
-  if (rc == FPHIP_OK)
-    rc = launch(g, 0, g->P.d, 0.0, 0);
-  g->last_ms = ms;
+  g->last_ms = total_ms;
   if (status)
     memcpy(status, st.data(), sizeof(int) * B);
   if (info)

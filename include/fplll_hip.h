@@ -193,7 +193,8 @@ int fphip_gso_bkz(fphip_gso *g, int block_size, double delta, double eta, int fl
  * rnd(user, lattice, n) must return gmp_urandomm_ui(<generator of that lattice>, n): fplll passes
  * RandGen::get_gmp_state() (nr/nr_rand.inl:38-43); each lattice of a batch has its own stream, the
  * one a run of the reference on that lattice alone would draw from.
- * flags: FPHIP_BKZ_MAX_LOOPS, FPHIP_BKZ_BOUNDED_LLL, FPHIP_BKZ_GH_BND (fplll's values).
+ * flags: FPHIP_BKZ_MAX_LOOPS, FPHIP_BKZ_BOUNDED_LLL, FPHIP_BKZ_AUTO_ABORT (one tour per launch, the
+ * slope test on the host in between, as in fphip_gso_bkz), FPHIP_BKZ_GH_BND (fplll's values).
  * FPHIP_UNSUPPORTED: block sizes above 64, other flags, preprocessing nested deeper than 3 levels.
  * status / info as fphip_gso_bkz; status -7 = a mailbox request was not answered in time. */
 #define FPHIP_BKZ_BOUNDED_LLL 0x10

@@ -12,8 +12,7 @@ import conftest as C
 
 pytestmark = pytest.mark.gpu
 
-# BKZ_AUTO_ABORT is not offered by the strategies entry point yet
-FIXTURES = [p for p in C.bkz_strategy_fixtures() if "autoabort" not in p]
+FIXTURES = C.bkz_strategy_fixtures()
 if os.environ.get("FPHIP_BKZS_ONLY"):
     FIXTURES = [p for p in FIXTURES if any(t in p for t in os.environ["FPHIP_BKZS_ONLY"].split(","))]
 
@@ -34,7 +33,8 @@ def test_bkz_strategies_matches_reference(ctx, path):
         rnd, draws = C.gmp_streams_native(batch, f["rng_seed"])
     st, info = g.bkz_strategies(f["block_size"], f["strategies"], rnd, f["delta"], f["eta"],
                                 max_loops=f["max_loops"], gh_bnd=bool(f["flags"] & 0x80),
-                                bounded_lll=bool(f["flags"] & 0x10), gh_factor=f["gh_factor"])
+                                bounded_lll=bool(f["flags"] & 0x10), gh_factor=f["gh_factor"],
+                                auto_abort=bool(f["flags"] & 0x20))
     out = g.get_basis()
     nodes = [(int(i[1]) & 0xffffffff) | (int(i[2]) << 32) for i in info]
     print("status", st, "expected", f["status"], "tours/calls", info[:, 0], info[:, 3], "nodes", nodes,
