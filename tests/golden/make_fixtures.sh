@@ -70,6 +70,9 @@ REFDRV_STRATEGIES=$T/stratB.json REFDRV_BKZ_FLAGS=0x80 REFDRV_RNG_SEED=5 $D bkzf
 REFDRV_STRATEGIES=$T/stratA.json REFDRV_BKZ_FLAGS=0x80 REFDRV_BKZ_AUTO_ABORT=1 REFDRV_RNG_SEED=9 $D bkzfix q 56 28 12 4 36 0 > $G/bkzs_q56_b36_autoabort.json
 REFDRV_STRATEGIES=$T/stratB.json REFDRV_BKZ_FLAGS=0x10 REFDRV_RNG_SEED=11 $D bkzfix q 64 32 14 6 34 1 > $G/bkzs_q64_b34_bounded_lll.json
 REFDRV_STRATEGIES=$T/stratB.json REFDRV_BKZ_FLAGS=0x80 REFDRV_RNG_SEED=13 $D bkzfix r 40 0 40 4 32 2 > $G/bkzs_r40_b32_rerand.json
+# three nested tours (40 -> 30 -> 20) with expectations scaled to 0.8x
+python3 $G/make_strategies.py $T/gen.json $T/stratC.json 40 10 30 0.8
+REFDRV_STRATEGIES=$T/stratC.json REFDRV_BKZ_FLAGS=0x80 REFDRV_RNG_SEED=21 $D bkzfix q 56 28 12 5 40 1 > $G/bkzs_q56_b40_nested3.json
 rm -rf $T
 # --- C3 (BASELINE configs[2]): the 180-dim q-ary lattice, LLL + BKZ-20 by the reference, its
 #     beta=60 blocks as the plugin sees them, and pruner-generated strategies for the tour bench

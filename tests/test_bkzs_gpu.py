@@ -13,6 +13,12 @@ import conftest as C
 pytestmark = pytest.mark.gpu
 
 FIXTURES = C.bkz_strategy_fixtures()
+# bkzs_q56_b40_nested3 (three nested tours, 24 k enumerations, 410 rerandomisations) was added after
+# the round's last GPU session: it is pinned oracle-vs-reference on the CPU
+# (test_bkz_strategies_oracle_vs_ref.py) and joins the device run once it has been seen green there
+# (FPHIP_BKZS_ALL=1 runs it).
+if not os.environ.get("FPHIP_BKZS_ALL"):
+    FIXTURES = [p for p in FIXTURES if "nested3" not in p]
 if os.environ.get("FPHIP_BKZS_ONLY"):
     FIXTURES = [p for p in FIXTURES if any(t in p for t in os.environ["FPHIP_BKZS_ONLY"].split(","))]
 
