@@ -365,8 +365,13 @@ def bkz_strategy_fixtures():
 
 
 def load_bkz_fixture(path):
-    with open(path) as f:
-        j = json.load(f)
+    if path.endswith(".gz"):
+        import gzip
+        with gzip.open(path, "rt") as f:
+            j = json.load(f)
+    else:
+        with open(path) as f:
+            j = json.load(f)
     d, n = j["d"], j["n"]
     out = {k: j[k] for k in ("d", "n", "block_size", "max_loops", "nodes")}
     if "strategies" in j:
@@ -380,6 +385,7 @@ def load_bkz_fixture(path):
         out["rng_seed"] = j["rng_seed"]
     out["auto_abort"] = bool(j.get("auto_abort", 0))
     out["name"] = os.path.basename(path)[:-5]
+    out["ref_seconds"] = j.get("ref_seconds")
     out["status"] = BKZ_REF_STATUS_TO_OURS[j["ref_status"]]
     out["delta"] = float.fromhex(j["delta"])
     out["eta"] = float.fromhex(j["eta"])

@@ -83,6 +83,8 @@ for k in 0 1 2; do
   $D enumfix 0 $G/basis_q180_seed0_lll_bkz20.txt 0 0 0 $f 60 prune:0.5 1 0 0.99 > $G/c3_b60_k${k}_pruner.json
 done
 $D genstrat $G/basis_q180_seed0_lll_bkz20.txt 60 > $G/strategies_q180_b60.json
+# config 3 at full size: one BKZ-60 tour of that lattice with those strategies (49 s)
+REFDRV_STRATEGIES=$G/strategies_q180_b60.json REFDRV_BKZ_FLAGS=0x80 REFDRV_RNG_SEED=1 $D bkzfix f:$G/basis_q180_seed0_lll_bkz20.txt 180 0 0 0 60 1 | gzip -9 > $G/c3_bkz60_tour_strategies.json.gz
 # sub-solutions (findsubsols): the evaluator's final table is added to the fixture
 REFDRV_SUBSOLS=1 $D enumfix  80 40 12 1  0 4 32 none      5 0 1.30 > $G/enum_d32_best5_subsols.json
 REFDRV_SUBSOLS=1 $D enumfix 100 50 14 2 20 0 40 linear:20 1 0 0.99 > $G/enum_d40_lin20_best1_subsols.json

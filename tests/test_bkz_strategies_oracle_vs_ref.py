@@ -24,7 +24,7 @@ def test_bkz_with_strategies_matches_reference(path):
     st, info = g.bkz_param(f["block_size"], f["delta"], f["eta"], f["flags"], f["max_loops"],
                            f["gh_factor"], f["strategies"], f["rng_seed"])
     assert st == f["status"]
-    nodes = (int(info[1]) & 0xffffffff) | (int(info[2]) << 32)
+    nodes = (int(info[1]) & 0xffffffff) | ((int(info[2]) & 0xffffffff) << 32)
     assert nodes == f["nodes"]
     assert np.array_equal(g.b, f["b_out"])
     assert not np.array_equal(f["b_in"], f["b_out"])
@@ -51,3 +51,22 @@ def test_fixtures_cover_the_strategy_features():
         if len(S["coeff"]) > 0:
             feats.add("pruning")
     assert feats == {"preprocessing", "gh_bnd", "bounded_lll", "auto_abort", "pruning"}
+
+
+def test_config3_bkz60_tour_at_full_size():
+    """BASELINE config 3 at its full size: ONE BKZ-60 tour (BKZ_MAX_LOOPS 1, BKZ_GH_BND 1.1) of the
+    180-dimensional q-ary lattice (LLL + BKZ-20 by the reference first) with the pruner-generated
+    strategies of tests/golden/strategies_q180_b60.json — 15 160 enumerations, 1.22e9 nodes, 11
+    rerandomisations, 49 s in the reference.  The oracle must end on the reference's basis and node
+    count (~55 s on one core; the device run of the same golden is tests/perf/bkzs_c3.py)."""
+    f = C.load_bkz_fixture(os.path.join(C.GOLDEN, "c3_bkz60_tour_strategies.json.gz"))
+    assert (f["d"], f["block_size"], f["max_loops"], f["flags"]) == (180, 60, 1, 0x84)
+    g = C.OracleGSO(f["b_in"])
+    st, info = g.bkz_param(f["block_size"], f["delta"], f["eta"], f["flags"], f["max_loops"],
+                           f["gh_factor"], f["strategies"], f["rng_seed"])
+    nodes = (int(info[1]) & 0xffffffff) | ((int(info[2]) & 0xffffffff) << 32)
+    assert st == f["status"] == 8
+    assert nodes == f["nodes"] == 1224293770
+    assert info[3] == 15160 and info[4] == 11
+    assert np.array_equal(g.b, f["b_out"])
+    g.close()
