@@ -87,9 +87,14 @@ static void process_subsolution(enum_t *e, int offset, double newdist)
   e->subcb(e->user, newdist, e->fx, offset);
 }
 
-int64_t oracle_enumerate(int d, const double *mut, const double *rdiag, const double *pruning,
-                         double maxdist, int findsubsols, oracle_sol_cb cb, oracle_subsol_cb subcb,
-                         void *user, uint64_t *nodes, double *best_sol, double *best_dist)
+/* dual != 0: the dualenum instantiation of the recursion (enumerate_base.cpp:57-61, 103-105) and of
+ * the initial descent (enumerate.cpp:185-189): the centre partial sums are driven by alpha = x - c
+ * instead of x.  mut / rdiag are then the transformed inputs EnumerationDyn::enumerate builds for a
+ * dual call (enumerate.cpp:107-123) and the caller reverses the solution (:154-158). */
+static int64_t enumerate_impl(int d, const double *mut, const double *rdiag, const double *pruning,
+                              double maxdist, int findsubsols, oracle_sol_cb cb,
+                              oracle_subsol_cb subcb, void *user, uint64_t *nodes, double *best_sol,
+                              double *best_dist, int dual)
 {
   if (d <= 0 || d >= ORACLE_MAX_DIM)
     return -1;
@@ -124,7 +129,7 @@ int64_t oracle_enumerate(int d, const double *mut, const double *rdiag, const do
     {
       double newcenter = 0.0; /* center_partsum[k] = 0 for SVP, enumerate.cpp:82-86 */
       for (int j = k + 1; j < k_end; ++j)
-        newcenter -= e->x[j] * MUT(e, k, j);
+        newcenter -= (dual ? e->alpha[j] : e->x[j]) * MUT(e, k, j);
       e->x[k]        = round(newcenter);
       e->center[k]   = newcenter;
       e->partdist[k] = newdist;
@@ -184,7 +189,7 @@ int64_t oracle_enumerate(int d, const double *mut, const double *rdiag, const do
       /* :53-71 */
       e->partdist[k - 1] = newdist;
       for (int j = e->center_partsum_begin[k]; j > k - 1; --j)
-        CPS(e, k - 1, j) = CPS(e, k - 1, j + 1) - e->x[j] * MUT(e, k - 1, j);
+        CPS(e, k - 1, j) = CPS(e, k - 1, j + 1) - (dual ? e->alpha[j] : e->x[j]) * MUT(e, k - 1, j);
       if (e->center_partsum_begin[k] > e->center_partsum_begin[k - 1])
         e->center_partsum_begin[k - 1] = e->center_partsum_begin[k];
       e->center_partsum_begin[k] = k;
@@ -226,7 +231,7 @@ int64_t oracle_enumerate(int d, const double *mut, const double *rdiag, const do
       }
       /* :103-115 */
       e->partdist[k - 1] = newdist;
-      CPS(e, k - 1, k)   = CPS(e, k - 1, k + 1) - e->x[k] * MUT(e, k - 1, k);
+      CPS(e, k - 1, k)   = CPS(e, k - 1, k + 1) - (dual ? e->alpha[k] : e->x[k]) * MUT(e, k - 1, k);
       if (k > e->center_partsum_begin[k - 1])
         e->center_partsum_begin[k - 1] = k;
       e->center[k - 1] = CPS(e, k - 1, k);
@@ -242,4 +247,18 @@ done:;
   free(e->center_partsums);
   free(e);
   return ns;
+}
+
+int64_t oracle_enumerate(int d, const double *mut, const double *rdiag, const double *pruning,
+                         double maxdist, int findsubsols, oracle_sol_cb cb, oracle_subsol_cb subcb,
+                         void *user, uint64_t *nodes, double *best_sol, double *best_dist)
+{
+  return enumerate_impl(d, mut, rdiag, pruning, maxdist, findsubsols, cb, subcb, user, nodes, best_sol,
+                        best_dist, 0);
+}
+
+int64_t oracle_enumerate_dual(int d, const double *mut, const double *rdiag, const double *pruning,
+                              double maxdist, uint64_t *nodes, double *best_sol, double *best_dist)
+{
+  return enumerate_impl(d, mut, rdiag, pruning, maxdist, 0, NULL, NULL, NULL, nodes, best_sol, best_dist, 1);
 }

@@ -540,7 +540,7 @@ static int lll_size_reduction(oracle_gso *g, int kappa_min, int kappa_end, int s
   return 1;
 }
 
-static int svp_postprocessing(oracle_gso *g, int kappa, int bs, const double *sol)
+static int svp_postprocessing(oracle_gso *g, int kappa, int bs, const double *sol, int dual)
 {
   int nz_vectors = 0, i_vector = -1;
   for (int i = bs - 1; i >= 0; i--)
@@ -550,19 +550,29 @@ static int svp_postprocessing(oracle_gso *g, int kappa, int bs, const double *so
       if (i_vector == -1 && fabs(sol[i]) == 1)
         i_vector = i;
     }
+  const int pos = dual ? kappa + bs - 1 : kappa;
   if (nz_vectors == 1)
   {
-    move_row(g, kappa + i_vector, kappa);
+    move_row(g, kappa + i_vector, pos);
   }
   else if (i_vector != -1)
   {
     int sol_i = (int)sol[i_vector];
+    if (dual)
+      sol_i *= -1;
     for (int i = 0; i < bs; ++i)
       if (sol[i] != 0.0 && i != i_vector)
-        if (!row_addmul_we(g, kappa + i_vector, kappa + i, sol_i * sol[i], 0))
+      {
+        int ok = dual ? row_addmul_we(g, kappa + i, kappa + i_vector, sol_i * sol[i], 0)
+                      : row_addmul_we(g, kappa + i_vector, kappa + i, sol_i * sol[i], 0);
+        if (!ok)
           return -2;
-    row_op_end_range(g, kappa + i_vector, kappa + i_vector + 1);
-    move_row(g, kappa + i_vector, kappa);
+      }
+    if (dual)
+      row_op_end_range(g, kappa, kappa + bs);
+    else
+      row_op_end_range(g, kappa + i_vector, kappa + i_vector + 1);
+    move_row(g, kappa + i_vector, pos);
   }
   else
   { /* svp_postprocessing_generic, bkz.cpp:205-272 */
@@ -595,7 +605,9 @@ static int svp_postprocessing(oracle_gso *g, int kappa, int bs, const double *so
             while (x[k - off] <= x[k])
             {
               x[k] = x[k] - x[k - off];
-              if (!row_addmul_we(g, kappa + k - off, kappa + k, 1.0, 0)) /* row_add */
+              int ok = dual ? row_addmul_we(g, kappa + k, kappa + k - off, -1.0, 0) /* row_sub */
+                            : row_addmul_we(g, kappa + k - off, kappa + k, 1.0, 0); /* row_add */
+              if (!ok)
               {
                 free(x);
                 return -2;
@@ -611,7 +623,8 @@ static int svp_postprocessing(oracle_gso *g, int kappa, int bs, const double *so
     }
     free(x);
     row_op_end_range(g, kappa, kappa + bs);
-    move_row(g, kappa + bs - 1, kappa);
+    if (!dual)
+      move_row(g, kappa + bs - 1, kappa);
   }
   return 1;
 }
@@ -635,6 +648,7 @@ typedef struct
   void *rnd_user;
   uint64_t nodes;
   uint64_t enum_calls, rerandomizations;
+  double sld_potential; /* BKZReduction::sld_potential */
 } bkz_ctx;
 
 /* MatGSOInterface::get_root_det / get_log_det, gso_interface.cpp:220-242 */
@@ -751,14 +765,16 @@ static int svp_preprocessing(oracle_gso *g, bkz_ctx *cx, const bkz_par *par, int
 
 /* BKZReduction::svp_reduction (primal), bkz.cpp:274-358.
  * returns 1 ok (clean flag in *clean), else a failure status */
-static int svp_reduction(oracle_gso *g, bkz_ctx *cx, const bkz_par *par, int kappa, int bs, int *clean)
+static int svp_reduction(oracle_gso *g, bkz_ctx *cx, const bkz_par *par, int kappa, int bs, int *clean,
+                         int dual)
 {
   const double eta = cx->eta;
-  int rc           = lll_size_reduction(g, 0, kappa + 1, 0, eta);
+  const int first  = dual ? kappa + bs - 1 : kappa;
+  int rc           = lll_size_reduction(g, 0, first + 1, 0, eta);
   if (rc != 1)
     return rc;
-  double old_first    = R(g, kappa, kappa);
-  long old_first_expo = (long)(2 * g->row_expo[kappa]);
+  double old_first    = R(g, first, first);
+  long old_first_expo = (long)(2 * g->row_expo[first]);
   int rerandomize     = 0;
   double remaining_probability = 1.0;
   double *rdiag   = (double *)calloc(bs, sizeof(double));
@@ -778,9 +794,14 @@ static int svp_reduction(oracle_gso *g, bkz_ctx *cx, const bkz_par *par, int kap
         if (g->valid_cols[i] < i + 1) /* the enumeration would read a stale GSO row */
           fprintf(stderr, "STALE row %d (valid %d) in block kappa %d bs %d\n", i, g->valid_cols[i], kappa, bs);
     /* radius, bkz.cpp:309-323 */
-    double max_dist    = R(g, kappa, kappa);
-    long max_dist_expo = (long)(2 * g->row_expo[kappa]);
-    max_dist           = max_dist * cx->delta;
+    double max_dist    = R(g, first, first);
+    long max_dist_expo = (long)(2 * g->row_expo[first]);
+    if (dual)
+    { /* max_dist.pow_si(max_dist, -1): nr_FP_d.inl:189-192 */
+      max_dist      = pow(max_dist, (double)-1);
+      max_dist_expo = -max_dist_expo;
+    }
+    max_dist = max_dist * cx->delta;
     if ((par->flags & 0x80) && bs > 30)
     {
       double root_det = get_root_det(g, kappa, kappa + bs);
@@ -804,21 +825,42 @@ static int svp_reduction(oracle_gso *g, bkz_ctx *cx, const bkz_par *par, int kap
       if (e > normexp)
         normexp = e;
     }
+    if (dual)
+      normexp = -normexp; /* the inverse of r is normalised, enumerate.cpp:96-101 */
     double maxdist = ldexp(max_dist, (int)(max_dist_expo - normexp));
     memset(mut, 0, sizeof(double) * (size_t)bs * bs);
     for (int i = 0; i < bs; ++i)
     {
       long rexpo = (long)(2 * g->row_expo[i + kappa]);
-      rdiag[i]   = ldexp(R(g, i + kappa, i + kappa), (int)(rexpo - normexp));
+      if (dual)
+        rdiag[bs - i - 1] = 1.0 / ldexp(R(g, i + kappa, i + kappa), (int)(rexpo + normexp));
+      else
+        rdiag[i] = ldexp(R(g, i + kappa, i + kappa), (int)(rexpo - normexp));
       for (int j = i + 1; j < bs; ++j)
-        mut[(size_t)i * bs + j] =
-            ldexp(MU(g, j + kappa, i + kappa), (int)(g->row_expo[j + kappa] - g->row_expo[i + kappa]));
+      {
+        double m = ldexp(MU(g, j + kappa, i + kappa), (int)(g->row_expo[j + kappa] - g->row_expo[i + kappa]));
+        if (dual)
+          mut[(size_t)(bs - j - 1) * bs + (bs - i - 1)] = -m;
+        else
+          mut[(size_t)i * bs + j] = m;
+      }
     }
     double best_dist = 0.0;
     if (getenv("ORACLE_BKZ_DEBUG"))
-      fprintf(stderr, "call kappa %d dim %d maxdist %a r0 %a pruning %d\n", kappa, bs, maxdist, rdiag[0], pr);
-    int64_t nsol = oracle_enumerate(bs, mut, rdiag, pruning, maxdist, 0, NULL, NULL, NULL, nodes, sol,
-                                    &best_dist);
+      fprintf(stderr, "call kappa %d dim %d maxdist %a r0 %a pruning %d dual %d\n", kappa, bs, maxdist, rdiag[0], pr, dual);
+    int64_t nsol;
+    if (dual)
+    {
+      nsol = oracle_enumerate_dual(bs, mut, rdiag, pruning, maxdist, nodes, sol, &best_dist);
+      if (nsol > 0)
+        for (int a = 0, b2 = bs - 1; a < b2; ++a, --b2)
+        { /* reverse_by_swap, enumerate.cpp:154-158 */
+          double t = sol[a]; sol[a] = sol[b2]; sol[b2] = t;
+        }
+    }
+    else
+      nsol = oracle_enumerate(bs, mut, rdiag, pruning, maxdist, 0, NULL, NULL, NULL, nodes, sol,
+                              &best_dist);
     cx->enum_calls++;
     uint64_t t = 0;
     for (int i = 0; i <= bs; ++i)
@@ -828,7 +870,7 @@ static int svp_reduction(oracle_gso *g, bkz_ctx *cx, const bkz_par *par, int kap
       fprintf(stderr, "   nodes %llu nsol %lld\n", (unsigned long long)t, (long long)nsol);
     if (nsol > 0)
     {
-      rc = svp_postprocessing(g, kappa, bs, sol);
+      rc = svp_postprocessing(g, kappa, bs, sol, dual);
       if (rc != 1)
         break;
       rerandomize = 0;
@@ -840,13 +882,140 @@ static int svp_reduction(oracle_gso *g, bkz_ctx *cx, const bkz_par *par, int kap
   free(rdiag); free(mut); free(sol); free(nodes);
   if (rc != 1)
     return rc;
-  rc = lll_size_reduction(g, 0, kappa + 1, 0, eta);
+  rc = lll_size_reduction(g, 0, first + 1, 0, eta);
   if (rc != 1)
     return rc;
-  double new_first    = R(g, kappa, kappa);
-  long new_first_expo = (long)(2 * g->row_expo[kappa]);
+  double new_first    = R(g, first, first);
+  long new_first_expo = (long)(2 * g->row_expo[first]);
   new_first           = ldexp(new_first, (int)(new_first_expo - old_first_expo));
-  *clean              = (old_first <= new_first);
+  *clean              = dual ? (old_first >= new_first) : (old_first <= new_first);
+  return 1;
+}
+
+/* BKZReduction::trunc_tour, bkz.cpp:382-399 */
+static int bkz_trunc_tour(oracle_gso *g, bkz_ctx *cx, const bkz_par *par, int min_row, int max_row, int *clean)
+{
+  int c1 = 1, rc;
+  for (int kappa = min_row; kappa < max_row - par->block_size; ++kappa)
+  {
+    rc = svp_reduction(g, cx, par, kappa, par->block_size, &c1, 0);
+    if (rc != 1)
+      return rc;
+    *clean &= c1;
+  }
+  return 1;
+}
+
+/* BKZReduction::trunc_dtour, bkz.cpp:401-413 */
+static int bkz_trunc_dtour(oracle_gso *g, bkz_ctx *cx, const bkz_par *par, int min_row, int max_row, int *clean)
+{
+  int c1 = 1, rc;
+  for (int kappa = max_row - par->block_size; kappa > min_row; --kappa)
+  {
+    rc = svp_reduction(g, cx, par, kappa, par->block_size, &c1, 1);
+    if (rc != 1)
+      return rc;
+    *clean &= c1;
+  }
+  return 1;
+}
+
+/* BKZReduction::hkz, bkz.cpp:415-441 */
+static int bkz_hkz(oracle_gso *g, bkz_ctx *cx, const bkz_par *par, int min_row, int max_row, int *clean)
+{
+  int c1 = 1, rc;
+  for (int kappa = min_row; kappa < max_row - 1; ++kappa)
+  {
+    rc = svp_reduction(g, cx, par, kappa, max_row - kappa, &c1, 0);
+    if (rc != 1)
+      return rc;
+    *clean &= c1;
+  }
+  lll_size_reduction(g, max_row - 1, max_row, max_row - 2, cx->eta); /* bkz.cpp:437 */
+  return 1;
+}
+
+/* MatGSOInterface::get_log_det / get_slide_potential, gso_interface.cpp:230-258 (the stored r_ii are
+ * read as they are, like the reference's get_r) */
+static double get_log_det(oracle_gso *g, int start_row, int end_row)
+{
+  if (start_row < 0)
+    start_row = 0;
+  if (end_row > g->d)
+    end_row = g->d;
+  double log_det = 0.0;
+  for (int i = start_row; i < end_row; ++i)
+    log_det += log(ldexp(R(g, i, i), (int)(2 * g->row_expo[i])));
+  return log_det;
+}
+
+static double get_slide_potential(oracle_gso *g, int start_row, int end_row, int block_size)
+{
+  double potential = 0.0;
+  int p            = (end_row - start_row) / block_size;
+  if ((end_row - start_row) % block_size == 0)
+    --p;
+  for (int i = 0; i < p; ++i)
+    potential += (p - i) * get_log_det(g, i * block_size, (i + 1) * block_size);
+  return potential;
+}
+
+/* BKZReduction::sd_tour, bkz.cpp:443-463 */
+static int bkz_sd_tour(oracle_gso *g, bkz_ctx *cx, const bkz_par *par, int min_row, int max_row, int *clean_out)
+{
+  int clean = 1;
+  int rc    = bkz_trunc_dtour(g, cx, par, min_row, max_row, &clean);
+  if (rc != 1)
+    return rc;
+  rc = bkz_trunc_tour(g, cx, par, min_row, max_row, &clean);
+  *clean_out = clean;
+  return rc;
+}
+
+/* BKZReduction::slide_tour, bkz.cpp:465-520 */
+static int bkz_slide_tour(oracle_gso *g, bkz_ctx *cx, const bkz_par *par, int min_row, int max_row, int *clean_out)
+{
+  int p = (max_row - min_row) / par->block_size;
+  if ((max_row - min_row) % par->block_size)
+    ++p;
+  int clean, rc, c1 = 1;
+  do
+  {
+    clean = 1;
+    for (int i = 0; i < p; ++i)
+    {
+      int kappa      = min_row + i * par->block_size;
+      int block_size = max_row - kappa < par->block_size ? max_row - kappa : par->block_size;
+      rc             = svp_reduction(g, cx, par, kappa, block_size, &c1, 0);
+      if (rc != 1)
+        return rc;
+      clean &= c1;
+    }
+    if (par->flags & 0x10)
+    {
+      int info[4];
+      rc = oracle_gso_lll(g, min_row, min_row, max_row, cx->lll_delta, cx->eta, info);
+      if (rc != 1)
+        return rc;
+      if (info[1] > 0)
+        clean = 0;
+    }
+  } while (!clean);
+  for (int i = 0; i < p - 1; ++i)
+  {
+    int kappa = min_row + i * par->block_size + 1;
+    rc        = svp_reduction(g, cx, par, kappa, par->block_size, &c1, 1);
+    if (rc != 1)
+      return rc;
+  }
+  double new_potential = get_slide_potential(g, min_row, max_row, par->block_size);
+  if (new_potential >= cx->sld_potential)
+  {
+    *clean_out = 1;
+    return 1;
+  }
+  cx->sld_potential = new_potential;
+  *clean_out        = 0;
   return 1;
 }
 
@@ -858,7 +1027,7 @@ static int bkz_tour(oracle_gso *g, bkz_ctx *cx, const bkz_par *par, int min_row,
   const int block_size = par->block_size;
   for (int kappa = min_row; kappa < max_row - block_size; ++kappa)
   { /* trunc_tour */
-    rc = svp_reduction(g, cx, par, kappa, block_size, &c1);
+    rc = svp_reduction(g, cx, par, kappa, block_size, &c1, 0);
     if (rc != 1)
       return rc;
     clean &= c1;
@@ -866,7 +1035,7 @@ static int bkz_tour(oracle_gso *g, bkz_ctx *cx, const bkz_par *par, int min_row,
   int hkz_min = max_row - block_size > 0 ? max_row - block_size : 0;
   for (int kappa = hkz_min; kappa < max_row - 1; ++kappa)
   { /* hkz */
-    rc = svp_reduction(g, cx, par, kappa, max_row - kappa, &c1);
+    rc = svp_reduction(g, cx, par, kappa, max_row - kappa, &c1, 0);
     if (rc != 1)
       return rc;
     clean &= c1;
@@ -895,7 +1064,8 @@ static double current_slope(oracle_gso *g, int start_row, int stop_row)
 
 /* BKZReduction::bkz() (bkz.cpp:522-668), primal BKZ.  flags: fplll's BKZ_MAX_LOOPS 0x4,
  * BKZ_BOUNDED_LLL 0x10, BKZ_AUTO_ABORT 0x20 (BKZAutoAbort::test_abort with scale 1.0 and 5 tours,
- * bkz.cpp:800-809), BKZ_GH_BND 0x80.  strat NULL = empty strategies.
+ * bkz.cpp:800-809), BKZ_GH_BND 0x80, BKZ_SD_VARIANT 0x100 (self-dual BKZ: dual + primal truncated
+ * tours), BKZ_SLD_RED 0x200 (slide reduction).  strat NULL = empty strategies.
  * returns 1 RED_SUCCESS, 8 RED_BKZ_LOOPS_LIMIT, else a failure status (<= 0).
  * info[0] = tours executed, info[1..2] = enumeration nodes (lo, hi 32 bits), info[3] = enumeration
  * calls, info[4] = rerandomisations. */
@@ -923,12 +1093,27 @@ int oracle_gso_bkz_param(oracle_gso *g, int block_size, double delta, double eta
   cx.rnd_user  = rnd_user;
   bkz_par par  = {block_size, flags, gh_factor, 0.5, 3};
   int status = 1, tours = 0;
+  const int sd = (flags & 0x100) != 0, sld = (flags & 0x200) != 0; /* BKZ_SD_VARIANT, BKZ_SLD_RED */
+  if (sd && sld)
+    return -3;
+  if (sd && !(flags & (0x4 | 0x8 | 0x20)))
+    flags |= 0x20; /* "SD Variant of BKZ requires explicit termination condition", bkz.cpp:548-554 */
   const int auto_abort    = (flags & 0x20) != 0;
   const int use_max_loops = (flags & 0x4) != 0;
   int no_dec       = -1;
   double old_slope = DBL_MAX; /* numeric_limits<double>::max(), bkz.h BKZAutoAbort ctor */
   if (block_size < 2)
     goto done;
+  if (sld)
+  { /* bkz.cpp:567-571 */
+    oracle_gso_update_all(g);
+    cx.sld_potential = get_slide_potential(g, 0, num_rows, block_size);
+  }
+  if (sd)
+  { /* bkz.cpp:576-577 */
+    int rc0 = oracle_gso_lll(g, 0, 0, num_rows, cx.lll_delta, cx.eta, NULL);
+    (void)rc0;
+  }
   for (int i = 0;; ++i)
   {
     if (use_max_loops && i >= max_loops)
@@ -949,7 +1134,9 @@ int oracle_gso_bkz_param(oracle_gso *g, int block_size, double delta, double eta
         break;
     }
     int clean = 1;
-    int rc    = bkz_tour(g, &cx, &par, 0, num_rows, &clean);
+    int rc    = sd ? bkz_sd_tour(g, &cx, &par, 0, num_rows, &clean)
+                : sld ? bkz_slide_tour(g, &cx, &par, 0, num_rows, &clean)
+                      : bkz_tour(g, &cx, &par, 0, num_rows, &clean);
     if (rc != 1)
     {
       status = rc;
@@ -958,6 +1145,32 @@ int oracle_gso_bkz_param(oracle_gso *g, int block_size, double delta, double eta
     ++tours;
     if (clean || block_size >= num_rows)
       break;
+  }
+  /* post-processing, bkz.cpp:627-668 */
+  if (sd)
+  { /* hkz reduce the last window, which sd leaves unreduced */
+    int dummy = 1;
+    int rc    = bkz_hkz(g, &cx, &par, num_rows - block_size, num_rows, &dummy);
+    if (rc != 1)
+      status = rc;
+  }
+  if (sld)
+  { /* hkz reduce the blocks (which are otherwise only svp and dual svp reduced) */
+    int p = num_rows / block_size;
+    if (num_rows % block_size)
+      ++p;
+    for (int j = 0; j < p; ++j)
+    {
+      int kappa = j * block_size + 1;
+      int end   = num_rows < kappa + block_size - 1 ? num_rows : kappa + block_size - 1;
+      int dummy = 1;
+      int rc    = bkz_hkz(g, &cx, &par, kappa, end, &dummy);
+      if (rc != 1)
+      {
+        status = rc;
+        break;
+      }
+    }
   }
 done:
   if (info)

@@ -46,6 +46,13 @@ int64_t oracle_enumerate(int d, const double *mut, const double *rdiag, const do
                          double maxdist, int findsubsols, oracle_sol_cb cb, oracle_subsol_cb subcb,
                          void *user, uint64_t *nodes, double *best_sol, double *best_dist);
 
+/* The dual-enumeration instantiation of the same walk (dualenum = true, enumerate_base.cpp:57-61,
+ * 103-105; enumerate.cpp:185-189) on inputs already transformed as EnumerationDyn::enumerate does
+ * for a dual call (mut negated and index-reversed, rdiag inverted and reversed, enumerate.cpp:107-123);
+ * built-in FastEvaluator(1).  The caller reverses best_sol (enumerate.cpp:154-158). */
+int64_t oracle_enumerate_dual(int d, const double *mut, const double *rdiag, const double *pruning,
+                              double maxdist, uint64_t *nodes, double *best_sol, double *best_dist);
+
 /* ------------------------------------------------------------------------------------------
  * GSO / size reduction for ZT=long, FT=double, GSO_ROW_EXPO on (the BKZ fast path,
  * fplll/bkz.cpp:816-829).  State layout = one contiguous lattice; see gso_oracle.c.

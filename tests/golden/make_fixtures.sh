@@ -70,6 +70,14 @@ REFDRV_STRATEGIES=$T/stratB.json REFDRV_BKZ_FLAGS=0x80 REFDRV_RNG_SEED=5 $D bkzf
 REFDRV_STRATEGIES=$T/stratA.json REFDRV_BKZ_FLAGS=0x80 REFDRV_BKZ_AUTO_ABORT=1 REFDRV_RNG_SEED=9 $D bkzfix q 56 28 12 4 36 0 > $G/bkzs_q56_b36_autoabort.json
 REFDRV_STRATEGIES=$T/stratB.json REFDRV_BKZ_FLAGS=0x10 REFDRV_RNG_SEED=11 $D bkzfix q 64 32 14 6 34 1 > $G/bkzs_q64_b34_bounded_lll.json
 REFDRV_STRATEGIES=$T/stratB.json REFDRV_BKZ_FLAGS=0x80 REFDRV_RNG_SEED=13 $D bkzfix r 40 0 40 4 32 2 > $G/bkzs_r40_b32_rerand.json
+# --- self-dual BKZ (0x100) and slide reduction (0x200): dual svp_reduction / dual enumeration
+REFDRV_BKZ_FLAGS=0x100 $D bkzfix q 40 20 20 1 10 3 > $G/bkzd_q40_b10_sd_loops3.json
+REFDRV_BKZ_FLAGS=0x200 $D bkzfix q 40 20 20 1 10 0 > $G/bkzd_q40_b10_slide.json
+REFDRV_BKZ_FLAGS=0x100 $D bkzfix q 60 30 12 7 16 0 > $G/bkzd_q60_b16_sd_autoabort.json
+REFDRV_BKZ_FLAGS=0x210 $D bkzfix q 64 32 14 6 16 0 > $G/bkzd_q64_b16_slide_bounded_lll.json
+REFDRV_STRATEGIES=$T/stratB.json REFDRV_BKZ_FLAGS=0x180 REFDRV_RNG_SEED=7 $D bkzfix q 64 32 14 3 40 1 > $G/bkzd_q64_b40_sd_strategies.json
+REFDRV_STRATEGIES=$T/stratA.json REFDRV_BKZ_FLAGS=0x280 REFDRV_RNG_SEED=8 $D bkzfix q 70 35 14 9 32 2 > $G/bkzd_q70_b32_slide_strategies.json
+REFDRV_BKZ_FLAGS=0x200 $D bkzfix r 30 0 40 4 8 0 > $G/bkzd_r30_b8_slide.json
 # three nested tours (40 -> 30 -> 20) with expectations scaled to 0.8x
 python3 $G/make_strategies.py $T/gen.json $T/stratC.json 40 10 30 0.8
 REFDRV_STRATEGIES=$T/stratC.json REFDRV_BKZ_FLAGS=0x80 REFDRV_RNG_SEED=21 $D bkzfix q 56 28 12 5 40 1 > $G/bkzs_q56_b40_nested3.json
