@@ -701,7 +701,9 @@ int serve_plan(const BkzsHost &H, int lattice, BkzMail *m)
 {
   const int min_row = m->lo, max_row = m->hi, density = m->density;
   int np = 0, n_moves = 0, n_ops = 0;
-  if (max_row - min_row >= 2 && H.rnd)
+  // (a range of exactly two rows makes the reference spin for ever — gmp_urandomm_ui(state, 1) is
+  // always 0, so `while (b == a)` never ends, bkz.cpp:53-58; the block is left as it is instead)
+  if (max_row - min_row > 2 && H.rnd)
   {
     const size_t niter = 4 * (size_t)(max_row - min_row);
     for (size_t i = 0; i < niter && np < FPHIP_BKZS_PLAN_MAX; ++i)
@@ -727,6 +729,58 @@ int serve_plan(const BkzsHost &H, int lattice, BkzMail *m)
   return np;
 }
 }  // namespace
+
+// The two host-side decisions on their own (no device involved): what the mailbox service answers
+// for a block with the given r_ii / exponents, and the plan it draws for a rerandomisation.  Used by
+// the CPU test-suite to check this arithmetic against the oracle (tests/test_bkzs_host_cpu.py).
+extern "C" int fphip_debug_bkz_radius(const fphip_strategies *S, double gh_factor, int bs, int flags,
+                                      double delta, const double *r, const int *e2, double *max_dist,
+                                      int *prune, double *expectation)
+{
+  if (bs < 1 || bs > 64 || !r || !e2)
+    return FPHIP_ERROR;
+  BkzMail m;
+  memset(&m, 0, sizeof m);
+  m.type  = 1;
+  m.bs    = bs;
+  m.flags = flags;
+  m.delta = delta;
+  for (int i = 0; i < bs; ++i)
+  {
+    m.r[i]  = r[i];
+    m.e2[i] = e2[i];
+  }
+  BkzsHost H{S, gh_factor, nullptr, nullptr};
+  serve_radius(H, &m);
+  if (max_dist)
+    *max_dist = m.max_dist;
+  if (prune)
+    *prune = m.prune;
+  if (expectation)
+    *expectation = m.expectation;
+  return FPHIP_OK;
+}
+
+extern "C" int fphip_debug_bkz_plan(fphip_rand_fn rnd, void *rnd_user, int lattice, int lo, int hi,
+                                    int density, unsigned *plan, int *n_moves, int *n_ops)
+{
+  if (!rnd || !plan || hi - lo > 63)
+    return FPHIP_ERROR;
+  BkzMail m;
+  memset(&m, 0, sizeof m);
+  m.type    = 2;
+  m.lo      = lo;
+  m.hi      = hi;
+  m.density = density;
+  BkzsHost H{nullptr, 1.1, rnd, rnd_user};
+  const int np = serve_plan(H, lattice, &m);
+  memcpy(plan, m.plan, sizeof(unsigned) * (size_t)np);
+  if (n_moves)
+    *n_moves = m.n_moves;
+  if (n_ops)
+    *n_ops = m.n_ops;
+  return FPHIP_OK;
+}
 
 extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double delta, double eta,
                                         int flags, int max_loops, double gh_factor,

@@ -716,6 +716,9 @@ static int rerandomize_block(oracle_gso *g, bkz_ctx *cx, int min_row, int max_ro
 {
   if (max_row - min_row < 2)
     return 1;
+  if (max_row - min_row == 2)
+    return 1; /* the reference never returns from this case (gmp_urandomm_ui(state, 1) == 0 for ever,
+                 bkz.cpp:53-58); it does not occur with sane strategies (3-blocks are not pruned) */
   cx->rerandomizations++;
   size_t niter = 4 * (size_t)(max_row - min_row);
   for (size_t i = 0; i < niter; ++i)
@@ -1182,6 +1185,29 @@ done:
     info[4] = (int)cx.rerandomizations;
   }
   return status;
+}
+
+/* The radius and the pruning set svp_reduction (primal) would use for the block [kappa, kappa+bs) of
+ * the CURRENT state (rows must be valid): bkz.cpp:309-325.  max_dist is scaled by 2^-(2 row_expo[kappa])
+ * like r(kappa,kappa); *prune = index into strat->prune_* or -1.  For checking the product's host-side
+ * mailbox service on the CPU. */
+void oracle_gso_bkz_radius(oracle_gso *g, int kappa, int bs, int flags, double delta, double gh_factor,
+                           const oracle_strategies *strat, double *max_dist_out, int *prune_out)
+{
+  bkz_ctx cx;
+  memset(&cx, 0, sizeof cx);
+  cx.delta           = delta;
+  cx.strat           = strat;
+  double max_dist    = R(g, kappa, kappa);
+  long max_dist_expo = (long)(2 * g->row_expo[kappa]);
+  max_dist           = max_dist * delta;
+  if ((flags & 0x80) && bs > 30)
+  {
+    double root_det = get_root_det(g, kappa, kappa + bs);
+    adjust_radius_to_gh_bound(&max_dist, max_dist_expo, bs, root_det, gh_factor);
+  }
+  *max_dist_out = max_dist;
+  *prune_out    = get_pruning(g, &cx, kappa, bs);
 }
 
 /* the strategy-less form used by the device parity tests: use_max_loops bit 0 = BKZ_MAX_LOOPS,

@@ -108,6 +108,9 @@ typedef unsigned long (*oracle_rand_fn)(void *user, unsigned long n);
 int oracle_gso_bkz_param(oracle_gso *g, int block_size, double delta, double eta, int flags,
                          int max_loops, double gh_factor, const oracle_strategies *strat,
                          oracle_rand_fn rnd, void *rnd_user, int *info);
+/* radius and pruning choice of the block [kappa, kappa+bs) in the current state (bkz.cpp:309-325) */
+void oracle_gso_bkz_radius(oracle_gso *g, int kappa, int bs, int flags, double delta, double gh_factor,
+                           const oracle_strategies *strat, double *max_dist_out, int *prune_out);
 /* raw (scaled) state access; true values need the row exponents (gso_interface.h:694-732) */
 const double *oracle_gso_mu(const oracle_gso *g);      /* d×d */
 const double *oracle_gso_r(const oracle_gso *g);       /* d×d */
