@@ -31,6 +31,13 @@ template <int NQ>
 __global__ void bkzs_kernel(GsoBatch P, BkzStrat S, BkzMail *mailbox, int *abort_flag, int block_size,
                             int top_flags, double delta, double eta, double logdelta, int max_loops,
                             int stack_doubles);
+namespace sdv
+{
+template <int NQ>
+__global__ void bkzd_kernel(GsoBatch P, BkzStrat S, BkzMail *mailbox, int *abort_flag, int block_size,
+                            int top_flags, double delta, double eta, double logdelta, int max_loops,
+                            int stack_doubles, int run_mode);
+}
 template <int NQ> __global__ void hlll_kernel(HhBatch P, double delta, double theta, long long iter_cap);
 template <int NQ>
 __global__ void lll_kernel(GsoBatch P, int kmin, int kstart, int kend, double delta, double eta,
@@ -656,9 +663,17 @@ struct BkzsHost
 void serve_radius(const BkzsHost &H, BkzMail *m)
 {
   const int bs      = m->bs;
-  const long expo   = m->e2[0];
+  const bool dual   = (m->flags & 0x20000) != 0;  // a dual block of self-dual BKZ (bkzd_kernel.hip)
+  long expo         = m->e2[0];
   const double r0   = m->r[0];
-  double max_dist   = r0 * m->delta;  // max_dist *= delta
+  double max_dist   = r0;
+  if (dual)
+  {  // radius from the LAST row: max_dist.pow_si(max_dist, -1); max_dist_expo *= -1, bkz.cpp:311-316
+    max_dist = ::pow(m->r[bs - 1], static_cast<double>(-1));
+    expo     = -(long)m->e2[bs - 1];
+  }
+  max_dist = max_dist * m->delta;  // max_dist *= delta
+  const long expo0 = m->e2[0];     // get_pruning always looks at r(kappa, kappa), bkz.cpp:89-97
   // MatGSOInterface::get_root_det / get_log_det, gso_interface.cpp:220-242
   double log_det = 0.0;
   for (int i = 0; i < bs; ++i)
@@ -676,9 +691,9 @@ void serve_radius(const BkzsHost &H, BkzMail *m)
   if (H.S)
   {
     double gh_max_dist = r0;
-    adjust_radius_to_gh_bound(gh_max_dist, expo, bs, root_det, 1.0);
-    const double radius    = r0 * pow(2, expo);
-    const double gh        = gh_max_dist * pow(2, expo);
+    adjust_radius_to_gh_bound(gh_max_dist, expo0, bs, root_det, 1.0);
+    const double radius    = r0 * pow(2, expo0);
+    const double gh        = gh_max_dist * pow(2, expo0);
     const double gh_factor = radius / gh;
     double closest         = pow(2, 80);
     best                   = H.S->prune_off[bs];
@@ -791,8 +806,15 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
     return FPHIP_ERROR;
   // one wavefront enumerates a block: sizes up to 64; BKZ_MAX_LOOPS, BKZ_BOUNDED_LLL, BKZ_AUTO_ABORT,
   // BKZ_GH_BND
-  if (block_size > 64 || (flags & ~(0x4 | 0x10 | 0x20 | 0x80)))
+  // BKZ_SD_VARIANT (0x100) only behind FPHIP_EXPERIMENTAL_SD: its kernel (bkzd_kernel.hip) has not been
+  // run on hardware yet
+  const bool sd = (flags & 0x100) != 0;
+  if (sd && !getenv("FPHIP_EXPERIMENTAL_SD"))
     return FPHIP_UNSUPPORTED;
+  if (block_size > 64 || (flags & ~(0x4 | 0x10 | 0x20 | 0x80 | 0x100)))
+    return FPHIP_UNSUPPORTED;
+  if (sd && !(flags & (0x4 | 0x20)))
+    flags |= 0x20;  // "SD Variant of BKZ requires explicit termination condition", bkz.cpp:548-554
   const int bsz = block_size < g->P.d ? block_size : g->P.d;
   if (S)
   {
@@ -934,18 +956,39 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
     default: BCHK(hipFuncSetAttribute((const void *)bkzs_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); break;
     }
   }
+  if (sd && lds > 64 * 1024)
+  {
+    switch (nq)
+    {
+    case 1: BCHK(hipFuncSetAttribute((const void *)sdv::bkzd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); break;
+    case 2: BCHK(hipFuncSetAttribute((const void *)sdv::bkzd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); break;
+    case 3: BCHK(hipFuncSetAttribute((const void *)sdv::bkzd_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); break;
+    default: BCHK(hipFuncSetAttribute((const void *)sdv::bkzd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); break;
+    }
+  }
   BkzsHost H{S, gh_factor, rnd, rnd_user};
   std::vector<unsigned long long> handled(B, 0);
   std::vector<int> active(B, 1);
   BCHK(hipMemcpy(g->P.bkz_active, active.data(), sizeof(int) * B, hipMemcpyHostToDevice));
   // one launch (kflags / kloops as the kernel sees them) with the mailbox service; afterwards the
   // identity-layout GSO of the new bases (same values: every entry is a function of b)
-  auto run_once = [&](int kflags, int kloops, float *ms, int *st_out, int *info_out) -> int
+  auto run_once = [&](int kflags, int kloops, float *ms, int *st_out, int *info_out, int run_mode = 7) -> int
   {
     int rc1 = launch(g, 0, g->P.d, 0.0, 2);  // bf / row_expo of every row from b
     if (rc1 != FPHIP_OK)
       return rc1;
     GCHK(hipEventRecord(g->ev[0], s));
+    if (sd)
+    {
+      switch (nq)
+      {
+      case 1: hipLaunchKernelGGL(sdv::bkzd_kernel<1>, dim3(grid), dim3(wpb * 64), lds, s, g->P, DS, mail, d_abort, block_size, kflags | 0x100, delta, eta, logd, kloops, stack_doubles, run_mode); break;
+      case 2: hipLaunchKernelGGL(sdv::bkzd_kernel<2>, dim3(grid), dim3(wpb * 64), lds, s, g->P, DS, mail, d_abort, block_size, kflags | 0x100, delta, eta, logd, kloops, stack_doubles, run_mode); break;
+      case 3: hipLaunchKernelGGL(sdv::bkzd_kernel<3>, dim3(grid), dim3(wpb * 64), lds, s, g->P, DS, mail, d_abort, block_size, kflags | 0x100, delta, eta, logd, kloops, stack_doubles, run_mode); break;
+      default: hipLaunchKernelGGL(sdv::bkzd_kernel<4>, dim3(grid), dim3(wpb * 64), lds, s, g->P, DS, mail, d_abort, block_size, kflags | 0x100, delta, eta, logd, kloops, stack_doubles, run_mode); break;
+      }
+    }
+    else
     switch (nq)
     {
     case 1: hipLaunchKernelGGL(bkzs_kernel<1>, dim3(grid), dim3(wpb * 64), lds, s, g->P, DS, mail, d_abort, block_size, kflags, delta, eta, logd, kloops, stack_doubles); break;
@@ -1062,7 +1105,8 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
       if (n_active == 0)
         break;
       BCHK(hipMemcpy(g->P.bkz_active, active.data(), sizeof(int) * B, hipMemcpyHostToDevice));
-      rc = run_once(kbase | 0x4, 1, &ms, s1.data(), one.data());  // exactly one tour
+      // exactly one tour (self-dual BKZ: the prelude lll() goes with the first one only)
+      rc = run_once(kbase | 0x4, 1, &ms, s1.data(), one.data(), sd && loop == 0 ? 3 : 2);
       if (rc != FPHIP_OK)
         break;
       total_ms += ms;
@@ -1081,6 +1125,28 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
           continue;        // tour done, not clean: next loop
         st[L]     = s1[L];  // 1: clean (or block_size >= num_rows); <= 0: failure
         active[L] = 0;
+      }
+    }    if (sd && rc == FPHIP_OK)
+    {
+      // closing pass of self-dual BKZ on every lattice that ended regularly: hkz of the last window
+      // (bkz.cpp:627-641), its own launch
+      for (size_t L = 0; L < B; ++L)
+        active[L] = (st[L] == 1 || st[L] == 8) ? 1 : 0;
+      BCHK(hipMemcpy(g->P.bkz_active, active.data(), sizeof(int) * B, hipMemcpyHostToDevice));
+      rc = run_once(kbase | 0x4, 1, &ms, s1.data(), one.data(), 4);
+      total_ms += ms;
+      for (size_t L = 0; L < B && rc == FPHIP_OK; ++L)
+      {
+        if (!active[L])
+          continue;
+        const unsigned long long a0 = ((unsigned long long)(unsigned)inf[4 * L + 2] << 32) | (unsigned)inf[4 * L + 1];
+        const unsigned long long a1 = ((unsigned long long)(unsigned)one[4 * L + 2] << 32) | (unsigned)one[4 * L + 1];
+        const unsigned long long t  = a0 + a1;
+        inf[4 * L + 1] = (int)(unsigned)(t & 0xffffffffull);
+        inf[4 * L + 2] = (int)(unsigned)(t >> 32);
+        inf[4 * L + 3] += one[4 * L + 3];
+        if (s1[L] <= 0)
+          st[L] = s1[L];
       }
     }
   }

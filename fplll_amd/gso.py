@@ -125,7 +125,8 @@ class MatGSOBatch:
         return st, info
 
     def bkz_strategies(self, block_size, strategies, rnd, delta=LLL_DEF_DELTA, eta=LLL_DEF_ETA,
-                       max_loops=0, gh_bnd=False, bounded_lll=False, gh_factor=1.1, auto_abort=False):
+                       max_loops=0, gh_bnd=False, bounded_lll=False, gh_factor=1.1, auto_abort=False,
+                       sd=False):
         """BKZReduction::bkz() with a strategies table (preprocessing tours, pruning, GH bound,
         rerandomisation; bkz.cpp:43-124, 274-441, 522-668) on every (LLL-reduced) lattice.
         strategies: dict with the flattened arrays of include/fplll_hip.h's fphip_strategies
@@ -169,7 +170,7 @@ class MatGSOBatch:
         st = np.zeros(self.batch, dtype=np.int32)
         info = np.zeros((self.batch, 4), dtype=np.int32)
         flags = ((0x4 if max_loops > 0 else 0) | (0x80 if gh_bnd else 0) | (0x10 if bounded_lll else 0) |
-                 (0x20 if auto_abort else 0))
+                 (0x20 if auto_abort else 0) | (0x100 if sd else 0))  # sd: BKZ_SD_VARIANT (experimental)
         rc = fn(self.h, block_size, delta, eta, flags, max_loops, gh_factor, sp, cb, None,
                 st.ctypes.data_as(ctypes.c_void_p), info.ctypes.data_as(ctypes.c_void_p))
         if rc == _lib.FPHIP_UNSUPPORTED:

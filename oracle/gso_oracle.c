@@ -1198,9 +1198,15 @@ void oracle_gso_bkz_radius(oracle_gso *g, int kappa, int bs, int flags, double d
   memset(&cx, 0, sizeof cx);
   cx.delta           = delta;
   cx.strat           = strat;
-  double max_dist    = R(g, kappa, kappa);
-  long max_dist_expo = (long)(2 * g->row_expo[kappa]);
-  max_dist           = max_dist * delta;
+  const int first    = (flags & 0x20000) ? kappa + bs - 1 : kappa; /* 0x20000: a dual block */
+  double max_dist    = R(g, first, first);
+  long max_dist_expo = (long)(2 * g->row_expo[first]);
+  if (flags & 0x20000)
+  {
+    max_dist      = pow(max_dist, (double)-1);
+    max_dist_expo = -max_dist_expo;
+  }
+  max_dist = max_dist * delta;
   if ((flags & 0x80) && bs > 30)
   {
     double root_det = get_root_det(g, kappa, kappa + bs);

@@ -69,7 +69,8 @@ def test_radius_and_pruning_choice_match_oracle(name):
         ex = np.asarray(g.row_expo, dtype=np.int64)
         for bs in range(2, f["block_size"] + 1, 3):
             for kappa in range(0, d - bs + 1, 5):
-                for flags, ghf in ((0x80, 1.1), (0x0, 1.1), (0x80, 1.3)):
+                # 0x20000: a dual block (self-dual BKZ): radius from 1 / r of the block's last row
+                for flags, ghf in ((0x80, 1.1), (0x0, 1.1), (0x80, 1.3), (0x20080, 1.1), (0x20000, 1.1)):
                     omd, opr = ctypes.c_double(), ctypes.c_int()
                     olib.oracle_gso_bkz_radius(g.h, kappa, bs, flags, f["delta"], ghf, ctypes.byref(st),
                                                ctypes.byref(omd), ctypes.byref(opr))
