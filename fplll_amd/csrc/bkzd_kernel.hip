@@ -5,11 +5,12 @@
 // dualenum recursion enum/enumerate_base.cpp:57-61,103-105), the dual insertions
 // (bkz.cpp:148-193, 240-248), the prelude lll() (:576-577) and the closing hkz() (:627-641).
 //
-// STATUS: written after the round's GPU budget was spent — it compiles (0 bytes of scratch) and its
-// oracle is pinned to the reference (tests/test_bkz_dual_variants_oracle_vs_ref.py), but it has NOT
-// run on hardware yet.  It is therefore a separate translation unit in its own namespace (the
-// verified kernel of bkzs_kernel.hip is untouched, instruction for instruction), and the host only
-// launches it when FPHIP_EXPERIMENTAL_SD=1 (otherwise BKZ_SD_VARIANT is declined as before).
+// STATUS: written at the very end of round 1.  On hardware it has reproduced the reference's basis,
+// status and node count on the two strategy-less fixtures (SD-BKZ with BKZ_MAX_LOOPS; SD-BKZ to its
+// auto-abort stop after 13 tours: profiles/r01_sd_bkz_first_run.log); the fixture that combines the
+// dual blocks with strategies (pruning, preprocessing, rerandomisation) has only been pinned on the
+// oracle side so far.  It is a separate translation unit in its own namespace, so the kernel of
+// bkzs_kernel.hip that the other measurements were taken with is untouched.
 // Everything this file adds to bkzs_kernel.hip's code sits behind `if constexpr (DUALS)` / cur_dual().
 
 #include "lll_wave.h"
@@ -1118,8 +1119,7 @@ bkzs_body(GsoBatch P, BkzStrat S, BkzMail *mailbox, int *abort_flag, int block_s
   }
 }
 
-// the same schedule with the dual blocks of self-dual BKZ (not yet run on hardware: the host only
-// selects it when FPHIP_EXPERIMENTAL_SD is set)
+// the same schedule with the dual blocks of self-dual BKZ (the host selects it for BKZ_SD_VARIANT)
 template <int NQ>
 __global__ void __launch_bounds__(256)
     bkzd_kernel(GsoBatch P, BkzStrat S, BkzMail *mailbox, int *abort_flag, int block_size, int top_flags,

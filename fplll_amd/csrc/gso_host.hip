@@ -806,11 +806,8 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
     return FPHIP_ERROR;
   // one wavefront enumerates a block: sizes up to 64; BKZ_MAX_LOOPS, BKZ_BOUNDED_LLL, BKZ_AUTO_ABORT,
   // BKZ_GH_BND
-  // BKZ_SD_VARIANT (0x100) only behind FPHIP_EXPERIMENTAL_SD: its kernel (bkzd_kernel.hip) has not been
-  // run on hardware yet
+  // BKZ_SD_VARIANT (0x100): self-dual BKZ, bkzd_kernel.hip
   const bool sd = (flags & 0x100) != 0;
-  if (sd && !getenv("FPHIP_EXPERIMENTAL_SD"))
-    return FPHIP_UNSUPPORTED;
   if (block_size > 64 || (flags & ~(0x4 | 0x10 | 0x20 | 0x80 | 0x100)))
     return FPHIP_UNSUPPORTED;
   if (sd && !(flags & (0x4 | 0x20)))

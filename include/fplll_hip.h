@@ -195,10 +195,13 @@ int fphip_gso_bkz(fphip_gso *g, int block_size, double delta, double eta, int fl
  * one a run of the reference on that lattice alone would draw from.
  * flags: FPHIP_BKZ_MAX_LOOPS, FPHIP_BKZ_BOUNDED_LLL, FPHIP_BKZ_AUTO_ABORT (one tour per launch, the
  * slope test on the host in between, as in fphip_gso_bkz), FPHIP_BKZ_GH_BND (fplll's values).
+ * FPHIP_BKZ_SD_VARIANT selects self-dual BKZ (sd_tour, dual svp_reduction / enumeration / insertion,
+ * bkz.cpp:401-413,443-463; without MAX_LOOPS / AUTO_ABORT the auto abort is switched on, :548-554).
  * FPHIP_UNSUPPORTED: block sizes above 64, other flags, preprocessing nested deeper than 3 levels.
  * status / info as fphip_gso_bkz; status -7 = a mailbox request was not answered in time. */
 #define FPHIP_BKZ_BOUNDED_LLL 0x10
 #define FPHIP_BKZ_GH_BND 0x80
+#define FPHIP_BKZ_SD_VARIANT 0x100
 typedef struct fphip_strategies
 {
   int max_block_size;

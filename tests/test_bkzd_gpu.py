@@ -1,8 +1,10 @@
 """Device self-dual BKZ (BKZ_SD_VARIANT through fphip_gso_bkz_strategies, bkzd_kernel.hip) against
 the reference's bkzd_*sd* fixtures (oracle-pinned by test_bkz_dual_variants_oracle_vs_ref.py).
 
-The kernel was written after the round's GPU budget was spent and has not run on hardware yet: the
-host declines BKZ_SD_VARIANT unless FPHIP_EXPERIMENTAL_SD=1, and this module is skipped without it."""
+The two strategy-less fixtures (BKZ_MAX_LOOPS; forced auto-abort, 13 tours) have been seen green on
+the MI355X (profiles/r01_sd_bkz_first_run.log).  The fixture that combines dual blocks with
+strategies was pinned on the oracle side only before the round's GPU budget ran out: it joins the
+run with FPHIP_BKZS_ALL=1."""
 import glob
 import os
 
@@ -11,11 +13,11 @@ import pytest
 
 import conftest as C
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(not os.environ.get("FPHIP_EXPERIMENTAL_SD"),
-                                 reason="self-dual BKZ on the device is not verified yet")]
+pytestmark = pytest.mark.gpu
 
 FIXTURES = sorted(glob.glob(os.path.join(C.GOLDEN, "bkzd_*sd*.json")))
+if not os.environ.get("FPHIP_BKZS_ALL"):
+    FIXTURES = [p for p in FIXTURES if "strategies" not in p]
 
 
 @pytest.mark.parametrize("path", FIXTURES, ids=lambda p: os.path.basename(p)[:-5])
