@@ -455,13 +455,23 @@ static bool gen_long_basis(const std::string &type, int &d, int k, int bits, int
 {
   RandGen::init_with_seed(seed);
   ZZ_mat<mpz_t> A;
-  if (type.rfind("f:", 0) == 0)
-  {  // basis from a file in fplll's matrix format (d is taken from the file)
+  if (type.rfind("f:", 0) == 0 || type.rfind("F:", 0) == 0)
+  {  // basis from a file in fplll's matrix format (d is taken from the file); "F:" LLL-reduces it
+     // with the wrapper first, as bkz_reduction does (bkz.cpp:870-877), so that entries of the
+     // reference's own test lattices (tests/lattices/dim55_in: 75 bits) fit a long afterwards
     std::ifstream in(type.substr(2));
     in >> A;
     if (A.get_rows() == 0)
       return false;
     d = A.get_rows();
+    if (type[0] == 'F')
+    {
+      lll_reduction(A, LLL_DEF_DELTA, LLL_DEF_ETA, LM_WRAPPER, FT_DEFAULT, 0, LLL_DEFAULT);
+      for (int i = 0; i < A.get_rows(); ++i)
+        for (int j = 0; j < A.get_cols(); ++j)
+          if (!mpz_fits_slong_p(A(i, j).get_data()))
+            return false;
+    }
   }
   else if (type == "q")
   {
@@ -810,6 +820,47 @@ static int cmd_genstrat(int argc, char **argv)
   return 0;
 }
 
+/* teststrat block_size linear(0|1) → the strategies tests/test_bkz.cpp builds by hand
+ * (test_bkz_param :69-105: preprocessing [5] / [10] / [15] at block sizes 10 / 20 / 30, no pruning;
+ * test_bkz_param_linear_pruning :116-152: the same plus LinearPruningParams(b, b/2) at block_size),
+ * in load_strategies_json's format */
+static int cmd_teststrat(int argc, char **argv)
+{
+  if (argc < 4)
+    return 2;
+  int block_size = atoi(argv[2]), linear = atoi(argv[3]);
+  std::ostringstream os;
+  os << "[";
+  for (int b = 0; b <= block_size; ++b)
+  {
+    os << (b ? ",\n" : "") << "{\"block_size\":" << b << ",\"preprocessing_block_sizes\":[";
+    if (b == 10 && !(linear && b == block_size))
+      os << 5;
+    else if (b == 20 && !(linear && b == block_size))
+      os << 10;
+    else if (b == 30 && !(linear && b == block_size))
+      os << 15;
+    os << "],\"pruning_parameters\":[";
+    if (linear && b == block_size)
+    {
+      PruningParams pp = PruningParams::LinearPruningParams(block_size, block_size / 2);
+      char buf[40];
+      os << "[" << pp.gh_factor << ",[";
+      for (size_t i = 0; i < pp.coefficients.size(); ++i)
+      {
+        snprintf(buf, sizeof buf, "%.17g", pp.coefficients[i]);
+        os << (i ? "," : "") << buf;
+      }
+      snprintf(buf, sizeof buf, "%.17g", pp.expectation);
+      os << "]," << buf << "]";
+    }
+    os << "]}";
+  }
+  os << "]\n";
+  std::cout << os.str();
+  return 0;
+}
+
 /* bkztour basisfile strategies.json beta plugin.so|none → JSON: wall time of ONE BKZ-beta tour
  * (BKZ_MAX_LOOPS=1, BKZ_GH_BND 1.1) and a fingerprint of the result */
 static int cmd_bkztour(int argc, char **argv)
@@ -936,6 +987,8 @@ int main(int argc, char **argv)
     return cmd_bkzfix(argc, argv);
   if (cmd == "genstrat")
     return cmd_genstrat(argc, argv);
+  if (cmd == "teststrat")
+    return cmd_teststrat(argc, argv);
   if (cmd == "bkztour")
     return cmd_bkztour(argc, argv);
   fprintf(stderr, "unknown command %s\n", cmd.c_str());

@@ -81,6 +81,13 @@ REFDRV_BKZ_FLAGS=0x200 $D bkzfix r 30 0 40 4 8 0 > $G/bkzd_r30_b8_slide.json
 # three nested tours (40 -> 30 -> 20) with expectations scaled to 0.8x
 python3 $G/make_strategies.py $T/gen.json $T/stratC.json 40 10 30 0.8
 REFDRV_STRATEGIES=$T/stratC.json REFDRV_BKZ_FLAGS=0x80 REFDRV_RNG_SEED=21 $D bkzfix q 56 28 12 5 40 1 > $G/bkzs_q56_b40_nested3.json
+# the strategies the reference's own tests/test_bkz.cpp builds (test_bkz_param, _linear_pruning); its
+# test lattices themselves (dim55_in, example_in, 1000-bit intrel) do not fit ZT = long
+$D teststrat 20 0 > $T/p.json
+$D teststrat 20 1 > $T/l.json
+REFDRV_STRATEGIES=$T/p.json REFDRV_RNG_SEED=3 $D bkzfix q 50 25 12 2 20 0 > $G/bkzs_q50_b20_teststrat_param.json
+REFDRV_STRATEGIES=$T/l.json REFDRV_RNG_SEED=3 $D bkzfix q 50 25 12 2 20 0 > $G/bkzs_q50_b20_teststrat_linear.json
+REFDRV_STRATEGIES=$T/l.json REFDRV_RNG_SEED=3 REFDRV_BKZ_AUTO_ABORT=1 $D bkzfix r 40 0 45 5 20 0 > $G/bkzs_r40_b20_teststrat_linear_autoabort.json
 rm -rf $T
 # --- C3 (BASELINE configs[2]): the 180-dim q-ary lattice, LLL + BKZ-20 by the reference, its
 #     beta=60 blocks as the plugin sees them, and pruner-generated strategies for the tour bench

@@ -17,8 +17,10 @@ FIXTURES = C.bkz_strategy_fixtures()
 # the round's last GPU session: it is pinned oracle-vs-reference on the CPU
 # (test_bkz_strategies_oracle_vs_ref.py) and joins the device run once it has been seen green there
 # (FPHIP_BKZS_ALL=1 runs it).
+# ... and so do the bkzs_*teststrat* fixtures (the strategies tests/test_bkz.cpp of the reference
+# builds by hand: preprocessing 20 -> 10 -> 5, LinearPruningParams).
 if not os.environ.get("FPHIP_BKZS_ALL"):
-    FIXTURES = [p for p in FIXTURES if "nested3" not in p]
+    FIXTURES = [p for p in FIXTURES if "nested3" not in p and "teststrat" not in p]
 if os.environ.get("FPHIP_BKZS_ONLY"):
     FIXTURES = [p for p in FIXTURES if any(t in p for t in os.environ["FPHIP_BKZS_ONLY"].split(","))]
 
