@@ -1216,6 +1216,27 @@ void oracle_gso_bkz_radius(oracle_gso *g, int kappa, int bs, int flags, double d
   *prune_out    = get_pruning(g, &cx, kappa, bs);
 }
 
+/* One BKZReduction::svp_reduction(kappa, block_size, BKZParam(block_size, {}), dual) (bkz.cpp:274-358)
+ * with empty strategies — the call the reference's own dual-SVP known-answer test makes
+ * (tests/test_svp.cpp:214-262).  returns 1 or a failure status; *clean as the reference's return. */
+int oracle_gso_svp_reduction(oracle_gso *g, int kappa, int block_size, int dual, double delta,
+                             double eta, int *clean, uint64_t *nodes)
+{
+  bkz_ctx cx;
+  memset(&cx, 0, sizeof cx);
+  cx.delta     = delta;
+  cx.lll_delta = delta;
+  cx.eta       = eta;
+  bkz_par par  = {block_size, 0, 1.1, 0.5, 3};
+  int c        = 1;
+  int rc       = svp_reduction(g, &cx, &par, kappa, block_size, &c, dual);
+  if (clean)
+    *clean = c;
+  if (nodes)
+    *nodes = cx.nodes;
+  return rc;
+}
+
 /* the strategy-less form used by the device parity tests: use_max_loops bit 0 = BKZ_MAX_LOOPS,
  * bit 1 = BKZ_AUTO_ABORT.  info[3]: tours, nodes lo, nodes hi. */
 int oracle_gso_bkz(oracle_gso *g, int block_size, double delta, double eta, int use_max_loops,

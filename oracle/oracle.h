@@ -108,6 +108,9 @@ typedef unsigned long (*oracle_rand_fn)(void *user, unsigned long n);
 int oracle_gso_bkz_param(oracle_gso *g, int block_size, double delta, double eta, int flags,
                          int max_loops, double gh_factor, const oracle_strategies *strat,
                          oracle_rand_fn rnd, void *rnd_user, int *info);
+/* one svp_reduction(kappa, block_size, empty strategies, dual), bkz.cpp:274-358 */
+int oracle_gso_svp_reduction(oracle_gso *g, int kappa, int block_size, int dual, double delta,
+                             double eta, int *clean, uint64_t *nodes);
 /* radius and pruning choice of the block [kappa, kappa+bs) in the current state (bkz.cpp:309-325) */
 void oracle_gso_bkz_radius(oracle_gso *g, int kappa, int bs, int flags, double delta, double gh_factor,
                            const oracle_strategies *strat, double *max_dist_out, int *prune_out);
