@@ -403,11 +403,16 @@ def hlll_fixtures():
 
 
 def load_hlll_fixture(path):
-    with open(path) as f:
-        j = json.load(f)
+    if path.endswith(".gz"):
+        import gzip
+        with gzip.open(path, "rt") as f:
+            j = json.load(f)
+    else:
+        with open(path) as f:
+            j = json.load(f)
     d, n = j["d"], j["n"]
     out = {"d": d, "n": n, "name": os.path.basename(path)[:-5],
-           "status": HLLL_REF_STATUS_TO_OURS[j["ref_status"]]}
+           "status": HLLL_REF_STATUS_TO_OURS[j["ref_status"]], "ref_seconds": j.get("ref_seconds")}
     for k in ("delta", "eta", "theta", "c"):
         out[k] = float.fromhex(j[k])
     out["b_in"] = np.array(j["b_in"], dtype=np.int64).reshape(d, n)

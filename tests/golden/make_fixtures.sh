@@ -50,6 +50,8 @@ $D hlllfix q 72 36 16 2 > $G/hlll_q72.json
 $D hlllfix r 30  0 40 4 > $G/hlll_r30.json
 $D hlllfix u 24  0 30 5 > $G/hlll_u24.json
 $D hlllfix n 64  0 10 6 > $G/hlll_n64.json
+# config 5's lattice at full size, FT = double (12 s)
+$D hlllfix n 256 0 10 6 | gzip -9 > $G/c5_hlll_n256_double.json.gz
 # --- BKZ (BKZReduction<long,double>::bkz, empty strategies): type d k bits seed block_size max_loops
 $D bkzfix q 40 20 20 1 10 0 > $G/bkz_q40_b10.json
 $D bkzfix q 40 20 20 1 20 0 > $G/bkz_q40_b20.json
