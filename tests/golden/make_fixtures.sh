@@ -91,6 +91,8 @@ REFDRV_STRATEGIES=$T/p.json REFDRV_RNG_SEED=3 $D bkzfix q 50 25 12 2 20 0 > $G/b
 REFDRV_STRATEGIES=$T/l.json REFDRV_RNG_SEED=3 $D bkzfix q 50 25 12 2 20 0 > $G/bkzs_q50_b20_teststrat_linear.json
 REFDRV_STRATEGIES=$T/l.json REFDRV_RNG_SEED=3 REFDRV_BKZ_AUTO_ABORT=1 $D bkzfix r 40 0 45 5 20 0 > $G/bkzs_r40_b20_teststrat_linear_autoabort.json
 rm -rf $T
+# config 2 at full size (4 s)
+$D bkzfix q 120 60 20 0 20 0 | gzip -9 > $G/c2_bkz20_q120.json.gz
 # --- C3 (BASELINE configs[2]): the 180-dim q-ary lattice, LLL + BKZ-20 by the reference, its
 #     beta=60 blocks as the plugin sees them, and pruner-generated strategies for the tour bench
 $D dumpbasis 180 90 20 0 20 > $G/basis_q180_seed0_lll_bkz20.txt

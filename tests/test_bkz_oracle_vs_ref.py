@@ -22,3 +22,18 @@ def test_bkz_oracle_matches_reference(path):
     assert np.array_equal(g.b, f["b_out"])
     assert not np.array_equal(f["b_in"], f["b_out"])
     g.close()
+
+
+def test_config2_at_full_size():
+    """BASELINE config 2 at its full size: BKZ-20 (no strategies, BKZ_DEFAULT, to convergence) on a
+    120-dimensional q-ary lattice (gen_qary_prime(60, 20), LLL-reduced first): 138 tours, 1.03e7
+    enumeration nodes, 4.3 s in the reference — basis, status and node count identical (~4 s)."""
+    f = C.load_bkz_fixture(os.path.join(C.GOLDEN, "c2_bkz20_q120.json.gz"))
+    assert (f["d"], f["block_size"], f["max_loops"]) == (120, 20, 0)
+    g = C.OracleGSO(f["b_in"])
+    st, info = g.bkz(f["block_size"], f["delta"], f["eta"], f["max_loops"], f["auto_abort"])
+    assert st == f["status"] == 1
+    assert info[0] == 138
+    assert ((int(info[1]) & 0xffffffff) | (int(info[2]) << 32)) == f["nodes"] == 10252068
+    assert np.array_equal(g.b, f["b_out"])
+    g.close()
