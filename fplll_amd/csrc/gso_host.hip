@@ -16,6 +16,7 @@
 
 #include "../../include/fplll_hip.h"
 #include "gso_device.h"
+#include "gso_sweep2.h"
 
 #ifndef FPHIP_GSO_RING
 #define FPHIP_GSO_RING 6
@@ -58,6 +59,9 @@ struct fphip_gso
   int waves_per_block;
   int blocks_per_cu;
   bool dirty;  // the integer basis was uploaded after the last (re)float of the rows
+  // planes of mu for gso_sweep2_kernel (low / high words; row-major and transposed), [batch][2][d][ldd]
+  unsigned *muP, *muTP;
+  int sweep_version;  // 2 (default) or 1 (FPHIP_GSO_SWEEP=1: the first-generation kernel)
 };
 
 static int gfail(fphip_ctx *ctx, const char *what, hipError_t e)
@@ -140,7 +144,15 @@ static int gso_allocate(fphip_gso *g)
   GCHK(hipMalloc((void **)&g->P.bfT32, B * n * ldd * sizeof(float) + pad));
   GCHK(hipMalloc((void **)&g->P.b32, B * d * ldn * sizeof(int) + pad));
   GCHK(hipMalloc((void **)&g->P.narrow, B * d * sizeof(int)));
+  GCHK(hipMalloc((void **)&g->muP, B * 2 * d * ldd * sizeof(unsigned) + pad));
+  GCHK(hipMalloc((void **)&g->muTP, B * 2 * d * ldd * sizeof(unsigned) + pad));
   hipStream_t s0 = fphip_ctx_stream(ctx);
+  GCHK(hipMemsetAsync(g->muP, 0, B * 2 * d * ldd * sizeof(unsigned) + pad, s0));
+  GCHK(hipMemsetAsync(g->muTP, 0, B * 2 * d * ldd * sizeof(unsigned) + pad, s0));
+  {
+    const char *sv   = getenv("FPHIP_GSO_SWEEP");
+    g->sweep_version = (sv && atoi(sv) == 1) ? 1 : 2;
+  }
   GCHK(hipMemsetAsync(g->P.bfT32, 0, B * n * ldd * sizeof(float) + pad, s0));
   GCHK(hipMemsetAsync(g->P.b32, 0, B * d * ldn * sizeof(int) + pad, s0));
   GCHK(hipMemsetAsync(g->P.narrow, 0, B * d * sizeof(int), s0));
@@ -179,6 +191,8 @@ extern "C" void fphip_gso_destroy(fphip_gso *g)
   hipFree(g->P.bfT32);
   hipFree(g->P.b32);
   hipFree(g->P.narrow);
+  hipFree(g->muP);
+  hipFree(g->muTP);
   if (g->P.gf)
     hipFree(g->P.gf);
   if (g->P.vc)
@@ -221,6 +235,41 @@ static int launch(fphip_gso *g, int kmin, int kend, double eta, int mode, const 
   const int wpb  = g->waves_per_block;
   int grid       = (g->P.batch + wpb - 1) / wpb;
   hipStream_t s = fphip_ctx_stream(g->ctx);
+  if (!la && g->sweep_version == 2)
+  {  // gso_sweep2_kernel: its own ring geometry (gso_sweep2.h)
+    const int ring   = nq == 1 ? s2::Cfg<1>::RING : nq == 2 ? s2::Cfg<2>::RING : nq == 3 ? s2::Cfg<3>::RING : s2::Cfg<4>::RING;
+    const int wps    = nq == 4 ? s2::Cfg<4>::WAVES_PER_SIMD : s2::Cfg<1>::WAVES_PER_SIMD;
+    const size_t lds2 = (size_t)wpb * ring;
+    int bpc2          = g->blocks_per_cu > 0 ? g->blocks_per_cu : (int)((160 * 1024) / lds2);
+    if (bpc2 * wpb > 4 * wps)
+      bpc2 = 4 * wps / wpb;
+    if (bpc2 < 1)
+      bpc2 = 1;
+    const int cap2 = fphip_ctx_num_cus(g->ctx) * bpc2;
+    if (grid > cap2)
+      grid = cap2;
+    GCHK(hipEventRecord(g->ev[0], s));
+    switch (nq)
+    {
+    case 1:
+      hipLaunchKernelGGL(s2::gso_sweep2_kernel<1>, dim3(grid), dim3(wpb * 64), lds2, s, g->P, g->muP, g->muTP, kmin, kend, eta, mode);
+      break;
+    case 2:
+      hipLaunchKernelGGL(s2::gso_sweep2_kernel<2>, dim3(grid), dim3(wpb * 64), lds2, s, g->P, g->muP, g->muTP, kmin, kend, eta, mode);
+      break;
+    case 3:
+      hipLaunchKernelGGL(s2::gso_sweep2_kernel<3>, dim3(grid), dim3(wpb * 64), lds2, s, g->P, g->muP, g->muTP, kmin, kend, eta, mode);
+      break;
+    default:
+      hipLaunchKernelGGL(s2::gso_sweep2_kernel<4>, dim3(grid), dim3(wpb * 64), lds2, s, g->P, g->muP, g->muTP, kmin, kend, eta, mode);
+      break;
+    }
+    GCHK(hipGetLastError());
+    GCHK(hipEventRecord(g->ev[1], s));
+    GCHK(hipStreamSynchronize(s));
+    GCHK(hipEventElapsedTime(&g->last_ms, g->ev[0], g->ev[1]));
+    return FPHIP_OK;
+  }
   // per-wave LDS-DMA ring: FPHIP_GSO_RING slots of IPS KiB (IPS = ceil(NQ/2))
   const size_t lds = (size_t)wpb * (la ? FPHIP_RING_REDUCE : FPHIP_GSO_RING) * (size_t)((nq + 1) / 2) * 1024;
   int bpc          = g->blocks_per_cu > 0 ? g->blocks_per_cu : (int)((160 * 1024) / lds);
@@ -305,6 +354,26 @@ extern "C" int fphip_gso_broadcast_basis(fphip_gso *g, int src)
       GCHK(hipMemcpyAsync(g->P.b + (size_t)L * g->P.d * g->P.ldn,
                           g->P.b + (size_t)src * g->P.d * g->P.ldn, per, hipMemcpyDeviceToDevice,
                           fphip_ctx_stream(g->ctx)));
+  GCHK(hipStreamSynchronize(fphip_ctx_stream(g->ctx)));
+  g->dirty = true;
+  return FPHIP_OK;
+}
+
+// lattices count, count+1, … become copies of lattices 0 … count-1, cyclically (device-side
+// copies: a batch of `count` distinct inputs replicated to the full batch; used by benchmarks)
+extern "C" int fphip_gso_tile_basis(fphip_gso *g, int count)
+{
+  if (!g || count <= 0 || count > g->P.batch)
+    return FPHIP_ERROR;
+  const size_t per = (size_t)g->P.d * g->P.ldn;
+  int have         = count;  // always a multiple of count: the cyclic pattern survives the doubling
+  while (have < g->P.batch)
+  {
+    const int m = have < g->P.batch - have ? have : g->P.batch - have;
+    GCHK(hipMemcpyAsync(g->P.b + (size_t)have * per, g->P.b, (size_t)m * per * sizeof(long long),
+                        hipMemcpyDeviceToDevice, fphip_ctx_stream(g->ctx)));
+    have += m;
+  }
   GCHK(hipStreamSynchronize(fphip_ctx_stream(g->ctx)));
   g->dirty = true;
   return FPHIP_OK;

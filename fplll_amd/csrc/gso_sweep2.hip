@@ -1,0 +1,1014 @@
+// gso_sweep2.hip — batched floating-point Gram-Schmidt + size-reduction sweep for gfx950, second
+// generation of the kernel (the first one, gso_sweep_kernel in gso_kernel.hip, keeps serving as the
+// in-tree cross-check: FPHIP_GSO_SWEEP=1 selects it).
+//
+// Reference behaviour reproduced, bit for bit, for MatGSO<Z_NR<long>, FP_NR<double>> with
+// GSO_ROW_EXPO (the BKZ fast path, fplll/bkz.cpp:816-829):
+//   MatGSOInterface::update_gso_row   fplll/gso_interface.cpp:131-164
+//   MatGSO::get_gram + dot_product    fplll/gso.h:314-331, fplll/nr/numvect.h:386-396
+//   LLLReduction::babai               fplll/lll.cpp:166-224
+//   LLLReduction::size_reduction      fplll/lll.h:107-122
+//   MatGSO::row_addmul_we / update_bf fplll/gso.cpp:236-262, 24-48 ; row_op_end gso_interface.cpp:32-53
+//
+// One wavefront owns one lattice (see gso_kernel.hip for why).  What is new here is the shape of the
+// inner loops — the first kernel spent ~60 issued instructions and half a dozen branches per
+// streamed row and was bound by that, not by HBM:
+//   * EVERYTHING STREAMED IS A ROW OF 4-BYTE ELEMENTS, one LDS-DMA instruction each ("entry"):
+//     the float mirror of bf (Gram pass), the int32 mirror of b (integer AXPY) and mu kept as two
+//     planes of 32-bit words (low / high halves of the doubles; muP row-major for the size-reduction
+//     sweep, muTP transposed for the GSO recurrence).  An entry holds 64*NQ elements (NQ*256 B); a
+//     lane fetches 16 bytes = 4 elements, so a triangular window [lo, hi) is the lane mask
+//     [lo/4, ceil(hi/4)), set with one s_mov exec inside the issue sequence.
+//   * THE RING MOVES IN PAIRS of entries: a step consumes one pair (two Gram rows, two AXPY rows,
+//     or the two planes of one mu row) and issues one pair.  INFL entries are ALWAYS in flight —
+//     when a chain of phases has no more rows to request the issue side sends one-lane dummies —
+//     so every wait is the compile-time s_waitcnt vmcnt(INFL-2) and the loops have no pipeline
+//     states.  (Newer loads never complete before older ones, so anything else outstanding only
+//     makes that wait stricter.)
+//   * loops are CHUNK-MAJOR: the lane that owns the scalar of a step (bf(kappa,c), r(kappa,k),
+//     babai_mu[j], the multiplier of row j) is read with v_readlane from a register whose index is
+//     a compile-time constant of the loop.
+//   * rows whose multiplier is zero are neither fetched nor multiplied in the integer AXPY;
+//     r(kappa,kappa) is finished from registers with one subtraction chain; the row's mu / r are
+//     stored once, when babai has confirmed it.
+// Rows that are not "narrow" (an entry of magnitude >= 2^24, so that the 4-byte mirrors are not
+// exact) take the plain-load paths gram_wide / axpy_wide on the 8-byte arrays: same arithmetic.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (no FMA contraction).
+
+#include "gso_wave.h"
+#include "gso_sweep2.h"
+
+namespace fphip
+{
+namespace s2
+{
+
+extern __shared__ __attribute__((aligned(16))) unsigned s2_smem[];
+
+enum
+{
+  K_GRAM  = 0,
+  K_REC   = 1,
+  K_SWEEP = 2,
+  K_AXPY  = 3,
+  K_DUMMY = 4
+};
+
+// All members are wave-uniform (SGPRs) except lane4 / lane16.
+template <int NQ> struct Stream
+{
+  using C = Cfg<NQ>;
+  unsigned base;            // LDS byte address of this wave's ring
+  unsigned hoff, toff;      // byte offsets of the pair slot to fill next / to read next
+  unsigned lane4, lane16;   // per lane
+  const char *dummy;        // a valid 16-byte aligned address of this lattice (dummy requests)
+  // ---- the chain being requested: current segment, then `nkind`, then dummies
+  int kind, left, nkind, nleft;
+  // Gram: rows c, c+1 of the float mirror (stride gstride bytes), lanes of gmask
+  const char *gp;
+  long gstride;
+  unsigned long long gmask;
+  // recurrence: planes of row k of muTP, elements (k, last]
+  const char *rp;
+  long rstride, rplane;
+  unsigned long long rhimask;
+  int rk;
+  // size-reduction sweep: planes of row j of muP, elements [sr_start, j), j descending
+  const char *sp;
+  long sstride, splane;
+  unsigned long long slomask;
+  int sj;
+  // integer AXPY: rows of the int32 mirror whose multiplier is not zero, descending
+  const char *ap;
+  long astride;
+  unsigned long long amask;
+  unsigned long long ab0, ab1, ab2, ab3;  // chunk aq, aq-1, … (shifted down as they are exhausted)
+  int aq;
+
+  __device__ __forceinline__ void dma_pair(const char *p0, const char *p1, unsigned long long mask)
+  {
+    const unsigned dst = base + hoff;
+    // s_mov exec doubles as the wait state the LDS-DMA needs after the M0 write
+    asm volatile("s_mov_b32 m0, %2\n\t"
+                 "s_mov_b64 exec, %3\n\t"
+                 "global_load_lds_dwordx4 %4, %0\n\t"
+                 "s_add_u32 m0, m0, %5\n\t"
+                 "s_nop 0\n\t"
+                 "global_load_lds_dwordx4 %4, %1\n\t"
+                 "s_mov_b64 exec, -1"
+                 :
+                 : "s"(p0), "s"(p1), "s"(dst), "s"(mask), "v"(lane16), "n"(C::ESZ)
+                 : "memory", "m0", "scc");
+    hoff = (hoff + 2 * C::ESZ == (unsigned)C::RING) ? 0u : hoff + 2 * C::ESZ;
+  }
+  __device__ __forceinline__ void issue_gram()
+  {
+    dma_pair(gp, gp + gstride, gmask);
+    gp += 2 * gstride;
+  }
+  __device__ __forceinline__ void issue_rec()
+  {
+    const unsigned long long m = rhimask & (~0ull << ((rk + 1) >> 2));
+    dma_pair(rp, rp + rplane, m);
+    rp += rstride;
+    ++rk;
+  }
+  __device__ __forceinline__ void issue_sweep()
+  {
+    const unsigned long long m = slomask & (~0ull >> (64 - ((sj + 3) >> 2)));
+    dma_pair(sp, sp + splane, m);
+    sp -= sstride;
+    --sj;
+  }
+  __device__ __forceinline__ void issue_axpy()
+  {
+    while (ab0 == 0 && aq > 0)
+    {  // next lower chunk that has a multiplier
+      ab0 = ab1;
+      ab1 = ab2;
+      ab2 = ab3;
+      ab3 = 0;
+      --aq;
+    }
+    unsigned long long b = ab0;
+    const int j0         = 63 - __builtin_clzll(b);
+    b &= ~(1ull << j0);
+    int j1 = j0;
+    if (b)
+    {
+      j1 = 63 - __builtin_clzll(b);
+      b &= ~(1ull << j1);
+    }
+    ab0            = b;
+    const char *q0 = ap + (long)(aq * 64 + j0) * astride;
+    const char *q1 = ap + (long)(aq * 64 + j1) * astride;
+    dma_pair(q0, q1, amask);
+  }
+  __device__ __forceinline__ void issue_dummy() { dma_pair(dummy, dummy, 1ull); }
+
+  __device__ __forceinline__ void advance_segment()
+  {
+    kind  = nkind;
+    left  = nleft;
+    nkind = K_DUMMY;
+    nleft = 0x7fffffff;
+  }
+  // generic (branchy) request of one pair: chain prologues only
+  __device__ __forceinline__ void issue_any()
+  {
+    while (left == 0)
+      advance_segment();
+    switch (kind)
+    {
+    case K_GRAM: issue_gram(); break;
+    case K_REC: issue_rec(); break;
+    case K_SWEEP: issue_sweep(); break;
+    case K_AXPY: issue_axpy(); break;
+    default: issue_dummy(); break;
+    }
+    if (kind != K_DUMMY)
+      --left;
+  }
+  // Start a chain: whatever is still in flight is abandoned (its LDS writes land before those of
+  // the requests made from now on), the ring is refilled with the first NPAIR-1 pairs.
+  __device__ __forceinline__ void begin(int k0, int n0, int k1, int n1)
+  {
+    kind  = k0;
+    left  = n0;
+    nkind = k1;
+    nleft = n1;
+    if (left == 0)
+      advance_segment();
+    toff = hoff;
+#pragma unroll 1
+    for (int i = 0; i < C::NPAIR - 1; ++i)
+      issue_any();
+  }
+
+  // wait for the oldest pair, hand out its LDS word index (per lane: + lane, + 64 q, second entry
+  // at + ESZ/4) and move the tail
+  __device__ __forceinline__ unsigned wait_pair()
+  {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::INFL - 2) : "memory");
+    const unsigned w = ((base + toff) >> 2);
+    toff             = (toff + 2 * C::ESZ == (unsigned)C::RING) ? 0u : toff + 2 * C::ESZ;
+    return w;
+  }
+
+  // `nsteps` steps of one consumer; ALLOWED = the segment kinds the issue side can be in meanwhile
+  template <unsigned ALLOWED, class Cons> __device__ __forceinline__ void run(Cons &cons, int nsteps)
+  {
+    while (nsteps > 0)
+    {
+      if (left == 0)
+        advance_segment();
+      const int m = nsteps < left ? nsteps : left;
+      bool done   = false;
+      if constexpr ((ALLOWED & (1u << K_GRAM)) != 0)
+        if (!done && kind == K_GRAM)
+        {
+#pragma unroll 1
+          for (int i = 0; i < m; ++i)
+          {
+            const unsigned w = wait_pair();
+            cons.load(w, lane4);
+            issue_gram();
+            cons.compute();
+          }
+          done = true;
+        }
+      if constexpr ((ALLOWED & (1u << K_REC)) != 0)
+        if (!done && kind == K_REC)
+        {
+#pragma unroll 1
+          for (int i = 0; i < m; ++i)
+          {
+            const unsigned w = wait_pair();
+            cons.load(w, lane4);
+            issue_rec();
+            cons.compute();
+          }
+          done = true;
+        }
+      if constexpr ((ALLOWED & (1u << K_SWEEP)) != 0)
+        if (!done && kind == K_SWEEP)
+        {
+#pragma unroll 1
+          for (int i = 0; i < m; ++i)
+          {
+            const unsigned w = wait_pair();
+            cons.load(w, lane4);
+            issue_sweep();
+            cons.compute();
+          }
+          done = true;
+        }
+      if constexpr ((ALLOWED & (1u << K_AXPY)) != 0)
+        if (!done && kind == K_AXPY)
+        {
+#pragma unroll 1
+          for (int i = 0; i < m; ++i)
+          {
+            const unsigned w = wait_pair();
+            cons.load(w, lane4);
+            issue_axpy();
+            cons.compute();
+          }
+          done = true;
+        }
+      if (!done)
+      {  // dummies (or a kind this consumer never meets: treated as exhausted)
+#pragma unroll 1
+        for (int i = 0; i < m; ++i)
+        {
+          const unsigned w = wait_pair();
+          cons.load(w, lane4);
+          issue_dummy();
+          cons.compute();
+        }
+      }
+      if (kind != K_DUMMY)
+        left -= m;
+      nsteps -= m;
+    }
+  }
+};
+
+// Device-resident planes of mu (one lattice)
+struct Planes
+{
+  unsigned *muP;   // [2][d][ldd]  word p of mu(j,k) at muP[p*pl + j*ldd + k]
+  unsigned *muTP;  // [2][d][ldd]  word p of mu(j,k) at muTP[p*pl + k*ldd + j]
+  size_t pl;       // d * ldd
+};
+
+__device__ __forceinline__ double rl2(double v, int lane) { return g_rl_f64(v, lane); }
+
+// ---------------------------------------------------------------------------------------------
+// consumers.  load(w, lane4) reads this lane's words of the pair at LDS word index w; compute()
+// uses them.  `i` is the wave-uniform position inside the consumer's chunk.
+// ---------------------------------------------------------------------------------------------
+template <int NQ, int CQ, int QA> struct GramCons  // QA: chunks 0..QA-1 hold a column j <= last
+{
+  double (&acc)[NQ];
+  const double &bkq;  // bk[CQ]
+  int cc;             // row c = 64 CQ + cc of the first entry
+  bool second;        // the second entry is a row too (false: tail of an odd count)
+  float w0[NQ], w1[NQ];
+  __device__ __forceinline__ void load(unsigned w, unsigned lane4)
+  {
+    const unsigned a = w + (lane4 >> 2);
+#pragma unroll
+    for (int q = 0; q < QA; ++q)
+    {
+      w0[q] = __uint_as_float(s2_smem[a + 64 * q]);
+      w1[q] = __uint_as_float(s2_smem[a + 64 * q + Cfg<NQ>::ESZ / 4]);
+    }
+  }
+  __device__ __forceinline__ void compute()
+  {
+    const double s0 = rl2(bkq, cc);
+    const double s1 = rl2(bkq, cc + 1);
+#pragma unroll
+    for (int q = 0; q < QA; ++q)
+    {
+      const double p0 = s0 * (double)w0[q];
+      acc[q]          = acc[q] + p0;
+      if (second)
+      {
+        const double p1 = s1 * (double)w1[q];
+        acc[q]          = acc[q] + p1;
+      }
+    }
+    cc += 2;
+  }
+};
+
+template <int NQ, int KQ, int QA> struct RecCons
+{
+  double (&acc)[NQ];
+  int kk;  // row k = 64 KQ + kk
+  unsigned lane;
+  unsigned lo[NQ], hi[NQ];
+  __device__ __forceinline__ void load(unsigned w, unsigned lane4)
+  {
+    const unsigned a = w + (lane4 >> 2);
+#pragma unroll
+    for (int q = KQ; q < QA; ++q)
+    {
+      lo[q] = s2_smem[a + 64 * q];
+      hi[q] = s2_smem[a + 64 * q + Cfg<NQ>::ESZ / 4];
+    }
+  }
+  __device__ __forceinline__ void compute()
+  {
+    const double rk = rl2(acc[KQ], kk);  // r(kappa,k) is final
+#pragma unroll
+    for (int q = KQ; q < QA; ++q)
+    {
+      const double m = __hiloint2double((int)hi[q], (int)lo[q]);
+      const double t = m * rk;
+      const double u = acc[q] - t;
+      if (q == KQ)
+        acc[q] = ((int)lane > kk) ? u : acc[q];  // rows j > k only
+      else
+        acc[q] = u;
+    }
+    ++kk;
+  }
+};
+
+// rnd_we, nr/nr_FP_d.inl:226-233
+__device__ __forceinline__ double rnd_we(double b, int e)
+{
+  if (fexponent(b) + e >= 53)
+    return b;
+  return ldexp(rint(ldexp(b, e)), -e);
+}
+
+template <int NQ, int JQ> struct SweepCons
+{
+  double (&bm)[NQ];
+  double (&xs)[NQ];
+  const int (&e)[NQ];
+  unsigned long long &nzb;  // multipliers of chunk JQ that are not zero
+  int jj;                   // row j = 64 JQ + jj, descending
+  int sr_start;
+  unsigned lane;
+  unsigned lo[NQ], hi[NQ];
+  __device__ __forceinline__ void load(unsigned w, unsigned lane4)
+  {
+    const unsigned a = w + (lane4 >> 2);
+#pragma unroll
+    for (int q = 0; q <= JQ; ++q)
+    {
+      lo[q] = s2_smem[a + 64 * q];
+      hi[q] = s2_smem[a + 64 * q + Cfg<NQ>::ESZ / 4];
+    }
+  }
+  __device__ __forceinline__ void compute()
+  {
+    const double bmj = rl2(bm[JQ], jj);
+    const int ej     = __builtin_amdgcn_readlane(e[JQ], jj);
+    const double X   = rnd_we(bmj, ej);
+    if (X != 0.0)
+    {
+      nzb |= 1ull << jj;
+      xs[JQ] = ((int)lane == jj) ? X : xs[JQ];
+#pragma unroll
+      for (int q = 0; q <= JQ; ++q)
+      {
+        const double m = __hiloint2double((int)hi[q], (int)lo[q]);
+        const double t = X * m;
+        const double u = bm[q] - t;
+        // chunks below JQ hold only k < j; the chunk of j itself needs the test
+        const bool on = (q < JQ || (int)lane < jj) && (int)(lane + 64 * q) >= sr_start;
+        bm[q]         = on ? u : bm[q];
+      }
+    }
+    --jj;
+  }
+};
+
+template <int NQ, int JQ> struct AxpyCons
+{
+  long long (&bv)[NQ];
+  const long long &lxq;      // multipliers of chunk JQ (lane j)
+  unsigned long long bits;   // multipliers of the chunk not yet applied
+  bool small;                // every multiplier fits 32 bits
+  int w0[NQ], w1[NQ];
+  __device__ __forceinline__ void load(unsigned w, unsigned lane4)
+  {
+    const unsigned a = w + (lane4 >> 2);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+    {
+      w0[q] = (int)s2_smem[a + 64 * q];
+      w1[q] = (int)s2_smem[a + 64 * q + Cfg<NQ>::ESZ / 4];
+    }
+  }
+  __device__ __forceinline__ void compute()
+  {
+    const int j0 = 63 - __builtin_clzll(bits);
+    bits &= ~(1ull << j0);
+    long long l0 = g_rl_i64(lxq, j0), l1 = 0;
+    if (bits)
+    {
+      const int j1 = 63 - __builtin_clzll(bits);
+      bits &= ~(1ull << j1);
+      l1 = g_rl_i64(lxq, j1);
+    }
+    if (small)
+    {
+      const int s0 = (int)l0, s1 = (int)l1;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+      {
+        bv[q] = bv[q] + (long long)w0[q] * (long long)s0;
+        bv[q] = bv[q] + (long long)w1[q] * (long long)s1;
+      }
+    }
+    else
+    {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+      {
+        bv[q] = (long long)((unsigned long long)bv[q] +
+                            (unsigned long long)(long long)w0[q] * (unsigned long long)l0);
+        bv[q] = (long long)((unsigned long long)bv[q] +
+                            (unsigned long long)(long long)w1[q] * (unsigned long long)l1);
+      }
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// phases (compile-time recursion over the chunks)
+// ---------------------------------------------------------------------------------------------
+template <int NQ, int QA, int CQ = 0>
+__device__ __forceinline__ void gram_phase(Stream<NQ> &S, double (&acc)[NQ], const double (&bk)[NQ], int n)
+{
+  if constexpr (CQ < NQ)
+  {
+    const int rows = min(n - 64 * CQ, 64);
+    if (rows > 0)
+    {
+      GramCons<NQ, CQ, QA> g{acc, bk[CQ], 0, true};
+      S.template run<(1u << K_GRAM) | (1u << K_REC)>(g, rows >> 1);
+      if (rows & 1)
+      {
+        g.second = false;
+        S.template run<(1u << K_GRAM) | (1u << K_REC)>(g, 1);
+      }
+      gram_phase<NQ, QA, CQ + 1>(S, acc, bk, n);
+    }
+  }
+}
+
+// rows k = 0 .. cnt-1 of the recurrence (cnt = last: row `last` has nothing to subtract from)
+template <int NQ, int QA, int KQ = 0>
+__device__ __forceinline__ void rec_phase(Stream<NQ> &S, double (&acc)[NQ], int cnt, unsigned lane)
+{
+  if constexpr (KQ < QA)
+  {
+    const int rows = min(cnt - 64 * KQ, 64);
+    if (rows > 0)
+    {
+      RecCons<NQ, KQ, QA> r{acc, 0, lane};
+      S.template run<(1u << K_REC)>(r, rows);
+      rec_phase<NQ, QA, KQ + 1>(S, acc, cnt, lane);
+    }
+  }
+}
+
+// Gram pass then recurrence with the (wave-uniform) number of active chunks as a compile-time
+// constant: QA = (last >> 6) + 1
+template <int NQ, int QA>
+__device__ __forceinline__ void gram_rec_qa(Stream<NQ> &S, double (&acc)[NQ], const double (&bk)[NQ], int n,
+                                            int nrec, unsigned lane, bool narrow, int kappa, double &gkk)
+{
+  if (narrow)
+    gram_phase<NQ, QA>(S, acc, bk, n);
+  gkk = g_rl_f64(acc[QA - 1], kappa & 63);  // lane kappa of chunk QA-1 = kappa >> 6
+  rec_phase<NQ, QA>(S, acc, nrec, lane);
+}
+
+// rows j = kappa-1 … sr_start+1 through the ring, then j = sr_start (no mu needed)
+template <int NQ, int JQ = NQ - 1>
+__device__ __forceinline__ void sweep_phase(Stream<NQ> &S, double (&bm)[NQ], double (&xs)[NQ], const int (&e)[NQ],
+                                            unsigned long long (&nz)[NQ], int kappa, int sr_start,
+                                            unsigned lane)
+{
+  if constexpr (JQ >= 0)
+  {
+    // rows of this chunk: j in [max(64 JQ, sr_start), min(64 JQ + 63, kappa - 1)]
+    const int hi = min(kappa - 1, 64 * JQ + 63);
+    const int lo = max(sr_start, 64 * JQ);
+    if (hi >= lo)
+    {
+      SweepCons<NQ, JQ> s{bm, xs, e, nz[JQ], hi - 64 * JQ, sr_start, lane};
+      // every row but j = sr_start has a window of mu to stream
+      const int streamed = (lo == sr_start) ? (hi - lo) : (hi - lo + 1);
+      S.template run<(1u << K_SWEEP)>(s, streamed);
+      if (lo == sr_start)
+      {  // last row: its multiplier only
+#pragma unroll
+        for (int q = 0; q <= JQ; ++q)
+          s.lo[q] = s.hi[q] = 0;
+        s.compute();
+      }
+    }
+    sweep_phase<NQ, JQ - 1>(S, bm, xs, e, nz, kappa, sr_start, lane);
+  }
+}
+
+template <int NQ, int JQ = NQ - 1>
+__device__ __forceinline__ void axpy_phase(Stream<NQ> &S, long long (&bv)[NQ], const long long (&lxv)[NQ],
+                                           const unsigned long long (&nz)[NQ], bool small)
+{
+  if constexpr (JQ >= 0)
+  {
+    if (nz[JQ] != 0)
+    {
+      AxpyCons<NQ, JQ> a{bv, lxv[JQ], nz[JQ], small};
+      S.template run<(1u << K_AXPY)>(a, (__builtin_popcountll(nz[JQ]) + 1) >> 1);
+    }
+    axpy_phase<NQ, JQ - 1>(S, bv, lxv, nz, small);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// plain-load twins of the Gram pass and the AXPY for rows that are not narrow (same arithmetic)
+// ---------------------------------------------------------------------------------------------
+template <int NQ, int CQ = 0>
+__device__ __forceinline__ void gram_wide(const Lattice<NQ> &T, double (&acc)[NQ], const double (&bk)[NQ], int last)
+{
+  if constexpr (CQ < NQ)
+  {
+    const int n = T.n, lane = T.lane, ldd = T.ldd;
+    const int hi = min(n - 64 * CQ, 64);
+    for (int cc = 0; cc < hi; ++cc)
+    {
+      const double bkc = g_rl_f64(bk[CQ], cc);
+      const int c      = 64 * CQ + cc;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+      {
+        const int j = lane + 64 * q;
+        if (j <= last)
+        {
+          const double p = bkc * T.bfT[(size_t)c * ldd + j];
+          acc[q]         = acc[q] + p;
+        }
+      }
+    }
+    gram_wide<NQ, CQ + 1>(T, acc, bk, last);
+  }
+}
+
+template <int NQ, int JQ = NQ - 1>
+__device__ __forceinline__ void axpy_wide(const Lattice<NQ> &T, long long (&bv)[NQ], const long long (&lxv)[NQ],
+                                          int kappa)
+{
+  if constexpr (JQ >= 0)
+  {
+    const int n = T.n, lane = T.lane, ldn = T.ldn;
+    for (int jj = min(kappa - 1 - 64 * JQ, 63); jj >= 0; --jj)
+    {
+      const long long lx = g_rl_i64(lxv[JQ], jj);
+      const int j        = 64 * JQ + jj;
+      if (lx != 0)
+      {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+        {
+          const int c = lane + 64 * q;
+          if (c < n)
+            bv[q] = (long long)((unsigned long long)bv[q] +
+                                (unsigned long long)T.b[(size_t)j * ldn + c] * (unsigned long long)lx);
+        }
+      }
+    }
+    axpy_wide<NQ, JQ - 1>(T, bv, lxv, kappa);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// One GSO pass of row kappa: Gram row g(kappa, j <= kappa) then the recurrence for j < kappa.
+// On return acc[] lane j < kappa = r(kappa,j); gkk = g(kappa,kappa).
+// ---------------------------------------------------------------------------------------------
+template <int NQ>
+__device__ __forceinline__ void gso_pass(Lattice<NQ> &T, const Planes &PL, Stream<NQ> &S, int kappa,
+                                         const double (&bk)[NQ], double (&acc)[NQ], double &gkk)
+{
+  const int n = T.n, ldd = T.ldd;
+  const int qact = (kappa >> 6) + 1;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+    acc[q] = -0.0;  // -0.0 + p == p for every p: the first product starts the sum (numvect.h:389)
+  const bool narrow = T.np > kappa;  // rows 0..kappa are read
+  // recurrence rows k = 0..kappa-2 (row kappa-1 has nothing below it)
+  const int nrec = kappa > 0 ? kappa - 1 : 0;
+  S.rp      = (const char *)PL.muTP;
+  S.rstride = (long)ldd * 4;
+  S.rplane  = (long)PL.pl * 4;
+  S.rk      = 0;
+  S.rhimask = kappa > 0 ? (~0ull >> (63 - ((kappa - 1) >> 2))) : 0ull;
+  if (narrow)
+  {
+    S.gp      = (const char *)T.bfT32;
+    S.gstride = (long)ldd * 4;
+    S.gmask   = ~0ull >> (63 - (kappa >> 2));
+    S.begin(K_GRAM, (n + 1) >> 1, K_REC, nrec);
+  }
+  else
+  {
+    gram_wide<NQ>(T, acc, bk, kappa);
+    S.begin(K_REC, nrec, K_DUMMY, 0x7fffffff);
+  }
+  const unsigned lane = (unsigned)T.lane;
+  if constexpr (NQ == 1)
+    gram_rec_qa<NQ, 1>(S, acc, bk, n, nrec, lane, narrow, kappa, gkk);
+  else if constexpr (NQ == 2)
+  {
+    if (qact == 1)
+      gram_rec_qa<NQ, 1>(S, acc, bk, n, nrec, lane, narrow, kappa, gkk);
+    else
+      gram_rec_qa<NQ, 2>(S, acc, bk, n, nrec, lane, narrow, kappa, gkk);
+  }
+  else if constexpr (NQ == 3)
+  {
+    if (qact == 1)
+      gram_rec_qa<NQ, 1>(S, acc, bk, n, nrec, lane, narrow, kappa, gkk);
+    else if (qact == 2)
+      gram_rec_qa<NQ, 2>(S, acc, bk, n, nrec, lane, narrow, kappa, gkk);
+    else
+      gram_rec_qa<NQ, 3>(S, acc, bk, n, nrec, lane, narrow, kappa, gkk);
+  }
+  else
+  {
+    if (qact == 1)
+      gram_rec_qa<NQ, 1>(S, acc, bk, n, nrec, lane, narrow, kappa, gkk);
+    else if (qact == 2)
+      gram_rec_qa<NQ, 2>(S, acc, bk, n, nrec, lane, narrow, kappa, gkk);
+    else if (qact == 3)
+      gram_rec_qa<NQ, 3>(S, acc, bk, n, nrec, lane, narrow, kappa, gkk);
+    else
+      gram_rec_qa<NQ, 4>(S, acc, bk, n, nrec, lane, narrow, kappa, gkk);
+  }
+}
+
+// r(kappa,kappa) = g(kappa,kappa) - sum_k mu(kappa,k) r(kappa,k), k ascending (gso_interface.cpp:147-151)
+template <int NQ>
+__device__ __forceinline__ double finish_diag2(const double (&mu)[NQ], const double (&rr)[NQ], double gkk,
+                                               int kappa)
+{
+  double p[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+    p[q] = mu[q] * rr[q];
+  double g = gkk;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+  {
+    const int hi = min(kappa - 64 * q, 64);
+    for (int kk = 0; kk < hi; ++kk)
+      g = g - g_rl_f64(p[q], kk);
+  }
+  return g;
+}
+
+// store the confirmed row kappa: r, mu, the planes (row of muP, column of muTP), r(kappa,kappa)
+template <int NQ>
+__device__ __forceinline__ void store_gso_row(Lattice<NQ> &T, const Planes &PL, int kappa, const double (&mu)[NQ],
+                                              const double (&rr)[NQ], double rkk)
+{
+  const int lane = T.lane, ldd = T.ldd;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+  {
+    const int j = lane + 64 * q;
+    if (j < kappa)
+    {
+      T.r[(size_t)kappa * ldd + j]  = rr[q];
+      T.mu[(size_t)kappa * ldd + j] = mu[q];
+      const unsigned lo = (unsigned)__double2loint(mu[q]), hi = (unsigned)__double2hiint(mu[q]);
+      PL.muP[(size_t)kappa * ldd + j]          = lo;
+      PL.muP[PL.pl + (size_t)kappa * ldd + j]  = hi;
+      PL.muTP[(size_t)j * ldd + kappa]         = lo;
+      PL.muTP[PL.pl + (size_t)j * ldd + kappa] = hi;
+    }
+    else if (j == kappa)
+    {
+      T.r[(size_t)kappa * ldd + kappa] = rkk;
+      T.rdg[kappa]                     = rkk;
+    }
+  }
+}
+
+// mu(kappa,j) = r(kappa,j) / r(j,j), gso_interface.cpp:154; false on a non-finite value
+template <int NQ>
+__device__ __forceinline__ bool mu_from_r(const Lattice<NQ> &T, int kappa, const double (&acc)[NQ],
+                                          const double (&rd)[NQ], double (&mu)[NQ])
+{
+  bool ok = true;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+  {
+    const int j = T.lane + 64 * q;
+    mu[q]       = 0.0;
+    if (j < kappa)
+    {
+      const double m = acc[q] / rd[q];
+      if (!isfinite(m))
+        ok = false;
+      mu[q] = m;
+    }
+  }
+  return __all(ok);
+}
+
+// update_gso_row(kappa, kappa) from column 0.  false: RED_GSO_FAILURE.
+template <int NQ>
+__device__ __forceinline__ bool update_full(Lattice<NQ> &T, const Planes &PL, Stream<NQ> &S, int kappa)
+{
+  const int n = T.n, lane = T.lane, ldd = T.ldd;
+  double bk[NQ], rd[NQ], acc[NQ], mu[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+  {
+    const int c = lane + 64 * q;
+    bk[q]       = (c < n) ? T.bfT[(size_t)c * ldd + kappa] : 0.0;
+    rd[q]       = (c < kappa) ? T.rdg[c] : 1.0;
+  }
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+  {
+    settle(bk[q]);
+    settle(rd[q]);
+  }
+  double gkk = 0.0;
+  gso_pass<NQ>(T, PL, S, kappa, bk, acc, gkk);
+  const bool ok    = mu_from_r<NQ>(T, kappa, acc, rd, mu);
+  const double rkk = finish_diag2<NQ>(mu, acc, gkk, kappa);
+  store_gso_row<NQ>(T, PL, kappa, mu, acc, rkk);
+  return ok;
+}
+
+// LLLReduction::babai(kappa, kappa, 0) followed by update_gso_row(kappa, kappa) (lll.h:107-122).
+// 1 ok, 0 GSO failure, -1 babai failure, -2 multiplier beyond 63 bits.
+template <int NQ>
+__device__ __forceinline__ int babai2(Lattice<NQ> &T, const Planes &PL, Stream<NQ> &S, int kappa, double eta)
+{
+  const int n = T.n, lane = T.lane, ldd = T.ldd, ldn = T.ldn;
+  const int sr_start = 0;
+  double bk[NQ], rd[NQ], acc[NQ], mu[NQ];
+  long long rexpj[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+  {
+    const int c = lane + 64 * q;
+    bk[q]       = (c < n) ? T.bfT[(size_t)c * ldd + kappa] : 0.0;
+    rd[q]       = (c < kappa) ? T.rdg[c] : 1.0;
+    rexpj[q]    = (c < kappa) ? T.rexp[c] : 0;
+  }
+  long long rexpk    = T.rexp[kappa];
+  long long max_expo = LLONG_MAX;
+  // ordinary loads are waited for HERE: hipcc would otherwise place its own vmcnt wait at their
+  // first use, inside a ring loop, and drain the DMA pipe on every step
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+  {
+    settle(bk[q]);
+    settle(rd[q]);
+    settle(rexpj[q]);
+  }
+  settle(rexpk);
+  double gkk         = 0.0;
+  for (int iter = 0;; ++iter)
+  {
+    gso_pass<NQ>(T, PL, S, kappa, bk, acc, gkk);
+    if (!mu_from_r<NQ>(T, kappa, acc, rd, mu))
+      return 0;
+    int e[NQ];
+    bool need = false;
+    int mexp  = INT_MIN;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+    {
+      const int j = lane + 64 * q;
+      e[q]        = 0;
+      if (j < kappa)
+      {
+        e[q]           = (int)(rexpk - rexpj[q]);
+        const double f = fabs(ldexp(mu[q], e[q]));  // get_mu, gso_interface.h:694-702
+        need |= (j >= sr_start) && (f > eta);
+        const long long ex = (long long)e[q] + fexponent(mu[q]);
+        mexp               = max(mexp, (int)max(ex, (long long)INT_MIN + 2));
+      }
+    }
+    if (!__any(need))
+      break;
+    if (iter >= 2)
+    {  // lll.cpp:187-195
+      const long long new_max = (long long)wave_max_i32(mexp);
+      if (new_max > max_expo - 5)
+        return -1;
+      max_expo = new_max;
+    }
+    // ---- lll.cpp:202-220: lane k owns babai_mu[k]
+    double bm[NQ], xs[NQ];
+    unsigned long long nz[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+    {
+      bm[q] = mu[q];
+      xs[q] = 0.0;
+      nz[q] = 0;
+    }
+    S.sp      = (const char *)(PL.muP + (size_t)(kappa - 1) * ldd);
+    S.sstride = (long)ldd * 4;
+    S.splane  = (long)PL.pl * 4;
+    S.sj      = kappa - 1;
+    S.slomask = ~0ull << (sr_start >> 2);
+    S.begin(K_SWEEP, kappa - 1 - sr_start, K_DUMMY, 0x7fffffff);
+    sweep_phase<NQ>(S, bm, xs, e, nz, kappa, sr_start, (unsigned)lane);
+    // ---- the multipliers: row_addmul_we(kappa, j, -X, e_j) -> get_si_exp_we, nr_FP_d.inl:46-53
+    long long lxv[NQ];
+    bool too_big = false, big32 = false;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+    {
+      lxv[q] = 0;
+      if (xs[q] != 0.0)
+      {
+        if (fexponent(-xs[q]) + e[q] - 63 > 0)
+          too_big = true;
+        lxv[q] = (long long)ldexp(-xs[q], e[q]);
+        big32 |= (lxv[q] != (long long)(int)lxv[q]);
+      }
+    }
+    if (__any(too_big))
+      return -2;  // nothing has been stored yet: the basis is unchanged
+    const bool small = !__any(big32);
+    // ---- integer AXPY on row kappa (row_add / row_sub / row_addmul_si, gso.cpp:84-158)
+    long long bv[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+    {
+      const int c = lane + 64 * q;
+      bv[q]       = (c < n) ? T.b[(size_t)kappa * ldn + c] : 0;
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+      settle(bv[q]);
+    if (T.np >= kappa)
+    {
+      int pairs = 0;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+        pairs += (__builtin_popcountll(nz[q]) + 1) >> 1;
+      // the issue side walks the chunks downwards: ab0 = chunk NQ-1 (= aq), ab1 the one below, …
+      S.aq  = NQ - 1;
+      S.ab0 = nz[NQ - 1];
+      S.ab1 = NQ >= 2 ? nz[NQ >= 2 ? NQ - 2 : 0] : 0;
+      S.ab2 = NQ >= 3 ? nz[NQ >= 3 ? NQ - 3 : 0] : 0;
+      S.ab3 = NQ >= 4 ? nz[NQ >= 4 ? NQ - 4 : 0] : 0;
+      S.ap      = (const char *)T.b32;
+      S.astride = (long)ldn * 4;
+      S.amask   = ~0ull >> (63 - ((n - 1) >> 2));
+      S.begin(K_AXPY, pairs, K_DUMMY, 0x7fffffff);
+      axpy_phase<NQ>(S, bv, lxv, nz, small);
+    }
+    else
+      axpy_wide<NQ>(T, bv, lxv, kappa);
+    // ---- row_op_end: update_bf(kappa), gso.cpp:24-48
+    store_row_and_refloat<NQ, true>(T, kappa, bv, bk, rexpk);
+    // the requests of the next pass must see these stores
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __threadfence_block();
+  }
+  const double rkk = finish_diag2<NQ>(mu, acc, gkk, kappa);
+  store_gso_row<NQ>(T, PL, kappa, mu, acc, rkk);
+  return 1;
+}
+
+// mode 0: update_gso() (every row, no size reduction); mode 1: size_reduction(kmin,kend);
+// mode 2: (re)build bfT / row_expo / the narrow mirrors from b for every row (after a basis upload)
+template <int NQ>
+__global__ void __launch_bounds__(256, Cfg<NQ>::WAVES_PER_SIMD)
+    gso_sweep2_kernel(GsoBatch P, unsigned *muP, unsigned *muTP, int kmin, int kend, double eta, int mode)
+{
+  using C        = Cfg<NQ>;
+  const int lane = threadIdx.x & 63;
+  const int wpb  = blockDim.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  Stream<NQ> S;
+  S.base   = (unsigned)(wave * C::RING);
+  S.hoff   = 0;
+  S.toff   = 0;
+  S.lane4  = lane * 4;
+  S.lane16 = lane * 16;
+  for (int L = blockIdx.x * wpb + wave; L < P.batch; L += gridDim.x * wpb)
+  {
+    Lattice<NQ> T;
+    T.d           = P.d;
+    T.n           = P.n;
+    T.ldd         = P.ldd;
+    T.ldn         = P.ldn;
+    T.row_expo_on = P.row_expo;
+    T.lane        = lane;
+    T.b           = P.b + (size_t)L * P.d * P.ldn;
+    T.bfT         = P.bfT + (size_t)L * P.n * P.ldd;
+    T.mu          = P.mu + (size_t)L * P.d * P.ldd;
+    T.muT         = P.muT + (size_t)L * P.d * P.ldd;
+    T.r           = P.r + (size_t)L * P.d * P.ldd;
+    T.rdg         = P.rdg + (size_t)L * P.d;
+    T.rexp        = P.rexp + (size_t)L * P.d;
+    T.bfT32       = P.bfT32 + (size_t)L * P.n * P.ldd;
+    T.b32         = P.b32 + (size_t)L * P.d * P.ldn;
+    T.narrow_flag = P.narrow + (size_t)L * P.d;
+    T.np          = 0;
+    Planes PL;
+    PL.pl   = (size_t)P.d * P.ldd;
+    PL.muP  = muP + (size_t)L * 2 * PL.pl;
+    PL.muTP = muTP + (size_t)L * 2 * PL.pl;
+    S.dummy = (const char *)T.b32;
+    if (mode != 2)
+    {  // narrow prefix from the per-row flags (FPHIP_GSO_NARROW=0: P.use_narrow == 0)
+      int p = 0;
+      while (P.use_narrow && p < P.d && __builtin_amdgcn_readfirstlane(T.narrow_flag[p]) != 0)
+        ++p;
+      T.np = p;
+    }
+    int status = 1;
+    if (mode == 2)
+    {
+      for (int i = 0; i < P.d; ++i)
+      {
+        long long bv[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+        {
+          const int c = lane + 64 * q;
+          bv[q]       = (c < P.n) ? T.b[(size_t)i * P.ldn + c] : 0;
+        }
+        store_row_and_refloat<NQ, true>(T, i, bv);
+      }
+    }
+    else
+    {
+      for (int kappa = kmin; kappa < kend; ++kappa)
+      {
+        // the requests of this row must see the stores of the previous one
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __threadfence_block();
+        if (mode == 1 && kappa > 0)
+        {
+          const int rc = babai2<NQ>(T, PL, S, kappa, eta);
+          if (rc != 1)
+          {
+            status = rc;
+            break;
+          }
+        }
+        else if (!update_full<NQ>(T, PL, S, kappa))
+        {
+          status = 0;
+          break;
+        }
+      }
+    }
+    if (lane == 0)
+      P.status[L] = status;
+  }
+}
+
+template __global__ void gso_sweep2_kernel<1>(GsoBatch, unsigned *, unsigned *, int, int, double, int);
+template __global__ void gso_sweep2_kernel<2>(GsoBatch, unsigned *, unsigned *, int, int, double, int);
+template __global__ void gso_sweep2_kernel<3>(GsoBatch, unsigned *, unsigned *, int, int, double, int);
+template __global__ void gso_sweep2_kernel<4>(GsoBatch, unsigned *, unsigned *, int, int, double, int);
+
+}  // namespace s2
+}  // namespace fphip

@@ -608,8 +608,9 @@ template <int NQ> __device__ void finish_diag(Lattice<NQ> &T, int kappa)
 
 // Store the integer row held in registers into slot pk and re-float it: MatGSO::update_bf,
 // gso.cpp:24-48 (mantissa/exponent per entry, renormalised to the row maximum).
-template <int NQ, bool MIRRORS = false>
-__device__ __forceinline__ void store_row_and_refloat(Lattice<NQ> &T, int pk, const long long (&bv)[NQ])
+template <int NQ, bool MIRRORS, bool OUT>
+__device__ __forceinline__ void store_row_and_refloat_impl(Lattice<NQ> &T, int pk, const long long (&bv)[NQ],
+                                                           double (&fout)[NQ], long long &eout)
 {
   const int n = T.n, lane = T.lane, ldd = T.ldd, ldn = T.ldn;
   int ce[NQ];
@@ -649,6 +650,8 @@ __device__ __forceinline__ void store_row_and_refloat(Lattice<NQ> &T, int pk, co
     {
       const double f              = T.row_expo_on ? ldexp(cm[q], ce[q] - emax) : cm[q];
       T.bfT[(size_t)c * ldd + pk] = f;
+      if constexpr (OUT)
+        fout[q] = f;
       if constexpr (MIRRORS)
       {  // narrow mirrors (exact while |entry| < 2^24)
         T.bfT32[(size_t)c * ldd + pk] = (float)f;
@@ -674,6 +677,22 @@ __device__ __forceinline__ void store_row_and_refloat(Lattice<NQ> &T, int pk, co
   }
   if (lane == 0)
     T.rexp[pk] = T.row_expo_on ? (long long)emax : 0;
+  if constexpr (OUT)
+    eout = T.row_expo_on ? (long long)emax : 0;
+}
+template <int NQ, bool MIRRORS = false>
+__device__ __forceinline__ void store_row_and_refloat(Lattice<NQ> &T, int pk, const long long (&bv)[NQ])
+{
+  double f[NQ];
+  long long e;
+  store_row_and_refloat_impl<NQ, MIRRORS, false>(T, pk, bv, f, e);
+}
+// … and hand back the re-floated row (lane c = column c) and its exponent
+template <int NQ, bool MIRRORS = false>
+__device__ __forceinline__ void store_row_and_refloat(Lattice<NQ> &T, int pk, const long long (&bv)[NQ],
+                                                      double (&fout)[NQ], long long &eout)
+{
+  store_row_and_refloat_impl<NQ, MIRRORS, true>(T, pk, bv, fout, eout);
 }
 
 // LLLReduction::babai(kappa, kappa, 0).  1 ok, 0 GSO failure, -1 babai failure, -2 multiplier.

@@ -138,6 +138,8 @@ int fphip_gso_set_basis(fphip_gso *g, int first_lattice, int count, const int64_
 int fphip_gso_get_basis(fphip_gso *g, int first_lattice, int count, int64_t *b);
 /* copy lattice `src` into every slot (device-to-device; benchmarks) */
 int fphip_gso_broadcast_basis(fphip_gso *g, int src);
+/* lattices count, count+1, ... := copies of lattices 0 .. count-1, cyclically (device-side) */
+int fphip_gso_tile_basis(fphip_gso *g, int count);
 /* MatGSO::update_bf for every row (gso.cpp:24-48).  Done automatically by the first sweep /
  * reduction after set_basis or broadcast_basis; explicit calls are harmless. */
 int fphip_gso_refresh(fphip_gso *g);

@@ -7,6 +7,7 @@
 set -e
 cd "$(dirname "$0")/../.."
 D=oracle/_ref/ref_driver
+R=oracle/_ref
 G=tests/golden
 #            n  k bits seed bkz first d  pruning   max_sols strategy rfac
 $D enumfix  40 20 10  3   0   0   12 none       1         0 0.99 > $G/enum_d12_best1.json
@@ -98,7 +99,6 @@ $D bkzfix q 120 60 20 0 20 0 | gzip -9 > $G/c2_bkz20_q120.json.gz
 $D dumpbasis 180 90 20 0 20 > $G/basis_q180_seed0_lll_bkz20.txt
 for k in 0 1 2; do
   f=$((k*1))
-  REFDRV_INPUT_ONLY=1 $D enumfix 0 $G/basis_q180_seed0_lll_bkz20.txt 0 0 0 $f 60 linear:30 1 0 0.99 > $G/c3_b60_k${k}_linear30_input.json
   $D enumfix 0 $G/basis_q180_seed0_lll_bkz20.txt 0 0 0 $f 60 prune:0.5 1 0 0.99 > $G/c3_b60_k${k}_pruner.json
 done
 $D genstrat $G/basis_q180_seed0_lll_bkz20.txt 60 > $G/strategies_q180_b60.json
@@ -108,3 +108,10 @@ REFDRV_STRATEGIES=$G/strategies_q180_b60.json REFDRV_BKZ_FLAGS=0x80 REFDRV_RNG_S
 REFDRV_SUBSOLS=1 $D enumfix  80 40 12 1  0 4 32 none      5 0 1.30 > $G/enum_d32_best5_subsols.json
 REFDRV_SUBSOLS=1 $D enumfix 100 50 14 2 20 0 40 linear:20 1 0 0.99 > $G/enum_d40_lin20_best1_subsols.json
 md5sum $G/enum_*.json > $G/MD5SUMS
+# a 200-dimensional LLL-reduced q-ary basis (8-bit q) for the NQ = 4 (more than 192 columns) cases of
+# the sweep / LLL / Householder device tests: reference latticegen + `fplll -a lll -m fast -f double`
+$R/latticegen -randseed 7 q 200 100 8 p > /tmp/q200.txt && $R/fplll -a lll -m fast -f double /tmp/q200.txt | gzip -9 > $G/basis_q200_seed7_lll.txt.gz
+# the bench's blocks with the reference's results (5-10e9 nodes each, ~12 CPU-minutes in total)
+for k in 0 1 2; do
+  $D enumfix 0 $G/basis_q180_seed0_lll_bkz20.txt 0 0 0 $k 60 linear:30 1 0 0.99 > $G/c3_b60_k${k}_linear30.json
+done
