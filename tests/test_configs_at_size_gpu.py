@@ -129,22 +129,56 @@ def test_config2_bkz20_q120_matches_reference(ctx):
 # ---------------------------------------------------------------------------------------------
 # config 3
 # ---------------------------------------------------------------------------------------------
+def _check_pruned_result(f, ev, res):
+    """Parity of a pruned enumeration whose radius shrinks (enumerate.cpp:231-239) is order
+    dependent by nature: whichever candidate is met first shrinks every level bound
+    pruning[k]*radius, and may thereby cut the branch of a candidate another order would have met —
+    the reference's sequential walk and a parallel walk may legitimately end on different vectors
+    (enumlib has the same property, README.md:315).  What IS checkable, and checked here:
+      1. the device's vector has the squared norm it reported (recomputed from mu, r);
+      2. completeness: a sequential walk (the oracle) started at the device's final radius finds
+         nothing shorter — every node inside the pruned region of that radius was inside the
+         device's region all along, so a shorter vector there would be one the device missed;
+      3. the same holds from the reference's side: its result is not shorter than the device's,
+         unless its vector lies outside the pruned region of the device's final radius."""
+    from fplll_amd.enumeration import FastEvaluator
+    dist, x = ev.solutions[0][0], np.array(ev.solutions[0][1], dtype=np.float64)
+    d = f["d"]
+    # |sum_i x_i b*_i ...|^2 = sum_k r_k (x_k + sum_{j>k} mu_jk x_j)^2, mut[k][j] = mu(j,k)
+    tot = 0.0
+    for k in range(d):
+        c = x[k] + float(np.dot(f["mut"][k, k + 1:], x[k + 1:]))
+        tot += f["rdiag"][k] * c * c
+    assert abs(tot - dist) <= 1e-9 * dist, (tot, dist)
+    ev_o = FastEvaluator(1, 0)
+    C.oracle_enumerate(f["mut"], f["rdiag"], f["pruning"], dist, ev_o)
+    # (it may find nothing at all: the device's own vector passed the level bounds of the larger
+    # radius that held when it was met, not necessarily those of its own norm)
+    assert all(s[0] == dist for s in ev_o.solutions), \
+        ("a sequential walk at the device's final radius finds a shorter vector", ev_o.solutions, dist)
+    ref_best = min(s[0] for s in f["sol_log"])
+    return ref_best
+
+
 @pytest.mark.parametrize("k", [0, 1, 2])
 def test_config3_pruner_block_matches_reference(ctx, k):
     """One beta = 60 block under the reference pruner's coefficients (2-3 M nodes, the default.json
-    regime), FastEvaluator(1): the final squared norm is the reference's."""
+    regime), FastEvaluator(1): valid, complete at its own final radius, and — on blocks 0 and 1 —
+    the reference's very norm (on block 2 the parallel walk ends on a SHORTER vector than the
+    reference's sequential one: 0.66917 against 0.68177, see _check_pruned_result)."""
     from fplll_amd.enumeration import FastEvaluator, enumerate_block
     f = C.load_fixture(os.path.join(C.GOLDEN, "c3_b60_k%d_pruner.json" % k))
     ev = FastEvaluator(f["max_sols"], f["strategy"])
     res = enumerate_block(ctx, f["mut"], f["rdiag"], f["pruning"], f["maxdist"], ev)
     assert len(ev.solutions) == 1 and len(f["sol_log"]) >= 1
-    ref_best = min(s[0] for s in f["sol_log"])
-    assert ev.solutions[0][0] == ref_best, (ev.solutions[0][0], ref_best)
-    # under a shrinking radius the visit set depends on the order; it can only be smaller than or
-    # about the reference's (the parallel walk finds short vectors earlier, not later)
+    ref_best = _check_pruned_result(f, ev, res)
+    if k < 2:
+        assert ev.solutions[0][0] == ref_best, (ev.solutions[0][0], ref_best)
+    else:
+        assert ev.solutions[0][0] <= ref_best
     assert 0 < res.total_nodes < 2 * f["total_nodes"]
-    print("C3 block %d (pruner): %d nodes (reference %d), %.2f ms" %
-          (k, res.total_nodes, f["total_nodes"], res.stats.kernel_ms))
+    print("C3 block %d (pruner): %d nodes (reference %d), norm %r (reference %r), %.2f ms" %
+          (k, res.total_nodes, f["total_nodes"], ev.solutions[0][0], ref_best, res.stats.kernel_ms))
 
 
 @pytest.mark.parametrize("k", [0, 1, 2])
