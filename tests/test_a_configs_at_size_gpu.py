@@ -39,6 +39,74 @@ def _q200():
 
 
 # ---------------------------------------------------------------------------------------------
+# The two long runs come first and run TOGETHER (each is one launch that keeps one wavefront busy
+# for minutes — the reduction kernels are throughput devices — so the two launches overlap on the
+# GPU from two host threads with a context each); with pytest-xdist (pytest.ini: -n 4) the rest of
+# the GPU suite runs beside them on the other workers.
+# ---------------------------------------------------------------------------------------------
+def _run_config3_tour(ctx, out):
+    """One BKZ-60 tour (BKZ_MAX_LOOPS 1, BKZ_GH_BND) of the 180-dim lattice with the pruner
+    strategies, on the device: 15 160 enumerations, 11 rerandomisations, 1.22e9 nodes."""
+    from fplll_amd.gso import MatGSOBatch
+    f = C.load_bkz_fixture(os.path.join(C.GOLDEN, "c3_bkz60_tour_strategies.json.gz"))
+    B = 2
+    g = MatGSOBatch(ctx, B, f["d"], f["n"])
+    g.set_basis(np.stack([f["b_in"]] * B))
+    rnd, draws = C.gmp_streams_native(B, f["rng_seed"])
+    t = time.time()
+    st, info = g.bkz_strategies(f["block_size"], f["strategies"], rnd, f["delta"], f["eta"],
+                                max_loops=f["max_loops"], gh_bnd=True, gh_factor=f["gh_factor"])
+    out["c3"] = dict(wall=time.time() - t, st=[int(x) for x in st], nodes=[_nodes(i) for i in info],
+                     basis_ok=[bool(np.array_equal(b, f["b_out"])) for b in g.get_basis()],
+                     expect=(f["status"], f["nodes"]), ref_s=f["ref_seconds"])
+    g.close()
+
+
+def _run_config5_hlll(out):
+    import fplll_amd
+    from fplll_amd.householder import MatHouseholderBatch
+    f = _c5()
+    assert (f["d"], f["n"]) == (256, 256)
+    ctx2 = fplll_amd.Context(int(os.environ.get("LOCAL_RANK", "0")))
+    try:
+        B = 2
+        h = MatHouseholderBatch(ctx2, B, 256, 256, row_expo=True)
+        h.set_basis(np.stack([f["b_in"]] * B))
+        t = time.time()
+        st, info = h.hlll(f["delta"], f["eta"], f["theta"], f["c"])
+        out["c5"] = dict(wall=time.time() - t, st=[int(x) for x in st], swaps=[int(i[0]) for i in info],
+                         basis_ok=[bool(np.array_equal(b, f["b_out"])) for b in h.get_basis(0, B)],
+                         expect=f["status"], ref_s=f["ref_seconds"])
+        h.close()
+    except BaseException as e:  # noqa: reported by the calling thread
+        out["c5_error"] = repr(e)
+    finally:
+        ctx2.close()
+
+
+def test_config3_bkz60_tour_and_config5_hlll_match_reference(ctx):
+    """config 3: one BKZ-60 tour with the pruner strategies of the 180-dim lattice (basis, status,
+    1 224 293 770 nodes = the reference's); config 5's lattice: HLLL of the 256-dim NTRU-like
+    basis in double (basis, status, 146 491 swaps = the reference's) — the NQ = 4 instantiation of
+    the HLLL kernel.  Both launches run at the same time."""
+    import threading
+    out = {}
+    th = threading.Thread(target=_run_config5_hlll, args=(out,))
+    th.start()
+    _run_config3_tour(ctx, out)
+    th.join()
+    assert "c5_error" not in out, out.get("c5_error")
+    c3, c5 = out["c3"], out["c5"]
+    print("config 3 tour: %.1f s on the device (reference %.1f s on one core), %d nodes; "
+          "config 5 HLLL (double): %.1f s (reference %.1f s), %d swaps"
+          % (c3["wall"], c3["ref_s"], c3["nodes"][0], c5["wall"], c5["ref_s"], c5["swaps"][0]))
+    assert c3["st"] == [c3["expect"][0]] * 2 and c3["nodes"] == [c3["expect"][1]] * 2
+    assert c3["expect"][1] == 1224293770 and all(c3["basis_ok"])
+    assert c5["st"] == [c5["expect"]] * 2 == [1, 1] and c5["swaps"] == [146491] * 2
+    assert all(c5["basis_ok"])
+
+
+# ---------------------------------------------------------------------------------------------
 # NQ = 4 (193..256 rows / columns): four registers per lane in every kernel
 # ---------------------------------------------------------------------------------------------
 def test_nq4_size_reduction_sweep_matches_oracle(ctx):
@@ -198,47 +266,3 @@ def test_config3_linear_block_matches_reference(ctx, k):
           (k, res.total_nodes, f["total_nodes"], res.stats.kernel_ms))
 
 
-def test_config3_bkz60_tour_matches_reference(ctx):
-    """One BKZ-60 tour (BKZ_MAX_LOOPS 1, BKZ_GH_BND) of the 180-dim lattice with the pruner
-    strategies, on the device: 15 160 enumerations, 11 rerandomisations, 1.22e9 nodes."""
-    from fplll_amd.gso import MatGSOBatch
-    f = C.load_bkz_fixture(os.path.join(C.GOLDEN, "c3_bkz60_tour_strategies.json.gz"))
-    B = 2
-    g = MatGSOBatch(ctx, B, f["d"], f["n"])
-    g.set_basis(np.stack([f["b_in"]] * B))
-    rnd, draws = C.gmp_streams_native(B, f["rng_seed"])
-    t = time.time()
-    st, info = g.bkz_strategies(f["block_size"], f["strategies"], rnd, f["delta"], f["eta"],
-                                max_loops=f["max_loops"], gh_bnd=True, gh_factor=f["gh_factor"])
-    wall = time.time() - t
-    out = g.get_basis()
-    print("config 3 tour: %.1f s on the device (reference %.1f s on one core), %d nodes"
-          % (wall, f["ref_seconds"], _nodes(info[0])))
-    for L in range(B):
-        assert st[L] == f["status"]
-        assert _nodes(info[L]) == f["nodes"] == 1224293770
-        assert np.array_equal(out[L], f["b_out"])
-    g.close()
-
-
-# ---------------------------------------------------------------------------------------------
-# config 5 (the lattice at full size; FT = double)
-# ---------------------------------------------------------------------------------------------
-def test_config5_hlll_n256_double_matches_reference(ctx):
-    from fplll_amd.householder import MatHouseholderBatch
-    f = _c5()
-    assert (f["d"], f["n"]) == (256, 256)
-    B = 2
-    h = MatHouseholderBatch(ctx, B, 256, 256, row_expo=True)
-    h.set_basis(np.stack([f["b_in"]] * B))
-    t = time.time()
-    st, info = h.hlll(f["delta"], f["eta"], f["theta"], f["c"])
-    wall = time.time() - t
-    out = h.get_basis(0, B)
-    print("config 5 (double): %d swaps, %.1f s on the device (reference %.1f s on one core)"
-          % (int(info[0][0]), wall, f["ref_seconds"]))
-    for L in range(B):
-        assert st[L] == f["status"] == 1
-        assert int(info[L][0]) == 146491
-        assert np.array_equal(out[L], f["b_out"])
-    h.close()
