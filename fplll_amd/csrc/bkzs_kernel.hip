@@ -218,10 +218,21 @@ __global__ void __launch_bounds__(256)
       if (lane == 0)
         __hip_atomic_store(&mail->req_seq, mail_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
       bool ok = true;
-      for (unsigned spin = 0; mail_load_u64(&mail->rsp_seq) < mail_seq; ++spin)
+      // The wait is bounded by the host's LIVENESS, not by its speed: the service thread bumps
+      // mailbox[0].heartbeat on every sweep over the mailboxes (one thread serves the whole batch,
+      // a sweep can take long when thousands of lattices rerandomise at once or `rnd` is a Python
+      // callable); a wave gives up only when that word has stood still for ~2^20 polls.
+      unsigned long long hb = mail_load_u64(&mailbox[0].heartbeat);
+      for (unsigned spin = 0, still = 0; mail_load_u64(&mail->rsp_seq) < mail_seq; ++spin)
       {
         __builtin_amdgcn_s_sleep(32);
-        if (spin > (1u << 20) || (spin & 1023u) == 1023u && uni(__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)))
+        if ((spin & 63u) == 63u)
+        {
+          const unsigned long long h2 = mail_load_u64(&mailbox[0].heartbeat);
+          still                        = (h2 == hb) ? still + 64u : 0u;
+          hb                           = h2;
+        }
+        if (still > (1u << 20) || (spin & 1023u) == 1023u && uni(__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)))
         {  // the host is gone: every wave gives up (one timeout, not one per lattice)
           ok = false;
           if (lane == 0)

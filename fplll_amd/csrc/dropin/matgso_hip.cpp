@@ -1,0 +1,219 @@
+// matgso_hip.cpp — see matgso_hip.h.  Host C++ only (g++, the reference's headers, the C ABI of
+// libfplll_hip.so); built into fplll_amd/lib/libfplll_hip_gso.so.
+#include "matgso_hip.h"
+
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include <dlfcn.h>
+
+using namespace fplll;
+
+namespace fplll_hip
+{
+
+typedef Z_NR<long> ZT;
+typedef FP_NR<double> FT;
+
+static double now_s()
+{
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+MatGSOHip::MatGSOHip(Matrix<ZT> &arg_b, Matrix<ZT> &arg_u, Matrix<ZT> &arg_uinv_t, int flags, int device)
+    : MatGSO<ZT, FT>(arg_b, arg_u, arg_uinv_t, flags)
+{
+  // only the configuration the device kernels reproduce; anything else stays a plain MatGSO
+  if (flags != GSO_ROW_EXPO || arg_u.get_rows() != 0 || arg_uinv_t.get_rows() != 0)
+    return;
+  if (device < 0)
+    device = getenv("FPLLL_HIP_DEVICE") ? atoi(getenv("FPLLL_HIP_DEVICE")) : 0;
+  if (fphip_create(device, &ctx_) != FPHIP_OK)
+  {
+    ctx_ = nullptr;
+    return;
+  }
+  own_ctx_ = true;
+  if (fphip_gso_create(ctx_, 1, b.get_rows(), b.get_cols(), 1, &g_) != FPHIP_OK)
+    g_ = nullptr;  // e.g. more than 256 rows: FPHIP_UNSUPPORTED, the object works as a MatGSO
+  const size_t d = b.get_rows(), n = b.get_cols();
+  hb_.resize(d * n);
+  hmu_.resize(d * d);
+  hr_.resize(d * d);
+  hexp_.resize(d);
+}
+
+MatGSOHip::~MatGSOHip()
+{
+  if (g_)
+    fphip_gso_destroy(g_);
+  if (ctx_ && own_ctx_)
+    fphip_destroy(ctx_);
+}
+
+const char *MatGSOHip::last_error() const { return ctx_ ? fphip_last_error(ctx_) : "no device context"; }
+
+void MatGSOHip::upload_basis()
+{
+  const int d = b.get_rows(), n = b.get_cols();
+  for (int i = 0; i < d; ++i)
+    for (int j = 0; j < n; ++j)
+      hb_[(size_t)i * n + j] = b(i, j).get_si();
+  fphip_gso_set_basis(g_, 0, 1, hb_.data());
+}
+
+// Device state -> host members.  The integer rows that changed go through row_op_begin /
+// row_op_end (gso_interface.cpp:32-53: update_bf, Gram-cache invalidation) like any row operation
+// of the reference; mu, r, row exponents are then the device's (bit-identical to what
+// update_gso_row would compute from this basis: tests/test_gso_gpu.py), and every row is marked
+// valid up to its diagonal.
+void MatGSOHip::mirror_from_device(bool basis_changed)
+{
+  const int d = b.get_rows(), n = b.get_cols();
+  discover_all_rows();
+  if (basis_changed)
+  {
+    fphip_gso_get_basis(g_, 0, 1, hb_.data());
+    for (int i = 0; i < d; ++i)
+    {
+      bool diff = false;
+      for (int j = 0; j < n && !diff; ++j)
+        diff = (b(i, j).get_si() != hb_[(size_t)i * n + j]);
+      if (!diff)
+        continue;
+      row_op_begin(i, i + 1);
+      for (int j = 0; j < n; ++j)
+        b(i, j) = (long)hb_[(size_t)i * n + j];
+      row_op_end(i, i + 1);
+    }
+  }
+  fphip_gso_get_mu(g_, 0, hmu_.data());
+  fphip_gso_get_r(g_, 0, hr_.data());
+  fphip_gso_get_row_expo(g_, 0, hexp_.data());
+  for (int i = 0; i < d; ++i)
+  {
+    for (int j = 0; j < i; ++j)
+    {
+      mu(i, j) = hmu_[(size_t)i * d + j];
+      r(i, j)  = hr_[(size_t)i * d + j];
+    }
+    r(i, i) = hr_[(size_t)i * d + i];
+    // (row_expo was set by update_bf from the same integers; the device's value is the same)
+    gso_valid_cols[i] = i + 1;
+  }
+}
+
+bool MatGSOHip::update_gso_device()
+{
+  if (!g_)
+    return update_gso();
+  const double t0 = now_s();
+  upload_basis();
+  int st = 0;
+  const int rc = fphip_gso_update(g_, &st);
+  if (rc == FPHIP_OK && st == 1)
+    mirror_from_device(false);
+  device_seconds += now_s() - t0;
+  ++n_device_calls;
+  return rc == FPHIP_OK && st == 1;
+}
+
+int MatGSOHip::size_reduction_device(int kappa_min, int kappa_end, double eta)
+{
+  if (!g_)
+    return -100;
+  const double t0 = now_s();
+  upload_basis();
+  int st = 0;
+  const int rc = fphip_gso_size_reduce(g_, kappa_min, kappa_end, eta, &st);
+  if (rc != FPHIP_OK)
+    st = -100;
+  else if (st == 1)
+  {
+    // rows >= kappa_end keep stale mu / r on the device: bring the whole GSO up to date there
+    int st2 = 0;
+    if (fphip_gso_update(g_, &st2) == FPHIP_OK && st2 == 1)
+      mirror_from_device(true);
+    else
+      st = 0;
+  }
+  device_seconds += now_s() - t0;
+  ++n_device_calls;
+  return st;
+}
+
+int MatGSOHip::lll_device(int kappa_min, int kappa_start, int kappa_end, double delta, double eta, int info[4])
+{
+  if (!g_)
+    return -100;
+  const double t0 = now_s();
+  upload_basis();
+  int st = 0;
+  const int rc = fphip_gso_lll(g_, kappa_min, kappa_start, kappa_end, delta, eta, &st, info);
+  if (rc != FPHIP_OK)
+    st = -100;
+  else if (st != -2)
+    mirror_from_device(true);
+  device_seconds += now_s() - t0;
+  ++n_device_calls;
+  return st;
+}
+
+}  // namespace fplll_hip
+
+// ---------------------------------------------------------------------------------------------
+// LLLReduction<Z_NR<long>, FP_NR<double>>::lll — explicit specialisation of the member the
+// reference declares in fplll/lll.h:54 and defines in fplll/lll.cpp:44-164.  With this library
+// ahead of libfplll.so in the symbol search order, every call of lll() — including those the
+// reference's own bkz.cpp makes — lands here.
+// ---------------------------------------------------------------------------------------------
+FPLLL_BEGIN_NAMESPACE
+
+typedef bool (*lll_member_fn)(LLLReduction<Z_NR<long>, FP_NR<double>> *, int, int, int, int);
+
+template <>
+bool LLLReduction<Z_NR<long>, FP_NR<double>>::lll(int kappa_min, int kappa_start, int kappa_end,
+                                                  int size_reduction_start)
+{
+  fplll_hip::MatGSOHip *h = dynamic_cast<fplll_hip::MatGSOHip *>(&m);
+  const bool plain = !enable_early_red && !siegel && size_reduction_start == 0;
+  if (h && h->on_device() && plain)
+  {
+    if (kappa_end == -1)
+      kappa_end = m.d;
+    // (the reference's lll() returns at once on an empty matrix, lll.cpp:50-51)
+    if (m.d == 0)
+      return set_status(RED_SUCCESS);
+    int info[4]  = {0, 0, 0, 0};
+    const int st = h->lll_device(kappa_min, kappa_start, kappa_end, delta.get_d(), eta.get_d(), info);
+    if (st != -2 && st != -100)
+    {
+      final_kappa    = info[0];
+      n_swaps        = info[1];
+      zeros          = info[2];
+      last_early_red = -1;
+      // the working vectors the host path would have grown (babai() of a later host call uses them)
+      extend_vect(lovasz_tests, kappa_end);
+      extend_vect(babai_mu, kappa_end);
+      extend_vect(babai_expo, kappa_end);
+      switch (st)
+      {
+      case 1: return set_status(RED_SUCCESS);
+      case 0: return set_status(RED_GSO_FAILURE);
+      case -1: return set_status(RED_BABAI_FAILURE);
+      default: return set_status(RED_LLL_FAILURE);
+      }
+    }
+    // a multiplier beyond 63 bits or a device error: nothing was changed, the host path takes over
+  }
+  static lll_member_fn next = (lll_member_fn)dlsym(
+      RTLD_NEXT, "_ZN5fplll12LLLReductionINS_4Z_NRIlEENS_5FP_NRIdEEE3lllEiiii");
+  if (!next)
+  {
+    status = RED_LLL_FAILURE;
+    return false;
+  }
+  return next(this, kappa_min, kappa_start, kappa_end, size_reduction_start);
+}
+
+FPLLL_END_NAMESPACE

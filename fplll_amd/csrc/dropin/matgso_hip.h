@@ -1,0 +1,76 @@
+// matgso_hip.h — the GSO half of the drop-in: fplll's own MatGSO class with a device behind it.
+//
+// fplll has no hook for the Gram-Schmidt object: LLLReduction / BKZReduction take a
+// MatGSOInterface<ZT,FT>& and read mu / r through inline accessors of its HOST matrices
+// (fplll/gso_interface.h:675-732).  Two pieces make the reference's UNMODIFIED drivers run on the
+// device nevertheless:
+//
+//  1. fplll_hip::MatGSOHip — a MatGSO<Z_NR<long>, FP_NR<double>> (fplll/gso.h:33; the types BKZ
+//     runs on, bkz.cpp:816-829) that owns a device-resident copy (C ABI fphip_gso_*, batch of one)
+//     and offers the reference's coarse operations on it: update_gso(), size_reduction(range),
+//     lll(range).  After each of them the host members (b, bf, mu, r, row_expo, gso_valid_cols, the
+//     Gram cache) are brought back in line, so every inline accessor of the reference keeps
+//     working — "mirror host mu/r at call boundaries".
+//  2. an explicit specialisation of LLLReduction<Z_NR<long>, FP_NR<double>>::lll (fplll/lll.h:54,
+//     body fplll/lll.cpp:44-164) in libfplll_hip_gso.so: when the MatGSO it was constructed with
+//     is a MatGSOHip, the whole LLL loop runs on the device (fphip_gso_lll: bit-identical basis,
+//     swap count, status); otherwise the call is forwarded to the reference's own definition.
+//     The library only has to come before libfplll.so in the link order (or LD_PRELOAD): bkz.cpp
+//     reaches lll() through the PLT, so BKZReduction::svp_preprocessing / svp_reduction / bkz()
+//     (bkz.cpp:100-124, 274-358, 522-672) — compiled from the reference as is — drive the device.
+//
+// The enumeration half is the run-time plugin (fplll_hip_extenum, extenum_shim.cpp).
+#ifndef FPLLL_HIP_MATGSO_HIP_H
+#define FPLLL_HIP_MATGSO_HIP_H
+
+#include <fplll/fplll.h>
+
+#include "../../../include/fplll_hip.h"
+
+namespace fplll_hip
+{
+
+class MatGSOHip : public fplll::MatGSO<fplll::Z_NR<long>, fplll::FP_NR<double>>
+{
+public:
+  typedef fplll::Z_NR<long> ZT;
+  typedef fplll::FP_NR<double> FT;
+
+  // Same arguments as MatGSO's constructor (gso.h:56-75).  flags must be GSO_ROW_EXPO (what BKZ
+  // uses); transformation matrices are not kept on the device (pass empty ones).  device < 0: the
+  // device of FPLLL_HIP_DEVICE or 0.
+  MatGSOHip(fplll::Matrix<ZT> &arg_b, fplll::Matrix<ZT> &arg_u, fplll::Matrix<ZT> &arg_uinv_t, int flags,
+            int device = -1);
+  ~MatGSOHip();
+
+  bool on_device() const { return g_ != nullptr; }
+  const char *last_error() const;
+
+  // MatGSOInterface::update_gso() (gso_interface.h:767-775) on the device
+  bool update_gso_device();
+  // LLLReduction::size_reduction(kappa_min, kappa_end) (lll.h:107-122) on the device; eta as in the
+  // LLLReduction object.  Returns the device status: 1 ok, 0 GSO failure, -1 babai failure,
+  // -2 multiplier beyond 63 bits (nothing was changed; fall back to the host path)
+  int size_reduction_device(int kappa_min, int kappa_end, double eta);
+  // LLLReduction(m, delta, eta, LLL_DEFAULT).lll(kappa_min, kappa_start, kappa_end, 0) on the
+  // device.  info[4]: final_kappa, n_swaps, zeros, loop iterations.
+  int lll_device(int kappa_min, int kappa_start, int kappa_end, double delta, double eta, int info[4]);
+
+  // statistics: device calls made through this object and the seconds spent in them
+  long n_device_calls = 0;
+  double device_seconds = 0.0;
+
+private:
+  void upload_basis();
+  void mirror_from_device(bool basis_changed);
+
+  fphip_ctx *ctx_ = nullptr;
+  fphip_gso *g_   = nullptr;
+  bool own_ctx_   = false;
+  std::vector<int64_t> hb_;      // staging: integer basis
+  std::vector<double> hmu_, hr_; // staging: mu, r
+  std::vector<int64_t> hexp_;
+};
+
+}  // namespace fplll_hip
+#endif

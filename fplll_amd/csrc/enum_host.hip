@@ -442,17 +442,20 @@ extern "C" int fphip_enum_run(fphip_ctx *ctx, int dim, double maxdist, const dou
         cut = k;
         break;
       }
+    // the top walk is replicated on every rank (like the split launches below): only shard 0
+    // counts its nodes, so that the per-level counts summed over the ranks stay the reference's
+    const int top_count = (o.shard_index == 0) ? 1 : 0;
     auto top_launch = [&](int in_idx, unsigned n_in, int stop, unsigned grid) -> int
     {
       HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
       if (subs)
         hipLaunchKernelGGL(enum_top_kernel<true>, dim3(grid), dim3(64), tlds, ctx->stream, ctx->g,
                            ctx->h, ctx->top[in_idx], n_in, ctx->top[in_idx ^ 1], stop, ctx->buf[cur],
-                           ctx->xhi_root, d, maxdist, 1, launch_idx);
+                           ctx->xhi_root, d, maxdist, top_count, launch_idx);
       else
         hipLaunchKernelGGL(enum_top_kernel<false>, dim3(grid), dim3(64), tlds, ctx->stream, ctx->g,
                            ctx->h, ctx->top[in_idx], n_in, ctx->top[in_idx ^ 1], stop, ctx->buf[cur],
-                           ctx->xhi_root, d, maxdist, 1, launch_idx);
+                           ctx->xhi_root, d, maxdist, top_count, launch_idx);
       HIPCHK(ctx, hipGetLastError());
       HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
       uint64_t nsub = 0;  // sub-solutions of the top levels arrive through the ring meanwhile

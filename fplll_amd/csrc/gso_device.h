@@ -94,6 +94,8 @@ struct BkzMail
   int n_moves, n_ops;  // type 2: plan[0..n_moves) = move_row(b, a) as b | a << 8, then n_ops row
   int pad1;            //         additions row a +/- row b as a | b << 8 | (add ? 1 : 0) << 16
   unsigned plan[FPHIP_BKZS_PLAN_MAX];
+  // mailbox[0] only: bumped by the host on every service sweep (the device's liveness test)
+  unsigned long long heartbeat;
 };
 // Batched Householder state (MatHouseholder<Z_NR<long>, FP_NR<double>>): b, V, R are [batch][d][ldn]
 // row-major (lane = column), sigma / rexp [batch][d].

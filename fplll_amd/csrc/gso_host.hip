@@ -794,8 +794,15 @@ int serve_plan(const BkzsHost &H, int lattice, BkzMail *m)
     {
       const size_t a = H.rnd(H.rnd_user, lattice, (unsigned long)(max_row - min_row - 1)) + min_row;
       size_t b       = a;
-      while (b == a)
+      // (the reference's loop is unbounded, bkz.cpp:56-57; a generator that keeps returning the
+      // same value — e.g. the 0 a failed Python callback yields through ctypes — must not hang the
+      // service thread with a kernel waiting on it: give up after 4096 equal draws)
+      for (int tries = 0; b == a; ++tries)
+      {
+        if (tries >= 4096)
+          return -1;
         b = H.rnd(H.rnd_user, lattice, (unsigned long)(max_row - min_row - 1)) + min_row;
+      }
       m->plan[np++] = (unsigned)b | ((unsigned)a << 8);
       ++n_moves;
     }
@@ -1033,6 +1040,8 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
     }
   }
   BkzsHost H{S, gh_factor, rnd, rnd_user};
+  bool rnd_failed              = false;
+  unsigned long long heartbeat = 0;
   std::vector<unsigned long long> handled(B, 0);
   std::vector<int> active(B, 1);
   BCHK(hipMemcpy(g->P.bkz_active, active.data(), sizeof(int) * B, hipMemcpyHostToDevice));
@@ -1043,6 +1052,7 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
     int rc1 = launch(g, 0, g->P.d, 0.0, 2);  // bf / row_expo of every row from b
     if (rc1 != FPHIP_OK)
       return rc1;
+    GCHK(hipMemsetAsync(d_abort, 0, sizeof(int), s));  // one launch's timeout must not poison the next
     GCHK(hipEventRecord(g->ev[0], s));
     if (sd)
     {
@@ -1074,11 +1084,15 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
           continue;
         if (m->type == 1)
           serve_radius(H, m);
-        else if (m->type == 2)
-          serve_plan(H, (int)L, m);
+        else if (m->type == 2 && serve_plan(H, (int)L, m) < 0)
+        {  // unusable generator: answer with an empty plan, report the error after the launch
+          m->n_moves = m->n_ops = 0;
+          rnd_failed            = true;
+        }
         handled[L] = seq;
         __atomic_store_n(&m->rsp_seq, seq, __ATOMIC_RELEASE);
       }
+      __atomic_store_n(&mail[0].heartbeat, ++heartbeat, __ATOMIC_RELEASE);
       const hipError_t q = hipStreamQuery(s);
       if (q == hipSuccess)
         break;
@@ -1217,7 +1231,14 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
     }
   }
 #undef BCHK
-  cleanup();
+  cleanup();  // (run_once's GCHKs return to this function, never past it: nothing leaks on a HIP error)
+  if (rnd_failed && rc == FPHIP_OK)
+  {
+    snprintf(fphip_ctx_errbuf(g->ctx), 512,
+             "bkz_strategies: the caller's rnd() kept returning the same value (rerandomize_block "
+             "needs two different rows); for large batches rnd should be a C function");
+    rc = FPHIP_ERROR;
+  }
   g->last_ms = total_ms;
   if (status)
     memcpy(status, st.data(), sizeof(int) * B);

@@ -1,0 +1,125 @@
+/*
+ * dropin_driver.cpp — TEST INFRASTRUCTURE ONLY.
+ *
+ * Runs the reference's UNMODIFIED LLLReduction / BKZReduction (oracle/_ref/libfplll.so, compiled
+ * from /root/reference as is) against the device-backed Gram-Schmidt object of the product
+ * (fplll_hip::MatGSOHip, fplll_amd/lib/libfplll_hip_gso.so — linked AHEAD of libfplll.so so that
+ * its LLLReduction<Z_NR<long>,FP_NR<double>>::lll is the one bkz.cpp's calls resolve to), exactly
+ * the way bkz_reduction_f does it for the host object (fplll/bkz.cpp:812-836).
+ *
+ *   dropin_driver bkz <basisfile> <beta> hip|cpu [max_loops] [plugin.so]
+ *   dropin_driver lll <basisfile> hip|cpu
+ * prints one JSON line: status, seconds, device calls / seconds, the output basis.
+ */
+#include <fplll/fplll.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <dlfcn.h>
+#include <fstream>
+#include <iostream>
+#include <memory>
+
+#include "../fplll_amd/csrc/dropin/matgso_hip.h"
+
+using namespace fplll;
+
+typedef std::array<uint64_t, FPLLL_EXTENUM_MAX_EXTENUM_DIM>(extenum_fn)(
+    const int, double, std::function<extenum_cb_set_config>, std::function<extenum_cb_process_sol>,
+    std::function<extenum_cb_process_subsol>, bool, bool);
+
+int main(int argc, char **argv)
+{
+  if (argc < 4)
+  {
+    fprintf(stderr, "usage: dropin_driver bkz basisfile beta hip|cpu [max_loops] [plugin.so] | lll basisfile hip|cpu\n");
+    return 2;
+  }
+  const std::string cmd = argv[1];
+  ZZ_mat<mpz_t> A;
+  {
+    std::ifstream is(argv[2]);
+    is >> A;
+  }
+  if (A.get_rows() == 0)
+  {
+    fprintf(stderr, "cannot read %s\n", argv[2]);
+    return 2;
+  }
+  const bool is_bkz   = (cmd == "bkz");
+  const int beta      = is_bkz ? atoi(argv[3]) : 0;
+  const std::string w = is_bkz ? argv[4] : argv[3];
+  const int max_loops = (is_bkz && argc > 5) ? atoi(argv[5]) : 0;
+  if (is_bkz && argc > 6 && strcmp(argv[6], "none") != 0)
+  {
+    void *hnd = dlopen(argv[6], RTLD_NOW | RTLD_GLOBAL);
+    extenum_fn *fn = hnd ? (extenum_fn *)dlsym(hnd, "fplll_hip_extenum") : nullptr;
+    if (!fn)
+    {
+      fprintf(stderr, "cannot load plugin %s: %s\n", argv[6], dlerror());
+      return 2;
+    }
+    set_external_enumerator(fn);
+  }
+  else
+    set_external_enumerator(nullptr);  // fplll's own enumerator (fplll counting rule)
+
+  ZZ_mat<long> bl, ul, ul_inv;
+  if (!convert<long, mpz_t>(bl, A, 10))
+  {
+    fprintf(stderr, "basis does not fit long\n");
+    return 2;
+  }
+  typedef Z_NR<long> ZT;
+  typedef FP_NR<double> FT;
+  std::unique_ptr<MatGSO<ZT, FT>> gso;
+  fplll_hip::MatGSOHip *hip = nullptr;
+  if (w == "hip")
+  {
+    hip = new fplll_hip::MatGSOHip(bl, ul, ul_inv, GSO_ROW_EXPO);
+    gso.reset(hip);
+    if (!hip->on_device())
+    {
+      fprintf(stderr, "MatGSOHip has no device: %s\n", hip->last_error());
+      return 3;
+    }
+  }
+  else
+    gso.reset(new MatGSO<ZT, FT>(bl, ul, ul_inv, GSO_ROW_EXPO));
+
+  LLLReduction<ZT, FT> lll_obj(*gso, LLL_DEF_DELTA, LLL_DEF_ETA, LLL_DEFAULT);
+  int status = 0;
+  long nodes = 0;
+  auto t0    = std::chrono::steady_clock::now();
+  if (is_bkz)
+  {
+    vector<Strategy> strategies;
+    BKZParam param(beta, strategies);
+    if (max_loops > 0)
+    {
+      param.flags |= BKZ_MAX_LOOPS;
+      param.max_loops = max_loops;
+    }
+    BKZReduction<ZT, FT> bkz_obj(*gso, lll_obj, param);
+    bkz_obj.bkz();
+    status = bkz_obj.status;
+    nodes  = bkz_obj.nodes;
+  }
+  else
+  {
+    lll_obj.lll();
+    status = lll_obj.status;
+  }
+  const double secs =
+      std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  printf("{\"what\":\"%s\",\"gso\":\"%s\",\"status\":%d,\"seconds\":%.3f,\"nodes\":%ld,\"n_swaps\":%d,"
+         "\"device_calls\":%ld,\"device_seconds\":%.3f,\"d\":%d,\"n\":%d,\"b_out\":[",
+         cmd.c_str(), w.c_str(), status, secs, nodes, lll_obj.n_swaps, hip ? hip->n_device_calls : 0L,
+         hip ? hip->device_seconds : 0.0, bl.get_rows(), bl.get_cols());
+  for (int i = 0; i < bl.get_rows(); ++i)
+    for (int j = 0; j < bl.get_cols(); ++j)
+      printf("%s%ld", (i || j) ? "," : "", bl(i, j).get_si());
+  printf("]}\n");
+  return 0;
+}

@@ -903,6 +903,100 @@ static int cmd_bkztour(int argc, char **argv)
   return (status == RED_SUCCESS || status == RED_BKZ_LOOPS_LIMIT) ? 0 : 1;
 }
 
+/* enumtime basisfile first d pruning rfac mode threads [radius_scale]
+ *   CPU-baseline leg: one Enumeration::enumerate call of block [first, first+d)
+ *   of the basis in `basisfile`, radius min(rfac r, 1.1 GH) (x radius_scale), timed with a steady
+ *   clock.  mode = internal (set_external_enumerator(nullptr): fplll's own recursive enumerator,
+ *   fplll counting rule) | enumlib (the reference's default plugin, fplll/enum-parallel/, which
+ *   counts nodes BEFORE the bound test) with set_threads(threads). */
+static int cmd_enumtime(int argc, char **argv)
+{
+  if (argc < 9)
+  {
+    fprintf(stderr, "usage: enumtime basisfile first d pruning rfac internal|enumlib threads [scale]\n");
+    return 2;
+  }
+  ZZ_mat<mpz_t> A, U, UT;
+  if (!read_basis(argv[2], A))
+    return 2;
+  int first = atoi(argv[3]), d = atoi(argv[4]);
+  std::string prspec = argv[5];
+  double rfac        = atof(argv[6]);
+  std::string mode   = argv[7];
+  int threads        = atoi(argv[8]);
+  double scale       = argc > 9 ? atof(argv[9]) : 1.0;
+  MatGSO<ZT, FT> M(A, U, UT, GSO_ROW_EXPO);
+  M.update_gso();
+  long expo;
+  FT max_dist = M.get_r_exp(first, first, expo);
+  max_dist *= rfac;
+  if (d > 30 && rfac <= 1.0)
+  {
+    FT root_det = M.get_root_det(first, first + d);
+    adjust_radius_to_gh_bound(max_dist, expo, d, root_det, 1.1);
+  }
+  max_dist *= scale;
+  vector<double> pruning =
+      make_pruning(prspec, d, &M, first, max_dist.get_d() * std::pow(2.0, (double)expo));
+  int used_threads = 1;
+  if (mode == "internal")
+    set_external_enumerator(nullptr);
+  else
+    used_threads = set_threads(threads);  // enumlib is the default plugin of this build
+  FastEvaluator<FT> ev(1, EVALSTRATEGY_BEST_N_SOLUTIONS, false);
+  Enumeration<ZT, FT> E(M, ev);
+  auto t0 = std::chrono::steady_clock::now();
+  E.enumerate(first, first + d, max_dist, expo, vector<FT>(), vector<enumxt>(), pruning);
+  double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  uint64_t tot = 0;
+  auto nodes   = E.get_nodes_array();
+  for (int i = 0; i <= d; ++i)
+    tot += nodes[i];
+  double best = ev.empty() ? 0.0 : ev.begin()->first.get_d();
+  printf("{\"mode\":\"%s\",\"threads\":%d,\"first\":%d,\"d\":%d,\"pruning\":\"%s\",\"scale\":%g,"
+         "\"total_nodes\":%llu,\"seconds\":%.6f,\"best_sqnorm\":%.17g}\n",
+         mode.c_str(), used_threads, first, d, prspec.c_str(), scale, (unsigned long long)tot, secs, best);
+  return 0;
+}
+
+/* sweeptime basisfile reps
+ *   CPU-baseline leg of the GSO roofline: LLLReduction::size_reduction(0, n)
+ *   (lll.h:107-122) on a freshly built MatGSO<Z_NR<long>, FP_NR<double>>(GSO_ROW_EXPO) — the types
+ *   BKZ runs on (bkz.cpp:816-829) — of the basis in `basisfile`, wall clock, mean of `reps`. */
+static int cmd_sweeptime(int argc, char **argv)
+{
+  if (argc < 4)
+    return 2;
+  ZZ_mat<mpz_t> A;
+  if (!read_basis(argv[2], A))
+    return 2;
+  int reps = atoi(argv[3]);
+  int n = A.get_rows(), m = A.get_cols();
+  double tot = 0.0;
+  int ok     = 1;
+  unsigned long long fp = 0;
+  for (int r = 0; r < reps; ++r)
+  {
+    ZZ_mat<long> B(n, m), U, UT;
+    for (int i = 0; i < n; ++i)
+      for (int j = 0; j < m; ++j)
+        B(i, j) = A(i, j).get_si();
+    MatGSO<Z_NR<long>, FP_NR<double>> M(B, U, UT, GSO_ROW_EXPO);
+    LLLReduction<Z_NR<long>, FP_NR<double>> L(M, LLL_DEF_DELTA, LLL_DEF_ETA, LLL_DEFAULT);
+    auto t0 = std::chrono::steady_clock::now();
+    bool good = L.size_reduction(0, n);
+    tot += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    ok &= good ? 1 : 0;
+    fp = 1469598103934665603ull;
+    for (int i = 0; i < n; ++i)
+      for (int j = 0; j < m; ++j)
+        fp = (fp ^ (unsigned long long)B(i, j).get_si()) * 1099511628211ull;
+  }
+  printf("{\"rows\":%d,\"cols\":%d,\"reps\":%d,\"ok\":%d,\"seconds_per_sweep\":%.9f,"
+         "\"basis_fnv\":\"%016llx\"}\n", n, m, reps, ok, tot / reps, fp);
+  return ok ? 0 : 1;
+}
+
 /* hhfix n k bits seed perturb row_expo → JSON: input basis (long) and the reference's Householder
  * R-factor after refresh_R_bf() + update_R() (MatHouseholder<Z_NR<long>,FP_NR<double>>) */
 static int cmd_hhfix(int argc, char **argv)
@@ -989,6 +1083,10 @@ int main(int argc, char **argv)
     return cmd_genstrat(argc, argv);
   if (cmd == "teststrat")
     return cmd_teststrat(argc, argv);
+  if (cmd == "enumtime")
+    return cmd_enumtime(argc, argv);
+  if (cmd == "sweeptime")
+    return cmd_sweeptime(argc, argv);
   if (cmd == "bkztour")
     return cmd_bkztour(argc, argv);
   fprintf(stderr, "unknown command %s\n", cmd.c_str());
