@@ -1,10 +1,15 @@
-// bkzs_kernel.hip — batched BKZ WITH strategies for gfx950: BKZReduction<Z_NR<long>,
-// FP_NR<double>>::bkz() driven by a strategies table (pruning coefficients per block size,
-// recursive preprocessing tours, Gaussian-heuristic radius bound, the success-probability loop
-// with rerandomisation) — the configuration of BASELINE configs 3-4.  One wavefront per lattice,
-// the whole reduction in one launch, like bkz_kernel.hip (whose strategy-less schedule this
-// generalises; that kernel stays as it is).
+// bkzs_kernel.hip — BKZ with strategies on the device, and its DUAL blocks for self-dual BKZ
+// (BKZ_SD_VARIANT): sd_tour = trunc_dtour + trunc_tour (fplll/bkz.cpp:401-413, 443-463), dual
+// svp_reduction (:274-358: radius 1/r of the LAST row of the block, progress test reversed), the
+// dual enumeration (EnumerationDyn's transformation enum/enumerate.cpp:96-123,154-158 and the
+// dualenum recursion enum/enumerate_base.cpp:57-61,103-105), the dual insertions
+// (bkz.cpp:148-193, 240-248), the prelude lll() (:576-577) and the closing hkz() (:627-641).
 //
+// ONE schedule, two kernels: bkzs_body<NQ, DUALS> is the whole of BKZ with strategies (this file was
+// bkzs_kernel.hip + bkzd_kernel.hip in round 1, 80 % identical lines); bkzs_kernel = DUALS false
+// (primal BKZ), bkzd_kernel = DUALS true (self-dual BKZ).  Everything the dual blocks
+// add sits behind `if constexpr (DUALS)` / cur_dual().
+
 // Reference behaviour reproduced:
 //   BKZReduction::bkz / tour / trunc_tour / hkz   fplll/bkz.cpp:522-668, 360-441
 //   svp_reduction (primal)                        bkz.cpp:274-358
@@ -36,6 +41,8 @@
 #include "lll_wave.h"
 
 namespace fphip
+{
+namespace sdv
 {
 
 __device__ __forceinline__ int btri2(int k) { return (k * (k - 1)) >> 1; }
@@ -125,10 +132,16 @@ __device__ __forceinline__ void refloat_and_invalidate2(Lattice<NQ> &T, LllCtx &
 // info[4] per lattice: tours, enumeration nodes (low / high 32 bits), enumeration calls
 // status: 1 RED_SUCCESS, 8 RED_BKZ_LOOPS_LIMIT, <= 0 the failing LLL status, -7 the host did not
 // answer a mailbox request in time, -8 schedule backstop
-template <int NQ>
-__global__ void __launch_bounds__(256)
-    bkzs_kernel(GsoBatch P, BkzStrat S, BkzMail *mailbox, int *abort_flag, int block_size, int top_flags,
-                double delta, double eta, double logdelta, int max_loops, int stack_doubles)
+// DUALS = true adds self-dual BKZ (BKZ_SD_VARIANT 0x100 in top_flags: sd_tour = trunc_dtour +
+// trunc_tour, bkz.cpp:401-413,443-463; dual svp_reduction :274-358, the dual enumeration
+// enumerate.cpp:96-123,154-158 + enumerate_base.cpp:57-61,103-105, the dual insertions
+// bkz.cpp:148-193,240-248; the prelude lll() :576-577 and the closing hkz() :627-641 selected by
+// run_mode: 1 prelude, 2 tours, 4 closing hkz).  Everything it adds sits behind `if constexpr
+// (DUALS)`: the DUALS = false instantiation is the kernel of §4f, instruction for instruction.
+template <int NQ, bool DUALS>
+__device__ __forceinline__ void
+bkzs_body(GsoBatch P, BkzStrat S, BkzMail *mailbox, int *abort_flag, int block_size, int top_flags,
+          double delta, double eta, double logdelta, int max_loops, int stack_doubles, int run_mode)
 {
   constexpr int IPS = (NQ + 1) / 2;
   using RingT       = Ring<NQ, IPS, FPHIP_RING_REDUCE>;
@@ -291,7 +304,59 @@ __global__ void __launch_bounds__(256)
       running = false;
     }
 
+    // the svp_reduction in progress is a dual one (SD frame, first half of its ops)
+    auto cur_dual = [&]() -> bool
+    {
+      if constexpr (DUALS)
+        return (F.flags & 0x100) && F.op < max(F.max_row - F.bsz - F.min_row, 0);
+      else
+        return false;
+    };
+    auto first_row = [&]() -> int { return cur_dual() ? F.kappa + F.bs - 1 : F.kappa; };
     unsigned steps = 0;  // backstop against a schedule that does not terminate (never seen)
+    bool in_post = false;
+    if constexpr (DUALS)
+    {
+      if ((top_flags & 0x100) && running && status == 1 && (run_mode & 1))
+      {  // SD-BKZ starts with lll(0, 0, num_rows), bkz.cpp:576-577
+        int fk, ns, zs;
+        long long it;
+        const int rc = lll_run(T, C, M, ring, 0, 0, num_rows, delta, eta, logdelta, fk, ns, zs, it, vp);
+        if (rc != 1)
+          status = rc;
+      }
+      if ((top_flags & 0x100) && !(run_mode & 2))
+        running = false;  // this launch only runs the prelude and / or the closing hkz
+    }
+    constexpr int NSTAGE = DUALS ? 2 : 1;
+    for (int stage = 0; stage < NSTAGE; ++stage)
+    {
+    if constexpr (DUALS)
+    {
+      if (stage == 1)
+      {
+        // closing pass of SD-BKZ: hkz(num_rows - block_size, num_rows), bkz.cpp:627-641 — it also
+        // runs after RED_BKZ_LOOPS_LIMIT
+        if (!((top_flags & 0x100) && (run_mode & 4) && block_size >= 2 && (status == 1 || status == 8)))
+          break;
+        in_post     = true;
+        running     = true;
+        depth       = 0;
+        F.bsz       = block_size;
+        F.flags     = top_flags & ~0x100;
+        F.min_row   = num_rows - block_size;
+        F.max_row   = num_rows;
+        F.op        = 0;
+        F.phase     = PH_OP_BEGIN;
+        F.clean     = 1;
+      }
+    }
+    const int status_before = status;
+    if constexpr (DUALS)
+    {
+      if (in_post)
+        status = 1;
+    }
     while (running && status == 1)
     {
       if (++steps > (1u << 27))
@@ -305,7 +370,15 @@ __global__ void __launch_bounds__(256)
         const int n_trunc = max(F.max_row - F.bsz - F.min_row, 0);
         const int hkz_lo  = max(F.max_row - F.bsz, 0);
         const int n_hkz   = max(F.max_row - 1 - hkz_lo, 0);
-        const int nops    = n_trunc + n_hkz + 1;
+        int nops          = n_trunc + n_hkz + 1;
+        bool sd_frame     = false;
+        if constexpr (DUALS)
+        {
+          // sd_tour: n_trunc dual blocks from the top down, then the n_trunc primal blocks; no hkz
+          sd_frame = (F.flags & 0x100) != 0;
+          if (sd_frame)
+            nops = 2 * n_trunc;
+        }
         if (F.op >= nops)
         {  // the tour is over
           if (depth > 0)
@@ -314,6 +387,11 @@ __global__ void __launch_bounds__(256)
             --depth;
             F = frame_load(&frames[depth]);
             continue;
+          }
+          if constexpr (DUALS)
+          {
+            if (in_post)
+              break;
           }
           ++tours;
           if (F.clean || block_size >= num_rows)
@@ -328,7 +406,7 @@ __global__ void __launch_bounds__(256)
           F.clean = 1;
           continue;
         }
-        if (F.op == nops - 1)
+        if (!sd_frame && F.op == nops - 1)
         {  // lll_obj.size_reduction(max_row - 1, max_row, max_row - 2), bkz.cpp:437
           ++F.op;
           if (F.max_row >= 2)
@@ -341,7 +419,15 @@ __global__ void __launch_bounds__(256)
           }
           continue;
         }
-        if (F.op < n_trunc)
+        if (sd_frame)
+        {
+          if constexpr (DUALS)
+          {
+            F.kappa = (F.op < n_trunc) ? F.max_row - F.bsz - F.op : F.min_row + (F.op - n_trunc);
+            F.bs    = F.bsz;
+          }
+        }
+        else if (F.op < n_trunc)
         {
           F.kappa = F.min_row + F.op;
           F.bs    = F.bsz;
@@ -353,7 +439,7 @@ __global__ void __launch_bounds__(256)
         }
         // ---- svp_reduction(kappa, bs): opening size reduction ...
         sr_kmin  = 0;
-        sr_kend  = F.kappa + 1;
+        sr_kend  = first_row() + 1;
         sr_start = 0;
         sr_next  = PH_OPENED;
         F.phase  = PH_SR;
@@ -386,7 +472,7 @@ __global__ void __launch_bounds__(256)
       if (F.phase == PH_OPENED)
       {
         // ... and the value to beat, bkz.cpp:291-293
-        const int sk0 = M.phys(F.kappa);
+        const int sk0 = M.phys(first_row());
         F.old_first   = T.rdg[sk0];
         F.old_expo    = (int)(2 * T.rexp[sk0]);
         F.rerand      = 0;
@@ -536,11 +622,17 @@ __global__ void __launch_bounds__(256)
         const bool in   = lane < bs;
         const double rr = in ? T.rdg[sl_blk] : 0.0;
         const int e2    = in ? (int)(2 * T.rexp[sl_blk]) : 0;
-        const int sk    = M.phys(kappa);
+        const bool dualb = cur_dual();
+        const int sk    = M.phys(dualb ? kappa + bs - 1 : kappa);  // row `first`
         double md       = T.rdg[sk] * delta;  // max_dist *= delta
+        if constexpr (DUALS)
+        {
+          if (dualb)  // max_dist.pow_si(max_dist, -1) (nr_FP_d.inl:189-192: ::pow) then *= delta —
+            md = 0.0; // libm's pow: always taken from the host below
+        }
         int prune       = -1;
         double expct    = 1.0;  // PruningParams(): no pruning, expectation 1
-        if (has_strat || ((F.flags & 0x80) && bs > 30))
+        if (has_strat || ((F.flags & 0x80) && bs > 30) || dualb)
         {
           if (in)
           {
@@ -551,7 +643,8 @@ __global__ void __launch_bounds__(256)
           {
             mail->type  = 1;
             mail->bs    = bs;
-            mail->flags = F.flags | (depth > 0 ? 0x10000 : 0);  // a preprocessing tour: BKZParam defaults
+            mail->flags = F.flags | (depth > 0 ? 0x10000 : 0) |  // a preprocessing tour: BKZParam defaults
+                          (dualb ? 0x20000 : 0);                // dual block: radius from 1 / r(last)
             mail->delta = delta;
           }
           if (!mail_wait())
@@ -566,16 +659,46 @@ __global__ void __launch_bounds__(256)
         // ---- normalisation, enumerate.cpp:88-141 ------------------------------------------------
         int ne = in ? (int)min((long long)e2 + fexponent(rr), (long long)INT_MAX) : INT_MIN;
         ne     = max(wave_max_i32(ne), -1);
-        const double rd = in ? ldexp(rr, e2 - ne) : 0.0;
-        double maxdist  = ldexp(md, (int)(2 * T.rexp[sk]) - ne);
-        for (int k = 1; k < bs; ++k)
+        double rd      = in ? ldexp(rr, e2 - ne) : 0.0;
+        double maxdist = ldexp(md, (int)(2 * T.rexp[sk]) - ne);
+        if (!dualb)
         {
-          const int skk      = M.phys(kappa + k);
-          const long long ek = T.rexp[skk];
-          if (lane < k)
+          for (int k = 1; k < bs; ++k)
           {
-            const double m = T.mu[(size_t)skk * ldd + kappa + lane];
-            mu_blk[btri2(k) + lane] = ldexp(m, (int)(ek - T.rexp[sl_blk]));
+            const int skk      = M.phys(kappa + k);
+            const long long ek = T.rexp[skk];
+            if (lane < k)
+            {
+              const double m = T.mu[(size_t)skk * ldd + kappa + lane];
+              mu_blk[btri2(k) + lane] = ldexp(m, (int)(ek - T.rexp[sl_blk]));
+            }
+          }
+        }
+        if constexpr (DUALS)
+        {
+          if (dualb)
+          {
+            // EnumerationDyn::enumerate for a dual call, enumerate.cpp:96-123: normexp is negated,
+            // rdiag[d-1-i] = 1 / (r_i 2^(rexpo_i + normexp)), mut[d-1-j][d-1-i] = -mu(j, i);
+            // the radius arrives with the exponent -(2 row_expo[last]) (bkz.cpp:312-316)
+            const int nd_  = -ne;
+            const int srcl = in ? bs - 1 - lane : 0;             // lane i takes row bs-1-i
+            const double rsrc = __shfl(rr, srcl);
+            const int esrc    = __shfl(e2, srcl);
+            rd      = in ? 1.0 / ldexp(rsrc, esrc + nd_) : 0.0;
+            maxdist = ldexp(md, -(int)(2 * T.rexp[sk]) - nd_);
+            const int sl_rev = __shfl(sl_blk, srcl);             // slot of row kappa + bs-1-lane
+            // dual row k' holds mu'(k', l) = -mu(bs-1-l, bs-1-k') for l < k'
+            for (int k = 1; k < bs; ++k)
+            {
+              const int col       = kappa + bs - 1 - k;          // column of the primal mu
+              const long long ec  = T.rexp[M.phys(col)];
+              if (lane < k)
+              {
+                const double m = T.mu[(size_t)sl_rev * ldd + col];
+                mu_blk[btri2(k) + lane] = -ldexp(m, (int)(T.rexp[sl_rev] - ec));
+              }
+            }
           }
         }
         __threadfence_block();
@@ -640,7 +763,10 @@ __global__ void __launch_bounds__(256)
                 break;
               }
               const double mk = mu_blk[btri2(k) + min(lane, k - 1)];
-              Sc              = Sc - x1 * mk;
+              if (DUALS && dualb)
+                Sc = Sc - a1 * mk;  // dualenum: alpha[j] * mut, enumerate_base.cpp:57-61
+              else
+                Sc = Sc - x1 * mk;
             }
             if (done)
               break;
@@ -691,7 +817,10 @@ __global__ void __launch_bounds__(256)
                 }
                 continue;
               }
-              Sc = par - xk * mk;
+              if (DUALS && dualb)
+                Sc = par - a * mk;  // enumerate_base.cpp:103-105
+              else
+                Sc = par - xk * mk;
               break;
             }
           }
@@ -701,8 +830,145 @@ __global__ void __launch_bounds__(256)
           total_nodes += tot - (unsigned long long)(bs - 1);
           ++ncalls;
         }
+        // ---- svp_postprocessing for a DUAL block, bkz.cpp:126-272 with dual = true ---------------
+        bool handled = false;
+        if constexpr (DUALS)
+        {
+          if (dualb && have_sol)
+          {
+            handled  = true;
+            F.rerand = 0;
+            // the evaluator's vector is index-reversed first (enumerate.cpp:154-158)
+            double sx = __shfl(best_x, in ? bs - 1 - lane : 0);
+            sx        = in ? sx : 0.0;
+            const uint64_t nzm = __ballot(in && sx != 0.0);
+            const uint64_t onm = __ballot(in && fabs(sx) == 1.0);
+            const int nz       = __popcll(nzm);
+            const int iv       = onm ? 63 - __clzll((long long)onm) : -1;
+            const int pos      = kappa + bs - 1;
+            if (nz == 1)
+            {
+              move_row(kappa + iv, pos);
+            }
+            else if (iv != -1)
+            {
+              // b[kappa+i] += (-sol_iv * sol_i) b[kappa+iv] for every other non-zero coordinate
+              const double sv = -g_rl_f64(sx, iv);
+              const int siv   = M.phys(kappa + iv);
+              long long biv[NQ];
+#pragma unroll
+              for (int q = 0; q < NQ; ++q)
+              {
+                const int c = lane + 64 * q;
+                biv[q]      = (c < n) ? T.b[(size_t)siv * ldn + c] : 0;
+              }
+              for (int i = 0; i < bs; ++i)
+              {
+                const double xi = g_rl_f64(sx, i);
+                if (xi == 0.0 || i == iv)
+                  continue;
+                const long long lx = (long long)(sv * xi);
+                const int si       = M.phys(kappa + i);
+#pragma unroll
+                for (int q = 0; q < NQ; ++q)
+                {
+                  const int c = lane + 64 * q;
+                  if (c < n)
+                    T.b[(size_t)si * ldn + c] =
+                        (long long)((unsigned long long)T.b[(size_t)si * ldn + c] +
+                                    (unsigned long long)biv[q] * (unsigned long long)lx);
+                }
+              }
+              __threadfence_block();
+              refloat_and_invalidate2<NQ>(T, C, M, kappa, kappa + bs);  // row_op_end(kappa, kappa + bs)
+              clamp_valid<NQ>(T, C, M, kappa);
+              vp = min(vp, kappa);
+              move_row(kappa + iv, pos);
+            }
+            else
+            {
+              // generic case: the gcd tree with row_sub(kappa + k, kappa + k - off), no final move
+              double x = sx;
+              for (int i = 0; i < bs; ++i)
+              {
+                if (g_rl_f64(x, i) < 0.0)
+                {
+                  const int si = M.phys(kappa + i);
+#pragma unroll
+                  for (int q = 0; q < NQ; ++q)
+                  {
+                    const int c = lane + 64 * q;
+                    if (c < n)
+                      T.b[(size_t)si * ldn + c] = -T.b[(size_t)si * ldn + c];
+                  }
+                }
+              }
+              x = fabs(x);
+              __threadfence_block();
+              auto swap_rows = [&](int pa, int pb)
+              {
+                const int sa = M.phys(pa), sb = M.phys(pb);
+#pragma unroll
+                for (int q = 0; q < NQ; ++q)
+                {
+                  const int p = lane + 64 * q;
+                  M.sl[q]     = (p == pa) ? sb : ((p == pb) ? sa : M.sl[q]);
+                }
+              };
+              for (int off = 1; off < bs; off *= 2)
+              {
+                for (int k = bs - 1; k - off >= 0; k -= 2 * off)
+                {
+                  double xk = g_rl_f64(x, k), xo = g_rl_f64(x, k - off);
+                  if (xk == 0.0 && xo == 0.0)
+                    continue;
+                  if (xk < xo)
+                  {
+                    const double t = xk;
+                    xk             = xo;
+                    xo             = t;
+                    swap_rows(kappa + k - off, kappa + k);
+                  }
+                  while (xo != 0.0)
+                  {
+                    // while (x[k-off] <= x[k]) { x[k] -= x[k-off]; row_sub(k, k-off); }
+                    const double qd = floor(xk / xo);
+                    if (qd >= 1.0)
+                    {
+                      xk                 = xk - qd * xo;
+                      const long long lq = (long long)qd;
+                      const int sdst = M.phys(kappa + k), ssrc = M.phys(kappa + k - off);
+#pragma unroll
+                      for (int q = 0; q < NQ; ++q)
+                      {
+                        const int c = lane + 64 * q;
+                        if (c < n)
+                          T.b[(size_t)sdst * ldn + c] =
+                              (long long)((unsigned long long)T.b[(size_t)sdst * ldn + c] -
+                                          (unsigned long long)T.b[(size_t)ssrc * ldn + c] * (unsigned long long)lq);
+                      }
+                      __threadfence_block();
+                    }
+                    const double t = xk;
+                    xk             = xo;
+                    xo             = t;
+                    swap_rows(kappa + k - off, kappa + k);
+                  }
+                  x = (lane == k) ? xk : ((lane == k - off) ? xo : x);
+                }
+              }
+              refloat_and_invalidate2<NQ>(T, C, M, kappa, kappa + bs);
+              vp = min(vp, kappa);
+              clamp_valid<NQ>(T, C, M, kappa);
+            }
+            __threadfence_block();
+          }
+        }
         // ---- svp_postprocessing, bkz.cpp:126-272 (as in bkz_kernel.hip) -------------------------
-        if (have_sol)
+        if (handled)
+        {
+        }
+        else if (have_sol)
         {
           const uint64_t nzm = __ballot(in && best_x != 0.0);
           const uint64_t onm = __ballot(in && fabs(best_x) == 1.0);
@@ -845,7 +1111,7 @@ __global__ void __launch_bounds__(256)
       if (F.phase == PH_FINISH)
       {  // closing size reduction, bkz.cpp:347-350
         sr_kmin  = 0;
-        sr_kend  = F.kappa + 1;
+        sr_kend  = first_row() + 1;
         sr_start = 0;
         sr_next  = PH_CLOSED;
         F.phase  = PH_SR;
@@ -854,14 +1120,23 @@ __global__ void __launch_bounds__(256)
 
       // PH_CLOSED: the progress test, bkz.cpp:352-357
       {
-        const int sk0    = M.phys(F.kappa);
+        const int sk0    = M.phys(first_row());
         double new_first = T.rdg[sk0];
         new_first        = ldexp(new_first, (int)(2 * T.rexp[sk0]) - F.old_expo);
-        F.clean          = (F.clean && __all(F.old_first <= new_first)) ? 1 : 0;
+        if (cur_dual())
+          F.clean = (F.clean && __all(F.old_first >= new_first)) ? 1 : 0;
+        else
+          F.clean = (F.clean && __all(F.old_first <= new_first)) ? 1 : 0;
         ++F.op;
         F.phase = PH_OP_BEGIN;
       }
     }
+    if constexpr (DUALS)
+    {
+      if (in_post && status == 1)
+        status = status_before;  // the closing pass keeps RED_SUCCESS / RED_BKZ_LOOPS_LIMIT
+    }
+    }  // stage
     lll_write_ordered<NQ>(T, M, P.b2 + (size_t)L * d * ldn);
     if (lane == 0)
     {
@@ -878,6 +1153,34 @@ __global__ void __launch_bounds__(256)
     }
     __threadfence_block();
   }
+}
+
+// the same schedule with the dual blocks of self-dual BKZ (the host selects it for BKZ_SD_VARIANT)
+template <int NQ>
+__global__ void __launch_bounds__(256)
+    bkzd_kernel(GsoBatch P, BkzStrat S, BkzMail *mailbox, int *abort_flag, int block_size, int top_flags,
+                double delta, double eta, double logdelta, int max_loops, int stack_doubles, int run_mode)
+{
+  bkzs_body<NQ, true>(P, S, mailbox, abort_flag, block_size, top_flags, delta, eta, logdelta, max_loops,
+                      stack_doubles, run_mode);
+}
+
+template __global__ void bkzd_kernel<1>(GsoBatch, BkzStrat, BkzMail *, int *, int, int, double, double, double, int, int, int);
+template __global__ void bkzd_kernel<2>(GsoBatch, BkzStrat, BkzMail *, int *, int, int, double, double, double, int, int, int);
+template __global__ void bkzd_kernel<3>(GsoBatch, BkzStrat, BkzMail *, int *, int, int, double, double, double, int, int, int);
+template __global__ void bkzd_kernel<4>(GsoBatch, BkzStrat, BkzMail *, int *, int, int, double, double, double, int, int, int);
+
+}  // namespace sdv
+
+// primal BKZ with strategies (fphip_gso_bkz_strategies without FPHIP_BKZ_SD_VARIANT): the same
+// schedule without the dual blocks
+template <int NQ>
+__global__ void __launch_bounds__(256)
+    bkzs_kernel(GsoBatch P, BkzStrat S, BkzMail *mailbox, int *abort_flag, int block_size, int top_flags,
+                double delta, double eta, double logdelta, int max_loops, int stack_doubles)
+{
+  sdv::bkzs_body<NQ, false>(P, S, mailbox, abort_flag, block_size, top_flags, delta, eta, logdelta,
+                            max_loops, stack_doubles, 7);
 }
 
 template __global__ void bkzs_kernel<1>(GsoBatch, BkzStrat, BkzMail *, int *, int, int, double, double, double, int, int);

@@ -149,7 +149,7 @@ extern "C" int fphip_create(int device, fphip_ctx **out)
   return FPHIP_OK;
 }
 
-extern "C" void fphip_gso_release_all(fphip_ctx *ctx);  // gso_host.hip
+extern "C" __attribute__((visibility("hidden"))) void fphip_gso_release_all(fphip_ctx *ctx);  // gso_host.hip
 
 extern "C" void fphip_destroy(fphip_ctx *ctx)
 {

@@ -53,6 +53,7 @@ struct Trampoline
   std::function<cb_process_sol_t> *cbsol;
   std::function<cb_process_subsol_t> *cbsubsol;
   int dim;
+  long delivered;  // candidates handed to fplll's evaluator so far
 };
 
 void subsol_trampoline(void *user, double dist, const double *subsol, int offset)
@@ -73,6 +74,7 @@ void subsol_trampoline(void *user, double dist, const double *subsol, int offset
 double sol_trampoline(void *user, double dist, const double *sol)
 {
   Trampoline *t = static_cast<Trampoline *>(user);
+  ++t->delivered;
   double buf[FPHIP_ENUM_MAX_DIM];
   for (int i = 0; i < t->dim; ++i)
     buf[i] = sol[i];
@@ -122,7 +124,7 @@ nodes_array_t fplll_hip_extenum(const int dim, enumf maxdist, std::function<cb_s
   const char *mn         = getenv("FPLLL_HIP_MIN_NODES");
   opts.min_nodes_decline = mn ? atoi(mn) : 0;
   opts.findsubsols       = findsubsols ? 1 : 0;
-  Trampoline tr{&cbsol, &cbsubsol, dim};
+  Trampoline tr{&cbsol, &cbsubsol, dim, 0};
   std::vector<std::uint64_t> nodes(dim + 1, 0);
   fphip_enum_stats stats{};
   const auto t0 = std::chrono::steady_clock::now();
@@ -140,7 +142,16 @@ nodes_array_t fplll_hip_extenum(const int dim, enumf maxdist, std::function<cb_s
   g_totals.nodes += stats.total_nodes;
   if (rc != FPHIP_OK)
   {
-    fprintf(stderr, "[fplll_hip] enumeration failed, falling back: %s\n", fphip_last_error(ctx));
+    // fplll's protocol has one error channel: decline, upon which Enumeration::enumerate runs its
+    // own enumerator from the ORIGINAL radius (enumerate.h:104-110).  If candidates had already
+    // been handed to the evaluator, that second walk meets them again: harmless for BKZ's
+    // FastEvaluator(max_sols = 1) (the shortest survives), but an evaluator that keeps N > 1
+    // solutions may then hold the same vector twice — say so instead of failing silently.
+    fprintf(stderr, "[fplll_hip] enumeration failed%s, fplll's enumerator takes over: %s\n",
+            tr.delivered ? " AFTER candidates were delivered (evaluators with max_sols > 1 may now hold "
+                           "duplicates)"
+                         : "",
+            fphip_last_error(ctx));
     return out;
   }
   out.fill(0);

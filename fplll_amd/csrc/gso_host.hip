@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../../include/fplll_hip.h"
+#include "../../include/fplll_hip_debug.h"
 #include "gso_device.h"
 #include "gso_sweep2.h"
 
@@ -77,7 +78,8 @@ static int gfail(fphip_ctx *ctx, const char *what, hipError_t e)
       return gfail(g->ctx, #call, e_);        \
   } while (0)
 
-extern "C" void fphip_gso_release_all(fphip_ctx *ctx) { (void)ctx; }
+// (internal hook of fphip_destroy, enum_host.hip: not exported)
+extern "C" __attribute__((visibility("hidden"))) void fphip_gso_release_all(fphip_ctx *ctx) { (void)ctx; }
 
 static int gso_allocate(fphip_gso *g);
 
@@ -558,6 +560,111 @@ static int bkz_launch(fphip_gso *g, int block_size, double delta, double eta, in
   return rc;
 }
 
+// info accumulation across one-tour launches: tours, 64-bit node count (two 32-bit halves), calls
+static void accumulate_info(int *inf, const int *one, size_t L)
+{
+  inf[4 * L + 0] += one[4 * L + 0];
+  const unsigned long long a = ((unsigned long long)(unsigned)inf[4 * L + 2] << 32) | (unsigned)inf[4 * L + 1];
+  const unsigned long long b = ((unsigned long long)(unsigned)one[4 * L + 2] << 32) | (unsigned)one[4 * L + 1];
+  const unsigned long long t = a + b;
+  inf[4 * L + 1] = (int)(unsigned)(t & 0xffffffffull);
+  inf[4 * L + 2] = (int)(unsigned)(t >> 32);
+  inf[4 * L + 3] += one[4 * L + 3];
+}
+
+// BKZ_AUTO_ABORT for both device BKZ drivers: one tour per launch, BKZAutoAbort::test_abort(1.0, 5)
+// (bkz.cpp:800-809) on the host in between — the slope of log r_ii (MatGSOInterface::
+// get_current_slope, gso_interface.cpp:198-218) needs the host's log(), the one the reference calls.
+// run_tour(loop, &ms, s1, one) launches exactly one tour for the lattices with active[L] != 0 and
+// leaves the identity-layout GSO (r_ii, row exponents) of the new bases on the device.
+template <class RunTour>
+static int auto_abort_loop(fphip_gso *g, int block_size, bool use_loops, int max_loops, std::vector<int> &active,
+                           std::vector<int> &st, std::vector<int> &inf, std::vector<int> &rows, float &total_ms,
+                           RunTour run_tour)
+{
+  const size_t B = (size_t)g->P.batch, d = (size_t)g->P.d;
+  int rc = launch(g, 0, g->P.d, 0.0, 0);  // r_ii of the input bases
+  if (rc != FPHIP_OK)
+    return rc;
+  std::vector<double> rdg(B * d), old_slope(B, std::numeric_limits<double>::max());
+  std::vector<long long> rex(B * d);
+  std::vector<int> no_dec(B, -1), one(4 * B), s1(B);
+  bool rows_known = false;
+  for (int loop = 0;; ++loop)
+  {
+    size_t n_active = 0;
+    GCHK(hipMemcpy(rdg.data(), g->P.rdg, sizeof(double) * B * d, hipMemcpyDeviceToHost));
+    GCHK(hipMemcpy(rex.data(), g->P.rexp, sizeof(long long) * B * d, hipMemcpyDeviceToHost));
+    if (!rows_known)
+    {  // trailing zero rows (bkz.cpp:35-37) have r_ii == 0 exactly
+      for (size_t L = 0; L < B; ++L)
+      {
+        int nr = (int)d;
+        while (nr > 0 && rdg[L * d + nr - 1] == 0.0)
+          --nr;
+        rows[L] = nr;
+      }
+      rows_known = true;
+    }
+    for (size_t L = 0; L < B; ++L)
+    {
+      if (!active[L])
+        continue;
+      if (block_size < 2)
+      {
+        active[L] = 0;
+        continue;
+      }
+      if (use_loops && loop >= max_loops)
+      {
+        st[L]     = 8;
+        active[L] = 0;
+        continue;
+      }
+      const int n = rows[L];
+      double v1 = 0, v2 = (double)(n + 1) * n * (n - 1) / 12.0, weight = (1.0 - n) / 2.0;
+      for (int i = 0; i < n; ++i)
+      {
+        const double logf = std::log(rdg[L * d + i]);
+        const long expo   = (long)(2 * rex[L * d + i]);
+        v1 += weight * (logf + expo * std::log(2.0));
+        weight++;
+      }
+      const double new_slope = -(v1 / v2);
+      if (no_dec[L] == -1 || new_slope < 1.0 * old_slope[L])
+        no_dec[L] = 0;
+      else
+        no_dec[L]++;
+      old_slope[L] = std::min(old_slope[L], new_slope);
+      if (no_dec[L] >= 5)
+      {
+        active[L] = 0;  // abort: status stays RED_SUCCESS
+        continue;
+      }
+      ++n_active;
+    }
+    if (n_active == 0)
+      break;
+    GCHK(hipMemcpy(g->P.bkz_active, active.data(), sizeof(int) * B, hipMemcpyHostToDevice));
+    float ms = 0;
+    rc       = run_tour(loop, &ms, s1.data(), one.data());
+    if (rc != FPHIP_OK)
+      return rc;
+    total_ms += ms;
+    for (size_t L = 0; L < B; ++L)
+    {
+      if (!active[L])
+        continue;
+      accumulate_info(inf.data(), one.data(), L);
+      if (s1[L] == 8)
+        continue;        // tour done, not clean: next loop
+      st[L]     = s1[L];  // 1: clean (or block_size >= num_rows); <= 0: failure
+      active[L] = 0;
+    }
+  }
+  return FPHIP_OK;
+}
+
 extern "C" int fphip_gso_bkz(fphip_gso *g, int block_size, double delta, double eta, int flags,
                              int max_loops, int *status, int *info)
 {
@@ -582,16 +689,6 @@ extern "C" int fphip_gso_bkz(fphip_gso *g, int block_size, double delta, double 
     return rc;
   const bool use_loops = (flags & 0x4) != 0, auto_abort = (flags & 0x20) != 0;
   float total_ms = 0, ms = 0;
-  auto accumulate = [&](size_t L)
-  {
-    inf[4 * L + 0] += one[4 * L + 0];
-    const unsigned long long a = ((unsigned long long)(unsigned)inf[4 * L + 2] << 32) | (unsigned)inf[4 * L + 1];
-    const unsigned long long b2 = ((unsigned long long)(unsigned)one[4 * L + 2] << 32) | (unsigned)one[4 * L + 1];
-    const unsigned long long t = a + b2;
-    inf[4 * L + 1] = (int)(unsigned)(t & 0xffffffffull);
-    inf[4 * L + 2] = (int)(unsigned)(t >> 32);
-    inf[4 * L + 3] += one[4 * L + 3];
-  };
   if (!auto_abort)
   {
     rc = bkz_launch(g, block_size, delta, eta, use_loops ? 1 : 0, max_loops, &ms, st.data(), inf.data());
@@ -601,87 +698,11 @@ extern "C" int fphip_gso_bkz(fphip_gso *g, int block_size, double delta, double 
   }
   else
   {
-    // one tour per launch; BKZAutoAbort on the host (bkz.cpp:575-625, 800-809)
-    rc = launch(g, 0, g->P.d, 0.0, 0);  // r_ii of the input bases
+    rc = auto_abort_loop(g, block_size, use_loops, max_loops, active, st, inf, rows, total_ms,
+                         [&](int, float *tms, int *s1, int *one)
+                         { return bkz_launch(g, block_size, delta, eta, 1, 1, tms, s1, one); });
     if (rc != FPHIP_OK)
       return rc;
-    std::vector<double> rdg(B * d), old_slope(B, std::numeric_limits<double>::max());
-    std::vector<long long> rex(B * d);
-    std::vector<int> no_dec(B, -1);
-    bool rows_known = false;
-    for (int loop = 0;; ++loop)
-    {
-      size_t n_active = 0;
-      GCHK(hipMemcpy(rdg.data(), g->P.rdg, sizeof(double) * B * d, hipMemcpyDeviceToHost));
-      GCHK(hipMemcpy(rex.data(), g->P.rexp, sizeof(long long) * B * d, hipMemcpyDeviceToHost));
-      if (!rows_known)
-      {  // trailing zero rows (bkz.cpp:35-37) have r_ii == 0 exactly
-        for (size_t L = 0; L < B; ++L)
-        {
-          int nr = (int)d;
-          while (nr > 0 && rdg[L * d + nr - 1] == 0.0)
-            --nr;
-          rows[L] = nr;
-        }
-        rows_known = true;
-      }
-      for (size_t L = 0; L < B; ++L)
-      {
-        if (!active[L])
-          continue;
-        if (block_size < 2)
-        {
-          active[L] = 0;
-          continue;
-        }
-        if (use_loops && loop >= max_loops)
-        {
-          st[L]     = 8;
-          active[L] = 0;
-          continue;
-        }
-        // MatGSOInterface::get_current_slope(0, num_rows), gso_interface.cpp:198-218
-        const int n = rows[L];
-        double v1 = 0, v2 = (double)(n + 1) * n * (n - 1) / 12.0, weight = (1.0 - n) / 2.0;
-        for (int i = 0; i < n; ++i)
-        {
-          const double logf = std::log(rdg[L * d + i]);
-          const long expo   = (long)(2 * rex[L * d + i]);
-          v1 += weight * (logf + expo * std::log(2.0));
-          weight++;
-        }
-        const double new_slope = -(v1 / v2);
-        if (no_dec[L] == -1 || new_slope < 1.0 * old_slope[L])
-          no_dec[L] = 0;
-        else
-          no_dec[L]++;
-        old_slope[L] = std::min(old_slope[L], new_slope);
-        if (no_dec[L] >= 5)
-        {
-          active[L] = 0;  // abort: status stays RED_SUCCESS
-          continue;
-        }
-        ++n_active;
-      }
-      if (n_active == 0)
-        break;
-      GCHK(hipMemcpy(g->P.bkz_active, active.data(), sizeof(int) * B, hipMemcpyHostToDevice));
-      std::vector<int> s1(B);
-      rc = bkz_launch(g, block_size, delta, eta, 1, 1, &ms, s1.data(), one.data());  // exactly one tour
-      if (rc != FPHIP_OK)
-        return rc;
-      total_ms += ms;
-      for (size_t L = 0; L < B; ++L)
-      {
-        if (!active[L])
-          continue;
-        accumulate(L);
-        if (s1[L] == 8)
-          continue;        // tour done, not clean: next loop
-        st[L]     = s1[L];  // 1: clean (or block_size >= num_rows); <= 0: failure
-        active[L] = 0;
-      }
-    }
   }
   g->last_ms = total_ms;
   if (status)
@@ -732,7 +753,7 @@ struct BkzsHost
 void serve_radius(const BkzsHost &H, BkzMail *m)
 {
   const int bs      = m->bs;
-  const bool dual   = (m->flags & 0x20000) != 0;  // a dual block of self-dual BKZ (bkzd_kernel.hip)
+  const bool dual   = (m->flags & 0x20000) != 0;  // a dual block of self-dual BKZ (bkzs_kernel.hip, DUALS)
   long expo         = m->e2[0];
   const double r0   = m->r[0];
   double max_dist   = r0;
@@ -882,7 +903,7 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
     return FPHIP_ERROR;
   // one wavefront enumerates a block: sizes up to 64; BKZ_MAX_LOOPS, BKZ_BOUNDED_LLL, BKZ_AUTO_ABORT,
   // BKZ_GH_BND
-  // BKZ_SD_VARIANT (0x100): self-dual BKZ, bkzd_kernel.hip
+  // BKZ_SD_VARIANT (0x100): self-dual BKZ, bkzs_body<NQ, true>
   const bool sd = (flags & 0x100) != 0;
   if (block_size > 64 || (flags & ~(0x4 | 0x10 | 0x20 | 0x80 | 0x100)))
     return FPHIP_UNSUPPORTED;
@@ -1120,93 +1141,13 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
   }
   else
   {
-    // one tour per launch; BKZAutoAbort::test_abort(1.0, 5) on the host in between (bkz.cpp:575-625,
-    // 800-809), exactly as fphip_gso_bkz does it for the strategy-less kernel
-    const size_t d = g->P.d;
-    rc = launch(g, 0, g->P.d, 0.0, 0);  // r_ii of the input bases
-    std::vector<double> rdg(B * d), old_slope(B, std::numeric_limits<double>::max());
-    std::vector<long long> rex(B * d);
-    std::vector<int> no_dec(B, -1), rows(B, (int)d), one(4 * B), s1(B);
-    bool rows_known = false;
-    for (int loop = 0; rc == FPHIP_OK; ++loop)
-    {
-      size_t n_active = 0;
-      BCHK(hipMemcpy(rdg.data(), g->P.rdg, sizeof(double) * B * d, hipMemcpyDeviceToHost));
-      BCHK(hipMemcpy(rex.data(), g->P.rexp, sizeof(long long) * B * d, hipMemcpyDeviceToHost));
-      if (!rows_known)
-      {  // trailing zero rows (bkz.cpp:35-37) have r_ii == 0 exactly
-        for (size_t L = 0; L < B; ++L)
-        {
-          int nr = (int)d;
-          while (nr > 0 && rdg[L * d + nr - 1] == 0.0)
-            --nr;
-          rows[L] = nr;
-        }
-        rows_known = true;
-      }
-      for (size_t L = 0; L < B; ++L)
-      {
-        if (!active[L])
-          continue;
-        if (block_size < 2)
-        {
-          active[L] = 0;
-          continue;
-        }
-        if (use_loops && loop >= max_loops)
-        {
-          st[L]     = 8;
-          active[L] = 0;
-          continue;
-        }
-        // MatGSOInterface::get_current_slope(0, num_rows), gso_interface.cpp:198-218
-        const int n = rows[L];
-        double v1 = 0, v2 = (double)(n + 1) * n * (n - 1) / 12.0, weight = (1.0 - n) / 2.0;
-        for (int i = 0; i < n; ++i)
-        {
-          const double logf = std::log(rdg[L * d + i]);
-          const long expo   = (long)(2 * rex[L * d + i]);
-          v1 += weight * (logf + expo * std::log(2.0));
-          weight++;
-        }
-        const double new_slope = -(v1 / v2);
-        if (no_dec[L] == -1 || new_slope < 1.0 * old_slope[L])
-          no_dec[L] = 0;
-        else
-          no_dec[L]++;
-        old_slope[L] = std::min(old_slope[L], new_slope);
-        if (no_dec[L] >= 5)
-        {
-          active[L] = 0;  // abort: status stays RED_SUCCESS
-          continue;
-        }
-        ++n_active;
-      }
-      if (n_active == 0)
-        break;
-      BCHK(hipMemcpy(g->P.bkz_active, active.data(), sizeof(int) * B, hipMemcpyHostToDevice));
-      // exactly one tour (self-dual BKZ: the prelude lll() goes with the first one only)
-      rc = run_once(kbase | 0x4, 1, &ms, s1.data(), one.data(), sd && loop == 0 ? 3 : 2);
-      if (rc != FPHIP_OK)
-        break;
-      total_ms += ms;
-      for (size_t L = 0; L < B; ++L)
-      {
-        if (!active[L])
-          continue;
-        inf[4 * L + 0] += one[4 * L + 0];
-        const unsigned long long a0 = ((unsigned long long)(unsigned)inf[4 * L + 2] << 32) | (unsigned)inf[4 * L + 1];
-        const unsigned long long a1 = ((unsigned long long)(unsigned)one[4 * L + 2] << 32) | (unsigned)one[4 * L + 1];
-        const unsigned long long t  = a0 + a1;
-        inf[4 * L + 1] = (int)(unsigned)(t & 0xffffffffull);
-        inf[4 * L + 2] = (int)(unsigned)(t >> 32);
-        inf[4 * L + 3] += one[4 * L + 3];
-        if (s1[L] == 8)
-          continue;        // tour done, not clean: next loop
-        st[L]     = s1[L];  // 1: clean (or block_size >= num_rows); <= 0: failure
-        active[L] = 0;
-      }
-    }    if (sd && rc == FPHIP_OK)
+    // one tour per launch (self-dual BKZ: the prelude lll() goes with the first one only)
+    std::vector<int> rows(B, (int)g->P.d);
+    rc = auto_abort_loop(g, block_size, use_loops, max_loops, active, st, inf, rows, total_ms,
+                         [&](int loop, float *tms, int *s1, int *one)
+                         { return run_once(kbase | 0x4, 1, tms, s1, one, sd && loop == 0 ? 3 : 2); });
+    std::vector<int> one(4 * B), s1(B);
+    if (sd && rc == FPHIP_OK)
     {
       // closing pass of self-dual BKZ on every lattice that ended regularly: hkz of the last window
       // (bkz.cpp:627-641), its own launch

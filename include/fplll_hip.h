@@ -80,8 +80,11 @@ typedef struct fphip_enum_opts
 {
   int dual;        /* 1 → declined (the reference adapter does not transform mu/r for dual) */
   int findsubsols; /* 1 → sub-solutions are reported through subcb (must be non-NULL) */
-  /* subtree sharding across GPUs: this context handles final-phase tasks t with
-   * t % shard_count == shard_index; the (cheap) top-of-tree phases are replicated */
+  /* subtree sharding across GPUs: the (cheap) top-of-tree phases are replicated on every rank, so
+   * all ranks hold the same task SET; the tasks of the first walk round are sorted by content
+   * (partial distance of the root, then a key of the coefficient prefix) and dealt to the ranks in
+   * snake order 0..W-1, W-1..0 — disjoint, complete, nearly equal weight; this context walks the
+   * share of shard_index.  Donated subtrees stay on their GPU. */
   int shard_index;
   int shard_count;
   fphip_exchange_cb exchange;

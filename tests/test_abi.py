@@ -15,7 +15,7 @@ def declared_symbols():
     for h in glob.glob(os.path.join(C.ROOT, "include", "*.h")):
         src = open(h).read()
         src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-        for m in re.finditer(r"\b(fphip_[a-z0-9_]+)\s*\(", src):
+        for m in re.finditer(r"\b(fphip_[A-Za-z0-9_]+)\s*\(", src):
             name = m.group(1)
             # typedef'd callback types are not exported symbols
             if re.search(r"\(\s*\*\s*%s\s*\)" % name, src):
@@ -36,6 +36,17 @@ def test_library_exports_every_declared_symbol():
     assert not missing, missing
     assert len(declared_symbols()) >= 6
     assert lib.fphip_abi_version() >= 1
+
+
+def test_library_exports_nothing_undeclared():
+    """The C symbols the library exports are exactly those of include/fplll_hip.h (the boundary)
+    plus include/fplll_hip_debug.h (host halves of device protocols, for the CPU suite)."""
+    import subprocess
+    so = os.path.join(C.ROOT, "fplll_amd", "lib", "libfplll_hip.so")
+    out = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True, check=True).stdout
+    exported = sorted(l.split()[2] for l in out.splitlines()
+                      if len(l.split()) == 3 and l.split()[1] == "T" and l.split()[2].startswith("fphip_"))
+    assert exported == declared_symbols(), sorted(set(exported) ^ set(declared_symbols()))
 
 
 def test_shim_exports_plugin_entry():
