@@ -41,6 +41,7 @@ __global__ void bkzd_kernel(GsoBatch P, BkzStrat S, BkzMail *mailbox, int *abort
                             int stack_doubles, int run_mode);
 }
 template <int NQ> __global__ void hlll_kernel(HhBatch P, double delta, double theta, long long iter_cap);
+template <int NQ> __global__ void hh_blocked_kernel(HhBatch P, double *Tbuf);
 template <int NQ>
 __global__ void lll_kernel(GsoBatch P, int kmin, int kstart, int kend, double delta, double eta,
                            double logdelta);
@@ -1265,6 +1266,7 @@ struct fphip_hh
   HhBatch P;
   hipEvent_t ev[2];
   float last_ms;
+  double *Tbuf;  // blocked (MFMA) mode only: T of every block of 16 reflectors, [batch][ceil(d/16)][256]
 };
 
 #define HCHK(call)                     \
@@ -1347,6 +1349,8 @@ extern "C" void fphip_hh_destroy(fphip_hh *h)
     hipEventDestroy(h->ev[0]);
   if (h->ev[1])
     hipEventDestroy(h->ev[1]);
+  if (h->Tbuf)
+    hipFree(h->Tbuf);
   delete h;
 }
 
@@ -1395,6 +1399,43 @@ extern "C" int fphip_hh_update_R(fphip_hh *h, int *status)
   case 2: hipLaunchKernelGGL(hh_update_kernel<2>, dim3(grid), dim3(wpb * 64), lds, s, h->P); break;
   case 3: hipLaunchKernelGGL(hh_update_kernel<3>, dim3(grid), dim3(wpb * 64), lds, s, h->P); break;
   default: hipLaunchKernelGGL(hh_update_kernel<4>, dim3(grid), dim3(wpb * 64), lds, s, h->P); break;
+  }
+  HCHK(hipGetLastError());
+  HCHK(hipEventRecord(h->ev[1], s));
+  HCHK(hipStreamSynchronize(s));
+  HCHK(hipEventElapsedTime(&h->last_ms, h->ev[0], h->ev[1]));
+  if (status)
+    HCHK(hipMemcpy(status, h->P.status, sizeof(int) * h->P.batch, hipMemcpyDeviceToHost));
+  return FPHIP_OK;
+}
+
+// The same R-factor in blocked compact-WY form on the MFMA matrix cores (hh_blocked.hip): the
+// opt-in fast mode — sums in another order, hence other roundings than the reference's; R / mu / r
+// agree with the exact mode to ~1e-13 relative (checked to 1e-9), row exponents and signs identical.
+extern "C" int fphip_hh_update_R_blocked(fphip_hh *h, int *status)
+{
+  if (!h)
+    return FPHIP_ERROR;
+  const int nq   = (h->P.n + 63) / 64;
+  const int nblk = (h->P.d + 15) / 16;
+  if (!h->Tbuf)
+    HCHK(hipMalloc((void **)&h->Tbuf, (size_t)h->P.batch * nblk * 256 * sizeof(double)));
+  const int ldx    = ((h->P.n + 31) & ~31) + 1;
+  const size_t lds = (size_t)(16 * ldx + 256) * sizeof(double);
+  int bpc          = (int)((160 * 1024) / lds);
+  if (bpc > 16)
+    bpc = 16;
+  int grid = h->P.batch;
+  if (grid > fphip_ctx_num_cus(h->ctx) * bpc)
+    grid = fphip_ctx_num_cus(h->ctx) * bpc;
+  hipStream_t s = fphip_ctx_stream(h->ctx);
+  HCHK(hipEventRecord(h->ev[0], s));
+  switch (nq)
+  {
+  case 1: hipLaunchKernelGGL(hh_blocked_kernel<1>, dim3(grid), dim3(64), lds, s, h->P, h->Tbuf); break;
+  case 2: hipLaunchKernelGGL(hh_blocked_kernel<2>, dim3(grid), dim3(64), lds, s, h->P, h->Tbuf); break;
+  case 3: hipLaunchKernelGGL(hh_blocked_kernel<3>, dim3(grid), dim3(64), lds, s, h->P, h->Tbuf); break;
+  default: hipLaunchKernelGGL(hh_blocked_kernel<4>, dim3(grid), dim3(64), lds, s, h->P, h->Tbuf); break;
   }
   HCHK(hipGetLastError());
   HCHK(hipEventRecord(h->ev[1], s));

@@ -19,6 +19,8 @@ def _bind(lib):
     lib.fphip_hh_set_basis.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp]
     lib.fphip_hh_broadcast_basis.argtypes = [vp, ctypes.c_int]
     lib.fphip_hh_update_R.argtypes = [vp, vp]
+    lib.fphip_hh_update_R_blocked.argtypes = [vp, vp]
+    lib.fphip_hh_update_R_blocked.restype = ctypes.c_int
     lib.fphip_hh_get_basis.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp]
     lib.fphip_hh_hlll.argtypes = [vp, ctypes.c_double, ctypes.c_double, ctypes.c_double,
                                   ctypes.c_double, vp, vp]
@@ -57,10 +59,12 @@ class MatHouseholderBatch:
     def broadcast_basis(self, src=0):
         self._chk(self.lib.fphip_hh_broadcast_basis(self.h, src), "broadcast_basis")
 
-    def update_R(self):
-        """refresh_R_bf() + update_R() for every lattice."""
+    def update_R(self, blocked=False):
+        """refresh_R_bf() + update_R() for every lattice.  blocked=True: the opt-in MFMA compact-WY
+        mode (same R to rounding — 1e-9 on mu / r —, not bit for bit)."""
         st = np.zeros(self.batch, dtype=np.int32)
-        self._chk(self.lib.fphip_hh_update_R(self.h, st.ctypes.data_as(ctypes.c_void_p)), "update_R")
+        fn = self.lib.fphip_hh_update_R_blocked if blocked else self.lib.fphip_hh_update_R
+        self._chk(fn(self.h, st.ctypes.data_as(ctypes.c_void_p)), "update_R")
         return st
 
     def get_basis(self, first=0, count=1):

@@ -242,6 +242,13 @@ void fphip_hh_destroy(fphip_hh *h);
 int fphip_hh_set_basis(fphip_hh *h, int first_lattice, int count, const int64_t *b);
 int fphip_hh_broadcast_basis(fphip_hh *h, int src);
 int fphip_hh_update_R(fphip_hh *h, int *status);
+/* The same R-factor in BLOCKED compact-WY form on the MFMA matrix cores (v_mfma_f64_16x16x4_f64):
+ * panels of 16 rows, R_panel -= ((R_panel V^T) T) V per block of 16 earlier reflectors.  OPT-IN
+ * fast mode: the sums run in another order than the reference's (householder.cpp:157-178 is one
+ * row, one reflector, one sequential dot product at a time), so R agrees with fphip_hh_update_R to
+ * rounding (checked to 1e-9 relative on mu = R_ij/R_jj and r = R_ij R_jj), not bit for bit; row
+ * exponents and signs are identical. */
+int fphip_hh_update_R_blocked(fphip_hh *h, int *status);
 int fphip_hh_get_basis(fphip_hh *h, int first_lattice, int count, int64_t *b);
 /* HLLLReduction<Z_NR<long>,FP_NR<double>>(m, delta, eta, theta, c, LLL_DEFAULT).hlll()
  * (hlll.cpp:26-169; size_reduction :262-351, lovasz_test :171-224, verify_size_reduction :455-496)

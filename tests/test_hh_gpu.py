@@ -67,3 +67,58 @@ def test_householder_agrees_with_gso(ctx):
             assert abs(R[i, j] * R[j, j] - r[i, j]) <= 1e-9 * max(1.0, abs(r[i, j]))
     h.close()
     g.close()
+
+
+@pytest.mark.parametrize("src,d", [("q48", 48), ("c3", 100), ("c3", 180), ("q200", 200), ("c5", 256),
+                                   ("q64raw", 64)])
+def test_blocked_mfma_mode_agrees_with_exact_mode(ctx, src, d):
+    """fphip_hh_update_R_blocked (compact-WY panels on v_mfma_f64_16x16x4_f64, hh_blocked.hip): the
+    opt-in fast mode.  Row exponents and signs identical to the exact mode.  On REDUCED bases (what
+    the R-factor is computed on inside HLLL / BKZ) R — hence mu = R_ij/R_jj and r = R_ij R_jj
+    (tests/test_gso.cpp:82-152) — agrees within 1e-9 relative, the north-star tolerance for
+    double-precision mu / r (observed ~1e-13).  On a raw, ill-conditioned q-ary basis the two modes
+    are two equally valid roundings of the same factorisation: each row of R agrees to 1e-10 of the
+    row's norm (backward error), which is all either of them promises there."""
+    from fplll_amd.householder import MatHouseholderBatch
+    from fplll_amd.gso import _unreduced_copy, load_basis_txt
+    import test_gso_gpu as T
+    reduced = True
+    if src == "q48":
+        b = C.load_gso_fixture(os.path.join(C.GOLDEN, "gso_q48_p3.json"))["b_out"]
+    elif src == "c3":
+        b = T._load_c3_basis()[:d, :]
+    elif src == "q200":
+        b = load_basis_txt(os.path.join(C.GOLDEN, "basis_q200_seed7_lll.txt.gz"))
+    elif src == "c5":  # (beyond plain doubles for mu / r: babai fails on it in the reference too)
+        b, reduced = C.load_hlll_fixture(os.path.join(C.GOLDEN, "c5_hlll_n256_double.json.gz"))["b_out"], False
+    else:
+        b, reduced = C.load_gso_fixture(os.path.join(C.GOLDEN, "gso_q64_p5.json"))["b_in"], False
+    n = b.shape[1]
+    for row_expo in (True, False):
+        h = MatHouseholderBatch(ctx, 5, d, n, row_expo=row_expo)
+        h.set_basis(np.stack([b] * 5))
+        assert list(h.update_R()) == [1] * 5
+        Re, ee = h.get_R(3)
+        ms_exact = h.last_kernel_ms
+        assert list(h.update_R(blocked=True)) == [1] * 5
+        ms_blk = h.last_kernel_ms
+        worst = 0.0
+        for L in (0, 3, 4):
+            Rb, eb = h.get_R(L)
+            assert np.array_equal(eb, ee)
+            Re_t, Rb_t = np.tril(Re[:, :d]), np.tril(Rb[:, :d])
+            de, db = np.diag(Re_t), np.diag(Rb_t)
+            assert np.all(db > 0)
+            rown = np.sqrt((Re_t ** 2).sum(axis=1))
+            assert np.all(np.abs(Rb_t - Re_t) <= 1e-10 * rown[:, None])
+            if reduced:
+                assert np.all(np.abs(db - de) <= 1e-9 * np.abs(de))
+                mu_e, mu_b = Re_t / de[None, :], Rb_t / db[None, :]
+                assert np.all(np.abs(mu_b - mu_e) <= 1e-9 * np.maximum(1.0, np.abs(mu_e)))
+                r_e, r_b = Re_t * de[None, :], Rb_t * db[None, :]
+                scale = np.maximum(np.abs(r_e), np.outer(de, de))
+                assert np.all(np.abs(r_b - r_e) <= 1e-9 * scale)
+                worst = max(worst, float(np.max(np.abs(mu_b - mu_e))))
+        print("blocked vs exact R-factor %s %dx%d row_expo=%d: max |dmu| %.2e; kernel %.2f ms vs %.2f ms (batch 5)"
+              % (src, d, n, row_expo, worst, ms_blk, ms_exact))
+        h.close()
