@@ -92,7 +92,9 @@ class Context:
     """One context per GPU (one process per GPU; device = LOCAL_RANK)."""
 
     def __init__(self, device=0):
+        import weakref
         self.lib = load()
+        self._children = weakref.WeakSet()  # batch objects living on this context
         self.handle = ctypes.c_void_p()
         rc = self.lib.fphip_create(int(device), ctypes.byref(self.handle))
         if rc != FPHIP_OK:
@@ -105,8 +107,18 @@ class Context:
     def last_error(self):
         return self.lib.fphip_last_error(self.handle).decode()
 
+    def adopt(self, child):
+        """Batch objects register here: they hold device memory of this context and must be
+        released before it (a test that fails half-way leaves them to the garbage collector)."""
+        self._children.add(child)
+
     def close(self):
         if getattr(self, "handle", None):
+            for c in list(getattr(self, "_children", ())):
+                try:
+                    c.close()
+                except Exception:
+                    pass
             self.lib.fphip_destroy(self.handle)
             self.handle = None
 

@@ -18,6 +18,7 @@
 #include "../../include/fplll_hip_debug.h"
 #include "gso_device.h"
 #include "gso_sweep2.h"
+#include "ftx.h"
 
 #ifndef FPHIP_GSO_RING
 #define FPHIP_GSO_RING 6
@@ -42,6 +43,17 @@ __global__ void bkzd_kernel(GsoBatch P, BkzStrat S, BkzMail *mailbox, int *abort
 }
 template <int NQ> __global__ void hlll_kernel(HhBatch P, double delta, double theta, long long iter_cap);
 template <int NQ> __global__ void hh_blocked_kernel(HhBatch P, double *Tbuf);
+struct HlllX
+{
+  double *Rlo, *Vlo;
+  double *sc;
+  long long *prevE;
+  double delta, theta;
+  long long iter_cap;
+};
+template <int NQ, class FT> __global__ void hlll_x_kernel(HhBatch P, HlllX X);
+__global__ void dd_op_kernel(const double *ahi, const double *alo, const double *bhi, const double *blo,
+                             double *ohi, double *olo, int op, int count);
 template <int NQ>
 __global__ void lll_kernel(GsoBatch P, int kmin, int kstart, int kend, double delta, double eta,
                            double logdelta);
@@ -1267,6 +1279,9 @@ struct fphip_hh
   hipEvent_t ev[2];
   float last_ms;
   double *Tbuf;  // blocked (MFMA) mode only: T of every block of 16 reflectors, [batch][ceil(d/16)][256]
+  // extended-precision HLLL (hlll_x.hip): low planes of R and V, per-row scalars
+  double *Rlo, *Vlo, *xsc;
+  long long *xprevE;
 };
 
 #define HCHK(call)                     \
@@ -1351,6 +1366,14 @@ extern "C" void fphip_hh_destroy(fphip_hh *h)
     hipEventDestroy(h->ev[1]);
   if (h->Tbuf)
     hipFree(h->Tbuf);
+  if (h->Rlo)
+    hipFree(h->Rlo);
+  if (h->Vlo)
+    hipFree(h->Vlo);
+  if (h->xsc)
+    hipFree(h->xsc);
+  if (h->xprevE)
+    hipFree(h->xprevE);
   delete h;
 }
 
@@ -1503,6 +1526,118 @@ extern "C" int fphip_hh_hlll(fphip_hh *h, double delta, double eta, double theta
     HCHK(hipMemcpy(status, h->P.status, sizeof(int) * B, hipMemcpyDeviceToHost));
   if (info)
     HCHK(hipMemcpy(info, h->P.info, sizeof(int) * 2 * B, hipMemcpyDeviceToHost));
+  return FPHIP_OK;
+}
+
+// HLLL in a selectable floating-point type (hlll_x.hip): precision 106 = double-double, the device
+// stand-in for the reference's FP_NR<dd_real> (BASELINE config 5 as stated); precision 53 = plain
+// double with the same tree-sum kernel.  Same algorithm and status / info convention as
+// fphip_hh_hlll; the sums run as wave-level trees (the exact-order double kernel is fphip_hh_hlll).
+extern "C" int fphip_hh_hlll_ex(fphip_hh *h, double delta, double eta, double theta, double c, int precision,
+                                int *status, int *info)
+{
+  (void)eta;
+  (void)c;
+  if (!h || (precision != 53 && precision != 106))
+    return FPHIP_ERROR;
+  const size_t B = (size_t)h->P.batch, d = h->P.d, ld = h->P.ldn;
+  if (!h->P.bf)
+  {
+    HCHK(hipMalloc((void **)&h->P.bf, B * d * ld * 8 + 4096));
+    HCHK(hipMalloc((void **)&h->P.info, B * 2 * sizeof(int)));
+    HCHK(hipMemset(h->P.bf, 0, B * d * ld * 8 + 4096));
+  }
+  if (!h->xsc)
+  {
+    HCHK(hipMalloc((void **)&h->xsc, B * 10 * d * sizeof(double)));
+    HCHK(hipMalloc((void **)&h->xprevE, B * d * sizeof(long long)));
+  }
+  if (precision == 106 && !h->Rlo)
+  {
+    HCHK(hipMalloc((void **)&h->Rlo, B * d * ld * 8 + 4096));
+    HCHK(hipMalloc((void **)&h->Vlo, B * d * ld * 8 + 4096));
+  }
+  HCHK(hipMemset(h->xsc, 0, B * 10 * d * sizeof(double)));
+  HCHK(hipMemset(h->xprevE, 0, B * d * sizeof(long long)));
+  if (precision == 106)
+  {
+    HCHK(hipMemset(h->Rlo, 0, B * d * ld * 8 + 4096));
+    HCHK(hipMemset(h->Vlo, 0, B * d * ld * 8 + 4096));
+  }
+  HCHK(hipDeviceSynchronize());
+  HlllX X;
+  X.Rlo      = precision == 106 ? h->Rlo : nullptr;
+  X.Vlo      = precision == 106 ? h->Vlo : nullptr;
+  X.sc       = h->xsc;
+  X.prevE    = h->xprevE;
+  X.delta    = delta;
+  X.theta    = theta;
+  X.iter_cap = 1LL << 40;
+  const int nq = (h->P.n + 63) / 64;
+  int grid     = h->P.batch;
+  if (grid > fphip_ctx_num_cus(h->ctx) * 8)
+    grid = fphip_ctx_num_cus(h->ctx) * 8;
+  hipStream_t s = fphip_ctx_stream(h->ctx);
+  HCHK(hipEventRecord(h->ev[0], s));
+  if (precision == 106)
+    switch (nq)
+    {
+    case 1: hipLaunchKernelGGL((hlll_x_kernel<1, DD>), dim3(grid), dim3(64), 0, s, h->P, X); break;
+    case 2: hipLaunchKernelGGL((hlll_x_kernel<2, DD>), dim3(grid), dim3(64), 0, s, h->P, X); break;
+    case 3: hipLaunchKernelGGL((hlll_x_kernel<3, DD>), dim3(grid), dim3(64), 0, s, h->P, X); break;
+    default: hipLaunchKernelGGL((hlll_x_kernel<4, DD>), dim3(grid), dim3(64), 0, s, h->P, X); break;
+    }
+  else
+    switch (nq)
+    {
+    case 1: hipLaunchKernelGGL((hlll_x_kernel<1, double>), dim3(grid), dim3(64), 0, s, h->P, X); break;
+    case 2: hipLaunchKernelGGL((hlll_x_kernel<2, double>), dim3(grid), dim3(64), 0, s, h->P, X); break;
+    case 3: hipLaunchKernelGGL((hlll_x_kernel<3, double>), dim3(grid), dim3(64), 0, s, h->P, X); break;
+    default: hipLaunchKernelGGL((hlll_x_kernel<4, double>), dim3(grid), dim3(64), 0, s, h->P, X); break;
+    }
+  HCHK(hipGetLastError());
+  HCHK(hipEventRecord(h->ev[1], s));
+  HCHK(hipStreamSynchronize(s));
+  HCHK(hipEventElapsedTime(&h->last_ms, h->ev[0], h->ev[1]));
+  if (status)
+    HCHK(hipMemcpy(status, h->P.status, sizeof(int) * B, hipMemcpyDeviceToHost));
+  if (info)
+    HCHK(hipMemcpy(info, h->P.info, sizeof(int) * 2 * B, hipMemcpyDeviceToHost));
+  return FPHIP_OK;
+}
+
+// low plane of R after fphip_hh_hlll_ex(precision 106): R(i,j) = hi + lo (hi through fphip_hh_get_R)
+extern "C" int fphip_hh_get_R_lo(fphip_hh *h, int lattice, double *Rlo)
+{
+  if (!h || !Rlo || !h->Rlo || lattice < 0 || lattice >= h->P.batch)
+    return FPHIP_ERROR;
+  HCHK(hipMemcpy2D(Rlo, (size_t)h->P.n * 8, h->Rlo + (size_t)lattice * h->P.d * h->P.ldn,
+                   (size_t)h->P.ldn * 8, (size_t)h->P.n * 8, h->P.d, hipMemcpyDeviceToHost));
+  return FPHIP_OK;
+}
+
+// double-double arithmetic of the device (ftx.h), element-wise on host arrays — for its unit test
+// against multiprecision.  op: 0 add, 1 sub, 2 mul, 3 div, 4 sqrt(a), 5 nint(a)
+extern "C" int fphip_debug_dd_op(fphip_ctx *ctx, int op, int count, const double *ahi, const double *alo,
+                                 const double *bhi, const double *blo, double *ohi, double *olo)
+{
+  if (!ctx || count <= 0)
+    return FPHIP_ERROR;
+  double *dv = nullptr;
+  const size_t nb = (size_t)count * sizeof(double);
+  if (hipMalloc((void **)&dv, 6 * nb) != hipSuccess)
+    return FPHIP_ERROR;
+  hipMemcpy(dv, ahi, nb, hipMemcpyHostToDevice);
+  hipMemcpy(dv + count, alo, nb, hipMemcpyHostToDevice);
+  hipMemcpy(dv + 2 * (size_t)count, bhi, nb, hipMemcpyHostToDevice);
+  hipMemcpy(dv + 3 * (size_t)count, blo, nb, hipMemcpyHostToDevice);
+  hipLaunchKernelGGL(dd_op_kernel, dim3((count + 255) / 256), dim3(256), 0, fphip_ctx_stream(ctx), dv, dv + count,
+                     dv + 2 * (size_t)count, dv + 3 * (size_t)count, dv + 4 * (size_t)count,
+                     dv + 5 * (size_t)count, op, count);
+  hipStreamSynchronize(fphip_ctx_stream(ctx));
+  hipMemcpy(ohi, dv + 4 * (size_t)count, nb, hipMemcpyDeviceToHost);
+  hipMemcpy(olo, dv + 5 * (size_t)count, nb, hipMemcpyDeviceToHost);
+  hipFree(dv);
   return FPHIP_OK;
 }
 

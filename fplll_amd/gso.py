@@ -55,6 +55,7 @@ class MatGSOBatch:
 
     def __init__(self, ctx, batch, d, n, row_expo=True):
         self.ctx = ctx
+        ctx.adopt(self)
         self.lib = ctx.lib
         _bind(self.lib)
         self.batch, self.d, self.n = batch, d, n
@@ -215,7 +216,8 @@ class MatGSOBatch:
 
     def close(self):
         if getattr(self, "h", None):
-            self.lib.fphip_gso_destroy(self.h)
+            if getattr(self.ctx, "handle", None):  # (a closed context has released everything)
+                self.lib.fphip_gso_destroy(self.h)
             self.h = None
 
     def __del__(self):

@@ -21,6 +21,11 @@ def _bind(lib):
     lib.fphip_hh_update_R.argtypes = [vp, vp]
     lib.fphip_hh_update_R_blocked.argtypes = [vp, vp]
     lib.fphip_hh_update_R_blocked.restype = ctypes.c_int
+    lib.fphip_hh_hlll_ex.argtypes = [vp, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                     ctypes.c_int, vp, vp]
+    lib.fphip_hh_hlll_ex.restype = ctypes.c_int
+    lib.fphip_hh_get_R_lo.argtypes = [vp, ctypes.c_int, vp]
+    lib.fphip_hh_get_R_lo.restype = ctypes.c_int
     lib.fphip_hh_get_basis.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp]
     lib.fphip_hh_hlll.argtypes = [vp, ctypes.c_double, ctypes.c_double, ctypes.c_double,
                                   ctypes.c_double, vp, vp]
@@ -73,15 +78,28 @@ class MatHouseholderBatch:
                                               b.ctypes.data_as(ctypes.c_void_p)), "get_basis")
         return b
 
-    def hlll(self, delta=0.99, eta=0.51, theta=0.001, c=0.1):
+    def hlll(self, delta=0.99, eta=0.51, theta=0.001, c=0.1, precision=None):
         """HLLLReduction::hlll() on every lattice (fplll/hlll.cpp:26-169).
+        precision None: the exact-order double kernel (bit-identical decisions); 106: double-double
+        arithmetic (FP_NR<dd_real>'s stand-in), 53: double — both with tree sums (hlll_x.hip).
         Returns (status[batch], info[batch][2] = swaps, iterations)."""
         st = np.zeros(self.batch, dtype=np.int32)
         info = np.zeros((self.batch, 2), dtype=np.int32)
-        self._chk(self.lib.fphip_hh_hlll(self.h, delta, eta, theta, c,
-                                         st.ctypes.data_as(ctypes.c_void_p),
-                                         info.ctypes.data_as(ctypes.c_void_p)), "hlll")
+        if precision is None:
+            self._chk(self.lib.fphip_hh_hlll(self.h, delta, eta, theta, c,
+                                             st.ctypes.data_as(ctypes.c_void_p),
+                                             info.ctypes.data_as(ctypes.c_void_p)), "hlll")
+        else:
+            self._chk(self.lib.fphip_hh_hlll_ex(self.h, delta, eta, theta, c, int(precision),
+                                                st.ctypes.data_as(ctypes.c_void_p),
+                                                info.ctypes.data_as(ctypes.c_void_p)), "hlll_ex")
         return st, info
+
+    def get_R_lo(self, lattice=0):
+        """low plane of R after hlll(precision=106)"""
+        R = np.empty((self.d, self.n))
+        self._chk(self.lib.fphip_hh_get_R_lo(self.h, lattice, R.ctypes.data_as(ctypes.c_void_p)), "get_R_lo")
+        return R
 
     def get_R(self, lattice=0):
         R = np.empty((self.d, self.n))
@@ -97,7 +115,8 @@ class MatHouseholderBatch:
 
     def close(self):
         if getattr(self, "h", None):
-            self.lib.fphip_hh_destroy(self.h)
+            if getattr(self.ctx, "handle", None):  # (a closed context has released everything)
+                self.lib.fphip_hh_destroy(self.h)
             self.h = None
 
     def __del__(self):

@@ -262,6 +262,15 @@ int fphip_hh_hlll(fphip_hh *h, double delta, double eta, double theta, double c,
                   int *info);
 /* R as d×n row-major: MatHouseholder::get_R(expo) (householder.h:179); entries right of the
  * diagonal are scratch, exactly as in the reference */
+/* HLLL in a selectable floating-point type: precision 106 = double-double arithmetic on the device
+ * (the stand-in for FP_NR<dd_real>, fplll/nr/nr_FP_dd.inl: BASELINE config 5 as stated; libqd's
+ * algorithms restated, csrc/ftx.h), precision 53 = plain double.  Same algorithm (hlll.cpp:26-499),
+ * status and info as fphip_hh_hlll; dot products and norms are wave-level tree sums, so results
+ * are the reference's up to rounding — decisions carry ~50 bits of slack at 106 bits.  After a
+ * precision-106 run R(i,j) = fphip_hh_get_R + fphip_hh_get_R_lo. */
+int fphip_hh_hlll_ex(fphip_hh *h, double delta, double eta, double theta, double c, int precision,
+                     int *status, int *info);
+int fphip_hh_get_R_lo(fphip_hh *h, int lattice, double *Rlo);
 int fphip_hh_get_R(fphip_hh *h, int lattice, double *R);
 int fphip_hh_get_row_expo(fphip_hh *h, int lattice, int64_t *row_expo);
 double fphip_hh_last_kernel_ms(const fphip_hh *h);

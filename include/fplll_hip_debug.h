@@ -29,6 +29,11 @@ int fphip_debug_bkz_plan(fphip_rand_fn rnd, void *rnd_user, int lattice, int lo,
  * bytes, `stride` bytes apart, with the sweep kernels' load instruction; milliseconds in *ms_out. */
 int fphip_debug_stream(fphip_ctx *ctx, long long rows, int row_bytes, long long stride, double *ms_out);
 
+/* The device's double-double arithmetic (csrc/ftx.h) element-wise on host arrays, for its unit test
+ * against multiprecision.  op: 0 add, 1 sub, 2 mul, 3 div, 4 sqrt(a), 5 nint(a). */
+int fphip_debug_dd_op(fphip_ctx *ctx, int op, int count, const double *ahi, const double *alo,
+                      const double *bhi, const double *blo, double *ohi, double *olo);
+
 #ifdef __cplusplus
 }
 #endif

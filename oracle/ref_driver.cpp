@@ -1044,6 +1044,68 @@ static int cmd_hhfix(int argc, char **argv)
   return 0;
 }
 
+/* hhmp basisfile prec → JSON: the reference's Householder R-factor of the basis in `basisfile`
+ * computed with FP_NR<mpfr_t> at `prec` bits (MatHouseholder<Z_NR<mpz_t>, FP_NR<mpfr_t>>,
+ * householder.cpp:587-589; prec = 106 is PREC_DD, defs.h:140): R(i, j <= i) as decimal strings with
+ * 40 significant digits.  The golden values the double-double device path is checked against (libqd,
+ * hence FP_NR<dd_real>, is absent: SURVEY.md 8(c)). */
+static int cmd_hhmp(int argc, char **argv)
+{
+  if (argc < 4)
+    return 2;
+  ZZ_mat<mpz_t> A, U, UT;
+  if (!read_basis(argv[2], A))
+    return 2;
+  const int prec = atoi(argv[3]);
+  const int old  = FP_NR<mpfr_t>::set_prec(prec);
+  {
+    MatHouseholder<Z_NR<mpz_t>, FP_NR<mpfr_t>> H(A, U, UT, 0);
+    H.refresh_R_bf();
+    H.update_R();
+    const int d = A.get_rows();
+    std::ostringstream os;
+    os << "{\"prec\":" << prec << ",\"d\":" << d << ",\"n\":" << A.get_cols() << ",\"R\":[";
+    char buf[128];
+    for (int i = 0; i < d; ++i)
+      for (int j = 0; j <= i; ++j)
+      {
+        FP_NR<mpfr_t> f;
+        H.get_R(f, i, j);
+        mpfr_snprintf(buf, sizeof buf, "%.40Re", f.get_data());
+        os << ((i || j) ? "," : "") << "\"" << buf << "\"";
+      }
+    os << "]}\n";
+    std::cout << os.str();
+  }
+  FP_NR<mpfr_t>::set_prec(old);
+  return 0;
+}
+
+/* hlllmp basisfile prec → JSON: the reference's hlll_reduction of the basis in `basisfile` with
+ * FP_NR<mpfr_t> at `prec` bits (LM_PROVED, FT_MPFR — `fplll -a hlll -m proved -f mpfr -p prec`):
+ * status, seconds, the output basis.  prec = 106 is the stand-in for the dd_real run the reference
+ * cannot make here (no libqd). */
+static int cmd_hlllmp(int argc, char **argv)
+{
+  if (argc < 4)
+    return 2;
+  ZZ_mat<mpz_t> A;
+  if (!read_basis(argv[2], A))
+    return 2;
+  const int prec = atoi(argv[3]);
+  auto t0        = std::chrono::steady_clock::now();
+  int status = hlll_reduction(A, LLL_DEF_DELTA, LLL_DEF_ETA, HLLL_DEF_THETA, HLLL_DEF_C, LM_PROVED, FT_MPFR, prec,
+                              LLL_DEFAULT, false);
+  double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  printf("{\"prec\":%d,\"status\":%d,\"seconds\":%.3f,\"d\":%d,\"n\":%d,\"b_out\":[", prec, status, secs,
+         A.get_rows(), A.get_cols());
+  for (int i = 0; i < A.get_rows(); ++i)
+    for (int j = 0; j < A.get_cols(); ++j)
+      printf("%s%ld", (i || j) ? "," : "", A(i, j).get_si());
+  printf("]}\n");
+  return 0;
+}
+
 /* dumpbasis n k bits seed bkz_pre  → the reduced basis in fplll's text format on stdout */
 static int cmd_dumpbasis(int argc, char **argv)
 {
@@ -1083,6 +1145,10 @@ int main(int argc, char **argv)
     return cmd_genstrat(argc, argv);
   if (cmd == "teststrat")
     return cmd_teststrat(argc, argv);
+  if (cmd == "hlllmp")
+    return cmd_hlllmp(argc, argv);
+  if (cmd == "hhmp")
+    return cmd_hhmp(argc, argv);
   if (cmd == "enumtime")
     return cmd_enumtime(argc, argv);
   if (cmd == "sweeptime")

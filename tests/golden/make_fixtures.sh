@@ -115,3 +115,7 @@ $R/latticegen -randseed 7 q 200 100 8 p > /tmp/q200.txt && $R/fplll -a lll -m fa
 for k in 0 1 2; do
   $D enumfix 0 $G/basis_q180_seed0_lll_bkz20.txt 0 0 0 $k 60 linear:30 1 0 0.99 > $G/c3_b60_k${k}_linear30.json
 done
+# R-factors at 106 bits of MPFR (the precision of dd_real, defs.h:140) of the HLLL-reduced bases of
+# hlll_{q40,n64,q72}.json: golden values for the double-double device path (ref_driver hhmp; the
+# python wrapper that adds the basis to the JSON is in the commit that introduced these files)
+#   $D hhmp <basis.txt> 106  ->  tests/golden/hhmp106_{q40,n64,q72}.json.gz

@@ -1,0 +1,155 @@
+"""Double-double on the device (BASELINE config 5 as stated: "HLLL (Householder, dd_real)").
+
+The reference's FP_NR<dd_real> sits on libqd, an un-vendored optional dependency that is absent here
+(SURVEY.md 8(c)): bit-for-bit parity with it is UNPINNED.  What pins the device path instead:
+  1. the arithmetic of csrc/ftx.h against multiprecision (mpmath) at double-double accuracy;
+  2. the Householder R-factor computed in double-double against the REAL reference run with
+     FP_NR<mpfr_t> at 106 bits (tests/golden/hhmp106_*.json.gz, oracle/ref_driver.cpp `hhmp`);
+  3. HLLL in double-double: status, a reduced basis of the same lattice, and — where the reference's
+     own double / long double / 106-bit runs all agree — the reference's basis
+     (config 5's 256-dim lattice: tests/test_a_configs_at_size_gpu.py)."""
+import ctypes
+import gzip
+import json
+import os
+
+import numpy as np
+import pytest
+
+import conftest as C
+
+pytestmark = pytest.mark.gpu
+mp = pytest.importorskip("mpmath")
+
+
+def _dd_op(ctx, op, a, b):
+    import fplll_amd
+    lib = fplll_amd.load()
+    lib.fphip_debug_dd_op.restype = ctypes.c_int
+    n = a.shape[0]
+    arrs = [np.ascontiguousarray(x, dtype=np.float64) for x in (a[:, 0], a[:, 1], b[:, 0], b[:, 1])]
+    ohi, olo = np.empty(n), np.empty(n)
+    vp = ctypes.c_void_p
+    rc = lib.fphip_debug_dd_op(ctx.handle, op, n, *[vp(x.ctypes.data) for x in arrs],
+                               vp(ohi.ctypes.data), vp(olo.ctypes.data))
+    assert rc == 0
+    return ohi, olo
+
+
+def _rand_dd(rng, n, lo_exp=-30, hi_exp=30):
+    hi = rng.standard_normal(n) * np.exp2(rng.integers(lo_exp, hi_exp, n).astype(np.float64))
+    lo = hi * np.exp2(-53.0) * rng.uniform(-0.5, 0.5, n)
+    s = hi + lo  # renormalise: |lo| <= ulp(hi)/2
+    return np.stack([s, lo - (s - hi)], axis=1)
+
+
+def test_double_double_arithmetic_against_mpmath(ctx):
+    mp.mp.prec = 400
+    rng = np.random.default_rng(5)
+    n = 2000
+    a, b = _rand_dd(rng, n), _rand_dd(rng, n)
+    b[:, 0] = np.where(b[:, 0] == 0, 1.0, b[:, 0])
+    val = lambda x: mp.mpf(float(x[0])) + mp.mpf(float(x[1]))  # noqa: E731
+    eps = mp.mpf(2) ** -104
+    for op, name, fn, tol in ((0, "add", lambda x, y: x + y, 1), (1, "sub", lambda x, y: x - y, 1),
+                              (2, "mul", lambda x, y: x * y, 4), (3, "div", lambda x, y: x / y, 8),
+                              (4, "sqrt", lambda x, y: mp.sqrt(abs(x)), 4)):
+        aa = np.abs(a) if op == 4 else a
+        if op == 4:
+            aa = np.stack([np.abs(a[:, 0]), np.where(a[:, 0] < 0, -a[:, 1], a[:, 1])], axis=1)
+        ohi, olo = _dd_op(ctx, op, aa, b)
+        worst = mp.mpf(0)
+        for i in range(n):
+            x, y = val(aa[i]), val(b[i])
+            want = fn(x, y)
+            got = mp.mpf(float(ohi[i])) + mp.mpf(float(olo[i]))
+            # add / sub ("sloppy" libqd addition): the error is relative to the larger operand
+            scale = max(abs(x), abs(y)) if op < 2 else abs(want)
+            err = abs(got - want) / scale if scale != 0 else abs(got - want)
+            worst = max(worst, err)
+        assert worst <= tol * eps, (name, mp.nstr(worst, 5))
+        print("dd %s: worst error %s (in units of 2^-104)" % (name, mp.nstr(worst / eps, 4)))
+    # nint: exact
+    q = _rand_dd(rng, n, 0, 60)
+    q[::7, 0] = np.round(q[::7, 0])  # integral high words: the low word decides
+    q[1::7, 0] = np.floor(q[1::7, 0]) + 0.5  # ties of the high word: the low word breaks them
+    q[:, 1] = np.where(np.abs(q[:, 0]) < 2 ** 52, q[:, 1], np.round(q[:, 1]) + 0.25)
+    s = q[:, 0] + q[:, 1]
+    q = np.stack([s, q[:, 1] - (s - q[:, 0])], axis=1)
+    ohi, olo = _dd_op(ctx, 5, q, q)
+    for i in range(n):
+        x = val(q[i])
+        got = mp.mpf(float(ohi[i])) + mp.mpf(float(olo[i]))
+        assert got == mp.floor(got) and abs(got - x) <= mp.mpf(1) / 2, (q[i], ohi[i], olo[i])
+
+
+@pytest.mark.parametrize("name", ["q40", "q72"])
+def test_r_factor_in_double_double_against_mpfr106(ctx, name):
+    """HLLL in double-double on an already HLLL-reduced basis leaves it alone and ends with the
+    R-factor of that basis in R: compared entry by entry with the reference's MatHouseholder run in
+    MPFR at 106 bits.  (The plain-double kernel on the same input agrees to ~1e-13 only.)"""
+    from fplll_amd.householder import MatHouseholderBatch
+    mp.mp.prec = 300
+    with gzip.open(os.path.join(C.GOLDEN, "hhmp106_%s.json.gz" % name), "rt") as f:
+        j = json.load(f)
+    d, n = j["d"], j["n"]
+    b = np.array(j["b"], dtype=np.int64).reshape(d, n)
+    want = iter(j["R"])
+    h = MatHouseholderBatch(ctx, 2, d, n, row_expo=True)
+    worst = {}
+    for prec in (106, 53):
+        h.set_basis(np.stack([b] * 2))
+        st, info = h.hlll(precision=prec)
+        assert list(st) == [1, 1] and int(info[0][0]) == 0  # no swap: the basis was reduced already
+        assert np.array_equal(h.get_basis(0, 1)[0], b)
+        R, e = h.get_R(1)
+        Rlo = h.get_R_lo(1) if prec == 106 else np.zeros_like(R)
+        w = mp.mpf(0)
+        want = iter(j["R"])
+        for i in range(d):
+            rown = mp.mpf(0)
+            row = []
+            for jj in range(i + 1):
+                ref = mp.mpf(next(want))
+                got = (mp.mpf(float(R[i, jj])) + mp.mpf(float(Rlo[i, jj]))) * mp.mpf(2) ** int(e[i])
+                row.append((ref, got))
+                rown += ref * ref
+            rown = mp.sqrt(rown)
+            for ref, got in row:
+                w = max(w, abs(got - ref) / rown)
+        worst[prec] = w
+    print("R-factor %s (%dx%d) vs MPFR-106: double-double %s, double %s (relative to the row norm)"
+          % (name, d, n, mp.nstr(worst[106], 4), mp.nstr(worst[53], 4)))
+    assert worst[106] <= mp.mpf(2) ** -92   # ~1e-28: double-double accuracy with d*n roundings of slack
+    assert worst[53] <= mp.mpf(2) ** -40
+    assert worst[106] * 2 ** 30 < worst[53] or worst[53] == 0
+    h.close()
+
+
+@pytest.mark.parametrize("path", C.hlll_fixtures(), ids=lambda p: os.path.basename(p)[:-5])
+def test_hlll_in_double_double_on_reference_fixtures(ctx, path):
+    """hlll(precision=106) on the inputs of the reference fixtures: success, and the reference's
+    output basis.  For the q-ary / knapsack / uniform lattices that is its double result (far from
+    the precision cliff: every decision of the algorithm has tens of bits of margin, and the
+    reference returns the same basis at 106 bits).  The NTRU-like hlll_n64 sits ON the cliff — the
+    reference's double and 106-bit runs return different bases — so there the golden is the
+    reference's 106-bit MPFR run (tests/golden/hlllmp106_n64.json, ref_driver hlllmp)."""
+    from fplll_amd.householder import MatHouseholderBatch
+    f = C.load_hlll_fixture(path)
+    if "n64" in path:
+        with open(os.path.join(C.GOLDEN, "hlllmp106_n64.json")) as g:
+            j = json.load(g)
+        f["b_out_106"] = np.array(j["b_out"], dtype=np.int64).reshape(j["d"], j["n"])
+    h = MatHouseholderBatch(ctx, 2, f["d"], f["n"], row_expo=True)
+    for prec in (106, 53):
+        h.set_basis(np.stack([f["b_in"]] * 2))
+        st, info = h.hlll(f["delta"], f["eta"], f["theta"], f["c"], precision=prec)
+        assert list(st) == [1, 1]
+        out = h.get_basis(0, 2)
+        assert np.array_equal(out[0], out[1])
+        same = np.array_equal(out[0], f.get("b_out_106", f["b_out"]) if prec == 106 else f["b_out"])
+        print("%s precision %d: %d swaps, %.1f ms, output %s the reference's" %
+              (os.path.basename(path), prec, int(info[0][0]), h.last_kernel_ms, "==" if same else "!="))
+        if prec == 106:
+            assert same
+    h.close()
