@@ -39,6 +39,7 @@ def _bind(lib):
 class MatHouseholderBatch:
     def __init__(self, ctx, batch, d, n, row_expo=False):
         self.ctx, self.lib = ctx, ctx.lib
+        ctx.adopt(self)
         _bind(self.lib)
         self.batch, self.d, self.n = batch, d, n
         self.h = ctypes.c_void_p()

@@ -266,3 +266,23 @@ def test_config3_linear_block_matches_reference(ctx, k):
           (k, res.total_nodes, f["total_nodes"], res.stats.kernel_ms))
 
 
+@pytest.mark.parametrize("precision", [106, 53])
+def test_config5_hlll_in_double_double_matches_reference(ctx, precision):
+    """BASELINE config 5 as stated — HLLL (Householder, dd_real) on the 256-dim NTRU-like lattice:
+    hlll(precision=106) runs the reference's algorithm in double-double arithmetic on the device
+    (csrc/hlll_x.hip, ftx.h) and returns the reference's basis with the reference's 146 491 swaps —
+    the basis `fplll -a hlll` returns in double, long double and 106-bit MPFR alike (md5 bed6b5d6…,
+    SURVEY.md 8(d) C5; 869 s for the 106-bit MPFR run on one core).  precision=53 is the same
+    tree-sum kernel in plain double."""
+    from fplll_amd.householder import MatHouseholderBatch
+    f = _c5()
+    h = MatHouseholderBatch(ctx, 2, 256, 256, row_expo=True)
+    h.set_basis(np.stack([f["b_in"]] * 2))
+    t = time.time()
+    st, info = h.hlll(f["delta"], f["eta"], f["theta"], f["c"], precision=precision)
+    wall = time.time() - t
+    out = h.get_basis(0, 2)
+    print("config 5 at precision %d: %d swaps, %.1f s on the device" % (precision, int(info[0][0]), wall))
+    assert list(st) == [1, 1] and [int(i[0]) for i in info] == [146491, 146491]
+    assert np.array_equal(out[0], f["b_out"]) and np.array_equal(out[1], f["b_out"])
+    h.close()
