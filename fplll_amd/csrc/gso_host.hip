@@ -50,6 +50,7 @@ struct HlllX
   long long *prevE;
   double delta, theta;
   long long iter_cap;
+  const int *only_failed;
 };
 template <int NQ, class FT> __global__ void hlll_x_kernel(HhBatch P, HlllX X);
 __global__ void dd_op_kernel(const double *ahi, const double *alo, const double *bhi, const double *blo,
@@ -1533,11 +1534,9 @@ extern "C" int fphip_hh_hlll(fphip_hh *h, double delta, double eta, double theta
 // stand-in for the reference's FP_NR<dd_real> (BASELINE config 5 as stated); precision 53 = plain
 // double with the same tree-sum kernel.  Same algorithm and status / info convention as
 // fphip_hh_hlll; the sums run as wave-level trees (the exact-order double kernel is fphip_hh_hlll).
-extern "C" int fphip_hh_hlll_ex(fphip_hh *h, double delta, double eta, double theta, double c, int precision,
-                                int *status, int *info)
+static int hh_hlll_ex(fphip_hh *h, double delta, double theta, int precision, const int *d_only_failed,
+                      int *status, int *info)
 {
-  (void)eta;
-  (void)c;
   if (!h || (precision != 53 && precision != 106))
     return FPHIP_ERROR;
   const size_t B = (size_t)h->P.batch, d = h->P.d, ld = h->P.ldn;
@@ -1573,6 +1572,7 @@ extern "C" int fphip_hh_hlll_ex(fphip_hh *h, double delta, double eta, double th
   X.delta    = delta;
   X.theta    = theta;
   X.iter_cap = 1LL << 40;
+  X.only_failed = d_only_failed;
   const int nq = (h->P.n + 63) / 64;
   int grid     = h->P.batch;
   if (grid > fphip_ctx_num_cus(h->ctx) * 8)
@@ -1603,6 +1603,76 @@ extern "C" int fphip_hh_hlll_ex(fphip_hh *h, double delta, double eta, double th
     HCHK(hipMemcpy(status, h->P.status, sizeof(int) * B, hipMemcpyDeviceToHost));
   if (info)
     HCHK(hipMemcpy(info, h->P.info, sizeof(int) * 2 * B, hipMemcpyDeviceToHost));
+  return FPHIP_OK;
+}
+
+extern "C" int fphip_hh_hlll_ex(fphip_hh *h, double delta, double eta, double theta, double c, int precision,
+                                int *status, int *info)
+{
+  (void)eta;
+  (void)c;
+  return hh_hlll_ex(h, delta, theta, precision, nullptr, status, info);
+}
+
+// The precision ladder of the reference's wrapper (hlll_reduction with LM_WRAPPER, wrapper.cpp:
+// 478-529: double, then the wider types, each stage continuing from the basis the previous one
+// left) on the device: stage 1 = the exact-order double kernel for the whole batch; the lattices it
+// gives up on with a precision alarm (RED_HLLL_SR_FAILURE -4, RED_HLLL_NORM_FAILURE -5) go on in
+// double-double.  stage[batch] (nullable) = 53 or 106: where each lattice ended.  A lattice that
+// fails at 106 bits keeps its status: the caller's MPFR stage (fplll's CPU path) is next.
+extern "C" int fphip_hh_hlll_ladder(fphip_hh *h, double delta, double eta, double theta, double c, int *status,
+                                    int *info, int *stage)
+{
+  if (!h)
+    return FPHIP_ERROR;
+  const size_t B = (size_t)h->P.batch;
+  std::vector<int> st(B, 0), inf(2 * B, 0);
+  int rc = fphip_hh_hlll(h, delta, eta, theta, c, st.data(), inf.data());
+  if (rc != FPHIP_OK)
+    return rc;
+  float ms = h->last_ms;
+  std::vector<int> stg(B, 53);
+  bool any = false;
+  // FPHIP_HLLL_LADDER_TEST=1 (tests only): treat the odd lattices as if stage 1 had raised an alarm, so
+  // that the escalation path runs on inputs where plain doubles never fail (row exponents make the
+  // double stage very robust: no long-sized lattice tried here trips it)
+  const bool force = getenv("FPHIP_HLLL_LADDER_TEST") && atoi(getenv("FPHIP_HLLL_LADDER_TEST")) == 1;
+  if (force)
+    for (size_t L = 1; L < B; L += 2)
+      if (st[L] == 1)
+        st[L] = -4;
+  for (size_t L = 0; L < B; ++L)
+    any |= (st[L] == -4 || st[L] == -5);
+  if (any)
+  {
+    // status still sits on the device (P.status): 1 = done, anything else goes on in double-double
+    std::vector<int> st2(B, 0), inf2(2 * B, 0), mask(B);
+    for (size_t L = 0; L < B; ++L)
+      mask[L] = (st[L] == -4 || st[L] == -5) ? 0 : 1;
+    int *d_mask = nullptr;
+    HCHK(hipMalloc((void **)&d_mask, B * sizeof(int)));
+    hipError_t e = hipMemcpy(d_mask, mask.data(), B * sizeof(int), hipMemcpyHostToDevice);
+    rc           = (e == hipSuccess) ? hh_hlll_ex(h, delta, theta, 106, d_mask, st2.data(), inf2.data()) : FPHIP_ERROR;
+    hipFree(d_mask);
+    if (rc != FPHIP_OK)
+      return rc;
+    ms += h->last_ms;
+    for (size_t L = 0; L < B; ++L)
+      if (!mask[L])
+      {
+        st[L]  = st2[L];
+        stg[L] = 106;
+        inf[2 * L] += inf2[2 * L];
+        inf[2 * L + 1] += inf2[2 * L + 1];
+      }
+  }
+  h->last_ms = ms;
+  if (status)
+    memcpy(status, st.data(), B * sizeof(int));
+  if (info)
+    memcpy(info, inf.data(), 2 * B * sizeof(int));
+  if (stage)
+    memcpy(stage, stg.data(), B * sizeof(int));
   return FPHIP_OK;
 }
 

@@ -52,6 +52,7 @@ struct HlllX
   long long *prevE;
   double delta, theta;
   long long iter_cap;
+  const int *only_failed;  // precision ladder: non-null = reduce only lattices whose entry is not 1
 };
 
 // status: 1 RED_SUCCESS, -2 multiplier beyond 63 bits, -4 RED_HLLL_SR_FAILURE,
@@ -63,6 +64,8 @@ template <int NQ, class FT> __global__ void __launch_bounds__(64) hlll_x_kernel(
   const FT zero = f_from(FT{}, 0.0);
   for (int L = blockIdx.x; L < P.batch; L += gridDim.x)
   {
+    if (X.only_failed && X.only_failed[L] == 1)
+      continue;  // an earlier, cheaper stage of the ladder has reduced this lattice
     long long *b    = P.b + (size_t)L * d * ld;
     double *bf      = P.bf + (size_t)L * d * ld;
     double *sigma   = P.sigma + (size_t)L * d;

@@ -24,6 +24,9 @@ def _bind(lib):
     lib.fphip_hh_hlll_ex.argtypes = [vp, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double,
                                      ctypes.c_int, vp, vp]
     lib.fphip_hh_hlll_ex.restype = ctypes.c_int
+    lib.fphip_hh_hlll_ladder.argtypes = [vp, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                         vp, vp, vp]
+    lib.fphip_hh_hlll_ladder.restype = ctypes.c_int
     lib.fphip_hh_get_R_lo.argtypes = [vp, ctypes.c_int, vp]
     lib.fphip_hh_get_R_lo.restype = ctypes.c_int
     lib.fphip_hh_get_basis.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp]
@@ -95,6 +98,17 @@ class MatHouseholderBatch:
                                                 st.ctypes.data_as(ctypes.c_void_p),
                                                 info.ctypes.data_as(ctypes.c_void_p)), "hlll_ex")
         return st, info
+
+    def hlll_ladder(self, delta=0.99, eta=0.51, theta=0.001, c=0.1):
+        """The wrapper's precision ladder on the device: double for the batch, double-double for the
+        lattices that raise a precision alarm.  Returns (status, info, stage[batch] in {53, 106})."""
+        st = np.zeros(self.batch, dtype=np.int32)
+        info = np.zeros((self.batch, 2), dtype=np.int32)
+        stage = np.zeros(self.batch, dtype=np.int32)
+        self._chk(self.lib.fphip_hh_hlll_ladder(self.h, delta, eta, theta, c, st.ctypes.data_as(ctypes.c_void_p),
+                                                info.ctypes.data_as(ctypes.c_void_p),
+                                                stage.ctypes.data_as(ctypes.c_void_p)), "hlll_ladder")
+        return st, info, stage
 
     def get_R_lo(self, lattice=0):
         """low plane of R after hlll(precision=106)"""

@@ -271,6 +271,14 @@ int fphip_hh_hlll(fphip_hh *h, double delta, double eta, double theta, double c,
 int fphip_hh_hlll_ex(fphip_hh *h, double delta, double eta, double theta, double c, int precision,
                      int *status, int *info);
 int fphip_hh_get_R_lo(fphip_hh *h, int lattice, double *Rlo);
+/* The precision ladder of the reference's wrapper (hlll_reduction, LM_WRAPPER: wrapper.cpp:478-529 —
+ * double first, then the wider types, each stage continuing from the basis the previous one left)
+ * with both stages on the device: the exact-order double kernel for the whole batch, then
+ * double-double for the lattices that stopped with a precision alarm (status -4 / -5).
+ * stage[batch] (nullable): 53 or 106.  A lattice that fails at 106 bits too keeps its status — the
+ * caller's MPFR stage is next. */
+int fphip_hh_hlll_ladder(fphip_hh *h, double delta, double eta, double theta, double c, int *status,
+                         int *info, int *stage);
 int fphip_hh_get_R(fphip_hh *h, int lattice, double *R);
 int fphip_hh_get_row_expo(fphip_hh *h, int lattice, int64_t *row_expo);
 double fphip_hh_last_kernel_ms(const fphip_hh *h);

@@ -153,3 +153,24 @@ def test_hlll_in_double_double_on_reference_fixtures(ctx, path):
         if prec == 106:
             assert same
     h.close()
+
+
+def test_precision_ladder_double_then_double_double(ctx, monkeypatch):
+    """fphip_hh_hlll_ladder — the wrapper's ladder (wrapper.cpp:478-529) with both stages on the
+    device.  On these inputs the double stage succeeds (stage 53 everywhere, results of hlll());
+    with FPHIP_HLLL_LADDER_TEST=1 the odd lattices are sent on to the double-double stage as if the
+    double stage had raised a precision alarm: they continue from the basis stage 1 left, end with
+    status 1 at stage 106 and the same basis."""
+    from fplll_amd.householder import MatHouseholderBatch
+    f = C.load_hlll_fixture(os.path.join(C.GOLDEN, "hlll_q40.json"))
+    h = MatHouseholderBatch(ctx, 4, f["d"], f["n"], row_expo=True)
+    h.set_basis(np.stack([f["b_in"]] * 4))
+    st, info, stage = h.hlll_ladder(f["delta"], f["eta"], f["theta"], f["c"])
+    assert list(st) == [1] * 4 and list(stage) == [53] * 4
+    assert all(np.array_equal(b, f["b_out"]) for b in h.get_basis(0, 4))
+    monkeypatch.setenv("FPHIP_HLLL_LADDER_TEST", "1")
+    h.set_basis(np.stack([f["b_in"]] * 4))
+    st, info, stage = h.hlll_ladder(f["delta"], f["eta"], f["theta"], f["c"])
+    assert list(st) == [1] * 4 and list(stage) == [53, 106, 53, 106]
+    assert all(np.array_equal(b, f["b_out"]) for b in h.get_basis(0, 4))
+    h.close()
