@@ -231,6 +231,32 @@ static inline double bdbl(unsigned long long b)
   return v;
 }
 
+// lower the pinned bound word to min(current, nb): bit patterns of non-negative doubles order like
+// integers.  Safe against the serving thread and against other host threads (fphip_enum_lower_bound).
+static void publish_bound_min(fphip_ctx *ctx, double nb)
+{
+  if (!(nb >= 0.0))
+    nb = 0.0;
+  const unsigned long long want = dbits(nb);
+  unsigned long long cur        = __atomic_load_n(&ctx->h->bound_bits, __ATOMIC_ACQUIRE);
+  while (want < cur &&
+         !__atomic_compare_exchange_n(&ctx->h->bound_bits, &cur, want, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE))
+  {
+  }
+}
+
+// Lower the enumeration bound of a context from ANY host thread while fphip_enum_run is in flight on
+// it: the waves poll the device mirror of this word (every 64 steps) and the word itself (rarely), so
+// a bound found on another GPU takes effect within microseconds instead of at the next chunk
+// boundary.  Never raises the bound; a no-op when no enumeration is running.
+extern "C" int fphip_enum_lower_bound(fphip_ctx *ctx, double bound)
+{
+  if (!ctx || !ctx->h)
+    return FPHIP_ERROR;
+  publish_bound_min(ctx, bound);
+  return FPHIP_OK;
+}
+
 static void drain(fphip_ctx *ctx, int dim, fphip_sol_cb cb, fphip_subsol_cb subcb, void *user,
                   uint64_t *nsol)
 {
@@ -252,9 +278,9 @@ static void drain(fphip_ctx *ctx, int dim, fphip_sol_cb cb, fphip_subsol_cb subc
       continue;
     }
     double nb = cb(user, dist, x);  // extenum_cb_process_sol: returns the new bound
-    if (!(nb >= 0.0))
-      nb = 0.0;
-    __atomic_store_n(&ctx->h->bound_bits, dbits(nb), __ATOMIC_RELEASE);
+    // (the reference's evaluators only ever shrink the bound; min() also keeps a smaller bound that
+    // another host thread published meanwhile — fphip_enum_lower_bound)
+    publish_bound_min(ctx, nb);
     ctx->ring_next++;
     __atomic_store_n(&ctx->h->consumed, ctx->ring_next, __ATOMIC_RELEASE);
     (void)dim;

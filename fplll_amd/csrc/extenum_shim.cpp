@@ -8,6 +8,16 @@
 // header: the signature below is spelled with the std types the reference's typedef
 // `extenum_fc_enumerate` uses (enumerate_ext_api.h:25-26, 88-92).
 //
+// In-process multi-GPU (FPLLL_HIP_DEVICES=0,1,2,… or "all"): one context per listed device, one host
+// thread per context for the duration of an enumeration call; the subtree tasks are dealt to the
+// contexts exactly as bench.py's ranks deal them (content-sorted snake, enum_host.hip), the
+// collective exchange points are a host barrier + MIN, and BETWEEN them every bound fplll's
+// evaluator returns is published to all other contexts at once (fphip_enum_lower_bound) — so a
+// bkz_reduction running in ONE fplll process scales over the GPUs of the node without RCCL.
+// Callbacks into fplll are serialised by a mutex (the evaluator is a std::multimap; enumlib does the
+// same, fplll/enum-parallel/enumeration.h:286).  A device may be listed twice (two contexts on one
+// GPU): that is how the path is tested on a one-GPU box.
+//
 // Protocol implemented (enumerate_ext.cpp:48-167): call cbfunc once with mutranspose=true to
 // receive mu^T / rdiag / pruning; report candidates through cbsol, which returns the new bound;
 // return per-level node counts, or [0] = ~0 to decline so fplll falls back to its own enumerator
@@ -18,8 +28,12 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <condition_variable>
+#include <cstring>
 #include <functional>
 #include <mutex>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/fplll_hip.h"
@@ -88,6 +102,163 @@ double sol_trampoline(void *user, double dist, const double *sol)
   }
 }
 
+// ---- in-process multi-GPU ------------------------------------------------------------------
+std::vector<fphip_ctx *> g_multi;  // contexts of FPLLL_HIP_DEVICES (empty: single-device mode)
+bool g_multi_tried = false;
+
+const std::vector<fphip_ctx *> &multi_contexts()
+{
+  if (g_multi_tried)
+    return g_multi;
+  g_multi_tried   = true;
+  const char *lst = getenv("FPLLL_HIP_DEVICES");
+  if (!lst || !*lst)
+    return g_multi;
+  std::vector<int> devs;
+  if (std::string(lst) == "all")
+    for (int i = 0; i < fphip_device_count(); ++i)
+      devs.push_back(i);
+  else
+    for (const char *p = lst; *p;)
+    {
+      devs.push_back(atoi(p));
+      while (*p && *p != ',')
+        ++p;
+      if (*p == ',')
+        ++p;
+    }
+  if (devs.size() < 2)
+    return g_multi;
+  for (int dv : devs)
+  {
+    fphip_ctx *c = nullptr;
+    if (fphip_create(dv, &c) != FPHIP_OK)
+    {
+      fprintf(stderr, "[fplll_hip] FPLLL_HIP_DEVICES: no context on device %d (%s); single-device mode\n", dv,
+              c ? fphip_last_error(c) : "?");
+      if (c)
+        fphip_destroy(c);
+      for (fphip_ctx *o : g_multi)
+        fphip_destroy(o);
+      g_multi.clear();
+      return g_multi;
+    }
+    g_multi.push_back(c);
+  }
+  return g_multi;
+}
+
+// The collective of the multi-GPU protocol among host threads: every participant deposits (bound,
+// active) and leaves with (min bound, any active).  A participant that has LEFT the protocol (its
+// fphip_enum_run returned, normally or not) no longer counts, so a failing shard cannot strand the
+// others at the barrier.
+struct HostExchange
+{
+  std::mutex m;
+  std::condition_variable cv;
+  int expected = 0, arrived = 0;
+  unsigned long long generation = 0;
+  double acc_bound = 0, out_bound = 0;
+  int acc_any = 0, out_any = 0;
+  void release_locked()
+  {
+    out_bound = acc_bound;
+    out_any   = acc_any;
+    arrived   = 0;
+    ++generation;
+    cv.notify_all();
+  }
+  double exchange(double bound, int active, int *any)
+  {
+    std::unique_lock<std::mutex> lk(m);
+    if (arrived == 0)
+    {
+      acc_bound = bound;
+      acc_any   = active;
+    }
+    else
+    {
+      acc_bound = bound < acc_bound ? bound : acc_bound;
+      acc_any |= active;
+    }
+    ++arrived;
+    const unsigned long long gen = generation;
+    if (arrived >= expected)
+      release_locked();
+    else
+      cv.wait(lk, [&] { return generation != gen; });
+    if (any)
+      *any = out_any;
+    return out_bound;
+  }
+  void leave()
+  {
+    std::lock_guard<std::mutex> lk(m);
+    --expected;
+    if (arrived > 0 && arrived >= expected)
+      release_locked();
+  }
+};
+
+struct MultiShared
+{
+  std::mutex cb_mutex;  // fplll's callbacks, one at a time
+  std::function<cb_process_sol_t> *cbsol;
+  std::function<cb_process_subsol_t> *cbsubsol;
+  int dim;
+  long delivered = 0;
+  const std::vector<fphip_ctx *> *ctxs;
+  HostExchange ex;
+};
+struct ShardUser
+{
+  MultiShared *sh;
+  int index;
+};
+
+void multi_subsol(void *user, double dist, const double *subsol, int offset)
+{
+  ShardUser *u = static_cast<ShardUser *>(user);
+  double buf[FPHIP_ENUM_MAX_DIM];
+  memcpy(buf, subsol, sizeof(double) * u->sh->dim);
+  std::lock_guard<std::mutex> lk(u->sh->cb_mutex);
+  try
+  {
+    (*u->sh->cbsubsol)(dist, buf, offset);
+  }
+  catch (...)
+  {
+  }
+}
+double multi_sol(void *user, double dist, const double *sol)
+{
+  ShardUser *u = static_cast<ShardUser *>(user);
+  double buf[FPHIP_ENUM_MAX_DIM];
+  memcpy(buf, sol, sizeof(double) * u->sh->dim);
+  double nb = 0.0;
+  {
+    std::lock_guard<std::mutex> lk(u->sh->cb_mutex);
+    ++u->sh->delivered;
+    try
+    {
+      nb = (*u->sh->cbsol)(dist, buf);
+    }
+    catch (...)
+    {
+      nb = 0.0;
+    }
+  }
+  // the other GPUs learn the new bound NOW, not at their next exchange point
+  for (size_t j = 0; j < u->sh->ctxs->size(); ++j)
+    if ((int)j != u->index)
+      fphip_enum_lower_bound((*u->sh->ctxs)[j], nb);
+  return nb;
+}
+double multi_exchange(void *user, double local_bound, int local_active, int *any_active)
+{
+  return static_cast<ShardUser *>(user)->sh->ex.exchange(local_bound, local_active, any_active);
+}
+
 fphip_ctx *context()
 {
   if (!g_ctx)
@@ -113,7 +284,8 @@ nodes_array_t fplll_hip_extenum(const int dim, enumf maxdist, std::function<cb_s
   if (dim < 2 || dim > FPHIP_ENUM_MAX_DIM || dual)
     return out;
   std::lock_guard<std::mutex> lock(g_mutex);
-  fphip_ctx *ctx = context();
+  const std::vector<fphip_ctx *> &multi = multi_contexts();
+  fphip_ctx *ctx                        = multi.empty() ? context() : multi[0];
   if (!ctx)
     return out;
 
@@ -124,6 +296,75 @@ nodes_array_t fplll_hip_extenum(const int dim, enumf maxdist, std::function<cb_s
   const char *mn         = getenv("FPLLL_HIP_MIN_NODES");
   opts.min_nodes_decline = mn ? atoi(mn) : 0;
   opts.findsubsols       = findsubsols ? 1 : 0;
+  if (!multi.empty())
+  {
+    const int W = (int)multi.size();
+    MultiShared sh;
+    sh.cbsol       = &cbsol;
+    sh.cbsubsol    = &cbsubsol;
+    sh.dim         = dim;
+    sh.ctxs        = &multi;
+    sh.ex.expected = W;
+    std::vector<ShardUser> users(W);
+    std::vector<std::vector<std::uint64_t>> nodes(W, std::vector<std::uint64_t>(dim + 1, 0));
+    std::vector<fphip_enum_stats> stats(W);
+    std::vector<int> rcs(W, FPHIP_ERROR);
+    std::vector<std::thread> th;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < W; ++i)
+    {
+      users[i] = ShardUser{&sh, i};
+      th.emplace_back(
+          [&, i]()
+          {
+            fphip_enum_opts o = opts;
+            o.shard_index     = i;
+            o.shard_count     = W;
+            o.exchange        = multi_exchange;
+            o.exchange_user   = &users[i];
+            o.exchange_chunks = 4;
+            rcs[i] = fphip_enum_run(multi[i], dim, maxdist, mu.data(), rdiag.data(), pruning.data(), &o,
+                                    multi_sol, findsubsols ? multi_subsol : nullptr, &users[i], nodes[i].data(),
+                                    &stats[i]);
+            sh.ex.leave();
+          });
+    }
+    for (auto &t : th)
+      t.join();
+    bool declined = true, failed = false;
+    for (int i = 0; i < W; ++i)
+    {
+      declined = declined && rcs[i] == FPHIP_UNSUPPORTED;
+      failed   = failed || (rcs[i] != FPHIP_OK && rcs[i] != FPHIP_UNSUPPORTED);
+    }
+    if (declined)
+    {  // every shard takes the same decision from the same estimate (before anything is launched)
+      g_totals.declined++;
+      return out;
+    }
+    g_totals.secs += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    g_totals.calls++;
+    double kmax = 0;
+    for (int i = 0; i < W; ++i)
+    {
+      kmax = stats[i].kernel_ms > kmax ? stats[i].kernel_ms : kmax;
+      g_totals.nodes += stats[i].total_nodes;
+    }
+    g_totals.kernel_ms += kmax;
+    if (failed)
+    {
+      for (int i = 0; i < W; ++i)
+        if (rcs[i] != FPHIP_OK)
+          fprintf(stderr, "[fplll_hip] shard %d of %d failed%s, fplll's enumerator takes over: %s\n", i, W,
+                  sh.delivered ? " AFTER candidates were delivered" : "", fphip_last_error(multi[i]));
+      return out;
+    }
+    out.fill(0);
+    for (int i = 0; i < W; ++i)
+      for (int k = 0; k <= dim; ++k)
+        out[k] += nodes[i][k];
+    return out;
+  }
   Trampoline tr{&cbsol, &cbsubsol, dim, 0};
   std::vector<std::uint64_t> nodes(dim + 1, 0);
   fphip_enum_stats stats{};
@@ -168,4 +409,8 @@ extern "C" void fplll_hip_extenum_shutdown(void)
   if (g_ctx)
     fphip_destroy(g_ctx);
   g_ctx = nullptr;
+  for (fphip_ctx *c : g_multi)
+    fphip_destroy(c);
+  g_multi.clear();
+  g_multi_tried = false;
 }

@@ -124,6 +124,11 @@ int fphip_enum_run(fphip_ctx *ctx, int dim, double maxdist, const double *mut, c
                    fphip_subsol_cb subcb, void *user, uint64_t *nodes_out,
                    fphip_enum_stats *stats);
 
+/* Lower the bound of the enumeration running on `ctx` from another host thread (never raises it; no
+ * effect when nothing runs): the in-process multi-GPU mode of the fplll plugin publishes a bound
+ * found on one GPU to the contexts of the others with it, between the collective exchange points. */
+int fphip_enum_lower_bound(fphip_ctx *ctx, double bound);
+
 /* ------------------------------------------------------------------------------------------ */
 /* Batched, device-resident Gram-Schmidt + size reduction                                       */
 /*   MatGSO<Z_NR<long>, FP_NR<double>> with GSO_ROW_EXPO (the BKZ fast path, bkz.cpp:816-829),  */

@@ -1106,6 +1106,22 @@ static int cmd_hlllmp(int argc, char **argv)
   return 0;
 }
 
+/* ishlll basisfile prec → {"reduced":0|1}: the reference's own predicate is_hlll_reduced
+ * (hlll.cpp:507-585; what tests/test_hlll.cpp asserts), evaluated with FP_NR<mpfr_t> at `prec` bits
+ * through hlll_reduction(..., nolll = true) (wrapper.cpp: "just verify if the basis is reduced"). */
+static int cmd_ishlll(int argc, char **argv)
+{
+  if (argc < 4)
+    return 2;
+  ZZ_mat<mpz_t> A;
+  if (!read_basis(argv[2], A))
+    return 2;
+  int status = hlll_reduction(A, LLL_DEF_DELTA, LLL_DEF_ETA, HLLL_DEF_THETA, HLLL_DEF_C, LM_PROVED, FT_MPFR,
+                              atoi(argv[3]), LLL_DEFAULT, true);
+  printf("{\"reduced\":%d,\"status\":%d}\n", status == RED_SUCCESS ? 1 : 0, status);
+  return 0;
+}
+
 /* dumpbasis n k bits seed bkz_pre  → the reduced basis in fplll's text format on stdout */
 static int cmd_dumpbasis(int argc, char **argv)
 {
@@ -1145,6 +1161,8 @@ int main(int argc, char **argv)
     return cmd_genstrat(argc, argv);
   if (cmd == "teststrat")
     return cmd_teststrat(argc, argv);
+  if (cmd == "ishlll")
+    return cmd_ishlll(argc, argv);
   if (cmd == "hlllmp")
     return cmd_hlllmp(argc, argv);
   if (cmd == "hhmp")

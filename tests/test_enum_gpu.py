@@ -308,3 +308,35 @@ def test_plugin_axis_with_reference_build():
         out = subprocess.run([drv, "plugin", so] + c.split(), capture_output=True, text=True,
                              timeout=600, env=env)
         assert out.returncode == 0, (c, out.stdout, out.stderr)
+
+
+def test_plugin_in_process_multi_device():
+    """FPLLL_HIP_DEVICES: the shim runs one host thread + one context per listed device inside ONE
+    fplll process (host barrier + MIN at the exchange points, fphip_enum_lower_bound in between).
+    "0,0" = two contexts on the one GPU of this box: the same protocol as two GPUs.  The reference
+    drives it through set_external_enumerator and compares with its internal enumerator — node
+    counts per level (fixed radius: identical), solutions, final radius — like the single-device
+    axis above; with more than one GPU visible the same cases run on "all"."""
+    import subprocess
+    import fplll_amd
+    drv = os.path.join(C.ROOT, "oracle", "_ref", "ref_driver")
+    so = os.path.join(C.ROOT, "fplll_amd", "lib", "libfplll_hip_extenum.so")
+    if not (os.path.exists(drv) and os.path.exists(so)):
+        pytest.skip("oracle/_ref not built")
+    lists = ["0,0", "0,0,0"]
+    if fplll_amd.load().fphip_device_count() > 1:
+        lists.append("all")
+    cases = [
+        ("80 40 12 1 0 0 32 none 100000000 0 0.99", None),    # fixed radius: counts identical
+        ("100 50 14 2 20 0 40 linear:20 100000000 0 0.99", None),
+        ("100 50 14 2 20 0 40 linear:20 1 0 0.99", None),      # shrinking radius, pruning
+        ("100 50 14 5 20 0 80 linear:70 100000000 0 0.99", "0.45"),  # d > 64: top walk replicated
+    ]
+    for devs in lists:
+        for c, scale in cases:
+            env = dict(os.environ, FPLLL_HIP_DEVICES=devs)
+            if scale:
+                env["REFDRV_RADIUS_SCALE"] = scale
+            out = subprocess.run([drv, "plugin", so] + c.split(), capture_output=True, text=True,
+                                 timeout=600, env=env)
+            assert out.returncode == 0, (devs, c, out.stdout[-2000:], out.stderr[-2000:])
