@@ -1,0 +1,28 @@
+// dev_mem.h — device allocations of the host layer are STREAM-ORDERED (hipMallocAsync / hipFreeAsync
+// on the context's stream).  hipFree synchronises the whole device: it waits for every stream, also
+// those of other contexts of the process — measured here: destroying a small batch object took
+// 28.6 s because another context had a 30 s reduction in flight (tests/perf/free_sync_probe.py).
+// One process may drive several contexts at once (in-process multi-GPU plugin, the long config-size
+// runs of the test-suite beside the rest of it), so nothing in this library may stall on a stranger's
+// kernel.  Every API call waits for its own stream before it returns, so a buffer is idle when it is
+// freed and ready when the caller's next (null-stream) copy touches it.
+#ifndef FPHIP_DEV_MEM_H
+#define FPHIP_DEV_MEM_H
+
+#include <hip/hip_runtime.h>
+
+static inline hipError_t fphip_dev_alloc(void **p, size_t bytes, hipStream_t s)
+{
+  return hipMallocAsync(p, bytes, s);
+}
+static inline void fphip_dev_free(void *p, hipStream_t s)
+{
+  if (!p)
+    return;
+  if (hipFreeAsync(p, s) != hipSuccess)
+  {
+    (void)hipGetLastError();
+    (void)hipFree(p);
+  }
+}
+#endif

@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "../../include/fplll_hip.h"
+#include "dev_mem.h"
 #include "enum_device.h"
 
 
@@ -118,7 +119,7 @@ extern "C" int fphip_create(int device, fphip_ctx **out)
   HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
   HIPCHK(ctx, hipEventCreate(&ctx->ev[0]));
   HIPCHK(ctx, hipEventCreate(&ctx->ev[1]));
-  HIPCHK(ctx, hipMalloc((void **)&ctx->g, sizeof(DevShared)));
+  HIPCHK(ctx, fphip_dev_alloc((void **)&ctx->g, sizeof(DevShared), ctx->stream));
   HIPCHK(ctx, hipHostMalloc((void **)&ctx->stage, sizeof(DevShared), hipHostMallocDefault));
   HIPCHK(ctx, hipHostMalloc((void **)&ctx->h, sizeof(HostCtl),
                             hipHostMallocCoherent | hipHostMallocMapped));
@@ -126,17 +127,17 @@ extern "C" int fphip_create(int device, fphip_ctx **out)
   ctx->cap = (unsigned)env_int("FPHIP_TASK_CAP", 1 << 19);
   for (int b = 0; b < 2; ++b)
   {
-    HIPCHK(ctx, hipMalloc((void **)&ctx->buf[b].col, (size_t)ctx->cap * 64 * sizeof(double)));
-    HIPCHK(ctx, hipMalloc((void **)&ctx->buf[b].x, (size_t)ctx->cap * 64 * sizeof(double)));
-    HIPCHK(ctx, hipMalloc((void **)&ctx->buf[b].pd, (size_t)ctx->cap * sizeof(double)));
-    HIPCHK(ctx, hipMalloc((void **)&ctx->buf[b].level, (size_t)ctx->cap * sizeof(int)));
-    HIPCHK(ctx, hipMalloc((void **)&ctx->buf[b].root, (size_t)ctx->cap * sizeof(int)));
-    HIPCHK(ctx, hipMalloc((void **)&ctx->buf[b].count, 64));
+    HIPCHK(ctx, fphip_dev_alloc((void **)&ctx->buf[b].col, (size_t)ctx->cap * 64 * sizeof(double), ctx->stream));
+    HIPCHK(ctx, fphip_dev_alloc((void **)&ctx->buf[b].x, (size_t)ctx->cap * 64 * sizeof(double), ctx->stream));
+    HIPCHK(ctx, fphip_dev_alloc((void **)&ctx->buf[b].pd, (size_t)ctx->cap * sizeof(double), ctx->stream));
+    HIPCHK(ctx, fphip_dev_alloc((void **)&ctx->buf[b].level, (size_t)ctx->cap * sizeof(int), ctx->stream));
+    HIPCHK(ctx, fphip_dev_alloc((void **)&ctx->buf[b].root, (size_t)ctx->cap * sizeof(int), ctx->stream));
+    HIPCHK(ctx, fphip_dev_alloc((void **)&ctx->buf[b].count, 64, ctx->stream));
     ctx->buf[b].cap = ctx->cap;
   }
-  HIPCHK(ctx, hipMalloc((void **)&ctx->keys, (size_t)ctx->cap * sizeof(unsigned long long)));
-  HIPCHK(ctx, hipMalloc((void **)&ctx->idxlist, (size_t)ctx->cap * sizeof(unsigned)));
-  HIPCHK(ctx, hipMalloc((void **)&ctx->xhi_root, (size_t)ctx->cap * 64 * sizeof(double)));
+  HIPCHK(ctx, fphip_dev_alloc((void **)&ctx->keys, (size_t)ctx->cap * sizeof(unsigned long long), ctx->stream));
+  HIPCHK(ctx, fphip_dev_alloc((void **)&ctx->idxlist, (size_t)ctx->cap * sizeof(unsigned), ctx->stream));
+  HIPCHK(ctx, fphip_dev_alloc((void **)&ctx->xhi_root, (size_t)ctx->cap * 64 * sizeof(double), ctx->stream));
   HIPCHK(ctx, hipMemset(ctx->xhi_root, 0, 64 * sizeof(double)));
   HIPCHK(ctx, hipFuncSetAttribute((const void *)enum_phase_kernel<true, false>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -161,39 +162,39 @@ extern "C" void fphip_destroy(fphip_ctx *ctx)
   for (int b = 0; b < 2; ++b)
   {
     if (ctx->buf[b].col)
-      hipFree(ctx->buf[b].col);
+      fphip_dev_free(ctx->buf[b].col, ctx->stream);
     if (ctx->buf[b].x)
-      hipFree(ctx->buf[b].x);
+      fphip_dev_free(ctx->buf[b].x, ctx->stream);
     if (ctx->buf[b].pd)
-      hipFree(ctx->buf[b].pd);
+      fphip_dev_free(ctx->buf[b].pd, ctx->stream);
     if (ctx->buf[b].level)
-      hipFree(ctx->buf[b].level);
+      fphip_dev_free(ctx->buf[b].level, ctx->stream);
     if (ctx->buf[b].root)
-      hipFree(ctx->buf[b].root);
+      fphip_dev_free(ctx->buf[b].root, ctx->stream);
     if (ctx->buf[b].count)
-      hipFree(ctx->buf[b].count);
+      fphip_dev_free(ctx->buf[b].count, ctx->stream);
   }
   if (ctx->xhi_root)
-    hipFree(ctx->xhi_root);
+    fphip_dev_free(ctx->xhi_root, ctx->stream);
   for (int b = 0; b < 2; ++b)
   {
     if (ctx->top[b].col)
-      hipFree(ctx->top[b].col);
+      fphip_dev_free(ctx->top[b].col, ctx->stream);
     if (ctx->top[b].xhi)
-      hipFree(ctx->top[b].xhi);
+      fphip_dev_free(ctx->top[b].xhi, ctx->stream);
     if (ctx->top[b].pd)
-      hipFree(ctx->top[b].pd);
+      fphip_dev_free(ctx->top[b].pd, ctx->stream);
     if (ctx->top[b].level)
-      hipFree(ctx->top[b].level);
+      fphip_dev_free(ctx->top[b].level, ctx->stream);
     if (ctx->top[b].count)
-      hipFree(ctx->top[b].count);
+      fphip_dev_free(ctx->top[b].count, ctx->stream);
   }
   if (ctx->keys)
-    hipFree(ctx->keys);
+    fphip_dev_free(ctx->keys, ctx->stream);
   if (ctx->idxlist)
-    hipFree(ctx->idxlist);
+    fphip_dev_free(ctx->idxlist, ctx->stream);
   if (ctx->g)
-    hipFree(ctx->g);
+    fphip_dev_free(ctx->g, ctx->stream);
   if (ctx->stage)
     hipHostFree(ctx->stage);
   if (ctx->h)
@@ -203,7 +204,10 @@ extern "C" void fphip_destroy(fphip_ctx *ctx)
   if (ctx->ev[1])
     hipEventDestroy(ctx->ev[1]);
   if (ctx->stream)
+  {
+    hipStreamSynchronize(ctx->stream);  // the stream-ordered frees above
     hipStreamDestroy(ctx->stream);
+  }
   delete ctx;
 }
 
@@ -444,11 +448,11 @@ extern "C" int fphip_enum_run(fphip_ctx *ctx, int dim, double maxdist, const dou
     const unsigned cap2 = (unsigned)env_int("FPHIP_TOP_TASK_CAP", 32768);
     for (int b = 0; b < 2 && !ctx->top[1].col; ++b)
     {
-      HIPCHK(ctx, hipMalloc((void **)&ctx->top[b].col, (size_t)cap2 * 128 * sizeof(double)));
-      HIPCHK(ctx, hipMalloc((void **)&ctx->top[b].xhi, (size_t)cap2 * 64 * sizeof(double)));
-      HIPCHK(ctx, hipMalloc((void **)&ctx->top[b].pd, (size_t)cap2 * sizeof(double)));
-      HIPCHK(ctx, hipMalloc((void **)&ctx->top[b].level, (size_t)cap2 * sizeof(int)));
-      HIPCHK(ctx, hipMalloc((void **)&ctx->top[b].count, 64));
+      HIPCHK(ctx, fphip_dev_alloc((void **)&ctx->top[b].col, (size_t)cap2 * 128 * sizeof(double), ctx->stream));
+      HIPCHK(ctx, fphip_dev_alloc((void **)&ctx->top[b].xhi, (size_t)cap2 * 64 * sizeof(double), ctx->stream));
+      HIPCHK(ctx, fphip_dev_alloc((void **)&ctx->top[b].pd, (size_t)cap2 * sizeof(double), ctx->stream));
+      HIPCHK(ctx, fphip_dev_alloc((void **)&ctx->top[b].level, (size_t)cap2 * sizeof(int), ctx->stream));
+      HIPCHK(ctx, fphip_dev_alloc((void **)&ctx->top[b].count, 64, ctx->stream));
       ctx->top[b].cap = cap2;
     }
     // root top task: level d, zero column, no coefficient chosen, zero partial distance

@@ -18,6 +18,7 @@
 #include "../../include/fplll_hip_debug.h"
 #include "gso_device.h"
 #include "gso_sweep2.h"
+#include "dev_mem.h"
 #include "ftx.h"
 
 #ifndef FPHIP_GSO_RING
@@ -76,6 +77,8 @@ struct fphip_gso
   bool dirty;  // the integer basis was uploaded after the last (re)float of the rows
   // planes of mu for gso_sweep2_kernel (low / high words; row-major and transposed), [batch][2][d][ldd]
   unsigned *muP, *muTP;
+  short *m16;   // 2-byte mirrors: [batch][n*ldd + d*ldn] (bT16 then b16 of each lattice)
+  int *flag16;  // [batch][d]
   int sweep_version;  // 2 (default) or 1 (FPHIP_GSO_SWEEP=1: the first-generation kernel)
 };
 
@@ -149,22 +152,26 @@ static int gso_allocate(fphip_gso *g)
   const size_t B   = (size_t)batch;
   const size_t ldd = g->P.ldd, ldn = g->P.ldn;
   const size_t pad = 4096;  // the DMA ring reads whole 16-byte lanes past the end of a row
-  GCHK(hipMalloc((void **)&g->P.b, B * d * ldn * sizeof(long long) + pad));
-  GCHK(hipMalloc((void **)&g->P.bfT, B * n * ldd * sizeof(double) + pad));
-  GCHK(hipMalloc((void **)&g->P.mu, B * d * ldd * sizeof(double) + pad));
-  GCHK(hipMalloc((void **)&g->P.muT, B * d * ldd * sizeof(double) + pad));
-  GCHK(hipMalloc((void **)&g->P.r, B * d * ldd * sizeof(double) + pad));
-  GCHK(hipMalloc((void **)&g->P.rdg, B * d * sizeof(double)));
-  GCHK(hipMalloc((void **)&g->P.rexp, B * d * sizeof(long long)));
-  GCHK(hipMalloc((void **)&g->P.status, B * sizeof(int)));
-  GCHK(hipMalloc((void **)&g->P.bfT32, B * n * ldd * sizeof(float) + pad));
-  GCHK(hipMalloc((void **)&g->P.b32, B * d * ldn * sizeof(int) + pad));
-  GCHK(hipMalloc((void **)&g->P.narrow, B * d * sizeof(int)));
-  GCHK(hipMalloc((void **)&g->muP, B * 2 * d * ldd * sizeof(unsigned) + pad));
-  GCHK(hipMalloc((void **)&g->muTP, B * 2 * d * ldd * sizeof(unsigned) + pad));
+  GCHK(fphip_dev_alloc((void **)&g->P.b, B * d * ldn * sizeof(long long) + pad, fphip_ctx_stream(g->ctx)));
+  GCHK(fphip_dev_alloc((void **)&g->P.bfT, B * n * ldd * sizeof(double) + pad, fphip_ctx_stream(g->ctx)));
+  GCHK(fphip_dev_alloc((void **)&g->P.mu, B * d * ldd * sizeof(double) + pad, fphip_ctx_stream(g->ctx)));
+  GCHK(fphip_dev_alloc((void **)&g->P.muT, B * d * ldd * sizeof(double) + pad, fphip_ctx_stream(g->ctx)));
+  GCHK(fphip_dev_alloc((void **)&g->P.r, B * d * ldd * sizeof(double) + pad, fphip_ctx_stream(g->ctx)));
+  GCHK(fphip_dev_alloc((void **)&g->P.rdg, B * d * sizeof(double), fphip_ctx_stream(g->ctx)));
+  GCHK(fphip_dev_alloc((void **)&g->P.rexp, B * d * sizeof(long long), fphip_ctx_stream(g->ctx)));
+  GCHK(fphip_dev_alloc((void **)&g->P.status, B * sizeof(int), fphip_ctx_stream(g->ctx)));
+  GCHK(fphip_dev_alloc((void **)&g->P.bfT32, B * n * ldd * sizeof(float) + pad, fphip_ctx_stream(g->ctx)));
+  GCHK(fphip_dev_alloc((void **)&g->P.b32, B * d * ldn * sizeof(int) + pad, fphip_ctx_stream(g->ctx)));
+  GCHK(fphip_dev_alloc((void **)&g->P.narrow, B * d * sizeof(int), fphip_ctx_stream(g->ctx)));
+  GCHK(fphip_dev_alloc((void **)&g->muP, B * 2 * d * ldd * sizeof(unsigned) + pad, fphip_ctx_stream(g->ctx)));
+  GCHK(fphip_dev_alloc((void **)&g->muTP, B * 2 * d * ldd * sizeof(unsigned) + pad, fphip_ctx_stream(g->ctx)));
   hipStream_t s0 = fphip_ctx_stream(ctx);
   GCHK(hipMemsetAsync(g->muP, 0, B * 2 * d * ldd * sizeof(unsigned) + pad, s0));
   GCHK(hipMemsetAsync(g->muTP, 0, B * 2 * d * ldd * sizeof(unsigned) + pad, s0));
+  GCHK(fphip_dev_alloc((void **)&g->m16, B * ((size_t)n * ldd + (size_t)d * ldn) * sizeof(short) + pad, fphip_ctx_stream(g->ctx)));
+  GCHK(fphip_dev_alloc((void **)&g->flag16, B * d * sizeof(int), fphip_ctx_stream(g->ctx)));
+  GCHK(hipMemsetAsync(g->m16, 0, B * ((size_t)n * ldd + (size_t)d * ldn) * sizeof(short) + pad, s0));
+  GCHK(hipMemsetAsync(g->flag16, 0, B * d * sizeof(int), s0));
   {
     const char *sv   = getenv("FPHIP_GSO_SWEEP");
     g->sweep_version = (sv && atoi(sv) == 1) ? 1 : 2;
@@ -174,7 +181,8 @@ static int gso_allocate(fphip_gso *g)
   GCHK(hipMemsetAsync(g->P.narrow, 0, B * d * sizeof(int), s0));
   {
     const char *nv = getenv("FPHIP_GSO_NARROW");  // 0 keeps every pass on the 8-byte rows (A/B runs)
-    g->P.use_narrow = (nv && atoi(nv) == 0) ? 0 : 1;
+    // FPHIP_GSO_NARROW: 0 = 8-byte arrays only, 1 = 4-byte mirrors, 2 (default) = 2-byte mirrors too
+    g->P.use_narrow = nv ? atoi(nv) : 2;
   }
   GCHK(hipMemsetAsync(g->P.b, 0, B * d * ldn * sizeof(long long) + pad, s0));
   GCHK(hipMemsetAsync(g->P.bfT, 0, B * n * ldd * sizeof(double) + pad, s0));
@@ -196,33 +204,35 @@ extern "C" void fphip_gso_destroy(fphip_gso *g)
   if (!g)
     return;
   hipStreamSynchronize(fphip_ctx_stream(g->ctx));
-  hipFree(g->P.b);
-  hipFree(g->P.bfT);
-  hipFree(g->P.mu);
-  hipFree(g->P.muT);
-  hipFree(g->P.r);
-  hipFree(g->P.rdg);
-  hipFree(g->P.rexp);
-  hipFree(g->P.status);
-  hipFree(g->P.bfT32);
-  hipFree(g->P.b32);
-  hipFree(g->P.narrow);
-  hipFree(g->muP);
-  hipFree(g->muTP);
+  fphip_dev_free(g->P.b, fphip_ctx_stream(g->ctx));
+  fphip_dev_free(g->P.bfT, fphip_ctx_stream(g->ctx));
+  fphip_dev_free(g->P.mu, fphip_ctx_stream(g->ctx));
+  fphip_dev_free(g->P.muT, fphip_ctx_stream(g->ctx));
+  fphip_dev_free(g->P.r, fphip_ctx_stream(g->ctx));
+  fphip_dev_free(g->P.rdg, fphip_ctx_stream(g->ctx));
+  fphip_dev_free(g->P.rexp, fphip_ctx_stream(g->ctx));
+  fphip_dev_free(g->P.status, fphip_ctx_stream(g->ctx));
+  fphip_dev_free(g->P.bfT32, fphip_ctx_stream(g->ctx));
+  fphip_dev_free(g->P.b32, fphip_ctx_stream(g->ctx));
+  fphip_dev_free(g->P.narrow, fphip_ctx_stream(g->ctx));
+  fphip_dev_free(g->muP, fphip_ctx_stream(g->ctx));
+  fphip_dev_free(g->muTP, fphip_ctx_stream(g->ctx));
+  fphip_dev_free(g->m16, fphip_ctx_stream(g->ctx));
+  fphip_dev_free(g->flag16, fphip_ctx_stream(g->ctx));
   if (g->P.gf)
-    hipFree(g->P.gf);
+    fphip_dev_free(g->P.gf, fphip_ctx_stream(g->ctx));
   if (g->P.vc)
-    hipFree(g->P.vc);
+    fphip_dev_free(g->P.vc, fphip_ctx_stream(g->ctx));
   if (g->P.b2)
-    hipFree(g->P.b2);
+    fphip_dev_free(g->P.b2, fphip_ctx_stream(g->ctx));
   if (g->P.lll_info)
-    hipFree(g->P.lll_info);
+    fphip_dev_free(g->P.lll_info, fphip_ctx_stream(g->ctx));
   if (g->P.enum_mu)
-    hipFree(g->P.enum_mu);
+    fphip_dev_free(g->P.enum_mu, fphip_ctx_stream(g->ctx));
   if (g->P.bkz_active)
-    hipFree(g->P.bkz_active);
+    fphip_dev_free(g->P.bkz_active, fphip_ctx_stream(g->ctx));
   if (g->P.bkz_rows)
-    hipFree(g->P.bkz_rows);
+    fphip_dev_free(g->P.bkz_rows, fphip_ctx_stream(g->ctx));
   if (g->ev[0])
     hipEventDestroy(g->ev[0]);
   if (g->ev[1])
@@ -268,16 +278,16 @@ static int launch(fphip_gso *g, int kmin, int kend, double eta, int mode, const 
     switch (nq)
     {
     case 1:
-      hipLaunchKernelGGL(s2::gso_sweep2_kernel<1>, dim3(grid), dim3(wpb * 64), lds2, s, g->P, g->muP, g->muTP, kmin, kend, eta, mode);
+      hipLaunchKernelGGL(s2::gso_sweep2_kernel<1>, dim3(grid), dim3(wpb * 64), lds2, s, g->P, g->muP, g->muTP, g->m16, g->flag16, kmin, kend, eta, mode);
       break;
     case 2:
-      hipLaunchKernelGGL(s2::gso_sweep2_kernel<2>, dim3(grid), dim3(wpb * 64), lds2, s, g->P, g->muP, g->muTP, kmin, kend, eta, mode);
+      hipLaunchKernelGGL(s2::gso_sweep2_kernel<2>, dim3(grid), dim3(wpb * 64), lds2, s, g->P, g->muP, g->muTP, g->m16, g->flag16, kmin, kend, eta, mode);
       break;
     case 3:
-      hipLaunchKernelGGL(s2::gso_sweep2_kernel<3>, dim3(grid), dim3(wpb * 64), lds2, s, g->P, g->muP, g->muTP, kmin, kend, eta, mode);
+      hipLaunchKernelGGL(s2::gso_sweep2_kernel<3>, dim3(grid), dim3(wpb * 64), lds2, s, g->P, g->muP, g->muTP, g->m16, g->flag16, kmin, kend, eta, mode);
       break;
     default:
-      hipLaunchKernelGGL(s2::gso_sweep2_kernel<4>, dim3(grid), dim3(wpb * 64), lds2, s, g->P, g->muP, g->muTP, kmin, kend, eta, mode);
+      hipLaunchKernelGGL(s2::gso_sweep2_kernel<4>, dim3(grid), dim3(wpb * 64), lds2, s, g->P, g->muP, g->muTP, g->m16, g->flag16, kmin, kend, eta, mode);
       break;
     }
     GCHK(hipGetLastError());
@@ -492,16 +502,16 @@ static int ensure_lll_buffers(fphip_gso *g)
   const size_t B = (size_t)g->P.batch, d = g->P.d, ldd = g->P.ldd, ldn = g->P.ldn;
   // (each buffer on its own: a failed allocation must not leave a half-initialised set behind)
   if (!g->P.gf)
-    GCHK(hipMalloc((void **)&g->P.gf, B * d * ldd * sizeof(double) + 4096));
+    GCHK(fphip_dev_alloc((void **)&g->P.gf, B * d * ldd * sizeof(double) + 4096, fphip_ctx_stream(g->ctx)));
   if (!g->P.vc)
-    GCHK(hipMalloc((void **)&g->P.vc, B * d * sizeof(int)));
+    GCHK(fphip_dev_alloc((void **)&g->P.vc, B * d * sizeof(int), fphip_ctx_stream(g->ctx)));
   if (!g->P.lll_info)
-    GCHK(hipMalloc((void **)&g->P.lll_info, B * 4 * sizeof(int)));
+    GCHK(fphip_dev_alloc((void **)&g->P.lll_info, B * 4 * sizeof(int), fphip_ctx_stream(g->ctx)));
   if (!g->P.b2)
   {
-    GCHK(hipMalloc((void **)&g->P.b2, B * d * ldn * sizeof(long long) + 4096));
-    GCHK(hipMemset(g->P.b2, 0, B * d * ldn * sizeof(long long) + 4096));
-    GCHK(hipDeviceSynchronize());
+    GCHK(fphip_dev_alloc((void **)&g->P.b2, B * d * ldn * sizeof(long long) + 4096, fphip_ctx_stream(g->ctx)));
+    // (stream-ordered: no device-wide synchronisation — other contexts may have kernels running)
+    GCHK(hipMemsetAsync(g->P.b2, 0, B * d * ldn * sizeof(long long) + 4096, fphip_ctx_stream(g->ctx)));
   }
   return FPHIP_OK;
 }
@@ -691,11 +701,11 @@ extern "C" int fphip_gso_bkz(fphip_gso *g, int block_size, double delta, double 
     return rc;
   const size_t B = (size_t)g->P.batch, d = g->P.d;
   if (!g->P.enum_mu)
-    GCHK(hipMalloc((void **)&g->P.enum_mu, B * (64 * 63 / 2) * sizeof(double)));
+    GCHK(fphip_dev_alloc((void **)&g->P.enum_mu, B * (64 * 63 / 2) * sizeof(double), fphip_ctx_stream(g->ctx)));
   if (!g->P.bkz_active)
-    GCHK(hipMalloc((void **)&g->P.bkz_active, B * sizeof(int)));
+    GCHK(fphip_dev_alloc((void **)&g->P.bkz_active, B * sizeof(int), fphip_ctx_stream(g->ctx)));
   if (!g->P.bkz_rows)
-    GCHK(hipMalloc((void **)&g->P.bkz_rows, B * sizeof(int)));
+    GCHK(fphip_dev_alloc((void **)&g->P.bkz_rows, B * sizeof(int), fphip_ctx_stream(g->ctx)));
   std::vector<int> active(B, 1), st(B, 1), inf(4 * B, 0), one(4 * B), rows(B, (int)d);
   GCHK(hipMemcpy(g->P.bkz_active, active.data(), sizeof(int) * B, hipMemcpyHostToDevice));
   rc = launch(g, 0, g->P.d, 0.0, 2);  // bf / row_expo of every row from b
@@ -972,11 +982,11 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
     return rc;
   const size_t B = (size_t)g->P.batch;
   if (!g->P.enum_mu)
-    GCHK(hipMalloc((void **)&g->P.enum_mu, B * (64 * 63 / 2) * sizeof(double)));
+    GCHK(fphip_dev_alloc((void **)&g->P.enum_mu, B * (64 * 63 / 2) * sizeof(double), fphip_ctx_stream(g->ctx)));
   if (!g->P.bkz_active)
-    GCHK(hipMalloc((void **)&g->P.bkz_active, B * sizeof(int)));
+    GCHK(fphip_dev_alloc((void **)&g->P.bkz_active, B * sizeof(int), fphip_ctx_stream(g->ctx)));
   if (!g->P.bkz_rows)
-    GCHK(hipMalloc((void **)&g->P.bkz_rows, B * sizeof(int)));
+    GCHK(fphip_dev_alloc((void **)&g->P.bkz_rows, B * sizeof(int), fphip_ctx_stream(g->ctx)));
 
   // device copy of what the kernel reads of the strategies; mailboxes; abort flag
   BkzStrat DS;
@@ -986,11 +996,11 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
   BkzMail *mail   = nullptr;
   auto cleanup = [&]()
   {
-    hipFree(d_pre_off);
-    hipFree(d_pre);
-    hipFree(d_coeff_off);
-    hipFree(d_coeff);
-    hipFree(d_abort);
+    fphip_dev_free(d_pre_off, fphip_ctx_stream(g->ctx));
+    fphip_dev_free(d_pre, fphip_ctx_stream(g->ctx));
+    fphip_dev_free(d_coeff_off, fphip_ctx_stream(g->ctx));
+    fphip_dev_free(d_coeff, fphip_ctx_stream(g->ctx));
+    fphip_dev_free(d_abort, fphip_ctx_stream(g->ctx));
     if (mail)
       hipHostFree(mail);
   };
@@ -1010,10 +1020,10 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
     const int npre = S->pre_off[S->max_block_size + 1];
     const int nset = S->prune_off[S->max_block_size + 1];
     const int ncoe = S->coeff_off[nset];
-    BCHK(hipMalloc((void **)&d_pre_off, sizeof(int) * nb));
-    BCHK(hipMalloc((void **)&d_pre, sizeof(int) * (npre > 0 ? npre : 1)));
-    BCHK(hipMalloc((void **)&d_coeff_off, sizeof(int) * (nset + 1)));
-    BCHK(hipMalloc((void **)&d_coeff, sizeof(double) * (ncoe > 0 ? ncoe : 1)));
+    BCHK(fphip_dev_alloc((void **)&d_pre_off, sizeof(int) * nb, fphip_ctx_stream(g->ctx)));
+    BCHK(fphip_dev_alloc((void **)&d_pre, sizeof(int) * (npre > 0 ? npre : 1), fphip_ctx_stream(g->ctx)));
+    BCHK(fphip_dev_alloc((void **)&d_coeff_off, sizeof(int) * (nset + 1), fphip_ctx_stream(g->ctx)));
+    BCHK(fphip_dev_alloc((void **)&d_coeff, sizeof(double) * (ncoe > 0 ? ncoe : 1), fphip_ctx_stream(g->ctx)));
     BCHK(hipMemcpy(d_pre_off, S->pre_off, sizeof(int) * nb, hipMemcpyHostToDevice));
     if (npre > 0)
       BCHK(hipMemcpy(d_pre, S->pre, sizeof(int) * npre, hipMemcpyHostToDevice));
@@ -1026,7 +1036,7 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
     DS.coeff_off      = d_coeff_off;
     DS.coeff          = d_coeff;
   }
-  BCHK(hipMalloc((void **)&d_abort, sizeof(int)));
+  BCHK(fphip_dev_alloc((void **)&d_abort, sizeof(int), fphip_ctx_stream(g->ctx)));
   BCHK(hipMemset(d_abort, 0, sizeof(int)));
   BCHK(hipHostMalloc((void **)&mail, B * sizeof(BkzMail), hipHostMallocCoherent | hipHostMallocMapped));
   memset(mail, 0, B * sizeof(BkzMail));
@@ -1241,7 +1251,7 @@ extern "C" int fphip_debug_stream(fphip_ctx *ctx, long long rows, int row_bytes,
 {
   char *buf = nullptr;
   const size_t total = (size_t)rows * (size_t)stride + 4096;
-  if (hipMalloc((void **)&buf, total) != hipSuccess)
+  if (fphip_dev_alloc((void **)&buf, total, fphip_ctx_stream(ctx)) != hipSuccess)
     return FPHIP_ERROR;
   hipMemset(buf, 1, total);
   hipDeviceSynchronize();
@@ -1260,7 +1270,7 @@ extern "C" int fphip_debug_stream(fphip_ctx *ctx, long long rows, int row_bytes,
     *ms_out = ms;
   hipEventDestroy(e0);
   hipEventDestroy(e1);
-  hipFree(buf);
+  fphip_dev_free(buf, fphip_ctx_stream(ctx));
   return FPHIP_OK;
 }
 
@@ -1332,12 +1342,12 @@ static int hh_allocate(fphip_hh *h)
 {
   const int batch = h->P.batch, d = h->P.d;
   const size_t B = (size_t)batch, ld = h->P.ldn, pad = 4096;
-  HCHK(hipMalloc((void **)&h->P.b, B * d * ld * 8 + pad));
-  HCHK(hipMalloc((void **)&h->P.V, B * d * ld * 8 + pad));
-  HCHK(hipMalloc((void **)&h->P.R, B * d * ld * 8 + pad));
-  HCHK(hipMalloc((void **)&h->P.sigma, B * d * 8));
-  HCHK(hipMalloc((void **)&h->P.rexp, B * d * 8));
-  HCHK(hipMalloc((void **)&h->P.status, B * sizeof(int)));
+  HCHK(fphip_dev_alloc((void **)&h->P.b, B * d * ld * 8 + pad, fphip_ctx_stream(h->ctx)));
+  HCHK(fphip_dev_alloc((void **)&h->P.V, B * d * ld * 8 + pad, fphip_ctx_stream(h->ctx)));
+  HCHK(fphip_dev_alloc((void **)&h->P.R, B * d * ld * 8 + pad, fphip_ctx_stream(h->ctx)));
+  HCHK(fphip_dev_alloc((void **)&h->P.sigma, B * d * 8, fphip_ctx_stream(h->ctx)));
+  HCHK(fphip_dev_alloc((void **)&h->P.rexp, B * d * 8, fphip_ctx_stream(h->ctx)));
+  HCHK(fphip_dev_alloc((void **)&h->P.status, B * sizeof(int), fphip_ctx_stream(h->ctx)));
   HCHK(hipMemset(h->P.b, 0, B * d * ld * 8 + pad));
   HCHK(hipMemset(h->P.V, 0, B * d * ld * 8 + pad));
   HCHK(hipMemset(h->P.R, 0, B * d * ld * 8 + pad));
@@ -1351,30 +1361,30 @@ extern "C" void fphip_hh_destroy(fphip_hh *h)
   if (!h)
     return;
   hipStreamSynchronize(fphip_ctx_stream(h->ctx));
-  hipFree(h->P.b);
-  hipFree(h->P.V);
-  hipFree(h->P.R);
-  hipFree(h->P.sigma);
-  hipFree(h->P.rexp);
-  hipFree(h->P.status);
+  fphip_dev_free(h->P.b, fphip_ctx_stream(h->ctx));
+  fphip_dev_free(h->P.V, fphip_ctx_stream(h->ctx));
+  fphip_dev_free(h->P.R, fphip_ctx_stream(h->ctx));
+  fphip_dev_free(h->P.sigma, fphip_ctx_stream(h->ctx));
+  fphip_dev_free(h->P.rexp, fphip_ctx_stream(h->ctx));
+  fphip_dev_free(h->P.status, fphip_ctx_stream(h->ctx));
   if (h->P.bf)
-    hipFree(h->P.bf);
+    fphip_dev_free(h->P.bf, fphip_ctx_stream(h->ctx));
   if (h->P.info)
-    hipFree(h->P.info);
+    fphip_dev_free(h->P.info, fphip_ctx_stream(h->ctx));
   if (h->ev[0])
     hipEventDestroy(h->ev[0]);
   if (h->ev[1])
     hipEventDestroy(h->ev[1]);
   if (h->Tbuf)
-    hipFree(h->Tbuf);
+    fphip_dev_free(h->Tbuf, fphip_ctx_stream(h->ctx));
   if (h->Rlo)
-    hipFree(h->Rlo);
+    fphip_dev_free(h->Rlo, fphip_ctx_stream(h->ctx));
   if (h->Vlo)
-    hipFree(h->Vlo);
+    fphip_dev_free(h->Vlo, fphip_ctx_stream(h->ctx));
   if (h->xsc)
-    hipFree(h->xsc);
+    fphip_dev_free(h->xsc, fphip_ctx_stream(h->ctx));
   if (h->xprevE)
-    hipFree(h->xprevE);
+    fphip_dev_free(h->xprevE, fphip_ctx_stream(h->ctx));
   delete h;
 }
 
@@ -1443,7 +1453,7 @@ extern "C" int fphip_hh_update_R_blocked(fphip_hh *h, int *status)
   const int nq   = (h->P.n + 63) / 64;
   const int nblk = (h->P.d + 15) / 16;
   if (!h->Tbuf)
-    HCHK(hipMalloc((void **)&h->Tbuf, (size_t)h->P.batch * nblk * 256 * sizeof(double)));
+    HCHK(fphip_dev_alloc((void **)&h->Tbuf, (size_t)h->P.batch * nblk * 256 * sizeof(double), fphip_ctx_stream(h->ctx)));
   const int ldx    = ((h->P.n + 31) & ~31) + 1;
   const size_t lds = (size_t)(16 * ldx + 256) * sizeof(double);
   int bpc          = (int)((160 * 1024) / lds);
@@ -1495,10 +1505,9 @@ extern "C" int fphip_hh_hlll(fphip_hh *h, double delta, double eta, double theta
   const size_t B = (size_t)h->P.batch, d = h->P.d, ld = h->P.ldn;
   if (!h->P.bf)
   {
-    HCHK(hipMalloc((void **)&h->P.bf, B * d * ld * 8 + 4096));
-    HCHK(hipMalloc((void **)&h->P.info, B * 2 * sizeof(int)));
-    HCHK(hipMemset(h->P.bf, 0, B * d * ld * 8 + 4096));
-    HCHK(hipDeviceSynchronize());
+    HCHK(fphip_dev_alloc((void **)&h->P.bf, B * d * ld * 8 + 4096, fphip_ctx_stream(h->ctx)));
+    HCHK(fphip_dev_alloc((void **)&h->P.info, B * 2 * sizeof(int), fphip_ctx_stream(h->ctx)));
+    HCHK(hipMemsetAsync(h->P.bf, 0, B * d * ld * 8 + 4096, fphip_ctx_stream(h->ctx)));
   }
   const int nq  = (h->P.n + 63) / 64;
   const int wpb = 4;
@@ -1542,28 +1551,28 @@ static int hh_hlll_ex(fphip_hh *h, double delta, double theta, int precision, co
   const size_t B = (size_t)h->P.batch, d = h->P.d, ld = h->P.ldn;
   if (!h->P.bf)
   {
-    HCHK(hipMalloc((void **)&h->P.bf, B * d * ld * 8 + 4096));
-    HCHK(hipMalloc((void **)&h->P.info, B * 2 * sizeof(int)));
-    HCHK(hipMemset(h->P.bf, 0, B * d * ld * 8 + 4096));
+    HCHK(fphip_dev_alloc((void **)&h->P.bf, B * d * ld * 8 + 4096, fphip_ctx_stream(h->ctx)));
+    HCHK(fphip_dev_alloc((void **)&h->P.info, B * 2 * sizeof(int), fphip_ctx_stream(h->ctx)));
+    HCHK(hipMemsetAsync(h->P.bf, 0, B * d * ld * 8 + 4096, fphip_ctx_stream(h->ctx)));
   }
   if (!h->xsc)
   {
-    HCHK(hipMalloc((void **)&h->xsc, B * 10 * d * sizeof(double)));
-    HCHK(hipMalloc((void **)&h->xprevE, B * d * sizeof(long long)));
+    HCHK(fphip_dev_alloc((void **)&h->xsc, B * 10 * d * sizeof(double), fphip_ctx_stream(h->ctx)));
+    HCHK(fphip_dev_alloc((void **)&h->xprevE, B * d * sizeof(long long), fphip_ctx_stream(h->ctx)));
   }
   if (precision == 106 && !h->Rlo)
   {
-    HCHK(hipMalloc((void **)&h->Rlo, B * d * ld * 8 + 4096));
-    HCHK(hipMalloc((void **)&h->Vlo, B * d * ld * 8 + 4096));
+    HCHK(fphip_dev_alloc((void **)&h->Rlo, B * d * ld * 8 + 4096, fphip_ctx_stream(h->ctx)));
+    HCHK(fphip_dev_alloc((void **)&h->Vlo, B * d * ld * 8 + 4096, fphip_ctx_stream(h->ctx)));
   }
-  HCHK(hipMemset(h->xsc, 0, B * 10 * d * sizeof(double)));
-  HCHK(hipMemset(h->xprevE, 0, B * d * sizeof(long long)));
+  hipStream_t s0 = fphip_ctx_stream(h->ctx);
+  HCHK(hipMemsetAsync(h->xsc, 0, B * 10 * d * sizeof(double), s0));
+  HCHK(hipMemsetAsync(h->xprevE, 0, B * d * sizeof(long long), s0));
   if (precision == 106)
   {
-    HCHK(hipMemset(h->Rlo, 0, B * d * ld * 8 + 4096));
-    HCHK(hipMemset(h->Vlo, 0, B * d * ld * 8 + 4096));
+    HCHK(hipMemsetAsync(h->Rlo, 0, B * d * ld * 8 + 4096, s0));
+    HCHK(hipMemsetAsync(h->Vlo, 0, B * d * ld * 8 + 4096, s0));
   }
-  HCHK(hipDeviceSynchronize());
   HlllX X;
   X.Rlo      = precision == 106 ? h->Rlo : nullptr;
   X.Vlo      = precision == 106 ? h->Vlo : nullptr;
@@ -1650,10 +1659,10 @@ extern "C" int fphip_hh_hlll_ladder(fphip_hh *h, double delta, double eta, doubl
     for (size_t L = 0; L < B; ++L)
       mask[L] = (st[L] == -4 || st[L] == -5) ? 0 : 1;
     int *d_mask = nullptr;
-    HCHK(hipMalloc((void **)&d_mask, B * sizeof(int)));
+    HCHK(fphip_dev_alloc((void **)&d_mask, B * sizeof(int), fphip_ctx_stream(h->ctx)));
     hipError_t e = hipMemcpy(d_mask, mask.data(), B * sizeof(int), hipMemcpyHostToDevice);
     rc           = (e == hipSuccess) ? hh_hlll_ex(h, delta, theta, 106, d_mask, st2.data(), inf2.data()) : FPHIP_ERROR;
-    hipFree(d_mask);
+    fphip_dev_free(d_mask, fphip_ctx_stream(h->ctx));
     if (rc != FPHIP_OK)
       return rc;
     ms += h->last_ms;
@@ -1695,7 +1704,7 @@ extern "C" int fphip_debug_dd_op(fphip_ctx *ctx, int op, int count, const double
     return FPHIP_ERROR;
   double *dv = nullptr;
   const size_t nb = (size_t)count * sizeof(double);
-  if (hipMalloc((void **)&dv, 6 * nb) != hipSuccess)
+  if (fphip_dev_alloc((void **)&dv, 6 * nb, fphip_ctx_stream(ctx)) != hipSuccess)
     return FPHIP_ERROR;
   hipMemcpy(dv, ahi, nb, hipMemcpyHostToDevice);
   hipMemcpy(dv + count, alo, nb, hipMemcpyHostToDevice);
@@ -1707,7 +1716,7 @@ extern "C" int fphip_debug_dd_op(fphip_ctx *ctx, int op, int count, const double
   hipStreamSynchronize(fphip_ctx_stream(ctx));
   hipMemcpy(ohi, dv + 4 * (size_t)count, nb, hipMemcpyDeviceToHost);
   hipMemcpy(olo, dv + 5 * (size_t)count, nb, hipMemcpyDeviceToHost);
-  hipFree(dv);
+  fphip_dev_free(dv, fphip_ctx_stream(ctx));
   return FPHIP_OK;
 }
 

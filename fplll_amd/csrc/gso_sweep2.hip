@@ -86,9 +86,18 @@ template <int NQ> struct Stream
   unsigned long long ab0, ab1, ab2, ab3;  // chunk aq, aq-1, … (shifted down as they are exhausted)
   int aq;
 
-  __device__ __forceinline__ void dma_pair(const char *p0, const char *p1, unsigned long long mask)
+  // a wave-uniform 64-bit value the compiler may have parked in VGPRs: back into SGPRs (free when it
+  // already is scalar) — the "s" constraint of an inline asm does not do that for 64-bit operands
+  static __device__ __forceinline__ unsigned long long uni64(unsigned long long v)
   {
-    const unsigned dst = base + hoff;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+  }
+  __device__ __forceinline__ void dma_pair(const char *p0, const char *p1, unsigned long long mask_)
+  {
+    const unsigned dst            = base + hoff;
+    const unsigned long long mask = uni64(mask_);
     // s_mov exec doubles as the wait state the LDS-DMA needs after the M0 write
     asm volatile("s_mov_b32 m0, %2\n\t"
                  "s_mov_b64 exec, %3\n\t"
@@ -281,6 +290,14 @@ struct Planes
   unsigned *muP;   // [2][d][ldd]  word p of mu(j,k) at muP[p*pl + j*ldd + k]
   unsigned *muTP;  // [2][d][ldd]  word p of mu(j,k) at muTP[p*pl + k*ldd + j]
   size_t pl;       // d * ldd
+  // 2-byte mirrors: while every entry of a row is below 2^15 in magnitude the Gram pass streams the
+  // INTEGER column (bT16[c][j] = b(j,c)) and scales it by 2^-row_expo(j) in registers — bf(j,c) IS
+  // b(j,c) * 2^-row_expo(j) exactly (gso.cpp:27-40) — and the AXPY streams b16: half the bytes of
+  // the 4-byte mirrors again
+  short *bT16;   // [n][ldd]
+  short *b16;    // [d][ldn]
+  int *flag16;   // [d]
+  int np16;      // rows 0..np16-1 all carry the flag (wave-uniform)
 };
 
 __device__ __forceinline__ double rl2(double v, int lane) { return g_rl_f64(v, lane); }
@@ -289,21 +306,38 @@ __device__ __forceinline__ double rl2(double v, int lane) { return g_rl_f64(v, l
 // consumers.  load(w, lane4) reads this lane's words of the pair at LDS word index w; compute()
 // uses them.  `i` is the wave-uniform position inside the consumer's chunk.
 // ---------------------------------------------------------------------------------------------
-template <int NQ, int CQ, int QA> struct GramCons  // QA: chunks 0..QA-1 hold a column j <= last
+// EB = bytes per streamed element: 4 (float mirror of bf) or 2 (int16 mirror of b, scaled by sc[q] =
+// 2^-row_expo of the lane's row: the same double, exactly)
+template <int NQ, int CQ, int QA, int EB> struct GramCons  // QA: chunks 0..QA-1 hold a column j <= last
 {
   double (&acc)[NQ];
   const double &bkq;  // bk[CQ]
+  const double (&sc)[NQ];
   int cc;             // row c = 64 CQ + cc of the first entry
   bool second;        // the second entry is a row too (false: tail of an odd count)
-  float w0[NQ], w1[NQ];
+  double x0[NQ], x1[NQ];
   __device__ __forceinline__ void load(unsigned w, unsigned lane4)
   {
-    const unsigned a = w + (lane4 >> 2);
-#pragma unroll
-    for (int q = 0; q < QA; ++q)
+    if constexpr (EB == 4)
     {
-      w0[q] = __uint_as_float(s2_smem[a + 64 * q]);
-      w1[q] = __uint_as_float(s2_smem[a + 64 * q + Cfg<NQ>::ESZ / 4]);
+      const unsigned a = w + (lane4 >> 2);
+#pragma unroll
+      for (int q = 0; q < QA; ++q)
+      {
+        x0[q] = (double)__uint_as_float(s2_smem[a + 64 * q]);
+        x1[q] = (double)__uint_as_float(s2_smem[a + 64 * q + Cfg<NQ>::ESZ / 4]);
+      }
+    }
+    else
+    {
+      const short *h   = (const short *)s2_smem;
+      const unsigned a = 2 * w + (lane4 >> 2);
+#pragma unroll
+      for (int q = 0; q < QA; ++q)
+      {
+        x0[q] = (double)(int)h[a + 64 * q];
+        x1[q] = (double)(int)h[a + 64 * q + Cfg<NQ>::ESZ / 2];
+      }
     }
   }
   __device__ __forceinline__ void compute()
@@ -313,11 +347,13 @@ template <int NQ, int CQ, int QA> struct GramCons  // QA: chunks 0..QA-1 hold a 
 #pragma unroll
     for (int q = 0; q < QA; ++q)
     {
-      const double p0 = s0 * (double)w0[q];
+      const double v0 = (EB == 4) ? x0[q] : x0[q] * sc[q];
+      const double p0 = s0 * v0;
       acc[q]          = acc[q] + p0;
       if (second)
       {
-        const double p1 = s1 * (double)w1[q];
+        const double v1 = (EB == 4) ? x1[q] : x1[q] * sc[q];
+        const double p1 = s1 * v1;
         acc[q]          = acc[q] + p1;
       }
     }
@@ -411,7 +447,7 @@ template <int NQ, int JQ> struct SweepCons
   }
 };
 
-template <int NQ, int JQ> struct AxpyCons
+template <int NQ, int JQ, int EB> struct AxpyCons
 {
   long long (&bv)[NQ];
   const long long &lxq;      // multipliers of chunk JQ (lane j)
@@ -420,12 +456,26 @@ template <int NQ, int JQ> struct AxpyCons
   int w0[NQ], w1[NQ];
   __device__ __forceinline__ void load(unsigned w, unsigned lane4)
   {
-    const unsigned a = w + (lane4 >> 2);
-#pragma unroll
-    for (int q = 0; q < NQ; ++q)
+    if constexpr (EB == 4)
     {
-      w0[q] = (int)s2_smem[a + 64 * q];
-      w1[q] = (int)s2_smem[a + 64 * q + Cfg<NQ>::ESZ / 4];
+      const unsigned a = w + (lane4 >> 2);
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+      {
+        w0[q] = (int)s2_smem[a + 64 * q];
+        w1[q] = (int)s2_smem[a + 64 * q + Cfg<NQ>::ESZ / 4];
+      }
+    }
+    else
+    {
+      const short *h   = (const short *)s2_smem;
+      const unsigned a = 2 * w + (lane4 >> 2);
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+      {
+        w0[q] = (int)h[a + 64 * q];
+        w1[q] = (int)h[a + 64 * q + Cfg<NQ>::ESZ / 2];
+      }
     }
   }
   __device__ __forceinline__ void compute()
@@ -466,22 +516,23 @@ template <int NQ, int JQ> struct AxpyCons
 // ---------------------------------------------------------------------------------------------
 // phases (compile-time recursion over the chunks)
 // ---------------------------------------------------------------------------------------------
-template <int NQ, int QA, int CQ = 0>
-__device__ __forceinline__ void gram_phase(Stream<NQ> &S, double (&acc)[NQ], const double (&bk)[NQ], int n)
+template <int NQ, int QA, int EB, int CQ = 0>
+__device__ __forceinline__ void gram_phase(Stream<NQ> &S, double (&acc)[NQ], const double (&bk)[NQ],
+                                           const double (&sc)[NQ], int n)
 {
   if constexpr (CQ < NQ)
   {
     const int rows = min(n - 64 * CQ, 64);
     if (rows > 0)
     {
-      GramCons<NQ, CQ, QA> g{acc, bk[CQ], 0, true};
+      GramCons<NQ, CQ, QA, EB> g{acc, bk[CQ], sc, 0, true};
       S.template run<(1u << K_GRAM) | (1u << K_REC)>(g, rows >> 1);
       if (rows & 1)
       {
         g.second = false;
         S.template run<(1u << K_GRAM) | (1u << K_REC)>(g, 1);
       }
-      gram_phase<NQ, QA, CQ + 1>(S, acc, bk, n);
+      gram_phase<NQ, QA, EB, CQ + 1>(S, acc, bk, sc, n);
     }
   }
 }
@@ -505,11 +556,14 @@ __device__ __forceinline__ void rec_phase(Stream<NQ> &S, double (&acc)[NQ], int 
 // Gram pass then recurrence with the (wave-uniform) number of active chunks as a compile-time
 // constant: QA = (last >> 6) + 1
 template <int NQ, int QA>
-__device__ __forceinline__ void gram_rec_qa(Stream<NQ> &S, double (&acc)[NQ], const double (&bk)[NQ], int n,
-                                            int nrec, unsigned lane, bool narrow, int kappa, double &gkk)
+__device__ __forceinline__ void gram_rec_qa(Stream<NQ> &S, double (&acc)[NQ], const double (&bk)[NQ],
+                                            const double (&sc)[NQ], int n, int nrec, unsigned lane, int narrow,
+                                            int kappa, double &gkk)
 {
-  if (narrow)
-    gram_phase<NQ, QA>(S, acc, bk, n);
+  if (narrow == 2)
+    gram_phase<NQ, QA, 2>(S, acc, bk, sc, n);
+  else if (narrow == 1)
+    gram_phase<NQ, QA, 4>(S, acc, bk, sc, n);
   gkk = g_rl_f64(acc[QA - 1], kappa & 63);  // lane kappa of chunk QA-1 = kappa >> 6
   rec_phase<NQ, QA>(S, acc, nrec, lane);
 }
@@ -543,7 +597,7 @@ __device__ __forceinline__ void sweep_phase(Stream<NQ> &S, double (&bm)[NQ], dou
   }
 }
 
-template <int NQ, int JQ = NQ - 1>
+template <int NQ, int EB, int JQ = NQ - 1>
 __device__ __forceinline__ void axpy_phase(Stream<NQ> &S, long long (&bv)[NQ], const long long (&lxv)[NQ],
                                            const unsigned long long (&nz)[NQ], bool small)
 {
@@ -551,10 +605,10 @@ __device__ __forceinline__ void axpy_phase(Stream<NQ> &S, long long (&bv)[NQ], c
   {
     if (nz[JQ] != 0)
     {
-      AxpyCons<NQ, JQ> a{bv, lxv[JQ], nz[JQ], small};
+      AxpyCons<NQ, JQ, EB> a{bv, lxv[JQ], nz[JQ], small};
       S.template run<(1u << K_AXPY)>(a, (__builtin_popcountll(nz[JQ]) + 1) >> 1);
     }
-    axpy_phase<NQ, JQ - 1>(S, bv, lxv, nz, small);
+    axpy_phase<NQ, EB, JQ - 1>(S, bv, lxv, nz, small);
   }
 }
 
@@ -618,16 +672,19 @@ __device__ __forceinline__ void axpy_wide(const Lattice<NQ> &T, long long (&bv)[
 // One GSO pass of row kappa: Gram row g(kappa, j <= kappa) then the recurrence for j < kappa.
 // On return acc[] lane j < kappa = r(kappa,j); gkk = g(kappa,kappa).
 // ---------------------------------------------------------------------------------------------
+// sc[q] = 2^-row_expo of row lane + 64 q (rows <= kappa): the scale of the 2-byte Gram path
 template <int NQ>
 __device__ __forceinline__ void gso_pass(Lattice<NQ> &T, const Planes &PL, Stream<NQ> &S, int kappa,
-                                         const double (&bk)[NQ], double (&acc)[NQ], double &gkk)
+                                         const double (&bk)[NQ], const double (&sc)[NQ], double (&acc)[NQ],
+                                         double &gkk)
 {
   const int n = T.n, ldd = T.ldd;
   const int qact = (kappa >> 6) + 1;
 #pragma unroll
   for (int q = 0; q < NQ; ++q)
     acc[q] = -0.0;  // -0.0 + p == p for every p: the first product starts the sum (numvect.h:389)
-  const bool narrow = T.np > kappa;  // rows 0..kappa are read
+  // rows 0..kappa are read: 2-byte mirrors, else 4-byte mirrors, else the 8-byte arrays
+  const int narrow = (PL.np16 > kappa) ? 2 : (T.np > kappa) ? 1 : 0;
   // recurrence rows k = 0..kappa-2 (row kappa-1 has nothing below it)
   const int nrec = kappa > 0 ? kappa - 1 : 0;
   S.rp      = (const char *)PL.muTP;
@@ -635,7 +692,14 @@ __device__ __forceinline__ void gso_pass(Lattice<NQ> &T, const Planes &PL, Strea
   S.rplane  = (long)PL.pl * 4;
   S.rk      = 0;
   S.rhimask = kappa > 0 ? (~0ull >> (63 - ((kappa - 1) >> 2))) : 0ull;
-  if (narrow)
+  if (narrow == 2)
+  {
+    S.gp      = (const char *)PL.bT16;
+    S.gstride = (long)ldd * 2;
+    S.gmask   = ~0ull >> (63 - (kappa >> 3));  // a lane fetches 8 elements
+    S.begin(K_GRAM, (n + 1) >> 1, K_REC, nrec);
+  }
+  else if (narrow == 1)
   {
     S.gp      = (const char *)T.bfT32;
     S.gstride = (long)ldd * 4;
@@ -649,33 +713,33 @@ __device__ __forceinline__ void gso_pass(Lattice<NQ> &T, const Planes &PL, Strea
   }
   const unsigned lane = (unsigned)T.lane;
   if constexpr (NQ == 1)
-    gram_rec_qa<NQ, 1>(S, acc, bk, n, nrec, lane, narrow, kappa, gkk);
+    gram_rec_qa<NQ, 1>(S, acc, bk, sc, n, nrec, lane, narrow, kappa, gkk);
   else if constexpr (NQ == 2)
   {
     if (qact == 1)
-      gram_rec_qa<NQ, 1>(S, acc, bk, n, nrec, lane, narrow, kappa, gkk);
+      gram_rec_qa<NQ, 1>(S, acc, bk, sc, n, nrec, lane, narrow, kappa, gkk);
     else
-      gram_rec_qa<NQ, 2>(S, acc, bk, n, nrec, lane, narrow, kappa, gkk);
+      gram_rec_qa<NQ, 2>(S, acc, bk, sc, n, nrec, lane, narrow, kappa, gkk);
   }
   else if constexpr (NQ == 3)
   {
     if (qact == 1)
-      gram_rec_qa<NQ, 1>(S, acc, bk, n, nrec, lane, narrow, kappa, gkk);
+      gram_rec_qa<NQ, 1>(S, acc, bk, sc, n, nrec, lane, narrow, kappa, gkk);
     else if (qact == 2)
-      gram_rec_qa<NQ, 2>(S, acc, bk, n, nrec, lane, narrow, kappa, gkk);
+      gram_rec_qa<NQ, 2>(S, acc, bk, sc, n, nrec, lane, narrow, kappa, gkk);
     else
-      gram_rec_qa<NQ, 3>(S, acc, bk, n, nrec, lane, narrow, kappa, gkk);
+      gram_rec_qa<NQ, 3>(S, acc, bk, sc, n, nrec, lane, narrow, kappa, gkk);
   }
   else
   {
     if (qact == 1)
-      gram_rec_qa<NQ, 1>(S, acc, bk, n, nrec, lane, narrow, kappa, gkk);
+      gram_rec_qa<NQ, 1>(S, acc, bk, sc, n, nrec, lane, narrow, kappa, gkk);
     else if (qact == 2)
-      gram_rec_qa<NQ, 2>(S, acc, bk, n, nrec, lane, narrow, kappa, gkk);
+      gram_rec_qa<NQ, 2>(S, acc, bk, sc, n, nrec, lane, narrow, kappa, gkk);
     else if (qact == 3)
-      gram_rec_qa<NQ, 3>(S, acc, bk, n, nrec, lane, narrow, kappa, gkk);
+      gram_rec_qa<NQ, 3>(S, acc, bk, sc, n, nrec, lane, narrow, kappa, gkk);
     else
-      gram_rec_qa<NQ, 4>(S, acc, bk, n, nrec, lane, narrow, kappa, gkk);
+      gram_rec_qa<NQ, 4>(S, acc, bk, sc, n, nrec, lane, narrow, kappa, gkk);
   }
 }
 
@@ -749,27 +813,75 @@ __device__ __forceinline__ bool mu_from_r(const Lattice<NQ> &T, int kappa, const
   return __all(ok);
 }
 
+// The 2-byte mirrors of row pk (after store_row_and_refloat): b16 row, bT16 column, flag, prefix.
+template <int NQ>
+__device__ __forceinline__ void store_mirror16(const Lattice<NQ> &T, Planes &PL, int pk, const long long (&bv)[NQ])
+{
+  const int n = T.n, lane = T.lane, ldd = T.ldd, ldn = T.ldn;
+  bool wide = false;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+  {
+    const int c = lane + 64 * q;
+    if (c < n)
+    {
+      PL.b16[(size_t)pk * ldn + c]  = (short)bv[q];
+      PL.bT16[(size_t)c * ldd + pk] = (short)bv[q];
+      wide |= (bv[q] >= (1ll << 15) || bv[q] < -(1ll << 15));
+    }
+  }
+  const bool w = __any(wide);
+  if (lane == 0)
+    PL.flag16[pk] = w ? 0 : 1;
+  if (w)
+    PL.np16 = min(PL.np16, pk);
+  else if (pk == PL.np16)
+  {
+    int p = pk + 1;
+    while (p < T.d && __builtin_amdgcn_readfirstlane(PL.flag16[p]) != 0)
+      ++p;
+    PL.np16 = p;
+  }
+}
+
+// sc[q] = 2^-row_expo(row lane + 64 q) for rows < kappa, 2^-rexpk for row kappa itself
+template <int NQ>
+__device__ __forceinline__ void scale_vector(const Lattice<NQ> &T, int kappa, const long long (&rexpj)[NQ],
+                                             long long rexpk, double (&sc)[NQ])
+{
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+  {
+    const int j = T.lane + 64 * q;
+    sc[q]       = ldexp(1.0, -(int)((j == kappa) ? rexpk : rexpj[q]));
+  }
+}
+
 // update_gso_row(kappa, kappa) from column 0.  false: RED_GSO_FAILURE.
 template <int NQ>
-__device__ __forceinline__ bool update_full(Lattice<NQ> &T, const Planes &PL, Stream<NQ> &S, int kappa)
+__device__ __forceinline__ bool update_full(Lattice<NQ> &T, Planes &PL, Stream<NQ> &S, int kappa)
 {
   const int n = T.n, lane = T.lane, ldd = T.ldd;
-  double bk[NQ], rd[NQ], acc[NQ], mu[NQ];
+  double bk[NQ], rd[NQ], acc[NQ], mu[NQ], sc[NQ];
+  long long rexpj[NQ];
 #pragma unroll
   for (int q = 0; q < NQ; ++q)
   {
     const int c = lane + 64 * q;
     bk[q]       = (c < n) ? T.bfT[(size_t)c * ldd + kappa] : 0.0;
     rd[q]       = (c < kappa) ? T.rdg[c] : 1.0;
+    rexpj[q]    = (c <= kappa) ? T.rexp[c] : 0;
   }
 #pragma unroll
   for (int q = 0; q < NQ; ++q)
   {
     settle(bk[q]);
     settle(rd[q]);
+    settle(rexpj[q]);
   }
+  scale_vector<NQ>(T, -1, rexpj, 0, sc);
   double gkk = 0.0;
-  gso_pass<NQ>(T, PL, S, kappa, bk, acc, gkk);
+  gso_pass<NQ>(T, PL, S, kappa, bk, sc, acc, gkk);
   const bool ok    = mu_from_r<NQ>(T, kappa, acc, rd, mu);
   const double rkk = finish_diag2<NQ>(mu, acc, gkk, kappa);
   store_gso_row<NQ>(T, PL, kappa, mu, acc, rkk);
@@ -779,7 +891,7 @@ __device__ __forceinline__ bool update_full(Lattice<NQ> &T, const Planes &PL, St
 // LLLReduction::babai(kappa, kappa, 0) followed by update_gso_row(kappa, kappa) (lll.h:107-122).
 // 1 ok, 0 GSO failure, -1 babai failure, -2 multiplier beyond 63 bits.
 template <int NQ>
-__device__ __forceinline__ int babai2(Lattice<NQ> &T, const Planes &PL, Stream<NQ> &S, int kappa, double eta)
+__device__ __forceinline__ int babai2(Lattice<NQ> &T, Planes &PL, Stream<NQ> &S, int kappa, double eta)
 {
   const int n = T.n, lane = T.lane, ldd = T.ldd, ldn = T.ldn;
   const int sr_start = 0;
@@ -806,9 +918,11 @@ __device__ __forceinline__ int babai2(Lattice<NQ> &T, const Planes &PL, Stream<N
   }
   settle(rexpk);
   double gkk         = 0.0;
+  double sc[NQ];
   for (int iter = 0;; ++iter)
   {
-    gso_pass<NQ>(T, PL, S, kappa, bk, acc, gkk);
+    scale_vector<NQ>(T, kappa, rexpj, rexpk, sc);
+    gso_pass<NQ>(T, PL, S, kappa, bk, sc, acc, gkk);
     if (!mu_from_r<NQ>(T, kappa, acc, rd, mu))
       return 0;
     int e[NQ];
@@ -883,7 +997,8 @@ __device__ __forceinline__ int babai2(Lattice<NQ> &T, const Planes &PL, Stream<N
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
       settle(bv[q]);
-    if (T.np >= kappa)
+    const int anarrow = (PL.np16 >= kappa) ? 2 : (T.np >= kappa) ? 1 : 0;  // rows below kappa are read
+    if (anarrow != 0)
     {
       int pairs = 0;
 #pragma unroll
@@ -895,16 +1010,28 @@ __device__ __forceinline__ int babai2(Lattice<NQ> &T, const Planes &PL, Stream<N
       S.ab1 = NQ >= 2 ? nz[NQ >= 2 ? NQ - 2 : 0] : 0;
       S.ab2 = NQ >= 3 ? nz[NQ >= 3 ? NQ - 3 : 0] : 0;
       S.ab3 = NQ >= 4 ? nz[NQ >= 4 ? NQ - 4 : 0] : 0;
-      S.ap      = (const char *)T.b32;
-      S.astride = (long)ldn * 4;
-      S.amask   = ~0ull >> (63 - ((n - 1) >> 2));
-      S.begin(K_AXPY, pairs, K_DUMMY, 0x7fffffff);
-      axpy_phase<NQ>(S, bv, lxv, nz, small);
+      if (anarrow == 2)
+      {
+        S.ap      = (const char *)PL.b16;
+        S.astride = (long)ldn * 2;
+        S.amask   = ~0ull >> (63 - ((n - 1) >> 3));
+        S.begin(K_AXPY, pairs, K_DUMMY, 0x7fffffff);
+        axpy_phase<NQ, 2>(S, bv, lxv, nz, small);
+      }
+      else
+      {
+        S.ap      = (const char *)T.b32;
+        S.astride = (long)ldn * 4;
+        S.amask   = ~0ull >> (63 - ((n - 1) >> 2));
+        S.begin(K_AXPY, pairs, K_DUMMY, 0x7fffffff);
+        axpy_phase<NQ, 4>(S, bv, lxv, nz, small);
+      }
     }
     else
       axpy_wide<NQ>(T, bv, lxv, kappa);
     // ---- row_op_end: update_bf(kappa), gso.cpp:24-48
     store_row_and_refloat<NQ, true>(T, kappa, bv, bk, rexpk);
+    store_mirror16<NQ>(T, PL, kappa, bv);
     // the requests of the next pass must see these stores
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __threadfence_block();
@@ -918,7 +1045,8 @@ __device__ __forceinline__ int babai2(Lattice<NQ> &T, const Planes &PL, Stream<N
 // mode 2: (re)build bfT / row_expo / the narrow mirrors from b for every row (after a basis upload)
 template <int NQ>
 __global__ void __launch_bounds__(256, Cfg<NQ>::WAVES_PER_SIMD)
-    gso_sweep2_kernel(GsoBatch P, unsigned *muP, unsigned *muTP, int kmin, int kend, double eta, int mode)
+    gso_sweep2_kernel(GsoBatch P, unsigned *muP, unsigned *muTP, short *m16, int *flag16, int kmin, int kend,
+                      double eta, int mode)
 {
   using C        = Cfg<NQ>;
   const int lane = threadIdx.x & 63;
@@ -954,6 +1082,11 @@ __global__ void __launch_bounds__(256, Cfg<NQ>::WAVES_PER_SIMD)
     PL.pl   = (size_t)P.d * P.ldd;
     PL.muP  = muP + (size_t)L * 2 * PL.pl;
     PL.muTP = muTP + (size_t)L * 2 * PL.pl;
+    // m16: [batch][n*ldd + d*ldn] shorts — bT16 then b16 of each lattice
+    PL.bT16   = m16 + (size_t)L * ((size_t)P.n * P.ldd + (size_t)P.d * P.ldn);
+    PL.b16    = PL.bT16 + (size_t)P.n * P.ldd;
+    PL.flag16 = flag16 + (size_t)L * P.d;
+    PL.np16   = 0;
     S.dummy = (const char *)T.b32;
     if (mode != 2)
     {  // narrow prefix from the per-row flags (FPHIP_GSO_NARROW=0: P.use_narrow == 0)
@@ -961,6 +1094,10 @@ __global__ void __launch_bounds__(256, Cfg<NQ>::WAVES_PER_SIMD)
       while (P.use_narrow && p < P.d && __builtin_amdgcn_readfirstlane(T.narrow_flag[p]) != 0)
         ++p;
       T.np = p;
+      p    = 0;
+      while (P.use_narrow > 1 && p < P.d && __builtin_amdgcn_readfirstlane(PL.flag16[p]) != 0)
+        ++p;
+      PL.np16 = p;  // (use_narrow: 0 = 8-byte arrays only, 1 = 4-byte mirrors, 2 = 2-byte mirrors too)
     }
     int status = 1;
     if (mode == 2)
@@ -975,6 +1112,7 @@ __global__ void __launch_bounds__(256, Cfg<NQ>::WAVES_PER_SIMD)
           bv[q]       = (c < P.n) ? T.b[(size_t)i * P.ldn + c] : 0;
         }
         store_row_and_refloat<NQ, true>(T, i, bv);
+        store_mirror16<NQ>(T, PL, i, bv);
       }
     }
     else
@@ -1005,10 +1143,10 @@ __global__ void __launch_bounds__(256, Cfg<NQ>::WAVES_PER_SIMD)
   }
 }
 
-template __global__ void gso_sweep2_kernel<1>(GsoBatch, unsigned *, unsigned *, int, int, double, int);
-template __global__ void gso_sweep2_kernel<2>(GsoBatch, unsigned *, unsigned *, int, int, double, int);
-template __global__ void gso_sweep2_kernel<3>(GsoBatch, unsigned *, unsigned *, int, int, double, int);
-template __global__ void gso_sweep2_kernel<4>(GsoBatch, unsigned *, unsigned *, int, int, double, int);
+template __global__ void gso_sweep2_kernel<1>(GsoBatch, unsigned *, unsigned *, short *, int *, int, int, double, int);
+template __global__ void gso_sweep2_kernel<2>(GsoBatch, unsigned *, unsigned *, short *, int *, int, int, double, int);
+template __global__ void gso_sweep2_kernel<3>(GsoBatch, unsigned *, unsigned *, short *, int *, int, int, double, int);
+template __global__ void gso_sweep2_kernel<4>(GsoBatch, unsigned *, unsigned *, short *, int *, int, int, double, int);
 
 }  // namespace s2
 }  // namespace fphip

@@ -12,6 +12,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+# background device runs shared between test_a_configs_at_size_gpu.py (starts them) and
+# test_zzz_long_runs_gpu.py (joins them)
+LONG_RUNS = {}
 
 
 def pytest_configure(config):

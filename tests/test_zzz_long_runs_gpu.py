@@ -1,0 +1,30 @@
+"""Joins the two long device runs that tests/test_a_configs_at_size_gpu.py started at the beginning of
+the GPU suite, and compares them with the reference's goldens:
+
+  config 3  one BKZ-60 tour with the pruner strategies of the 180-dim q-ary lattice on the device
+            (fplll/bkz.cpp:274-399, 522-672): basis, status, 1 224 293 770 nodes = the reference's
+  config 5  HLLL of the 256-dim NTRU-like lattice in double, the reference's summation order
+            (fplll/hlll.cpp:26-173): basis, status, 146 491 swaps — the NQ = 4 instantiation of the
+            exact HLLL kernel"""
+import pytest
+
+import conftest as C
+
+pytestmark = pytest.mark.gpu
+
+
+def test_config3_bkz60_tour_and_config5_hlll_match_reference():
+    if "thread_c3" not in C.LONG_RUNS:
+        pytest.skip("the long runs were not started (tests/test_a_configs_at_size_gpu.py deselected)")
+    for n in ("c3", "c5"):
+        C.LONG_RUNS["thread_" + n].join(1100)
+        assert not C.LONG_RUNS["thread_" + n].is_alive(), "the %s run did not finish" % n
+        assert n + "_error" not in C.LONG_RUNS, C.LONG_RUNS.get(n + "_error")
+    c3, c5 = C.LONG_RUNS["c3"], C.LONG_RUNS["c5"]
+    print("config 3 tour: %.1f s on the device (reference %.1f s on one core), %d nodes; "
+          "config 5 HLLL (double, exact order): %.1f s (reference %.1f s), %d swaps"
+          % (c3["wall"], c3["ref_s"], c3["nodes"][0], c5["wall"], c5["ref_s"], c5["swaps"][0]))
+    assert c3["st"] == [c3["expect"][0]] * 2 and c3["nodes"] == [c3["expect"][1]] * 2
+    assert c3["expect"][1] == 1224293770 and all(c3["basis_ok"])
+    assert c5["st"] == [c5["expect"]] * 2 == [1, 1] and c5["swaps"] == [146491] * 2
+    assert all(c5["basis_ok"])
