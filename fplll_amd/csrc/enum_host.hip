@@ -138,7 +138,7 @@ extern "C" int fphip_create(int device, fphip_ctx **out)
   HIPCHK(ctx, fphip_dev_alloc((void **)&ctx->keys, (size_t)ctx->cap * sizeof(unsigned long long), ctx->stream));
   HIPCHK(ctx, fphip_dev_alloc((void **)&ctx->idxlist, (size_t)ctx->cap * sizeof(unsigned), ctx->stream));
   HIPCHK(ctx, fphip_dev_alloc((void **)&ctx->xhi_root, (size_t)ctx->cap * 64 * sizeof(double), ctx->stream));
-  HIPCHK(ctx, hipMemset(ctx->xhi_root, 0, 64 * sizeof(double)));
+  HIPCHK(ctx, hipMemsetAsync(ctx->xhi_root, 0, 64 * sizeof(double), ctx->stream));
   HIPCHK(ctx, hipFuncSetAttribute((const void *)enum_phase_kernel<true, false>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(ctx, hipFuncSetAttribute((const void *)enum_phase_kernel<false, false>,

@@ -745,6 +745,44 @@ extern "C" int fphip_gso_bkz(fphip_gso *g, int block_size, double delta, double 
 // flight: the radius / pruning decision (host libm: log, exp, lgamma, pow — the reference's own
 // roundings) and the rerandomisation plan (drawn from the caller's generator, rnd(user, lattice,
 // n) = gmp_urandomm_ui(state of that lattice, n)).
+// Pinned, host-coherent buffers (mailboxes) are CACHED for the life of the process: hipHostMalloc /
+// hipHostFree synchronise the whole device like hipFree does (dev_mem.h), and a strategy-BKZ call
+// must not wait for another context's kernel.
+#include <mutex>
+namespace
+{
+struct PinnedBuf
+{
+  void *p;
+  size_t bytes;
+  bool busy;
+};
+std::mutex g_pinned_mutex;
+std::vector<PinnedBuf> g_pinned;
+void *pinned_get(size_t bytes)
+{
+  std::lock_guard<std::mutex> lk(g_pinned_mutex);
+  for (PinnedBuf &b : g_pinned)
+    if (!b.busy && b.bytes >= bytes)
+    {
+      b.busy = true;
+      return b.p;
+    }
+  void *p = nullptr;
+  if (hipHostMalloc(&p, bytes, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess)
+    return nullptr;
+  g_pinned.push_back(PinnedBuf{p, bytes, true});
+  return p;
+}
+void pinned_put(void *p)
+{
+  std::lock_guard<std::mutex> lk(g_pinned_mutex);
+  for (PinnedBuf &b : g_pinned)
+    if (b.p == p)
+      b.busy = false;
+}
+}  // namespace
+
 // ---------------------------------------------------------------------------------------------
 namespace
 {
@@ -1002,7 +1040,7 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
     fphip_dev_free(d_coeff, fphip_ctx_stream(g->ctx));
     fphip_dev_free(d_abort, fphip_ctx_stream(g->ctx));
     if (mail)
-      hipHostFree(mail);
+      pinned_put(mail);
   };
 #define BCHK(call)                         \
   do                                       \
@@ -1036,9 +1074,14 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
     DS.coeff_off      = d_coeff_off;
     DS.coeff          = d_coeff;
   }
-  BCHK(fphip_dev_alloc((void **)&d_abort, sizeof(int), fphip_ctx_stream(g->ctx)));
-  BCHK(hipMemset(d_abort, 0, sizeof(int)));
-  BCHK(hipHostMalloc((void **)&mail, B * sizeof(BkzMail), hipHostMallocCoherent | hipHostMallocMapped));
+  BCHK(fphip_dev_alloc((void **)&d_abort, sizeof(int), fphip_ctx_stream(g->ctx)));  // (cleared before every launch)
+  mail = (BkzMail *)pinned_get(B * sizeof(BkzMail));
+  if (!mail)
+  {
+    cleanup();
+    snprintf(fphip_ctx_errbuf(g->ctx), 512, "bkz_strategies: no pinned memory for %zu mailboxes", B);
+    return FPHIP_ERROR;
+  }
   memset(mail, 0, B * sizeof(BkzMail));
 
   const int need = (g->P.d > g->P.n ? g->P.d : g->P.n);
@@ -1348,9 +1391,10 @@ static int hh_allocate(fphip_hh *h)
   HCHK(fphip_dev_alloc((void **)&h->P.sigma, B * d * 8, fphip_ctx_stream(h->ctx)));
   HCHK(fphip_dev_alloc((void **)&h->P.rexp, B * d * 8, fphip_ctx_stream(h->ctx)));
   HCHK(fphip_dev_alloc((void **)&h->P.status, B * sizeof(int), fphip_ctx_stream(h->ctx)));
-  HCHK(hipMemset(h->P.b, 0, B * d * ld * 8 + pad));
-  HCHK(hipMemset(h->P.V, 0, B * d * ld * 8 + pad));
-  HCHK(hipMemset(h->P.R, 0, B * d * ld * 8 + pad));
+  HCHK(hipMemsetAsync(h->P.b, 0, B * d * ld * 8 + pad, fphip_ctx_stream(h->ctx)));
+  HCHK(hipMemsetAsync(h->P.V, 0, B * d * ld * 8 + pad, fphip_ctx_stream(h->ctx)));
+  HCHK(hipMemsetAsync(h->P.R, 0, B * d * ld * 8 + pad, fphip_ctx_stream(h->ctx)));
+  HCHK(hipStreamSynchronize(fphip_ctx_stream(h->ctx)));  // uploads use blocking copies on the null stream
   HCHK(hipEventCreate(&h->ev[0]));
   HCHK(hipEventCreate(&h->ev[1]));
   return FPHIP_OK;
