@@ -24,12 +24,12 @@
 
 namespace fphip
 {
-template <bool MU_LDS, bool SUBS>
+template <bool MU_LDS, bool SUBS, bool DUAL>
 __global__ void enum_phase_kernel(DevShared *g, HostCtl *h, TaskBuf in, TaskBuf out, int d,
                                   int Lmax, int stop, unsigned task_lo, unsigned task_hi,
                                   const unsigned *idxlist, int launch_idx, int count_nodes,
                                   unsigned budget, const double *xhi_root);
-template <bool SUBS>
+template <bool SUBS, bool DUAL>
 __global__ void enum_top_kernel(DevShared *g, HostCtl *h, TopBuf in, unsigned n_in, TopBuf out_top,
                                 int stop, TaskBuf out, double *xhi_root, int d, double maxdist,
                                 int count_nodes, int launch_idx);
@@ -139,13 +139,17 @@ extern "C" int fphip_create(int device, fphip_ctx **out)
   HIPCHK(ctx, fphip_dev_alloc((void **)&ctx->idxlist, (size_t)ctx->cap * sizeof(unsigned), ctx->stream));
   HIPCHK(ctx, fphip_dev_alloc((void **)&ctx->xhi_root, (size_t)ctx->cap * 64 * sizeof(double), ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(ctx->xhi_root, 0, 64 * sizeof(double), ctx->stream));
-  HIPCHK(ctx, hipFuncSetAttribute((const void *)enum_phase_kernel<true, false>,
+  HIPCHK(ctx, hipFuncSetAttribute((const void *)enum_phase_kernel<true, false, false>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  HIPCHK(ctx, hipFuncSetAttribute((const void *)enum_phase_kernel<false, false>,
+  HIPCHK(ctx, hipFuncSetAttribute((const void *)enum_phase_kernel<false, false, false>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  HIPCHK(ctx, hipFuncSetAttribute((const void *)enum_phase_kernel<true, true>,
+  HIPCHK(ctx, hipFuncSetAttribute((const void *)enum_phase_kernel<true, true, false>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  HIPCHK(ctx, hipFuncSetAttribute((const void *)enum_phase_kernel<false, true>,
+  HIPCHK(ctx, hipFuncSetAttribute((const void *)enum_phase_kernel<false, true, false>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(ctx, hipFuncSetAttribute((const void *)enum_phase_kernel<true, false, true>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(ctx, hipFuncSetAttribute((const void *)enum_phase_kernel<false, false, true>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   return FPHIP_OK;
 }
@@ -376,8 +380,14 @@ extern "C" int fphip_enum_run(fphip_ctx *ctx, int dim, double maxdist, const dou
   if (o.exchange_chunks <= 0)
     o.exchange_chunks = 1;
   const int d = dim;
-  if (d < 2 || d > FPHIP_ENUM_MAX_DIM || o.dual || (o.findsubsols && !subcb))
+  if (d < 2 || d > FPHIP_ENUM_MAX_DIM || (o.findsubsols && !subcb))
     return FPHIP_UNSUPPORTED;  // → ~uint64_t(0): fplll falls back (enumerate_ext.cpp:88)
+  // dual enumeration (enumerate_base.cpp:57-61, 103-105; the caller passes the transformed mu / r of
+  // enumerate.cpp:107-123): without sub-solutions, as the reference's dual caller has it
+  // (BKZReduction's evaluator is built with find_subsolutions = false, bkz.cpp:327-331)
+  const bool dual = o.dual != 0;
+  if (dual && o.findsubsols)
+    return FPHIP_UNSUPPORTED;
   const bool subs = o.findsubsols != 0;
   if (!(maxdist >= 0.0))
     return FPHIP_UNSUPPORTED;
@@ -478,12 +488,16 @@ extern "C" int fphip_enum_run(fphip_ctx *ctx, int dim, double maxdist, const dou
     auto top_launch = [&](int in_idx, unsigned n_in, int stop, unsigned grid) -> int
     {
       HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-      if (subs)
-        hipLaunchKernelGGL(enum_top_kernel<true>, dim3(grid), dim3(64), tlds, ctx->stream, ctx->g,
+      if (dual)
+        hipLaunchKernelGGL((enum_top_kernel<false, true>), dim3(grid), dim3(64), tlds, ctx->stream, ctx->g,
+                           ctx->h, ctx->top[in_idx], n_in, ctx->top[in_idx ^ 1], stop, ctx->buf[cur],
+                           ctx->xhi_root, d, maxdist, top_count, launch_idx);
+      else if (subs)
+        hipLaunchKernelGGL((enum_top_kernel<true, false>), dim3(grid), dim3(64), tlds, ctx->stream, ctx->g,
                            ctx->h, ctx->top[in_idx], n_in, ctx->top[in_idx ^ 1], stop, ctx->buf[cur],
                            ctx->xhi_root, d, maxdist, top_count, launch_idx);
       else
-        hipLaunchKernelGGL(enum_top_kernel<false>, dim3(grid), dim3(64), tlds, ctx->stream, ctx->g,
+        hipLaunchKernelGGL((enum_top_kernel<false, false>), dim3(grid), dim3(64), tlds, ctx->stream, ctx->g,
                            ctx->h, ctx->top[in_idx], n_in, ctx->top[in_idx ^ 1], stop, ctx->buf[cur],
                            ctx->xhi_root, d, maxdist, top_count, launch_idx);
       HIPCHK(ctx, hipGetLastError());
@@ -646,18 +660,22 @@ extern "C" int fphip_enum_run(fphip_ctx *ctx, int dim, double maxdist, const dou
       {
         HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
         const unsigned bud = (in_final && round < max_rounds) ? budget : 0u;
-#define FPHIP_LAUNCH(M, S)                                                                          \
-  hipLaunchKernelGGL((enum_phase_kernel<M, S>), dim3(grid), dim3(wpb * 64), lds, ctx->stream, ctx->g, \
+#define FPHIP_LAUNCH(M, S, D)                                                                       \
+  hipLaunchKernelGGL((enum_phase_kernel<M, S, D>), dim3(grid), dim3(wpb * 64), lds, ctx->stream, ctx->g, \
                      ctx->h, ctx->buf[cur], ctx->buf[nxt], d, L, stop, lo, hi, idxl, launch_idx,     \
                      count_nodes, bud, ctx->xhi_root)
-        if (mu_lds && !subs)
-          FPHIP_LAUNCH(true, false);
+        if (dual && mu_lds)
+          FPHIP_LAUNCH(true, false, true);
+        else if (dual)
+          FPHIP_LAUNCH(false, false, true);
+        else if (mu_lds && !subs)
+          FPHIP_LAUNCH(true, false, false);
         else if (!mu_lds && !subs)
-          FPHIP_LAUNCH(false, false);
+          FPHIP_LAUNCH(false, false, false);
         else if (mu_lds)
-          FPHIP_LAUNCH(true, true);
+          FPHIP_LAUNCH(true, true, false);
         else
-          FPHIP_LAUNCH(false, true);
+          FPHIP_LAUNCH(false, true, false);
 #undef FPHIP_LAUNCH
         HIPCHK(ctx, hipGetLastError());
         HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));

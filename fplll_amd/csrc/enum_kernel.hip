@@ -85,7 +85,10 @@ __device__ __forceinline__ unsigned long long load_sys_u64(const unsigned long l
 //       loop in CHILD with the child as the current node.
 //   STEP(k): the subtree below the current coefficient x[k] is exhausted — advance x[k] in
 //       zig-zag order (:80-89), test (:91-94): fail → STEP(k+1), survive → CHILD.
-template <bool MU_LDS, bool SUBS>
+// DUAL: the dualenum instantiation of the recursion (enumerate_base.cpp:57-61, 103-105): the centre
+// partial sums are driven by alpha = x - c instead of x; the inputs are then the transformed mu / r
+// EnumerationDyn::enumerate builds for a dual call (enumerate.cpp:107-123).
+template <bool MU_LDS, bool SUBS, bool DUAL>
 __global__ void __launch_bounds__(FPHIP_MAX_BLOCK)
     enum_phase_kernel(DevShared *__restrict__ g, HostCtl *__restrict__ h, TaskBuf in, TaskBuf out,
                       int d, int Lmax, int stop, unsigned task_lo, unsigned task_hi,
@@ -352,7 +355,7 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK)
           rep = nd > 0.0;  // process_solution, :42-46
           break;           // level 0 has no children: next sibling
         }
-        S = S - x1 * mk1;  // S_k = S_{k+1} - x[k]*mu(k,·), :53-58 (k >= 1 here: mk1 is row k)
+        S = S - (DUAL ? a1 : x1) * mk1;  // S_k = S_{k+1} - x[k]*mu(k,·), :53-58 (k >= 1 here: mk1 is row k)
       }
       if (done)
         break;
@@ -430,7 +433,7 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK)
           }
           continue;
         }
-        S = par - xk * mk;  // :104-110
+        S = par - (DUAL ? a : xk) * mk;  // :104-110
         break;              // → CHILD chain
       }
     }
@@ -443,14 +446,16 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK)
     atomicAdd(&g->iters, (unsigned long long)iter);
 }
 
-#define FPHIP_INST(M, S)                                                                            \
-  template __global__ void enum_phase_kernel<M, S>(DevShared *, HostCtl *, TaskBuf, TaskBuf, int,  \
-                                                   int, int, unsigned, unsigned, const unsigned *,  \
-                                                   int, int, unsigned, const double *);
-FPHIP_INST(true, false)
-FPHIP_INST(false, false)
-FPHIP_INST(true, true)
-FPHIP_INST(false, true)
+#define FPHIP_INST(M, S, D)                                                                            \
+  template __global__ void enum_phase_kernel<M, S, D>(DevShared *, HostCtl *, TaskBuf, TaskBuf, int,  \
+                                                      int, int, unsigned, unsigned, const unsigned *,  \
+                                                      int, int, unsigned, const double *);
+FPHIP_INST(true, false, false)
+FPHIP_INST(false, false, false)
+FPHIP_INST(true, true, false)
+FPHIP_INST(false, true, false)
+FPHIP_INST(true, false, true)
+FPHIP_INST(false, false, true)
 #undef FPHIP_INST
 
 // ---------------------------------------------------------------------------------------------
@@ -474,7 +479,7 @@ __device__ __forceinline__ int rl2i(const int (&v)[2], int idx)
   return idx < 64 ? rl_i32(v[0], idx) : rl_i32(v[1], idx - 64);
 }
 
-template <bool SUBS>
+template <bool SUBS, bool DUAL>
 __global__ void __launch_bounds__(64)
     enum_top_kernel(DevShared *__restrict__ g, HostCtl *__restrict__ h, TopBuf in, unsigned n_in,
                     TopBuf out_top, int stop, TaskBuf out, double *__restrict__ xhi_root, int d,
@@ -640,7 +645,7 @@ __global__ void __launch_bounds__(64)
         for (int q = 0; q < 2; ++q)
         {
           const double mk = mu[tri_off(k) + min(lane + 64 * q, k - 1)];
-          S[q]            = S[q] - x1 * mk;
+          S[q]            = S[q] - (DUAL ? a1 : x1) * mk;
         }
       }
       if (done)
@@ -700,7 +705,7 @@ __global__ void __launch_bounds__(64)
         }
 #pragma unroll
         for (int q = 0; q < 2; ++q)
-          S[q] = par[q] - xk * mk[q];
+          S[q] = par[q] - (DUAL ? a : xk) * mk[q];
         break;
       }
     }
@@ -713,10 +718,12 @@ __global__ void __launch_bounds__(64)
         atomicAdd(&g->nodes[lane + 64 * q], cnt[q]);
   }
 }
-template __global__ void enum_top_kernel<false>(DevShared *, HostCtl *, TopBuf, unsigned, TopBuf, int,
-                                                TaskBuf, double *, int, double, int, int);
-template __global__ void enum_top_kernel<true>(DevShared *, HostCtl *, TopBuf, unsigned, TopBuf, int,
-                                               TaskBuf, double *, int, double, int, int);
+template __global__ void enum_top_kernel<false, false>(DevShared *, HostCtl *, TopBuf, unsigned, TopBuf,
+                                                       int, TaskBuf, double *, int, double, int, int);
+template __global__ void enum_top_kernel<true, false>(DevShared *, HostCtl *, TopBuf, unsigned, TopBuf,
+                                                      int, TaskBuf, double *, int, double, int, int);
+template __global__ void enum_top_kernel<false, true>(DevShared *, HostCtl *, TopBuf, unsigned, TopBuf,
+                                                      int, TaskBuf, double *, int, double, int, int);
 
 // 64-bit content key of every task (its coefficient prefix x[Lt..d)): the task ORDER in the buffer
 // is not deterministic across ranks, the content is.  One wave per task.

@@ -78,7 +78,12 @@ typedef double (*fphip_exchange_cb)(void *user, double local_bound, int local_ac
 
 typedef struct fphip_enum_opts
 {
-  int dual;        /* 1 → declined (the reference adapter does not transform mu/r for dual) */
+  int dual;        /* 1 → the dualenum recursion (enumerate_base.cpp:57-61,103-105) on inputs the caller has
+                      already transformed as EnumerationDyn::enumerate does (mu negated and index-reversed,
+                      r inverted and reversed, enumerate.cpp:107-123); solutions arrive in that reversed
+                      index order (the caller reverses them, enumerate.cpp:154-158).  Declined together
+                      with findsubsols.  The extenum plugin (fplll_hip_extenum) still declines dual calls:
+                      the reference's adapter hands a plugin untransformed mu/r (enumerate_ext.cpp:57-74) */
   int findsubsols; /* 1 → sub-solutions are reported through subcb (must be non-NULL) */
   /* subtree sharding across GPUs: the (cheap) top-of-tree phases are replicated on every rank, so
    * all ranks hold the same task SET; the tasks of the first walk round are sorted by content

@@ -262,3 +262,10 @@ int64_t oracle_enumerate_dual(int d, const double *mut, const double *rdiag, con
 {
   return enumerate_impl(d, mut, rdiag, pruning, maxdist, 0, NULL, NULL, NULL, nodes, best_sol, best_dist, 1);
 }
+
+/* the same with a caller-supplied evaluator callback (the tests' Python evaluators) */
+int64_t oracle_enumerate_dual_cb(int d, const double *mut, const double *rdiag, const double *pruning,
+                                 double maxdist, oracle_sol_cb cb, void *user, uint64_t *nodes)
+{
+  return enumerate_impl(d, mut, rdiag, pruning, maxdist, 0, cb, NULL, user, nodes, NULL, NULL, 1);
+}

@@ -52,6 +52,8 @@ int64_t oracle_enumerate(int d, const double *mut, const double *rdiag, const do
  * built-in FastEvaluator(1).  The caller reverses best_sol (enumerate.cpp:154-158). */
 int64_t oracle_enumerate_dual(int d, const double *mut, const double *rdiag, const double *pruning,
                               double maxdist, uint64_t *nodes, double *best_sol, double *best_dist);
+int64_t oracle_enumerate_dual_cb(int d, const double *mut, const double *rdiag, const double *pruning,
+                                 double maxdist, oracle_sol_cb cb, void *user, uint64_t *nodes);
 
 /* ------------------------------------------------------------------------------------------
  * GSO / size reduction for ZT=long, FT=double, GSO_ROW_EXPO on (the BKZ fast path,

@@ -66,6 +66,11 @@ def oracle_lib():
             ctypes.c_int, SOLCB, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
             ctypes.c_void_p
         ]
+        lib.oracle_enumerate_dual_cb.restype = ctypes.c_int64
+        lib.oracle_enumerate_dual_cb.argtypes = [
+            ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double, SOLCB,
+            ctypes.c_void_p, ctypes.c_void_p
+        ]
         _oracle = lib
     return _oracle
 
@@ -128,8 +133,9 @@ SUBSOLCB = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_double, ctypes.POINT
                             ctypes.c_int)
 
 
-def oracle_enumerate(mut, rdiag, pruning, maxdist, evaluator, log=None, findsubsols=False):
-    """Run the C oracle with a Python evaluator (same protocol as the device path)."""
+def oracle_enumerate(mut, rdiag, pruning, maxdist, evaluator, log=None, findsubsols=False, dual=False):
+    """Run the C oracle with a Python evaluator (same protocol as the device path).  dual: the
+    dualenum recursion on already transformed inputs (enumerate.cpp:107-123)."""
     lib = oracle_lib()
     mut = np.ascontiguousarray(mut, dtype=np.float64)
     d = mut.shape[0]
@@ -153,6 +159,12 @@ def oracle_enumerate(mut, rdiag, pruning, maxdist, evaluator, log=None, findsubs
     c = SOLCB(cb)
     sc = SUBSOLCB(subcb) if findsubsols else None
     nodes = np.zeros(d + 1, dtype=np.uint64)
+    if dual:
+        assert not findsubsols
+        lib.oracle_enumerate_dual_cb(d, mut.ctypes.data_as(ctypes.c_void_p),
+                                     rdiag.ctypes.data_as(ctypes.c_void_p), pr, ctypes.c_double(maxdist),
+                                     c, None, nodes.ctypes.data_as(ctypes.c_void_p))
+        return nodes, state["m"]
     lib.oracle_enumerate(d, mut.ctypes.data_as(ctypes.c_void_p), rdiag.ctypes.data_as(ctypes.c_void_p),
                          pr, ctypes.c_double(maxdist), 1 if findsubsols else 0, c, sc, None,
                          nodes.ctypes.data_as(ctypes.c_void_p), None, None)

@@ -162,8 +162,9 @@ def test_edge_cases(ctx):
     for d in (1, 129, 200):
         with pytest.raises(Unsupported):
             enumerate_block(ctx, np.zeros((d, d)), np.ones(d), None, 1.0, FastEvaluator(1, 0))
-    with pytest.raises(Unsupported):
-        enumerate_block(ctx, np.zeros((8, 8)), np.ones(8), None, 1.0, FastEvaluator(1, 0), dual=True)
+    with pytest.raises(Unsupported):  # dual + sub-solutions: the reference never asks for it
+        enumerate_block(ctx, np.zeros((8, 8)), np.ones(8), None, 1.0, FastEvaluator(1, 0), dual=True,
+                        findsubsols=True)
     # orthogonal basis (mu = 0): the count is the number of half-space lattice points in the ball
     d = 6
     mut, rdiag, _ = C.synthetic_block(d, 1, 0.0, 1.0)
@@ -340,3 +341,63 @@ def test_plugin_in_process_multi_device():
             out = subprocess.run([drv, "plugin", so] + c.split(), capture_output=True, text=True,
                                  timeout=600, env=env)
             assert out.returncode == 0, (devs, c, out.stdout[-2000:], out.stderr[-2000:])
+
+
+def _dual_inputs(mut, rdiag):
+    """EnumerationDyn::enumerate's transformation for a dual call (enumerate.cpp:107-123)."""
+    d = len(rdiag)
+    rd = np.zeros(d)
+    mt = np.zeros((d, d))
+    for i in range(d):
+        rd[d - i - 1] = 1.0 / rdiag[i]
+        for j in range(i + 1, d):
+            mt[d - j - 1, d - i - 1] = -mut[i, j]
+    return mt, rd
+
+
+@pytest.mark.parametrize("d,seed,slope,rf,c", [
+    (3, 21, 0.05, 4.0, None), (24, 22, 0.03, 1.5, None), (48, 23, 0.05, 1.12, 1.0),
+    (64, 24, 0.055, 1.02, 1.25), (72, 25, 0.05, 1.0, 1.3), (96, 26, 0.045, 0.86, 1.45)])
+def test_dual_fixed_bound_counts_equal_oracle(ctx, d, seed, slope, rf, c):
+    """Dual enumeration through the C ABI (opts.dual): per-level node counts and
+    the multiset of candidates equal the oracle's dualenum walk (pinned against the reference through
+    the self-dual BKZ fixtures, test_bkz_dual_variants_oracle_vs_ref.py); the sizes above 64 take the
+    top-walk kernel."""
+    from fplll_amd.enumeration import FastEvaluator, enumerate_block
+    mut, rdiag, _ = C.synthetic_block(d, seed, slope, rf)
+    mt, rd = _dual_inputs(mut, rdiag)
+    import math
+    log_gh2 = (2.0 / d) * math.lgamma(d / 2.0 + 1.0) - math.log(math.pi) + np.log(rd).mean()
+    maxdist = float(rf * math.exp(log_gh2))
+    pruning = _lin_pruning(d, c)
+    ev_o, log_o = FastEvaluator(10**9, 0), []
+    nodes_o, _ = C.oracle_enumerate(mt, rd, pruning, maxdist, ev_o, log_o, dual=True)
+    ev, log = FastEvaluator(10**9, 0), []
+    res = enumerate_block(ctx, mt, rd, pruning, maxdist, ev, log=log, dual=True)
+    assert [int(v) for v in res.nodes] == [int(v) for v in nodes_o]
+    assert sorted((a, tuple(b)) for a, b in log) == sorted((a, tuple(b)) for a, b in log_o)
+    if 24 <= d <= 64:  # ... and the dual walk is a different walk from the primal one on these inputs
+        nodes_p, _ = C.oracle_enumerate(mt, rd, pruning, maxdist, FastEvaluator(10**9, 0))
+        assert [int(v) for v in nodes_o] != [int(v) for v in nodes_p]
+
+
+def test_dual_svp_kat_device(ctx):
+    """The reference's dual-SVP known answer (tests/lattices/example_dsvp_in/out, tests/test_svp.cpp:
+    214-262) through the device's dual enumeration: the shortest dual vector it finds has exactly the
+    KAT's length, and the run equals the oracle's on the same transformed inputs."""
+    import test_reference_kats as K
+    from fplll_amd.enumeration import FastEvaluator, enumerate_block
+    basis, answer = K.load("dsvp")
+    target = K.exact_dual_norm2(basis, answer)
+    b = K.lll(basis)
+    mut, rdiag = K.enum_input(b)
+    d = b.shape[0]
+    mt, rd = _dual_inputs(mut, rdiag)
+    maxdist = float(rd[0] * 1.0001)  # the dual vector d_{n-1} itself is inside
+    ev_o = FastEvaluator(1, 0)
+    _, m_o = C.oracle_enumerate(mt, rd, None, maxdist, ev_o, dual=True)
+    ev = FastEvaluator(1, 0)
+    res = enumerate_block(ctx, mt, rd, None, maxdist, ev, dual=True)
+    assert ev.solutions and res.final_maxdist == m_o
+    x = [int(v) for v in ev.solutions[0][1]][::-1]  # enumerate.cpp:154-158: reversed for dual
+    assert K.exact_dual_norm2(b, x) == target
