@@ -234,18 +234,24 @@ bkzs_body(GsoBatch P, BkzStrat S, BkzMail *mailbox, int *abort_flag, int block_s
       // The wait is bounded by the host's LIVENESS, not by its speed: the service thread bumps
       // mailbox[0].heartbeat on every sweep over the mailboxes (one thread serves the whole batch,
       // a sweep can take long when thousands of lattices rerandomise at once or `rnd` is a Python
-      // callable); a wave gives up only when that word has stood still for ~2^20 polls.
-      unsigned long long hb = mail_load_u64(&mailbox[0].heartbeat);
-      for (unsigned spin = 0, still = 0; mail_load_u64(&mail->rsp_seq) < mail_seq; ++spin)
+      // callable); a wave gives up only when that word has stood still for 30 s of wall clock
+      // (s_memrealtime, 100 MHz) — poll counts are no measure: a loaded host stalls for seconds.
+      unsigned long long hb     = mail_load_u64(&mailbox[0].heartbeat);
+      unsigned long long t_live = wall_clock64();
+      for (unsigned spin = 0; mail_load_u64(&mail->rsp_seq) < mail_seq; ++spin)
       {
         __builtin_amdgcn_s_sleep(32);
+        bool dead = false;
         if ((spin & 63u) == 63u)
         {
-          const unsigned long long h2 = mail_load_u64(&mailbox[0].heartbeat);
-          still                        = (h2 == hb) ? still + 64u : 0u;
-          hb                           = h2;
+          const unsigned long long h2  = mail_load_u64(&mailbox[0].heartbeat);
+          const unsigned long long now = wall_clock64();
+          if (h2 != hb)
+            t_live = now;
+          hb   = h2;
+          dead = uni((int)(now - t_live > 3000000000ull)) != 0;
         }
-        if (still > (1u << 20) || (spin & 1023u) == 1023u && uni(__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)))
+        if (dead || (spin & 1023u) == 1023u && uni(__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)))
         {  // the host is gone: every wave gives up (one timeout, not one per lattice)
           ok = false;
           if (lane == 0)

@@ -748,7 +748,9 @@ extern "C" int fphip_gso_bkz(fphip_gso *g, int block_size, double delta, double 
 // Pinned, host-coherent buffers (mailboxes) are CACHED for the life of the process: hipHostMalloc /
 // hipHostFree synchronise the whole device like hipFree does (dev_mem.h), and a strategy-BKZ call
 // must not wait for another context's kernel.
+#include <atomic>
 #include <mutex>
+#include <thread>
 namespace
 {
 struct PinnedBuf
@@ -1162,31 +1164,43 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
     }
     GCHK(hipGetLastError());
     GCHK(hipEventRecord(g->ev[1], s));
-    for (;;)
-    {  // serve the mailboxes while the kernel runs
-      for (size_t L = 0; L < B; ++L)
+    // Serve the mailboxes while the kernel runs, from a thread of its own that makes NO HIP call:
+    // the kernel's liveness test watches mail[0].heartbeat, and a HIP call (even hipStreamQuery)
+    // can stall for seconds behind another host thread's runtime work in the same process
+    // (measured: the config-3 tour timed out next to the rest of the GPU test suite).  This thread
+    // only waits for the stream.
+    std::atomic<bool> stop{false};
+    std::thread server([&]()
+    {
+      for (;;)
       {
-        BkzMail *m = &mail[L];
-        const unsigned long long seq = __atomic_load_n(&m->req_seq, __ATOMIC_ACQUIRE);
-        if (seq == handled[L])
-          continue;
-        if (m->type == 1)
-          serve_radius(H, m);
-        else if (m->type == 2 && serve_plan(H, (int)L, m) < 0)
-        {  // unusable generator: answer with an empty plan, report the error after the launch
-          m->n_moves = m->n_ops = 0;
-          rnd_failed            = true;
+        const bool last = stop.load(std::memory_order_acquire);  // one more sweep after the kernel ended
+        for (size_t L = 0; L < B; ++L)
+        {
+          BkzMail *m = &mail[L];
+          const unsigned long long seq = __atomic_load_n(&m->req_seq, __ATOMIC_ACQUIRE);
+          if (seq == handled[L])
+            continue;
+          if (m->type == 1)
+            serve_radius(H, m);
+          else if (m->type == 2 && serve_plan(H, (int)L, m) < 0)
+          {  // unusable generator: answer with an empty plan, report the error after the launch
+            m->n_moves = m->n_ops = 0;
+            rnd_failed            = true;
+          }
+          handled[L] = seq;
+          __atomic_store_n(&m->rsp_seq, seq, __ATOMIC_RELEASE);
         }
-        handled[L] = seq;
-        __atomic_store_n(&m->rsp_seq, seq, __ATOMIC_RELEASE);
+        __atomic_store_n(&mail[0].heartbeat, ++heartbeat, __ATOMIC_RELEASE);
+        if (last)
+          break;
       }
-      __atomic_store_n(&mail[0].heartbeat, ++heartbeat, __ATOMIC_RELEASE);
-      const hipError_t q = hipStreamQuery(s);
-      if (q == hipSuccess)
-        break;
-      if (q != hipErrorNotReady)
-        return gfail(g->ctx, "bkzs_kernel", q);
-    }
+    });
+    const hipError_t q = hipStreamSynchronize(s);
+    stop.store(true, std::memory_order_release);
+    server.join();
+    if (q != hipSuccess)
+      return gfail(g->ctx, "bkzs_kernel", q);
     GCHK(hipEventElapsedTime(ms, g->ev[0], g->ev[1]));
     GCHK(hipMemcpy(st_out, g->P.status, sizeof(int) * B, hipMemcpyDeviceToHost));
     GCHK(hipMemcpy(info_out, g->P.lll_info, sizeof(int) * 4 * B, hipMemcpyDeviceToHost));
