@@ -50,6 +50,7 @@ struct DevShared
   unsigned int pad;
   unsigned int task_head[FPHIP_MAX_LAUNCHES];
   unsigned int drain[FPHIP_MAX_LAUNCHES];  // set when a launch's task queue ran dry
+  double rp[128][2];  // (rdiag[k], pruning[k]) interleaved: one 16-byte scalar load per level
   double mu_tri[FPHIP_TRI128];  // mu_tri[k(k-1)/2 + i] = mu(k,i), i<k
 };
 

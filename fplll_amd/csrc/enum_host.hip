@@ -28,7 +28,7 @@ template <bool MU_LDS, bool SUBS, bool DUAL>
 __global__ void enum_phase_kernel(DevShared *g, HostCtl *h, TaskBuf in, TaskBuf out, int d,
                                   int Lmax, int stop, unsigned task_lo, unsigned task_hi,
                                   const unsigned *idxlist, int launch_idx, int count_nodes,
-                                  unsigned budget, const double *xhi_root);
+                                  unsigned budget, const double *xhi_root, double *gstk, int Tsplit);
 template <bool SUBS, bool DUAL>
 __global__ void enum_top_kernel(DevShared *g, HostCtl *h, TopBuf in, unsigned n_in, TopBuf out_top,
                                 int stop, TaskBuf out, double *xhi_root, int d, double maxdist,
@@ -54,6 +54,8 @@ struct fphip_ctx
   unsigned *idxlist            = nullptr;  // device: this rank's task indices, heaviest first
   double *xhi_root             = nullptr;  // device: [cap][64] coefficients of levels 64..127 per
                                            // level-64 ancestor (blocks larger than 64)
+  double *gstk                 = nullptr;  // device: per-wave scratch of the tall stack slots (split stack)
+  size_t gstk_doubles          = 0;
   TopBuf top[2] = {};                           // top tasks of blocks larger than 64 (allocated on demand)
   char err[512]                = {0};
   // GSO state lives in gso_host.hip, linked through this opaque slot
@@ -180,6 +182,8 @@ extern "C" void fphip_destroy(fphip_ctx *ctx)
   }
   if (ctx->xhi_root)
     fphip_dev_free(ctx->xhi_root, ctx->stream);
+  if (ctx->gstk)
+    fphip_dev_free(ctx->gstk, ctx->stream);
   for (int b = 0; b < 2; ++b)
   {
     if (ctx->top[b].col)
@@ -428,6 +432,8 @@ extern "C" int fphip_enum_run(fphip_ctx *ctx, int dim, double maxdist, const dou
   {
     st->rdiag[i]   = rdiag[i];
     st->pruning[i] = pruning ? pruning[i] : 1.0;
+    st->rp[i][0]   = st->rdiag[i];  // the walk kernel reads (r_ii, pruning_i) as one scalar load
+    st->rp[i][1]   = st->pruning[i];
     st->sub_bits[i] = dbits(rdiag[i]);  // subsoldists = rdiag, enumerate.cpp:143
   }
   for (int k = 1; k < d; ++k)
@@ -590,10 +596,35 @@ extern "C" int fphip_enum_run(fphip_ctx *ctx, int dim, double maxdist, const dou
     // measured +7 % on a 10^9-node tree with L = 49, but -5..10 % on 3 M-node trees with L = 44)
     const bool mu_lds = C < (unsigned)env_int("FPHIP_MU_GLOBAL_MIN_TASKS", 8192) ||
                         L < env_int("FPHIP_MU_GLOBAL_MIN_LEVEL", 47);
-    const size_t lds  = (size_t)(wpb + (mu_lds ? 1 : 0)) * triL * sizeof(double);
+    // Split stack: the slots k < Ts of the column stack stay in LDS, the tall ones go to a per-wave
+    // scratch in global memory.  Ts is the largest level whose LDS part still lets 32 waves (8 per
+    // SIMD) reside on a CU in the big walk launches (tri_off(36) = 630 doubles = 5 KB per wave); the
+    // split launches and small trees keep the whole stack in LDS.
+    int Ts = L + 1;
+    if (in_final && C >= 1024 && !mu_lds)
+    {
+      const int want = env_int("FPHIP_STACK_SPLIT", 36);
+      if (want > 1 && want < Ts)
+        Ts = want;
+    }
+    const int ldsRow = (Ts * (Ts - 1)) / 2;
+    // (+ one spare double per wave: the slot the lanes beyond a stack row write to)
+    const size_t lds  = ((size_t)(mu_lds ? triL : 0) + (size_t)wpb * ldsRow + (size_t)wpb) * sizeof(double);
     if (lds > 160 * 1024)
       return fail(ctx, "LDS request too large (%zu)", lds);
     int blocks_per_cu = (int)std::max<size_t>(1, std::min<size_t>(32 / wpb, (160 * 1024) / lds));
+    {
+      const size_t per_wave = (size_t)(triL - ldsRow + 1);
+      const size_t need     = per_wave * (size_t)wpb * (size_t)ctx->num_cus * (size_t)blocks_per_cu;
+      if (need > ctx->gstk_doubles)
+      {
+        if (ctx->gstk)
+          fphip_dev_free(ctx->gstk, ctx->stream);
+        ctx->gstk = nullptr;
+        HIPCHK(ctx, fphip_dev_alloc((void **)&ctx->gstk, need * sizeof(double), ctx->stream));
+        ctx->gstk_doubles = need;
+      }
+    }
     const int nxt     = cur ^ 1;
     // only the first final round is sharded across GPUs; donated tasks stay on their GPU
     const bool shard_now = in_final && round == 0 && o.shard_count > 1;
@@ -663,7 +694,7 @@ extern "C" int fphip_enum_run(fphip_ctx *ctx, int dim, double maxdist, const dou
 #define FPHIP_LAUNCH(M, S, D)                                                                       \
   hipLaunchKernelGGL((enum_phase_kernel<M, S, D>), dim3(grid), dim3(wpb * 64), lds, ctx->stream, ctx->g, \
                      ctx->h, ctx->buf[cur], ctx->buf[nxt], d, L, stop, lo, hi, idxl, launch_idx,     \
-                     count_nodes, bud, ctx->xhi_root)
+                     count_nodes, bud, ctx->xhi_root, ctx->gstk, Ts)
         if (dual && mu_lds)
           FPHIP_LAUNCH(true, false, true);
         else if (dual)

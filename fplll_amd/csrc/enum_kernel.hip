@@ -10,9 +10,12 @@
 // ---------------------
 // * One wavefront walks one subtree depth-first.  Control flow (the level k, enter/step mode) is
 //   wave-uniform, so there is no divergence; the 64 lanes are used as DATA lanes:
-//     - lane l of the "level registers" xs/cs/pds/dxs/ddxs/cnt holds the value for tree level l
-//       (x[l], center[l], partdist[l], dx[l], ddx[l], nodes[l]); a level is read with
-//       v_readlane (uniform index in an SGPR) and written with a lane-masked select;
+//     - lane l of the "level registers" xs/cs/pds/dxs/cnt holds the value for tree level l
+//       (x[l], center[l], partdist[l], dx[l], nodes[l]; ddx[l] is always sign(dx[l]) and is not
+//       stored); a level is read with v_readlane (uniform index in an SGPR) and written with
+//       v_writelane (scalar values) or a lane-masked select (vector values);
+//     - (r_ii, pruning_i) of a level come through the scalar cache (one s_load_dwordx4), issued
+//       at the top of a step and waited for right before their use;
 //     - lane i of the "row registers" holds row i of the centre partial sums
 //       center_partsums[i][·] (enumerate_base.h:84).  Choosing x[k] updates ALL rows i<k with one
 //       vector multiply + subtract:  S_k[i] = S_{k+1}[i] - x[k]*mu(k,i).  The reference's lazy
@@ -21,9 +24,20 @@
 //       produced by the same operation sequence (j = d-1 … k, multiply then subtract, no FMA), so
 //       centres, distances, node counts and solutions are bit-identical to the reference.
 // * Backtracking needs S_{k+1} again when the next sibling x[k] is tried, so each wave keeps a
-//   triangular stack of columns S_1..S_L in LDS (slot k holds k doubles, lane i touches only
-//   row i → conflict-free ds_read_b64/ds_write_b64, no cross-lane traffic through LDS).
-//   mu rows (row k = mu(k,0..k-1)) are staged once per workgroup in LDS, same triangular packing.
+//   triangular stack of columns S_1..S_L (slot k holds k doubles, lane i touches only row i →
+//   conflict-free ds_read_b64/ds_write_b64, no cross-lane traffic through LDS).  In the big walk
+//   launches the stack is SPLIT: slots below level 36 (where 9 nodes out of 10 of a pruned tree
+//   live) in LDS, the tall, rarely touched ones in a per-wave scratch in global memory — 5 KB of
+//   LDS per wave instead of 10, i.e. 8 resident waves per SIMD instead of 4.  mu rows (row k =
+//   mu(k,0..k-1), same triangular packing) are staged per workgroup in LDS in the small launches
+//   and read through L1 in the big ones.
+// * The walk is issue-bound, and on this machine the scalar unit issues as slowly as the vector
+//   unit (one instruction per SIMD turn): the two hot loops are written for the SUM of both —
+//   wave-uniform branches only (the file is compiled with -structurizecfg-skip-uniform-regions,
+//   see the comment at the loops), incremental triangular offsets, the step's column / mu row
+//   kept in registers across the CHILD → STEP hand-over, 32-bit level counters.  PMC, round 2:
+//   58 VALU + 38 SALU + 14 branch instructions per counted node (round 1: 92 + 49; the first
+//   uniform-loop version 51 + 87 — scalar-bound), 83 % of the vector issue slots used.
 // * The tree is split level-wise into phases: a phase walks every input task (a subtree root at
 //   level L) down to a stop level and emits each surviving node there as a task for the next
 //   phase (root column S, partial distance, coefficient prefix).  The final phase walks to the
@@ -52,6 +66,44 @@ __device__ __forceinline__ double rl_f64(double v, int lane)
   return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ int rl_i32(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+// element `off8 / 8` of the row at the wave-uniform pointer `row`: scalar base + 32-bit lane offset
+// (the global_load saddr form / one v_add for LDS) instead of a 64-bit address per lane
+__device__ __forceinline__ double ld_off(const double *row, unsigned off8)
+{
+  return *(const double *)((const char *)row + off8);
+}
+// (r_ii, pruning_i) of one level straight into SGPRs through the scalar cache: the table is read-only
+// for the whole enumeration, the index is wave-uniform.  Issue early (rp_issue), wait right before
+// the first use (rp_wait: s_waitcnt through the value, so that the compiler keeps the order).
+typedef int v4i __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ v4i rp_issue(const double *tab, int level)
+{
+  v4i q;
+  asm volatile("s_load_dwordx4 %0, %1, %2" : "=s"(q) : "s"(tab), "s"(level << 4));
+  return q;
+}
+__device__ __forceinline__ v4i rp_issue2(const double *tab, unsigned level8)
+{  // (level8 = 8 * level: the byte offset of the 16-byte pair is twice that)
+  v4i q;
+  asm volatile("s_load_dwordx4 %0, %1, %2" : "=s"(q) : "s"(tab), "s"(level8 << 1));
+  return q;
+}
+__device__ __forceinline__ void rp_wait(v4i &q) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(q)); }
+__device__ __forceinline__ double rp_r(const v4i &q) { return __hiloint2double(q.y, q.x); }
+__device__ __forceinline__ double rp_p(const v4i &q) { return __hiloint2double(q.w, q.z); }
+// v_writelane_b32: the wave-uniform `val` (an SGPR) into lane `lane` (an SGPR) of `old`; one VALU
+// instruction where a select needs a v_mov of the scalar plus a v_cndmask
+extern "C" __device__ int fphip_llvm_writelane(int, int, int) __asm("llvm.amdgcn.writelane.i32");
+__device__ __forceinline__ int wl_i32(int val, int lane, int old)
+{
+  return fphip_llvm_writelane(__builtin_amdgcn_readfirstlane(val), __builtin_amdgcn_readfirstlane(lane), old);
+}
+__device__ __forceinline__ double wl_f64(double val, int lane, double old)
+{
+  const int lo = wl_i32(__builtin_amdgcn_readfirstlane(__double2loint(val)), lane, __double2loint(old));
+  const int hi = wl_i32(__builtin_amdgcn_readfirstlane(__double2hiint(val)), lane, __double2hiint(old));
+  return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ unsigned long long rfl_u64(unsigned long long v)
 {
   unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
@@ -85,6 +137,29 @@ __device__ __forceinline__ unsigned long long load_sys_u64(const unsigned long l
 //       loop in CHILD with the child as the current node.
 //   STEP(k): the subtree below the current coefficient x[k] is exhausted — advance x[k] in
 //       zig-zag order (:80-89), test (:91-94): fail → STEP(k+1), survive → CHILD.
+// An empty statement the optimiser can neither delete nor merge: it keeps the join block of a
+// lane-masked `if` separate from the joins of the UNIFORM branches around it.  Without it the CFG
+// simplifier merges them, the uniformity analysis then sees "a phi at a divergent join", calls the
+// walk loops' exit conditions divergent, and the structuriser rewrites them with exit codes in
+// VGPRs and a copy of every level register per iteration.
+#define FPHIP_JOIN() asm volatile("")
+// The same on each `break` of a hot loop: the optimiser otherwise folds the exit paths into the
+// loop latch (one merged block with a "continue" flag and a phi — a register copy — per live value)
+#define FPHIP_EXIT() asm volatile("")
+// keeps a wave-uniform double in a VGPR pair: it is the second scalar operand of a VALU instruction
+// whose first one already sits in SGPRs (one constant-bus read per instruction on gfx9).  The
+// compiler treats the result as lane-varying: conditions computed from it go through a ballot.
+#define FPHIP_IN_VGPR(v) asm volatile("" : "+v"(v))
+// Hides a wave-uniform value from the optimiser (it stays in its SGPR): placed on the event code
+// right behind a hot loop it keeps all the loop's exits on ONE successor block, so that the loop
+// is a single-entry single-exit region of uniform branches the CFG structuriser leaves alone.
+#define FPHIP_OPAQUE(v)                          \
+  do                                             \
+  {                                              \
+    v = __builtin_amdgcn_readfirstlane(v);       \
+    asm volatile("" : "+s"(v));                  \
+  } while (0)
+
 // DUAL: the dualenum instantiation of the recursion (enumerate_base.cpp:57-61, 103-105): the centre
 // partial sums are driven by alpha = x - c instead of x; the inputs are then the transformed mu / r
 // EnumerationDyn::enumerate builds for a dual call (enumerate.cpp:107-123).
@@ -93,22 +168,35 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK)
     enum_phase_kernel(DevShared *__restrict__ g, HostCtl *__restrict__ h, TaskBuf in, TaskBuf out,
                       int d, int Lmax, int stop, unsigned task_lo, unsigned task_hi,
                       const unsigned *__restrict__ idxlist, int launch_idx, int count_nodes,
-                      unsigned budget, const double *__restrict__ xhi_root)
+                      unsigned budget, const double *__restrict__ xhi_root, double *__restrict__ gstk,
+                      int Tsplit)
 {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
+  const unsigned lane8 = (unsigned)lane << 3;  // byte offset of this lane's element in a row
   const int triL = (Lmax * (Lmax + 1)) >> 1;  // doubles for slots 1..Lmax
   // mu rows 1..Lmax-1 (packed like the stack slots).  MU_LDS: one copy per workgroup in LDS (lowest
   // latency: split launches and tails, where few waves run).  !MU_LDS: read straight from global
   // memory — <= 16 KB, read-only, L1-resident after the first touches — so that the LDS buys
   // more resident waves (the big walk launch, where throughput matters).
   const double *mu_s;
-  double *stk;
+  // The stack of centre columns (slot k = S_k restricted to the rows < k, k = 1..Lmax) is split:
+  // the slots below Ts — where 9 nodes out of 10 of a pruned tree live — stay in LDS, the tall,
+  // rarely touched slots k >= Ts go to a per-wave scratch in global memory (L2).  The LDS per wave
+  // is what bounds the resident waves of this latency-bound walk (5 KB per wave = 8 waves per SIMD
+  // against 4 with the whole stack of a 50-level task in LDS).
+  const int nw     = (int)(blockDim.x >> 6);
+  const int Ts     = min(Tsplit, Lmax + 1);
+  const int ldsRow = tri_off(Ts);  // doubles of LDS stack per wave
+  double *stk;                     // slot k < Ts at stk + tri_off(k)
+  int dummy_slot;  // (relative to stk) one spare double per wave behind all the LDS stacks: the
+                   // lanes beyond a slot write there (no exec-masked branch in the hot loop)
   if constexpr (MU_LDS)
   {
     double *mu_l = smem;
-    stk          = smem + triL + wave * triL;
+    stk          = smem + triL + wave * ldsRow;
+    dummy_slot   = nw * ldsRow - wave * ldsRow + wave;
     const int nmu = (Lmax * (Lmax - 1)) >> 1;
     for (int i = threadIdx.x; i < nmu; i += blockDim.x)
       mu_l[i] = g->mu_tri[i];
@@ -117,23 +205,28 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK)
   }
   else
   {
-    mu_s = g->mu_tri;
-    stk  = smem + wave * triL;
+    mu_s       = g->mu_tri;
+    stk        = smem + wave * ldsRow;
+    dummy_slot = nw * ldsRow - wave * ldsRow + wave;
   }
+  // slot k >= Ts at gst + tri_off(k); one spare double behind the last slot (index triL)
+  const unsigned dummy8 = (unsigned)dummy_slot << 3;
+  double *gst = gstk + (size_t)(blockIdx.x * nw + wave) * (size_t)(triL - ldsRow + 1) - ldsRow;
 
-  const double rd = g->rdiag[lane];
-  const double pr = g->pruning[lane];
+  const double *rptab = &g->rp[0][0];  // (r_ii, pruning_i) pairs, read through the scalar cache
   // The bound lives in two places: the pinned host word the callback thread writes, and a
   // device-memory mirror.  Waves poll the mirror (L2) often and the host word (PCIe) rarely;
   // whoever sees a smaller host value lowers the mirror for everybody.
   unsigned long long mbits = rfl_u64(load_sys_u64(&h->bound_bits));
   double maxdist           = __longlong_as_double((long long)mbits);
-  double bnd               = pr * maxdist;
+  double maxdist_v         = maxdist;  // the same value held in a VGPR pair (see FPHIP_IN_VGPR)
+  FPHIP_IN_VGPR(maxdist_v);
 
   // level registers (lane = level) and counters
   double xs = 0.0, cs = 0.0, pds = 0.0;
-  int dxs = 0, ddxs = 0;
+  int dxs = 0;  // (ddx is always sign(dx): not stored)
   unsigned long long cnt = 0;
+  unsigned cnt32         = 0;
   unsigned iter          = 0;
   // findsubsols (enumerate_base.cpp:36-40): lane = level, this wave's view of the best sub-solution
   // distance per level (subsoldists); the device-wide value in g->sub_bits is authoritative
@@ -145,19 +238,22 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK)
     unsigned long long nb_;                                                                       \
     if (from_host)                                                                                \
     {                                                                                             \
-      nb_ = rfl_u64(load_sys_u64(&h->bound_bits));                                                \
+      nb_ = load_sys_u64(&h->bound_bits);                                                         \
       if (nb_ < mbits && lane == 0)                                                               \
         atomicMin(&g->bound_bits, nb_);                                                           \
+      FPHIP_JOIN();                                                                               \
     }                                                                                             \
     else                                                                                          \
     {                                                                                             \
-      nb_ = rfl_u64(__hip_atomic_load(&g->bound_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); \
+      nb_ = __hip_atomic_load(&g->bound_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);        \
     }                                                                                             \
+    nb_ = rfl_u64(nb_); /* AFTER the join: the compiler then knows the value is wave-uniform */    \
     if (nb_ < mbits)                                                                              \
     {                                                                                             \
       mbits   = nb_;                                                                              \
       maxdist = __longlong_as_double((long long)mbits);                                           \
-      bnd     = pr * maxdist;                                                                     \
+      maxdist_v = maxdist;                                                                        \
+      FPHIP_IN_VGPR(maxdist_v);                                                                   \
     }                                                                                             \
   } while (0)
 
@@ -173,6 +269,7 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK)
     {  // queue empty: tell the waves still walking to shed work for the next launch
       if (budget != 0u && lane == 0)
         __hip_atomic_store(&g->drain[launch_idx], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      FPHIP_JOIN();
       break;
     }
 
@@ -186,7 +283,8 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK)
     const double col0 = in.col[ti * 64 + lane];  // S_Lt rows (lane < Lt)
     const double pd0  = in.pd[ti];
     int donate        = 1 << 20;
-    unsigned titer    = 0;
+    const unsigned iter0 = iter;  // (iterations of this task = iter - iter0)
+    unsigned tk8         = (unsigned)tri_off(Lt) << 3;  // 8 * tri_off(k), kept incrementally
     FPHIP_REFRESH_BOUND((t & 63u) == 0u);
 
     // the task root is a surviving node at level Lt whose column and distance are given
@@ -281,34 +379,110 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK)
         __hip_atomic_store(&r->seq, idx + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     };
 
-    bool done = false;
-    bool rep  = false;  // a candidate (level 0, nd > 0) is waiting to be reported
-    bool at0  = false;  // ... and it was found by the STEP loop: resume there, not in CHILD
-    while (!done)
+    // The walk is two hot loops (CHILD chain, STEP loop) inside an outer event loop.  The hot loops
+    // hold wave-uniform branches only — everything that needs a lane-masked branch (emitting a
+    // task, reporting a candidate, refreshing the bound) happens BETWEEN them — and this file is
+    // compiled with -structurizecfg-skip-uniform-regions: the AMDGPU backend otherwise rewrites
+    // every region that holds one divergent branch with exit codes, flag registers and a copy of
+    // every live register per iteration (16 of the 45 VALU and most of the 49 SALU instructions of
+    // a step were that).  FPHIP_OPAQUE on the event code behind a loop keeps the loop's exits on
+    // one successor block.  The scalar unit issues as slowly as the vector unit here (one
+    // instruction per SIMD turn), so scalar work is counted like vector work.
+    enum : int { EV_CHILD = 0, EV_EMIT = 1, EV_REPORT = 2, EV_DONE = 3, EV_RESTEP = 4, EV_OK = 5, EV_REFRESH = 6 };
+    // Levels whose surviving first children are handed to the next launch: [elo, elo + erng].  The
+    // split launches (stop >= 0, no budget) emit at level `stop` only; the walk launches (stop < 0)
+    // emit at every level >= donate once the task sheds work.
+    unsigned elo  = (stop >= 0 && stop < Lt) ? (unsigned)stop : (unsigned)donate;
+    unsigned erng = (stop >= 0 && stop < Lt) ? 0u : 0x7fffffffu;
+    bool buffer_full         = false;
+    bool resume_step         = false;  // re-enter the STEP loop at level k (after a report / refresh)
+    // (par, mk) = (S_{k+1}, row k of mu): what a step at level k needs to rebuild S_k.  Both are in
+    // registers whenever the STEP loop is entered: left there by the CHILD descent to level k or by
+    // the successful step at level k that preceded a failing first child.
+    double par = 0.0, mk = 0.0;
+    for (;;)
     {
+      int ev;
       // ================= CHILD chain: descend while the first child survives ====================
       // (state: a surviving, already counted node at level k with column S = S_k, distance nd)
-      // Candidates are reported OUTSIDE the two hot loops (one copy of the slow path, no live
-      // ranges of it inside them).
-      if (!at0)
-      for (;;)
+      if (!resume_step)
       {
-        k               = __builtin_amdgcn_readfirstlane(k);
-        const int kc    = k - 1;
-        // speculative load for the descending case: row kc of mu is needed right after the test
-        // (its latency overlaps the test); clamped (valid, unused) address when kc == 0
-        const double mk1 = mu_s[tri_off(max(kc, 1)) + min(lane, max(kc, 1) - 1)];
-        const double c1  = rl_f64(S, kc);  // center[kk-1] = center_partsums[kk-1][kk]
-        const double x1 = round(c1);      // roundto(): half away from zero, enumerate_base.h:33-34
-        const double a1 = x1 - c1;
-        const double n1 = nd + a1 * a1 * rl_f64(rd, kc);  // :28-29
-        if (!(n1 <= rl_f64(bnd, kc)))
-        {  // :31-32 no surviving child: next sibling at level k (the root has none: task done)
-          done = k >= Lt;
-          break;
+        for (;;)
+        {
+          const int kc       = k - 1;
+          const unsigned kc8 = (unsigned)kc << 3;
+          v4i q1             = rp_issue2(rptab, kc8);
+          // speculative load for the descending case: row kc of mu is needed right after the test
+          // (its latency overlaps the test).  tk8 = 8 * tri_off(k) is kept incrementally: row kc
+          // starts kc elements before row k.  At kc == 0 the clamp wraps and the lanes read the
+          // head of the table (valid, unused).
+          const unsigned tkc8 = tk8 - kc8;
+          const double mk1    = ld_off(mu_s, tkc8 + min(lane8, kc8 - 8u));
+          const double c1  = rl_f64(S, kc);  // center[kk-1] = center_partsums[kk-1][kk]
+          // roundto() = round(): half away from zero (enumerate_base.h:33-34), as round-to-even
+          // (one instruction) plus the correction of the ties that went towards zero
+          double x1 = rint(c1);
+          double a1 = x1 - c1;
+          if (fabs(a1) == 0.5 && ((a1 < 0.0) == (c1 > 0.0)))
+          {
+            x1 = x1 - (a1 + a1);
+            a1 = -a1;
+          }
+          rp_wait(q1);
+          const double n1 = nd + a1 * a1 * rp_r(q1);  // :28-29
+          // :31-32 (partdistbounds = pruning * maxdist); the ballot makes the test wave-uniform for
+          // the compiler although maxdist_v went through an asm statement
+          if (__builtin_amdgcn_ballot_w64(n1 <= rp_p(q1) * maxdist_v) == 0ull)
+          {  // no surviving child: next sibling at level k (the root has none: task done)
+            ev = (k >= Lt) ? EV_DONE : EV_RESTEP;
+            FPHIP_EXIT();
+            break;
+          }
+          if ((unsigned)(k - elo) <= erng)
+          {  // hand the subtree below this node to the next launch (outside the loop): k == stop in
+             // the split launches, k >= donate once this task sheds work (never the task root:
+             // donate starts beyond every level and the root is only visited first)
+            ev = EV_EMIT;
+            FPHIP_EXIT();
+            break;
+          }
+          // descend: level kc becomes the current level.  S is needed again when x[kc] steps to
+          // its next sibling; the lanes beyond the row write a dummy slot (no exec-masked branch)
+          if (k < Ts)
+            *(double *)((char *)stk + ((lane < k) ? tk8 + lane8 : dummy8)) = S;
+          else
+            *(double *)((char *)gst + ((lane < k) ? tk8 + lane8 : (unsigned)triL << 3)) = S;
+          const int s1  = (c1 >= x1) ? 1 : -1;  // :71 / :114 (dx = ddx = s1; ddx stays sign(dx))
+          const bool me = lane == kc;
+          cs            = wl_f64(c1, kc, cs);
+          xs            = me ? x1 : xs;
+          pds           = me ? nd : pds;
+          dxs           = wl_i32(s1, kc, dxs);
+          cnt32 += me ? 1u : 0u;  // ++nodes[kk-1]
+          if constexpr (SUBS)
+          {
+            if (n1 < rl_f64(sb, kc) && n1 != 0.0)
+              sub_report(kc, n1);
+          }
+          par = S;    // (S_{kc+1}, row kc): what a step at the new level needs
+          mk  = mk1;
+          k   = kc;
+          tk8 = tkc8;
+          nd  = n1;
+          // S_k = S_{k+1} - x[k]*mu(k,·), :53-58 (mk1 is row k; at k == 0 a dead value)
+          S = S - (DUAL ? a1 : x1) * mk1;
+          if (k == 0)
+          {  // level 0: process_solution, :42-46; no children
+            ev = (nd > 0.0) ? EV_REPORT : EV_RESTEP;
+            FPHIP_EXIT();
+            break;
+          }
         }
-        if ((k == stop || k >= donate) && k < Lt)
-        {  // hand the subtree below this node to the next launch
+        FPHIP_OPAQUE(ev);
+        if (ev == EV_DONE)
+          break;
+        if (ev == EV_EMIT)
+        {
           unsigned oi = 0;
           if (lane == 0)
             oi = atomicAdd(out.count, 1u);
@@ -324,119 +498,150 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK)
               out.level[oi] = k;
               out.root[oi]  = rid;
             }
-            break;  // → next sibling at level k
+            FPHIP_JOIN();
+            // → next sibling at level k
           }
-          // buffer full: keep walking this subtree inline (results stay exact)
-          if (lane == 0)
-            atomicOr(&g->error_flags, FPHIP_FLAG_TASK_OVERFLOW);
+          else
+          {  // buffer full: walk everything inline from here on (results stay exact)
+            if (lane == 0)
+              atomicOr(&g->error_flags, FPHIP_FLAG_TASK_OVERFLOW);
+            FPHIP_JOIN();
+            buffer_full = true;
+            donate      = 1 << 20;
+            elo         = 1u << 20;
+            erng        = 0u;
+            continue;
+          }
         }
-        // descend: level kc becomes the current level
-        if (lane < k)
-          stk[tri_off(k) + lane] = S;  // needed again when x[kc] steps to its next sibling
+        else if (ev == EV_REPORT)
         {
-          const int s1  = (c1 >= x1) ? 1 : -1;  // :71 / :114
-          const bool me = lane == kc;
-          cs            = me ? c1 : cs;
-          xs            = me ? x1 : xs;
-          pds           = me ? nd : pds;
-          dxs           = me ? s1 : dxs;
-          ddxs          = me ? s1 : ddxs;
-          cnt += me ? 1ull : 0ull;  // ++nodes[kk-1]
+          report(nd);
+          FPHIP_JOIN();
         }
-        if constexpr (SUBS)
-        {
-          if (n1 < rl_f64(sb, kc) && n1 != 0.0)
-            sub_report(kc, n1);
-        }
-        k  = kc;
-        nd = n1;
-        if (k == 0)
-        {
-          rep = nd > 0.0;  // process_solution, :42-46
-          break;           // level 0 has no children: next sibling
-        }
-        S = S - (DUAL ? a1 : x1) * mk1;  // S_k = S_{k+1} - x[k]*mu(k,·), :53-58 (k >= 1 here: mk1 is row k)
       }
-      if (done)
-        break;
-      if (rep)
-      {
-        report(nd);
-        rep = false;
+      if (resume_step)
+      {  // (par, mk) were lost to the slow path: reload them
+        const unsigned k8  = (unsigned)k << 3;
+        const unsigned cl8 = min(lane8, k8 - 8u);  // (k == 0: wraps, the lanes read valid, unused data)
+        if (k + 1 < Ts)
+          par = ld_off(stk, tk8 + k8 + cl8);
+        else
+          par = ld_off(gst, tk8 + k8 + cl8);
+        mk = ld_off(mu_s, tk8 + cl8);
       }
-      at0 = false;
+      resume_step = false;
       // ================= STEP loop: next sibling at level k, climbing while they fail ===========
+      double xk, a;
       for (;;)
       {
-        k = __builtin_amdgcn_readfirstlane(k);
-        ++titer;
-        if (((++iter) & 63u) == 0u)
-        {
-          FPHIP_REFRESH_BOUND((iter & 16383u) == 0u);
-          if (budget != 0u && titer >= 256u)
-          {  // work donation: once the task queue has run dry (other waves are idle), or this task
-             // exceeded its budget, keep only the subtree below the current level and emit every
-             // sibling subtree above it as a task for the next launch
-            const unsigned dr = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(
-                &g->drain[launch_idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            if (dr != 0u || titer >= budget)
-              donate = min(donate, k + 1);
-          }
-        }
-        // speculative loads for the surviving case (LDS latency overlaps the test); lanes beyond
-        // the row read a clamped (valid, unused) address so that no exec-mask branch is needed
-        const double par = stk[tri_off(k + 1) + min(lane, k)];              // S_{k+1}
-        const double mk  = mu_s[tri_off(k) + max(min(lane, k - 1), 0)];
-        double xk        = rl_f64(xs, k);
+        v4i qk           = rp_issue2(rptab, (unsigned)k << 3);
+        xk               = rl_f64(xs, k);
         const double ck  = rl_f64(cs, k);
-        const double pdk = rl_f64(pds, k);
-        int dxk = rl_i32(dxs, k), ddxk = rl_i32(ddxs, k);
-        if (pdk != 0.0)
-        {  // :80-89 (is_svp is always true here)
-          xk += (double)dxk;
-          ddxk = -ddxk;
-          dxk  = ddxk - dxk;
-        }
-        else
-        {
-          xk += 1.0;
-        }
+        const int pdlo   = __builtin_amdgcn_readlane(__double2loint(pds), k);
+        const int pdhi   = __builtin_amdgcn_readlane(__double2hiint(pds), k);
+        const double pdk = __hiloint2double(pdhi, pdlo);
+        int dxk          = rl_i32(dxs, k);
+        // :80-89 (is_svp is always true here): zig-zag around the centre unless the partial
+        // distance above is exactly +0 (then x only grows).  pdk is a sum of squares, never -0:
+        // the test and the selection of the step are scalar-unit work.
+        int pdor = pdlo | pdhi;
+        asm volatile("" : "+s"(pdor));  // (one 32-bit OR, not a 64-bit compare of a register pair)
+        const bool zig = pdor != 0;
+        int stepi      = zig ? dxk : 1;
+        asm volatile("" : "+s"(stepi));  // (keeps the select in front of the int -> double conversion)
+        xk += (double)stepi;
+        dxk = zig ? ((dxk > 0 ? -1 : 1) - dxk) : dxk;  // ddx = -ddx; dx = ddx - dx, ddx == sign(dx)
         const bool me = lane == k;
         xs            = me ? xk : xs;
-        dxs           = me ? dxk : dxs;
-        ddxs          = me ? ddxk : ddxs;
-        const double a = xk - ck;
-        nd             = pdk + a * a * rl_f64(rd, k);  // :91-92
-        if (!(nd <= rl_f64(bnd, k)))
-        {  // :93-94 → the parent steps to its next sibling
-          ++k;
-          if (k >= Lt)
-          {
-            done = true;
-            break;
-          }
-          continue;
+        dxs           = wl_i32(dxk, k, dxs);
+        asm volatile("" : "+v"(xs), "+v"(dxs));  // (the updates stay in front of the test: sunk behind
+                                                  //  it they would merge the loop's exits again)
+        a             = xk - ck;
+        rp_wait(qk);
+        nd = pdk + a * a * rp_r(qk);  // :91-92
+        if (__builtin_amdgcn_ballot_w64(nd <= rp_p(qk) * maxdist_v) != 0ull)
+        {
+          ev = EV_OK;
+          FPHIP_EXIT();
+          break;
         }
-        cnt += me ? 1ull : 0ull;  // ++nodes[kk]
+        // :93-94: the parent steps to its next sibling.  The loads for the surviving case at the
+        // new level are issued now: their latency (mu comes through L1 in the big launches)
+        // overlaps the next test.  Lanes beyond the row read a clamped (valid, unused) address.
+        {
+          const unsigned k8 = (unsigned)k << 3;  // (old k) * 8 = 8 * (new k - 1): the clamp, and
+          tk8 += k8;                             // row k + 1 starts k elements behind row k
+          ++k;
+          const unsigned cl8 = min(lane8, k8);
+          if (k + 1 < Ts)
+            par = ld_off(stk, tk8 + k8 + 8u + cl8);
+          else
+            par = ld_off(gst, tk8 + k8 + 8u + cl8);
+          mk = ld_off(mu_s, tk8 + cl8);
+        }
+        if (k >= Lt)
+        {
+          ev = EV_DONE;
+          FPHIP_EXIT();
+          break;
+        }
+        if (((++iter) & 63u) == 0u)
+        {
+          ev = EV_REFRESH;
+          FPHIP_EXIT();
+          break;
+        }
+      }
+      FPHIP_OPAQUE(ev);
+      if (ev == EV_OK)
+      {
+        cnt32 += (lane == k) ? 1u : 0u;  // ++nodes[kk]
         if constexpr (SUBS)
         {
           if (nd < rl_f64(sb, k) && nd != 0.0)
             sub_report(k, nd);
         }
-        if (k == 0)
+        if (k != 0)
         {
-          if (nd > 0.0)
-          {  // :97-101: report outside the loop, then come back to the next sibling of level 0
-            rep = true;
-            at0 = true;
-            break;
-          }
-          continue;
+          S = par - (DUAL ? a : xk) * mk;  // :104-110
+          continue;                        // → CHILD chain
         }
-        S = par - (DUAL ? a : xk) * mk;  // :104-110
-        break;              // → CHILD chain
+        // level 0, :97-101: report (nd > 0), then the next sibling of level 0
+        if (nd > 0.0)
+        {
+          report(nd);
+          FPHIP_JOIN();
+        }
+        resume_step = true;
+        continue;
+      }
+      if (ev == EV_DONE)
+        break;
+      // EV_REFRESH (every 64 failed steps)
+      {
+        cnt += cnt32;  // the per-level counters of the hot loops are 32 bits wide
+        cnt32 = 0u;
+        FPHIP_REFRESH_BOUND((iter & 16383u) == 0u);
+        const unsigned titer = iter - iter0;
+        if (budget != 0u && titer >= 256u && !buffer_full)
+        {  // work donation: once the task queue has run dry (other waves are idle), or this task
+           // exceeded its budget, keep only the subtree below the current level and emit every
+           // sibling subtree above it as a task for the next launch
+          const unsigned dr = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(
+              &g->drain[launch_idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+          if (dr != 0u || titer >= budget)
+          {
+            donate = min(donate, k + 1);
+            if (stop < 0)
+              elo = (unsigned)donate;
+          }
+        }
+        FPHIP_JOIN();
+        resume_step = true;
       }
     }
+    cnt += cnt32;
+    cnt32 = 0u;
   }
 #undef FPHIP_REFRESH_BOUND
 
@@ -449,7 +654,7 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK)
 #define FPHIP_INST(M, S, D)                                                                            \
   template __global__ void enum_phase_kernel<M, S, D>(DevShared *, HostCtl *, TaskBuf, TaskBuf, int,  \
                                                       int, int, unsigned, unsigned, const unsigned *,  \
-                                                      int, int, unsigned, const double *);
+                                                      int, int, unsigned, const double *, double *, int);
 FPHIP_INST(true, false, false)
 FPHIP_INST(false, false, false)
 FPHIP_INST(true, true, false)
