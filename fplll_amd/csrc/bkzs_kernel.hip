@@ -46,6 +46,22 @@ namespace sdv
 {
 
 __device__ __forceinline__ int btri2(int k) { return (k * (k - 1)) >> 1; }
+typedef __attribute__((address_space(3))) double lds_f64;
+typedef __attribute__((address_space(3))) char lds_char;
+typedef __attribute__((address_space(1))) double glb_f64;
+typedef __attribute__((address_space(1))) char glb_char;
+// v_writelane_b32 through the LLVM intrinsic (no clang builtin in this toolchain)
+extern "C" __device__ int fphip_bk_llvm_writelane(int, int, int) __asm("llvm.amdgcn.writelane.i32");
+__device__ __forceinline__ int bk_wl_i32(int val, int lane, int old)
+{
+  return fphip_bk_llvm_writelane(__builtin_amdgcn_readfirstlane(val), __builtin_amdgcn_readfirstlane(lane), old);
+}
+__device__ __forceinline__ double bk_wl_f64(double val, int lane, double old)
+{
+  const int lo = bk_wl_i32(__double2loint(val), lane, __double2loint(old));
+  const int hi = bk_wl_i32(__double2hiint(val), lane, __double2hiint(old));
+  return __hiloint2double(hi, lo);
+}
 
 __device__ __forceinline__ unsigned long long mail_load_u64(const unsigned long long *p)
 {
@@ -182,7 +198,20 @@ bkzs_body(GsoBatch P, BkzStrat S, BkzMail *mailbox, int *abort_flag, int block_s
     T.narrow_flag = (int *)T.rexp;
     T.np          = 0;
     LllCtx C{P.gf + (size_t)L * d * ldd, P.vc + (size_t)L * d};
-    double *mu_blk = P.enum_mu + (size_t)L * (64 * 63 / 2);
+    // scaled mu rows of the block being enumerated: in LDS behind this wave's column stack when the
+    // host asked for it (top_flags bit 30: few lattices per CU, where the L1 latency of every row
+    // is exposed), in global memory otherwise (large batches: LDS buys resident waves)
+    const bool mu_lds  = (top_flags & 0x40000000) != 0;
+    const int bsm      = max(2, min(block_size, d));
+    double *mu_blk_l   = stk + ((bsm * (bsm + 1)) / 2 + 2);
+    double *mu_blk_g   = P.enum_mu + (size_t)L * (64 * 63 / 2);
+    auto mu_blk_store = [&](int idx, double v)
+    {
+      if (mu_lds)
+        mu_blk_l[idx] = v;
+      else
+        mu_blk_g[idx] = v;
+    };
     BkzMail *mail  = mailbox + L;
     SlotMap<NQ> M;
     if (P.bkz_active[L] == 0)
@@ -283,7 +312,7 @@ bkzs_body(GsoBatch P, BkzStrat S, BkzMail *mailbox, int *abort_flag, int block_s
     BkzsFrame F;
     int depth  = 0;
     F.bsz      = block_size;
-    F.flags    = top_flags;
+    F.flags    = top_flags & ~0x40000000;
     F.min_row  = 0;
     F.max_row  = num_rows;
     F.op       = 0;
@@ -349,7 +378,7 @@ bkzs_body(GsoBatch P, BkzStrat S, BkzMail *mailbox, int *abort_flag, int block_s
         running     = true;
         depth       = 0;
         F.bsz       = block_size;
-        F.flags     = top_flags & ~0x100;
+        F.flags     = top_flags & ~0x100 & ~0x40000000;
         F.min_row   = num_rows - block_size;
         F.max_row   = num_rows;
         F.op        = 0;
@@ -676,7 +705,7 @@ bkzs_body(GsoBatch P, BkzStrat S, BkzMail *mailbox, int *abort_flag, int block_s
             if (lane < k)
             {
               const double m = T.mu[(size_t)skk * ldd + kappa + lane];
-              mu_blk[btri2(k) + lane] = ldexp(m, (int)(ek - T.rexp[sl_blk]));
+              mu_blk_store(btri2(k) + lane, ldexp(m, (int)(ek - T.rexp[sl_blk])));
             }
           }
         }
@@ -702,7 +731,7 @@ bkzs_body(GsoBatch P, BkzStrat S, BkzMail *mailbox, int *abort_flag, int block_s
               if (lane < k)
               {
                 const double m = T.mu[(size_t)sl_rev * ldd + col];
-                mu_blk[btri2(k) + lane] = -ldexp(m, (int)(T.rexp[sl_rev] - ec));
+                mu_blk_store(btri2(k) + lane, -ldexp(m, (int)(T.rexp[sl_rev] - ec)));
               }
             }
           }
@@ -720,43 +749,76 @@ bkzs_body(GsoBatch P, BkzStrat S, BkzMail *mailbox, int *abort_flag, int block_s
         double best_x = 0.0;
         bool have_sol = false;
         {
+          // The walk of enum_kernel.hip (see the comments there): two hot loops of wave-uniform
+          // branches (this file is compiled with -structurizecfg-skip-uniform-regions), ddx =
+          // sign(dx) not stored, round() as rint() + tie correction, scalar zig-zag bookkeeping,
+          // v_writelane for the scalar level values, the step's column / mu row handed over in
+          // registers, 32-bit level counters (a block's tree is far below 2^32 nodes per level:
+          // flushed every 2^20 failed steps all the same).
           double xs = 0.0, cs = 0.0, pds = 0.0;
-          int dxs = 0, ddxs = 0;
+          int dxs = 0;
           unsigned long long cnt = 0;
+          unsigned cnt32         = 0;
           double bnds = prn * maxdist;  // lane k: partdistbounds[k]
-          int k       = bs;
+          const int bsu = __builtin_amdgcn_readfirstlane(bs);  // (wave-uniform, and known to be)
+          int k         = bsu;
+          // explicit address spaces: a select between an LDS and a global pointer would otherwise
+          // be compiled into one FLAT load
+          const lds_f64 *mu_l3 = (const lds_f64 *)mu_blk_l;
+          const glb_f64 *mu_g1 = (const glb_f64 *)mu_blk_g;
           double Sc   = 0.0;
           double nd   = 0.0;
-          bool done   = false;
-          while (!done)
+          double par = 0.0, mk = 0.0;  // (S_{k+1}, row k of mu) whenever the STEP loop is entered
+          const unsigned lane8 = (unsigned)lane << 3;
+          const int dummy      = (bsu * (bsu + 1)) >> 1;  // first spare double behind the stack rows
+          unsigned fails       = 0;
+          const bool dualw     = DUALS && dualb;
+          enum : int { W_STEP = 0, W_DONE = 1, W_CHILD = 2 };
+          for (;;)
           {
+            int ev;
+            // ---- CHILD chain ----------------------------------------------------------------------
             for (;;)
             {
-              k               = __builtin_amdgcn_readfirstlane(k);
-              const int kc    = k - 1;
+              const int kc = k - 1;
+              const int r1 = max(kc, 1);
+              // speculative: row kc of mu for the descending case
+              const unsigned o1 = ((unsigned)btri2(r1) << 3) + min(lane8, (unsigned)(r1 - 1) << 3);
+              double mk1;
+              if (mu_lds)
+                mk1 = *(const lds_f64 *)((const lds_char *)mu_l3 + o1);
+              else
+                mk1 = *(const glb_f64 *)((const glb_char *)mu_g1 + o1);
               const double c1 = g_rl_f64(Sc, kc);
-              const double x1 = round(c1);
-              const double a1 = x1 - c1;
+              double x1       = rint(c1);  // round(): rint + the ties that went towards zero
+              double a1       = x1 - c1;
+              if (fabs(a1) == 0.5 && ((a1 < 0.0) == (c1 > 0.0)))
+              {
+                x1 = x1 - (a1 + a1);
+                a1 = -a1;
+              }
               const double n1 = nd + a1 * a1 * g_rl_f64(rd, kc);
               if (!(n1 <= g_rl_f64(bnds, kc)))
               {
-                done = k >= bs;
+                ev = (k >= bsu) ? W_DONE : W_STEP;
+                asm volatile("");
                 break;
               }
-              if (lane < k)
-                stk[btri2(k) + lane] = Sc;
+              stk[(lane < k) ? btri2(k) + lane : dummy] = Sc;
               {
                 const int s1  = (c1 >= x1) ? 1 : -1;
                 const bool me = lane == kc;
-                cs            = me ? c1 : cs;
+                cs            = bk_wl_f64(c1, kc, cs);
                 xs            = me ? x1 : xs;
                 pds           = me ? nd : pds;
-                dxs           = me ? s1 : dxs;
-                ddxs          = me ? s1 : ddxs;
-                cnt += me ? 1ull : 0ull;
+                dxs           = bk_wl_i32(s1, kc, dxs);
+                cnt32 += me ? 1u : 0u;
               }
-              k  = kc;
-              nd = n1;
+              par = Sc;
+              mk  = mk1;
+              k   = kc;
+              nd  = n1;
+              Sc  = Sc - (dualw ? a1 : x1) * mk1;  // dualenum: alpha[j] * mut, enumerate_base.cpp:57-61
               if (k == 0)
               {
                 if (nd > 0.0)
@@ -766,54 +828,47 @@ bkzs_body(GsoBatch P, BkzStrat S, BkzMail *mailbox, int *abort_flag, int block_s
                   maxdist  = nd;
                   bnds     = prn * nd;
                 }
+                ev = W_STEP;
+                asm volatile("");
                 break;
               }
-              const double mk = mu_blk[btri2(k) + min(lane, k - 1)];
-              if (DUALS && dualb)
-                Sc = Sc - a1 * mk;  // dualenum: alpha[j] * mut, enumerate_base.cpp:57-61
-              else
-                Sc = Sc - x1 * mk;
             }
-            if (done)
+            ev = __builtin_amdgcn_readfirstlane(ev);
+            asm volatile("" : "+s"(ev));
+            if (ev == W_DONE)
               break;
+            // ---- STEP loop -------------------------------------------------------------------------
+            double xk, a;
             for (;;)
             {
-              k                = __builtin_amdgcn_readfirstlane(k);
-              const double par = stk[btri2(k + 1) + min(lane, k)];
-              const double mk  = mu_blk[btri2(k) + max(min(lane, k - 1), 0)];
-              double xk        = g_rl_f64(xs, k);
+              xk               = g_rl_f64(xs, k);
               const double ck  = g_rl_f64(cs, k);
-              const double pdk = g_rl_f64(pds, k);
-              int dxk = __builtin_amdgcn_readlane(dxs, k), ddxk = __builtin_amdgcn_readlane(ddxs, k);
-              if (pdk != 0.0)
+              const int pdlo   = __builtin_amdgcn_readlane(__double2loint(pds), k);
+              const int pdhi   = __builtin_amdgcn_readlane(__double2hiint(pds), k);
+              const double pdk = __hiloint2double(pdhi, pdlo);
+              int dxk          = __builtin_amdgcn_readlane(dxs, k);
+              int pdor         = pdlo | pdhi;  // pdk is a sum of squares, never -0: zero <=> all bits zero
+              asm volatile("" : "+s"(pdor));
+              const bool zig = pdor != 0;
+              int stepi      = zig ? dxk : 1;
+              asm volatile("" : "+s"(stepi));
+              xk += (double)stepi;
+              dxk = zig ? ((dxk > 0 ? -1 : 1) - dxk) : dxk;  // ddx = -ddx; dx = ddx - dx
+              const bool me = lane == k;
+              xs            = me ? xk : xs;
+              dxs           = bk_wl_i32(dxk, k, dxs);
+              asm volatile("" : "+v"(xs), "+v"(dxs));
+              a  = xk - ck;
+              nd = pdk + a * a * g_rl_f64(rd, k);
+              if (nd <= g_rl_f64(bnds, k))
               {
-                xk += (double)dxk;
-                ddxk = -ddxk;
-                dxk  = ddxk - dxk;
-              }
-              else
-              {
-                xk += 1.0;
-              }
-              const bool me  = lane == k;
-              xs             = me ? xk : xs;
-              dxs            = me ? dxk : dxs;
-              ddxs           = me ? ddxk : ddxs;
-              const double a = xk - ck;
-              nd             = pdk + a * a * g_rl_f64(rd, k);
-              if (!(nd <= g_rl_f64(bnds, k)))
-              {
-                ++k;
-                if (k >= bs)
+                cnt32 += me ? 1u : 0u;
+                if (k != 0)
                 {
-                  done = true;
+                  ev = W_CHILD;
+                  asm volatile("");
                   break;
                 }
-                continue;
-              }
-              cnt += me ? 1ull : 0ull;
-              if (k == 0)
-              {
                 if (nd > 0.0)
                 {
                   best_x   = xs;
@@ -821,15 +876,37 @@ bkzs_body(GsoBatch P, BkzStrat S, BkzMail *mailbox, int *abort_flag, int block_s
                   maxdist  = nd;
                   bnds     = prn * nd;
                 }
-                continue;
+                continue;  // next sibling of level 0 ((par, mk) are not used there)
               }
-              if (DUALS && dualb)
-                Sc = par - a * mk;  // enumerate_base.cpp:103-105
-              else
-                Sc = par - xk * mk;
-              break;
+              ++k;
+              if (k >= bsu)
+              {
+                ev = W_DONE;
+                asm volatile("");
+                break;
+              }
+              {  // the loads for the surviving case at the new level, a whole test ahead
+                const unsigned cl8 = min(lane8, (unsigned)(k - 1) << 3);
+                par                = *(const double *)((const char *)stk + (((unsigned)btri2(k + 1) << 3) + cl8));
+                const unsigned o2  = ((unsigned)btri2(k) << 3) + cl8;
+                if (mu_lds)
+                  mk = *(const lds_f64 *)((const lds_char *)mu_l3 + o2);
+                else
+                  mk = *(const glb_f64 *)((const glb_char *)mu_g1 + o2);
+              }
+              if (((++fails) & 0xfffffu) == 0u)
+              {
+                cnt += cnt32;
+                cnt32 = 0u;
+              }
             }
+            ev = __builtin_amdgcn_readfirstlane(ev);
+            asm volatile("" : "+s"(ev));
+            if (ev == W_DONE)
+              break;
+            Sc = par - (dualw ? a : xk) * mk;  // enumerate_base.cpp:103-105
           }
+          cnt += cnt32;
           unsigned long long tot = cnt;
           for (int off = 32; off > 0; off >>= 1)
             tot += (unsigned long long)__shfl_xor((long long)tot, off);

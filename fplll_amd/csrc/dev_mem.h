@@ -25,4 +25,11 @@ static inline void fphip_dev_free(void *p, hipStream_t s)
     (void)hipFree(p);
   }
 }
+
+// Pinned, host-coherent buffers (mailboxes, the enumeration context's solution ring and staging
+// block) are CACHED for the life of the process: hipHostMalloc / hipHostFree synchronise the whole
+// device like hipFree does — measured: closing a small enumeration context took 349 s because the
+// config-3 tour of another context was in flight.  (Defined in enum_host.hip.)
+__attribute__((visibility("hidden"))) void *fphip_pinned_get(size_t bytes);
+__attribute__((visibility("hidden"))) void fphip_pinned_put(void *p);
 #endif

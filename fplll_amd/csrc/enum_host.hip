@@ -38,6 +38,46 @@ __global__ void task_key_kernel(TaskBuf in, unsigned n, int d, unsigned long lon
 }
 using namespace fphip;
 
+// ---- process-wide cache of pinned host buffers (dev_mem.h) ---------------------------------------
+#include <mutex>
+#include <vector>
+namespace
+{
+struct PinnedBuf
+{
+  void *p;
+  size_t bytes;
+  bool busy;
+};
+std::mutex g_pinned_mutex;
+std::vector<PinnedBuf> g_pinned;
+}  // namespace
+void *fphip_pinned_get(size_t bytes)
+{
+  std::lock_guard<std::mutex> lk(g_pinned_mutex);
+  PinnedBuf *best = nullptr;
+  for (PinnedBuf &b : g_pinned)
+    if (!b.busy && b.bytes >= bytes && (!best || b.bytes < best->bytes))
+      best = &b;
+  if (best)
+  {
+    best->busy = true;
+    return best->p;
+  }
+  void *p = nullptr;
+  if (hipHostMalloc(&p, bytes, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess)
+    return nullptr;
+  g_pinned.push_back(PinnedBuf{p, bytes, true});
+  return p;
+}
+void fphip_pinned_put(void *p)
+{
+  std::lock_guard<std::mutex> lk(g_pinned_mutex);
+  for (PinnedBuf &b : g_pinned)
+    if (b.p == p)
+      b.busy = false;
+}
+
 struct fphip_ctx
 {
   int device        = 0;
@@ -122,9 +162,10 @@ extern "C" int fphip_create(int device, fphip_ctx **out)
   HIPCHK(ctx, hipEventCreate(&ctx->ev[0]));
   HIPCHK(ctx, hipEventCreate(&ctx->ev[1]));
   HIPCHK(ctx, fphip_dev_alloc((void **)&ctx->g, sizeof(DevShared), ctx->stream));
-  HIPCHK(ctx, hipHostMalloc((void **)&ctx->stage, sizeof(DevShared), hipHostMallocDefault));
-  HIPCHK(ctx, hipHostMalloc((void **)&ctx->h, sizeof(HostCtl),
-                            hipHostMallocCoherent | hipHostMallocMapped));
+  ctx->stage = (DevShared *)fphip_pinned_get(sizeof(DevShared));
+  ctx->h     = (HostCtl *)fphip_pinned_get(sizeof(HostCtl));
+  if (!ctx->stage || !ctx->h)
+    HIPCHK(ctx, hipErrorOutOfMemory);
   memset(ctx->h, 0, sizeof(HostCtl));
   ctx->cap = (unsigned)env_int("FPHIP_TASK_CAP", 1 << 19);
   for (int b = 0; b < 2; ++b)
@@ -204,9 +245,9 @@ extern "C" void fphip_destroy(fphip_ctx *ctx)
   if (ctx->g)
     fphip_dev_free(ctx->g, ctx->stream);
   if (ctx->stage)
-    hipHostFree(ctx->stage);
+    fphip_pinned_put(ctx->stage);
   if (ctx->h)
-    hipHostFree(ctx->h);
+    fphip_pinned_put(ctx->h);
   if (ctx->ev[0])
     hipEventDestroy(ctx->ev[0]);
   if (ctx->ev[1])

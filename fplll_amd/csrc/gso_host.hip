@@ -745,45 +745,10 @@ extern "C" int fphip_gso_bkz(fphip_gso *g, int block_size, double delta, double 
 // flight: the radius / pruning decision (host libm: log, exp, lgamma, pow — the reference's own
 // roundings) and the rerandomisation plan (drawn from the caller's generator, rnd(user, lattice,
 // n) = gmp_urandomm_ui(state of that lattice, n)).
-// Pinned, host-coherent buffers (mailboxes) are CACHED for the life of the process: hipHostMalloc /
-// hipHostFree synchronise the whole device like hipFree does (dev_mem.h), and a strategy-BKZ call
-// must not wait for another context's kernel.
 #include <atomic>
-#include <mutex>
 #include <thread>
-namespace
-{
-struct PinnedBuf
-{
-  void *p;
-  size_t bytes;
-  bool busy;
-};
-std::mutex g_pinned_mutex;
-std::vector<PinnedBuf> g_pinned;
-void *pinned_get(size_t bytes)
-{
-  std::lock_guard<std::mutex> lk(g_pinned_mutex);
-  for (PinnedBuf &b : g_pinned)
-    if (!b.busy && b.bytes >= bytes)
-    {
-      b.busy = true;
-      return b.p;
-    }
-  void *p = nullptr;
-  if (hipHostMalloc(&p, bytes, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess)
-    return nullptr;
-  g_pinned.push_back(PinnedBuf{p, bytes, true});
-  return p;
-}
-void pinned_put(void *p)
-{
-  std::lock_guard<std::mutex> lk(g_pinned_mutex);
-  for (PinnedBuf &b : g_pinned)
-    if (b.p == p)
-      b.busy = false;
-}
-}  // namespace
+static inline void *pinned_get(size_t bytes) { return fphip_pinned_get(bytes); }
+static inline void pinned_put(void *p) { fphip_pinned_put(p); }
 
 // ---------------------------------------------------------------------------------------------
 namespace
@@ -1090,8 +1055,23 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
   const int nq   = (need + 63) / 64;
   const int wpb  = g->waves_per_block;
   const int bs   = block_size < 2 ? 2 : bsz;
-  const int stack_doubles = (bs * (bs + 1)) / 2 + 2;
   const size_t ring_bytes = (size_t)wpb * FPHIP_RING_REDUCE * (size_t)((nq + 1) / 2) * 1024;
+  // The scaled mu rows of the block under enumeration go to LDS (behind the column stack) when few
+  // lattices share a CU — every row's L1 latency is exposed to a lone wave — and when they fit;
+  // large batches keep them in global memory and spend the LDS on resident waves.
+  int stack_doubles = (bs * (bs + 1)) / 2 + 2;
+  int mu_lds_flag   = 0;
+  {
+    const int with_mu  = stack_doubles + (bs * (bs - 1)) / 2;
+    const size_t lds_m = ring_bytes + (size_t)wpb * with_mu * sizeof(double) + (size_t)wpb * FPHIP_BKZS_MAX_DEPTH * 64;
+    const int def      = (B <= (size_t)4 * (size_t)fphip_ctx_num_cus(g->ctx)) ? 1 : 0;
+    const char *e      = getenv("FPHIP_BKZ_MU_LDS");
+    if ((e ? atoi(e) : def) && lds_m <= 160 * 1024)
+    {
+      stack_doubles = with_mu;
+      mu_lds_flag   = 0x40000000;
+    }
+  }
   const size_t lds = ring_bytes + (size_t)wpb * stack_doubles * sizeof(double) +
                      (size_t)wpb * FPHIP_BKZS_MAX_DEPTH * 64;  // sizeof(BkzsFrame) == 64
   if (ring_bytes > 64 * 1024 || lds > 160 * 1024)
@@ -1148,19 +1128,19 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
     {
       switch (nq)
       {
-      case 1: hipLaunchKernelGGL(sdv::bkzd_kernel<1>, dim3(grid), dim3(wpb * 64), lds, s, g->P, DS, mail, d_abort, block_size, kflags | 0x100, delta, eta, logd, kloops, stack_doubles, run_mode); break;
-      case 2: hipLaunchKernelGGL(sdv::bkzd_kernel<2>, dim3(grid), dim3(wpb * 64), lds, s, g->P, DS, mail, d_abort, block_size, kflags | 0x100, delta, eta, logd, kloops, stack_doubles, run_mode); break;
-      case 3: hipLaunchKernelGGL(sdv::bkzd_kernel<3>, dim3(grid), dim3(wpb * 64), lds, s, g->P, DS, mail, d_abort, block_size, kflags | 0x100, delta, eta, logd, kloops, stack_doubles, run_mode); break;
-      default: hipLaunchKernelGGL(sdv::bkzd_kernel<4>, dim3(grid), dim3(wpb * 64), lds, s, g->P, DS, mail, d_abort, block_size, kflags | 0x100, delta, eta, logd, kloops, stack_doubles, run_mode); break;
+      case 1: hipLaunchKernelGGL(sdv::bkzd_kernel<1>, dim3(grid), dim3(wpb * 64), lds, s, g->P, DS, mail, d_abort, block_size, kflags | 0x100 | mu_lds_flag, delta, eta, logd, kloops, stack_doubles, run_mode); break;
+      case 2: hipLaunchKernelGGL(sdv::bkzd_kernel<2>, dim3(grid), dim3(wpb * 64), lds, s, g->P, DS, mail, d_abort, block_size, kflags | 0x100 | mu_lds_flag, delta, eta, logd, kloops, stack_doubles, run_mode); break;
+      case 3: hipLaunchKernelGGL(sdv::bkzd_kernel<3>, dim3(grid), dim3(wpb * 64), lds, s, g->P, DS, mail, d_abort, block_size, kflags | 0x100 | mu_lds_flag, delta, eta, logd, kloops, stack_doubles, run_mode); break;
+      default: hipLaunchKernelGGL(sdv::bkzd_kernel<4>, dim3(grid), dim3(wpb * 64), lds, s, g->P, DS, mail, d_abort, block_size, kflags | 0x100 | mu_lds_flag, delta, eta, logd, kloops, stack_doubles, run_mode); break;
       }
     }
     else
     switch (nq)
     {
-    case 1: hipLaunchKernelGGL(bkzs_kernel<1>, dim3(grid), dim3(wpb * 64), lds, s, g->P, DS, mail, d_abort, block_size, kflags, delta, eta, logd, kloops, stack_doubles); break;
-    case 2: hipLaunchKernelGGL(bkzs_kernel<2>, dim3(grid), dim3(wpb * 64), lds, s, g->P, DS, mail, d_abort, block_size, kflags, delta, eta, logd, kloops, stack_doubles); break;
-    case 3: hipLaunchKernelGGL(bkzs_kernel<3>, dim3(grid), dim3(wpb * 64), lds, s, g->P, DS, mail, d_abort, block_size, kflags, delta, eta, logd, kloops, stack_doubles); break;
-    default: hipLaunchKernelGGL(bkzs_kernel<4>, dim3(grid), dim3(wpb * 64), lds, s, g->P, DS, mail, d_abort, block_size, kflags, delta, eta, logd, kloops, stack_doubles); break;
+    case 1: hipLaunchKernelGGL(bkzs_kernel<1>, dim3(grid), dim3(wpb * 64), lds, s, g->P, DS, mail, d_abort, block_size, kflags | mu_lds_flag, delta, eta, logd, kloops, stack_doubles); break;
+    case 2: hipLaunchKernelGGL(bkzs_kernel<2>, dim3(grid), dim3(wpb * 64), lds, s, g->P, DS, mail, d_abort, block_size, kflags | mu_lds_flag, delta, eta, logd, kloops, stack_doubles); break;
+    case 3: hipLaunchKernelGGL(bkzs_kernel<3>, dim3(grid), dim3(wpb * 64), lds, s, g->P, DS, mail, d_abort, block_size, kflags | mu_lds_flag, delta, eta, logd, kloops, stack_doubles); break;
+    default: hipLaunchKernelGGL(bkzs_kernel<4>, dim3(grid), dim3(wpb * 64), lds, s, g->P, DS, mail, d_abort, block_size, kflags | mu_lds_flag, delta, eta, logd, kloops, stack_doubles); break;
     }
     GCHK(hipGetLastError());
     GCHK(hipEventRecord(g->ev[1], s));

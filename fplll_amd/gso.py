@@ -139,7 +139,8 @@ class MatGSOBatch:
         strategies: dict with the flattened arrays of include/fplll_hip.h's fphip_strategies
         (max_block_size, pre_off, pre, prune_off, prune_gh, prune_exp, coeff_off, coeff) or None.
         rnd(lattice, n) -> gmp_urandomm_ui of that lattice's generator (fplll: RandGen); a Python
-        callable or the address (ctypes.c_void_p) of a C function with fphip_rand_fn's signature.
+        callable, the address (ctypes.c_void_p) of a C function with fphip_rand_fn's signature, or a
+        tuple (address, user pointer).
         Returns (status[batch], info[batch][4])."""
         class Strat(ctypes.Structure):
             _fields_ = [("max_block_size", ctypes.c_int), ("pre_off", ctypes.c_void_p),
@@ -163,10 +164,14 @@ class MatGSOBatch:
             keep.append(st_)
             sp = ctypes.byref(st_)
         RND = ctypes.CFUNCTYPE(ctypes.c_ulong, ctypes.c_void_p, ctypes.c_int, ctypes.c_ulong)
+        rnd_user = None
         if rnd is None:
             cb = RND(0)
         elif callable(rnd):
             cb = RND(lambda _u, lattice, n: int(rnd(lattice, n)))
+        elif isinstance(rnd, tuple):  # (address of a C fphip_rand_fn, its user pointer)
+            cb = ctypes.cast(rnd[0], RND)
+            rnd_user = rnd[1]
         else:  # the address of a C function with fphip_rand_fn's signature
             cb = ctypes.cast(rnd, RND)
         fn = self.lib.fphip_gso_bkz_strategies
@@ -178,7 +183,7 @@ class MatGSOBatch:
         info = np.zeros((self.batch, 4), dtype=np.int32)
         flags = ((0x4 if max_loops > 0 else 0) | (0x80 if gh_bnd else 0) | (0x10 if bounded_lll else 0) |
                  (0x20 if auto_abort else 0) | (0x100 if sd else 0))  # sd: BKZ_SD_VARIANT (experimental)
-        rc = fn(self.h, block_size, delta, eta, flags, max_loops, gh_factor, sp, cb, None,
+        rc = fn(self.h, block_size, delta, eta, flags, max_loops, gh_factor, sp, cb, rnd_user,
                 st.ctypes.data_as(ctypes.c_void_p), info.ctypes.data_as(ctypes.c_void_p))
         if rc == _lib.FPHIP_UNSUPPORTED:
             raise NotImplementedError("block sizes above 64 / deeper preprocessing stay on the CPU")

@@ -36,30 +36,44 @@ unsigned long oracle_gmp_rng_next(void *user, unsigned long n)
  * matches fphip_rand_fn (include/fplll_hip.h): rnd(user, lattice, n).  Each stream is
  * RandGen::init_with_seed(seed) — what a run of the reference on that lattice alone starts from. */
 #include <stdlib.h>
-static gmp_randstate_t *streams;
-static int n_streams;
-static unsigned long long stream_draws;
-
-void oracle_gmp_streams_init(int batch, unsigned long seed)
+/* Instance-based: several runs (threads of one test process) each own their streams. */
+typedef struct
 {
-  for (int i = 0; i < n_streams; ++i)
-    gmp_randclear(streams[i]);
-  free(streams);
-  streams      = (gmp_randstate_t *)malloc(sizeof(gmp_randstate_t) * (size_t)batch);
-  n_streams    = batch;
-  stream_draws = 0;
+  gmp_randstate_t *streams;
+  int n_streams;
+  unsigned long long draws;
+} oracle_gmp_streams;
+
+void *oracle_gmp_streams_create(int batch, unsigned long seed)
+{
+  oracle_gmp_streams *s = (oracle_gmp_streams *)malloc(sizeof *s);
+  s->streams            = (gmp_randstate_t *)malloc(sizeof(gmp_randstate_t) * (size_t)batch);
+  s->n_streams          = batch;
+  s->draws              = 0;
   for (int i = 0; i < batch; ++i)
   {
-    gmp_randinit_default(streams[i]);
-    gmp_randseed_ui(streams[i], seed);
+    gmp_randinit_default(s->streams[i]);
+    gmp_randseed_ui(s->streams[i], seed);
   }
+  return s;
+}
+
+void oracle_gmp_streams_destroy(void *h)
+{
+  oracle_gmp_streams *s = (oracle_gmp_streams *)h;
+  if (!s)
+    return;
+  for (int i = 0; i < s->n_streams; ++i)
+    gmp_randclear(s->streams[i]);
+  free(s->streams);
+  free(s);
 }
 
 unsigned long oracle_gmp_streams_next(void *user, int lattice, unsigned long n)
 {
-  (void)user;
-  ++stream_draws;
-  return gmp_urandomm_ui(streams[lattice], n);
+  oracle_gmp_streams *s = (oracle_gmp_streams *)user;
+  ++s->draws;
+  return gmp_urandomm_ui(s->streams[lattice], n);
 }
 
-unsigned long long oracle_gmp_streams_draws(void) { return stream_draws; }
+unsigned long long oracle_gmp_streams_draws(void *h) { return ((oracle_gmp_streams *)h)->draws; }

@@ -90,14 +90,23 @@ def gmp_rng_lib():
     return _gmp_rng
 
 
+class NativeRnd(tuple):
+    """(address of an fphip_rand_fn, its user pointer): what `rnd` may be for the product wrappers."""
+
+
 def gmp_streams_native(batch, seed):
-    """The same streams as GmpStreams, served by C (oracle/gmp_rng.c): returns (address of an
-    fphip_rand_fn, draws()) — a Python callback per random number would dominate the run time of
-    the rerandomisation fixtures."""
+    """The same streams as GmpStreams, served by C (oracle/gmp_rng.c): returns ((address of an
+    fphip_rand_fn, user pointer), draws()) — a Python callback per random number would dominate the
+    run time of the rerandomisation fixtures.  Every call owns its streams (the long runs of
+    test_a_configs_at_size_gpu.py rerandomise in a thread next to the rest of the suite)."""
     lib = gmp_rng_lib()
-    lib.oracle_gmp_streams_init(ctypes.c_int(batch), ctypes.c_ulong(seed))
+    lib.oracle_gmp_streams_create.restype = ctypes.c_void_p
+    lib.oracle_gmp_streams_create.argtypes = [ctypes.c_int, ctypes.c_ulong]
     lib.oracle_gmp_streams_draws.restype = ctypes.c_ulonglong
-    return ctypes.cast(lib.oracle_gmp_streams_next, ctypes.c_void_p), lib.oracle_gmp_streams_draws
+    lib.oracle_gmp_streams_draws.argtypes = [ctypes.c_void_p]
+    h = lib.oracle_gmp_streams_create(batch, seed)
+    fn = ctypes.cast(lib.oracle_gmp_streams_next, ctypes.c_void_p)
+    return NativeRnd((fn, ctypes.c_void_p(h))), (lambda: lib.oracle_gmp_streams_draws(h))
 
 
 class GmpStreams:

@@ -112,7 +112,7 @@ def reference_plan(rnd, lo, hi, density):
 @pytest.mark.parametrize("lo,hi", [(1, 40), (17, 19), (5, 68), (30, 33), (3, 4)])
 def test_rerandomisation_plan_matches_reference_loop(lo, hi):
     lib = product_lib()
-    fn, draws = C.gmp_streams_native(2, 99)
+    (fn, user), draws = C.gmp_streams_native(2, 99)
     lib.fphip_debug_bkz_plan.restype = ctypes.c_int
     lib.fphip_debug_bkz_plan.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                          ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
@@ -121,7 +121,7 @@ def test_rerandomisation_plan_matches_reference_loop(lo, hi):
     for rep in range(3):  # consecutive calls continue the same stream
         plan = np.zeros(448, dtype=np.uint32)
         nm, no = ctypes.c_int(), ctypes.c_int()
-        rc = lib.fphip_debug_bkz_plan(fn, None, 1, lo, hi, 3, plan.ctypes.data, ctypes.byref(nm),
+        rc = lib.fphip_debug_bkz_plan(fn, user, 1, lo, hi, 3, plan.ctypes.data, ctypes.byref(nm),
                                       ctypes.byref(no))
         assert rc == 0
         moves, ops = reference_plan(py, lo, hi, 3)
