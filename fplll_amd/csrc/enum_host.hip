@@ -792,6 +792,13 @@ extern "C" int fphip_enum_run(fphip_ctx *ctx, int dim, double maxdist, const dou
       HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
       HIPCHK(ctx, hipMemcpy(&cnt, ctx->buf[nxt].count, 4, hipMemcpyDeviceToHost));
     }
+    if (!in_final && o.shard_count > 1 && cnt > ctx->cap)
+      // The multi-GPU partition deals the tasks of the replicated split launches by content; that
+      // needs every rank to hold the SAME task set.  After an overflow, which tasks made it into
+      // the buffer depends on the order of the atomics and differs per rank: a subtree could be
+      // walked twice or by nobody.  (A single GPU walks the overflow inline and stays exact.)
+      return fail(ctx, "task buffer overflow in a split launch (%u tasks, capacity %u) under sharding: "
+                       "raise FPHIP_TASK_CAP or lower the task target", cnt, ctx->cap);
     if (cnt > ctx->cap)
       cnt = ctx->cap;
     if (in_final && o.exchange)
