@@ -172,10 +172,21 @@ static int cmd_enumfix(int argc, char **argv)
   MatGSO<ZT, FT> M(A, U, UT, GSO_ROW_EXPO);
   M.update_gso();
 
+  // REFDRV_DUAL=1: a DUAL enumeration of the block, as svp_reduction(dual = true) runs it
+  // (bkz.cpp:308-331): radius from 1 / r of the block's LAST row, enumerate(..., dual = true).  The
+  // fixture then holds the TRANSFORMED inputs of EnumerationDyn::enumerate (enumerate.cpp:88-141),
+  // recomputed below through MatGSO's public getters — the plugin hook is handed untransformed
+  // mu / r for a dual call (enumerate_ext.cpp:57-74), so the recording enumerator is of no use here.
+  const bool dual = getenv("REFDRV_DUAL") != nullptr;
   long expo;
-  FT max_dist = M.get_r_exp(first, first, expo);
+  FT max_dist = M.get_r_exp(dual ? first + d - 1 : first, dual ? first + d - 1 : first, expo);
+  if (dual)
+  {
+    max_dist.pow_si(max_dist, -1, GMP_RNDU);
+    expo *= -1;
+  }
   max_dist *= rfac;  // bkz.cpp:311-318 (delta)
-  if (d > 30 && rfac <= 1.0)
+  if (!dual && d > 30 && rfac <= 1.0)
   {
     FT root_det = M.get_root_det(first, first + d);
     adjust_radius_to_gh_bound(max_dist, expo, d, root_det, 1.1);  // bkz.cpp:319-323
@@ -189,8 +200,44 @@ static int cmd_enumfix(int argc, char **argv)
   // REFDRV_SUBSOLS=1: the evaluator also collects sub-solutions (findsubsols, evaluator.h:185-205)
   LoggingEvaluator ev(max_sols, (EvaluatorStrategy)strategy, getenv("REFDRV_SUBSOLS") != nullptr);
   Enumeration<ZT, FT> E(M, ev);
+  const FT max_dist0 = max_dist;  // (enumerate() returns the final bound in max_dist)
   auto t0 = std::chrono::steady_clock::now();
-  E.enumerate(first, first + d, max_dist, expo, vector<FT>(), vector<enumxt>(), pruning);
+  E.enumerate(first, first + d, max_dist, expo, vector<FT>(), vector<enumxt>(), pruning, dual);
+  if (dual)
+  {  // what the internal enumerator worked on (enumerate.cpp:88-141, dual branch)
+    long normexp = -1;
+    for (int i = 0; i < d; ++i)
+    {
+      long rexpo;
+      FT fr   = M.get_r_exp(i + first, i + first, rexpo);
+      normexp = std::max(normexp, rexpo + fr.exponent());
+    }
+    normexp *= -1;
+    FT fmd;
+    fmd.mul_2si(max_dist0, expo - normexp);
+    g_rec.d       = d;
+    g_rec.maxdist = fmd.get_d(GMP_RNDU);
+    g_rec.dual    = true;
+    g_rec.mut.assign((size_t)d * d, 0.0);
+    g_rec.rdiag.assign(d, 0.0);
+    g_rec.pruning.assign(d, 1.0);
+    for (int i = 0; i < d && i < (int)pruning.size(); ++i)
+      g_rec.pruning[i] = pruning[i];
+    for (int i = 0; i < d; ++i)
+    {
+      long rexpo;
+      FT fr = M.get_r_exp(i + first, i + first, rexpo);
+      fr.mul_2si(fr, rexpo + normexp);
+      g_rec.rdiag[d - i - 1] = 1.0 / fr.get_d();
+    }
+    for (int i = 0; i < d; ++i)
+      for (int j = i + 1; j < d; ++j)
+      {
+        FT fmu;
+        M.get_mu(fmu, j + first, i + first);
+        g_rec.mut[(size_t)(d - j - 1) * d + (d - i - 1)] = -fmu.get_d();
+      }
+  }
   double secs =
       std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   auto nodes = E.get_nodes_array();
@@ -204,6 +251,8 @@ static int cmd_enumfix(int argc, char **argv)
      << " bkz_pre=" << bkz_pre << " first=" << first << " d=" << d << " pruning=" << prspec
      << " max_sols=" << max_sols << " strategy=" << strategy << " rfac=" << rfac << "\",\n";
   os << "\"d\":" << d << ",\n\"max_sols\":" << max_sols << ",\n\"strategy\":" << strategy << ",\n";
+  if (dual)
+    os << "\"dual\":1,\n";
   os << "\"maxdist\":" << hexd(g_rec.maxdist) << ",\n";
   dump_vec(os, "mut", g_rec.mut);
   dump_vec(os, "rdiag", g_rec.rdiag);

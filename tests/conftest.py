@@ -46,6 +46,12 @@ def enum_fixtures():
     return sorted(glob.glob(os.path.join(GOLDEN, "enum_*.json")))
 
 
+def dual_enum_fixtures():
+    """Dual enumerations of the real reference (tests/golden/make_fixtures.sh, REFDRV_DUAL=1): the
+    transformed inputs of EnumerationDyn::enumerate, per-level counts, every eval_sol call."""
+    return sorted(glob.glob(os.path.join(GOLDEN, "dualenum_*.json")))
+
+
 # ---- the C restatement oracle (test infrastructure; built on demand with gcc) -------------------
 _oracle = None
 SOLCB = ctypes.CFUNCTYPE(ctypes.c_double, ctypes.c_void_p, ctypes.c_double,

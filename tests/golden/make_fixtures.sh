@@ -28,6 +28,13 @@ REFDRV_RADIUS_SCALE=0.45 $D enumfix 100 50 14 5 20 0 80 linear:70 100000000 0 0.
 REFDRV_RADIUS_SCALE=0.45 $D enumfix 100 50 14 5 20 0 80 linear:70 1         0 0.99 > $G/enum_d80_lin70_best1.json
 REFDRV_RADIUS_SCALE=0.36 $D enumfix 110 55 14 6 20 0 96 linear:90 100000000 0 0.99 > $G/enum_d96_lin90_fixed.json
 
+# --- DUAL enumeration (REFDRV_DUAL=1: enumerate(..., dual = true) with the radius of svp_reduction's
+#     dual branch; the fixture holds the TRANSFORMED inputs of EnumerationDyn::enumerate, the
+#     reference's per-level counts and every eval_sol call, coefficients in enumeration order)
+REFDRV_DUAL=1 $D enumfix  60 30 10 4 20 10 36 none      100000000 0 0.99 > $G/dualenum_d36_fixed.json
+REFDRV_DUAL=1 $D enumfix  60 30 10 3 20  0 30 linear:15 1         0 0.99 > $G/dualenum_d30_lin15_best1.json
+REFDRV_DUAL=1 REFDRV_RADIUS_SCALE=0.4 $D enumfix 100 50 14 5 20 0 72 linear:60 100000000 0 0.99 > $G/dualenum_d72_lin60_fixed.json
+
 # --- GSO / size-reduction (MatGSO<long,double>, GSO_ROW_EXPO): n k bits seed perturb
 $D gsofix 30 15 10 1 0 > $G/gso_q30_p0.json
 $D gsofix 48 24 12 2 3 > $G/gso_q48_p3.json

@@ -401,3 +401,23 @@ def test_dual_svp_kat_device(ctx):
     assert ev.solutions and res.final_maxdist == m_o
     x = [int(v) for v in ev.solutions[0][1]][::-1]  # enumerate.cpp:154-158: reversed for dual
     assert K.exact_dual_norm2(b, x) == target
+
+
+@pytest.mark.parametrize("path", C.dual_enum_fixtures(), ids=lambda p: os.path.basename(p)[:-5])
+def test_dual_reference_fixture_parity(ctx, path):
+    """Dual enumeration against the REAL reference (tests/golden/dualenum_*.json: enumerate(...,
+    dual = true) of fplll, inputs transformed as EnumerationDyn::enumerate does): with a radius that
+    never shrinks the per-level node counts and the multiset of candidates are the reference's
+    (d = 36 and d = 72, the latter through the top-walk kernel); with BEST-1 the final norm is."""
+    f = C.load_fixture(path)
+    ev, log, res = _run(ctx, f, dual=True)
+    for dist, x in log:
+        assert 0.0 < dist <= f["maxdist"]
+    if f["max_sols"] >= 1000000 and f["strategy"] == 0:
+        assert [int(v) for v in res.nodes] == f["nodes"]
+        assert sorted((a, tuple(b)) for a, b in log) == sorted((a, tuple(b)) for a, b in f["sol_log"])
+        return
+    # shrinking radius (a pruned tree is order dependent, see the module docstring): never longer
+    # than the reference's result unless its vector is cut under the radius the device had reached
+    if res.final_maxdist != f["final_maxdist"]:
+        assert f["sol_log"] and res.final_maxdist < f["final_maxdist"]

@@ -23,6 +23,23 @@ def test_oracle_matches_reference_fixture(path):
     assert final == f["final_maxdist"]
 
 
+@pytest.mark.parametrize("path", C.dual_enum_fixtures(), ids=lambda p: os.path.basename(p)[:-5])
+def test_oracle_dual_walk_matches_reference_fixture(path):
+    """The dual enumeration pinned at the enumeration level: the reference's
+    enumerate(..., dual = true) against the oracle's dualenum walk on the transformed inputs —
+    per-level node counts, every eval_sol call in order (coefficients in enumeration order: the
+    reference reverses the evaluator's vectors after the walk, enumerate.cpp:154-158), final bound."""
+    f = C.load_fixture(path)
+    ev = FastEvaluator(f["max_sols"], f["strategy"])
+    log = []
+    nodes, final = C.oracle_enumerate(f["mut"], f["rdiag"], f["pruning"], f["maxdist"], ev, log, dual=True)
+    assert [int(v) for v in nodes] == f["nodes"]
+    assert len(log) == len(f["sol_log"])
+    for (d1, x1), (d2, x2) in zip(log, f["sol_log"]):
+        assert d1 == d2 and x1 == x2
+    assert final == f["final_maxdist"]
+
+
 def test_fixture_md5():
     import hashlib
     with open(os.path.join(C.GOLDEN, "MD5SUMS")) as fh:
