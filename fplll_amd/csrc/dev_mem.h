@@ -5,7 +5,11 @@
 // One process may drive several contexts at once (in-process multi-GPU plugin, the long config-size
 // runs of the test-suite beside the rest of it), so nothing in this library may stall on a stranger's
 // kernel.  Every API call waits for its own stream before it returns, so a buffer is idle when it is
-// freed and ready when the caller's next (null-stream) copy touches it.
+// freed.  An allocation is COMPLETE when fphip_dev_alloc returns (it waits for the stream — which is
+// idle at every call site: allocations happen at object creation and between launches, never on a
+// hot path), so the blocking null-stream hipMemcpy calls of the host layer may touch it at once;
+// without the wait the API leaves a use from another stream undefined (the pool could hand out a
+// block whose hipFreeAsync is still pending on the stream).
 #ifndef FPHIP_DEV_MEM_H
 #define FPHIP_DEV_MEM_H
 
@@ -13,7 +17,10 @@
 
 static inline hipError_t fphip_dev_alloc(void **p, size_t bytes, hipStream_t s)
 {
-  return hipMallocAsync(p, bytes, s);
+  hipError_t e = hipMallocAsync(p, bytes, s);
+  if (e != hipSuccess)
+    return e;
+  return hipStreamSynchronize(s);
 }
 static inline void fphip_dev_free(void *p, hipStream_t s)
 {

@@ -244,6 +244,11 @@ extern "C" void fphip_destroy(fphip_ctx *ctx)
     fphip_dev_free(ctx->idxlist, ctx->stream);
   if (ctx->g)
     fphip_dev_free(ctx->g, ctx->stream);
+  // Wait for the stream BEFORE the pinned buffers go back to the process-wide cache: after an error
+  // path (ring timeout, failed HIP call) a kernel may still be resident and writing its ring / bound /
+  // sequence words — another thread's fphip_create must not be handed that HostCtl meanwhile.
+  if (ctx->stream)
+    hipStreamSynchronize(ctx->stream);  // also completes the stream-ordered frees above
   if (ctx->stage)
     fphip_pinned_put(ctx->stage);
   if (ctx->h)
@@ -253,10 +258,7 @@ extern "C" void fphip_destroy(fphip_ctx *ctx)
   if (ctx->ev[1])
     hipEventDestroy(ctx->ev[1]);
   if (ctx->stream)
-  {
-    hipStreamSynchronize(ctx->stream);  // the stream-ordered frees above
     hipStreamDestroy(ctx->stream);
-  }
   delete ctx;
 }
 
@@ -668,7 +670,10 @@ extern "C" int fphip_enum_run(fphip_ctx *ctx, int dim, double maxdist, const dou
         if (ctx->gstk)
           fphip_dev_free(ctx->gstk, ctx->stream);
         ctx->gstk = nullptr;
-        HIPCHK(ctx, fphip_dev_alloc((void **)&ctx->gstk, need * sizeof(double), ctx->stream));
+        // + 256 doubles of padding: the STEP loop loads the column / mu row of level k + 1 one test
+        // ahead, before it knows that k + 1 exists (enum_kernel.hip) — for the last wave that read
+        // lands up to Lmax - 1 doubles behind its stack; the value is never used
+        HIPCHK(ctx, fphip_dev_alloc((void **)&ctx->gstk, (need + 256) * sizeof(double), ctx->stream));
         ctx->gstk_doubles = need;
       }
     }
@@ -784,7 +789,7 @@ extern "C" int fphip_enum_run(fphip_ctx *ctx, int dim, double maxdist, const dou
         int any      = 1;
         double glob  = o.exchange(o.exchange_user, local, 1, &any);
         if (glob < local)
-          __atomic_store_n(&ctx->h->bound_bits, dbits(glob), __ATOMIC_RELEASE);
+          publish_bound_min(ctx, glob);  // never raises: another host thread may have lowered it since
       }
     }
     ++launches;
@@ -813,7 +818,7 @@ extern "C" int fphip_enum_run(fphip_ctx *ctx, int dim, double maxdist, const dou
       int any      = cnt > 0;
       double glob  = o.exchange(o.exchange_user, local, cnt > 0, &any);
       if (glob < local)
-        __atomic_store_n(&ctx->h->bound_bits, dbits(glob), __ATOMIC_RELEASE);
+        publish_bound_min(ctx, glob);
       others_active = any != 0;
     }
     if (in_final)

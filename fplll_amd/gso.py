@@ -82,6 +82,7 @@ class MatGSOBatch:
 
     def broadcast_basis(self, src=0):
         self._chk(self.lib.fphip_gso_broadcast_basis(self.h, src), "broadcast_basis")
+        self._chk(self.lib.fphip_gso_refresh(self.h), "refresh")
 
     def tile_basis(self, count):
         """lattices count.. := copies of lattices 0..count-1, cyclically (device-side copies)"""

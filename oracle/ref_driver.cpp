@@ -946,10 +946,72 @@ static int cmd_bkztour(int argc, char **argv)
   for (int i = 0; i < A.get_rows(); ++i)
     for (int j = 0; j < A.get_cols(); ++j)
       fp = (fp ^ (unsigned long long)A(i, j).get_si()) * 1099511628211ull;
+  // the reference's own acceptance predicate on the OUTPUT basis (lll.cpp:226-257, what
+  // tests/test_lll.cpp asserts), evaluated at 256 bits so that it judges the basis, not the floats
+  int lll_red = -1;
+  double logvol = 0.0;
+  {
+    int old_prec = FP_NR<mpfr_t>::set_prec(256);
+    {
+      ZZ_mat<mpz_t> U2, UT2;
+      MatGSO<Z_NR<mpz_t>, FP_NR<mpfr_t>> M2(A, U2, UT2, 0);
+      lll_red = is_lll_reduced<Z_NR<mpz_t>, FP_NR<mpfr_t>>(M2, LLL_DEF_DELTA, LLL_DEF_ETA) ? 1 : 0;
+      FP_NR<mpfr_t> f;
+      for (int i = 0; i < A.get_rows(); ++i)
+      {
+        M2.get_r(f, i, i);
+        f.log(f);
+        logvol += f.get_d();
+      }
+    }
+    FP_NR<mpfr_t>::set_prec(old_prec);
+  }
+  if (getenv("REFDRV_DUMP_BASIS"))
+  {
+    std::ofstream os(getenv("REFDRV_DUMP_BASIS"));
+    os << A << std::endl;
+  }
   printf("{\"plugin\":\"%s\",\"beta\":%d,\"status\":%d,\"tour_seconds\":%.3f,\"r00\":%.17g,"
-         "\"slope\":%.9f,\"basis_fnv\":\"%016llx\"}\n",
-         plug.c_str(), beta, status, secs, r0.get_d(), slope, fp);
+         "\"slope\":%.9f,\"is_lll_reduced\":%d,\"log_volume\":%.12g,\"basis_fnv\":\"%016llx\"}\n",
+         plug.c_str(), beta, status, secs, r0.get_d(), slope, lll_red, logvol, fp);
   return (status == RED_SUCCESS || status == RED_BKZ_LOOPS_LIMIT) ? 0 : 1;
+}
+
+/* basisstat basisfile  → JSON: the reference's is_lll_reduced (256-bit GSO), slope of log r_ii
+ * (gso_interface.cpp:198-218), log-volume, r_00 — the acceptance test of a tour whose enumerations
+ * ran in another order than the reference's (a pruned shrinking-radius walk is order dependent) */
+static int cmd_basisstat(int argc, char **argv)
+{
+  if (argc < 3)
+    return 2;
+  ZZ_mat<mpz_t> A;
+  if (!read_basis(argv[2], A))
+    return 2;
+  ZZ_mat<mpz_t> U, UT;
+  MatGSO<ZT, FT> M(A, U, UT, GSO_ROW_EXPO);
+  M.update_gso();
+  FT r0;
+  M.get_r(r0, 0, 0);
+  double slope = M.get_current_slope(0, A.get_rows());
+  int lll_red;
+  double logvol = 0.0;
+  int old_prec  = FP_NR<mpfr_t>::set_prec(256);
+  {
+    ZZ_mat<mpz_t> U2, UT2;
+    MatGSO<Z_NR<mpz_t>, FP_NR<mpfr_t>> M2(A, U2, UT2, 0);
+    lll_red = is_lll_reduced<Z_NR<mpz_t>, FP_NR<mpfr_t>>(M2, LLL_DEF_DELTA, LLL_DEF_ETA) ? 1 : 0;
+    FP_NR<mpfr_t> f;
+    for (int i = 0; i < A.get_rows(); ++i)
+    {
+      M2.get_r(f, i, i);
+      f.log(f);
+      logvol += f.get_d();
+    }
+  }
+  FP_NR<mpfr_t>::set_prec(old_prec);
+  printf("{\"d\":%d,\"r00\":%.17g,\"slope\":%.9f,\"is_lll_reduced\":%d,\"log_volume\":%.12g}\n",
+         A.get_rows(), r0.get_d(), slope, lll_red, logvol);
+  return 0;
 }
 
 /* enumtime basisfile first d pruning rfac mode threads [radius_scale]
@@ -1222,6 +1284,8 @@ int main(int argc, char **argv)
     return cmd_sweeptime(argc, argv);
   if (cmd == "bkztour")
     return cmd_bkztour(argc, argv);
+  if (cmd == "basisstat")
+    return cmd_basisstat(argc, argv);
   fprintf(stderr, "unknown command %s\n", cmd.c_str());
   return 2;
 }

@@ -90,16 +90,23 @@ def _run_config5_hlll(out):
         out["c5_error"] = repr(e)
 
 
-def test_00_start_the_config3_tour_and_the_config5_hlll(ctx):
-    """Starts config 3's BKZ-60 tour with strategies (180-dim) and config 5's HLLL in exact-order
-    double (256-dim) in the background; tests/test_zzz_long_runs_gpu.py joins them and compares
-    with the reference's goldens."""
+def start_long_runs():
+    """Idempotent: starts the two background runs unless this process already has."""
     import threading
-    C.LONG_RUNS.clear()
+    if "thread_c3" in C.LONG_RUNS:
+        return
     for name, fn in (("c3", _run_config3_tour), ("c5", _run_config5_hlll)):
         th = threading.Thread(target=fn, args=(C.LONG_RUNS,), name="long-" + name, daemon=True)
         th.start()
         C.LONG_RUNS["thread_" + name] = th
+
+
+def test_00_start_the_config3_tour_and_the_config5_hlll(ctx):
+    """Starts config 3's BKZ-60 tour with strategies (180-dim) and config 5's HLLL in exact-order
+    double (256-dim) in the background; tests/test_zzz_long_runs_gpu.py joins them and compares
+    with the reference's goldens (and starts them itself when this test was deselected or ran in
+    another xdist worker: the comparison is never skipped)."""
+    start_long_runs()
     assert all(C.LONG_RUNS["thread_" + n].is_alive() or n in C.LONG_RUNS or n + "_error" in C.LONG_RUNS
                for n in ("c3", "c5"))
 
@@ -254,8 +261,7 @@ def test_config3_linear_block_matches_reference(ctx, k):
     squared norm identical to the reference's."""
     from fplll_amd.enumeration import FastEvaluator, enumerate_block
     path = os.path.join(C.GOLDEN, "c3_b60_k%d_linear30.json" % k)
-    if not os.path.exists(path):
-        pytest.skip("fixture not generated")
+    assert os.path.exists(path), "committed fixture missing: " + path
     f = C.load_fixture(path)
     ev = FastEvaluator(f["max_sols"], f["strategy"])
     res = enumerate_block(ctx, f["mut"], f["rdiag"], f["pruning"], f["maxdist"], ev)

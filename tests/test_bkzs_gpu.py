@@ -1,4 +1,4 @@
-"""Device BKZ WITH strategies (fphip_gso_bkz_strategies, bkzs_kernel.hip) against the reference:
+"""Device BKZ WITH strategies (fphip_gso_bkz_strategies, bkzs_body<NQ, false> in bkzs_kernel.hip) against the reference:
 tests/golden/bkzs_*.json hold BKZReduction::bkz() runs of the real reference with a strategies file
 (preprocessing tours, pruning sets, GH bound, rerandomisation; see
 test_bkz_strategies_oracle_vs_ref.py for the CPU-side pin of the same fixtures).  The device has to
@@ -12,15 +12,10 @@ import conftest as C
 
 pytestmark = pytest.mark.gpu
 
+# every bkzs_* fixture runs by default: the three-level nesting (bkzs_q56_b40_nested3: 24 k
+# enumerations, 410 rerandomisations) and the strategies the reference's tests/test_bkz.cpp builds by
+# hand (*teststrat*: preprocessing 20 -> 10 -> 5, LinearPruningParams) included.
 FIXTURES = C.bkz_strategy_fixtures()
-# bkzs_q56_b40_nested3 (three nested tours, 24 k enumerations, 410 rerandomisations) was added after
-# the round's last GPU session: it is pinned oracle-vs-reference on the CPU
-# (test_bkz_strategies_oracle_vs_ref.py) and joins the device run once it has been seen green there
-# (FPHIP_BKZS_ALL=1 runs it).
-# ... and so do the bkzs_*teststrat* fixtures (the strategies tests/test_bkz.cpp of the reference
-# builds by hand: preprocessing 20 -> 10 -> 5, LinearPruningParams).
-if not os.environ.get("FPHIP_BKZS_ALL"):
-    FIXTURES = [p for p in FIXTURES if "nested3" not in p and "teststrat" not in p]
 if os.environ.get("FPHIP_BKZS_ONLY"):
     FIXTURES = [p for p in FIXTURES if any(t in p for t in os.environ["FPHIP_BKZS_ONLY"].split(","))]
 

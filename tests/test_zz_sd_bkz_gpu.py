@@ -1,10 +1,7 @@
-"""Device self-dual BKZ (BKZ_SD_VARIANT through fphip_gso_bkz_strategies, bkzd_kernel.hip) against
-the reference's bkzd_*sd* fixtures (oracle-pinned by test_bkz_dual_variants_oracle_vs_ref.py).
-
-The two strategy-less fixtures (BKZ_MAX_LOOPS; forced auto-abort, 13 tours) have been seen green on
-the MI355X (profiles/r01_sd_bkz_first_run.log).  The fixture that combines dual blocks with
-strategies was pinned on the oracle side only before the round's GPU budget ran out: it joins the
-run with FPHIP_BKZS_ALL=1."""
+"""Device self-dual BKZ (BKZ_SD_VARIANT through fphip_gso_bkz_strategies: bkzs_body<NQ, true> in
+bkzs_kernel.hip) against the reference's bkzd_*sd* fixtures (oracle-pinned by
+test_bkz_dual_variants_oracle_vs_ref.py): BKZ_MAX_LOOPS, the forced auto-abort (13 tours) and dual
+blocks combined with strategies — all three run by default."""
 import glob
 import os
 
@@ -16,8 +13,6 @@ import conftest as C
 pytestmark = pytest.mark.gpu
 
 FIXTURES = sorted(glob.glob(os.path.join(C.GOLDEN, "bkzd_*sd*.json")))
-if not os.environ.get("FPHIP_BKZS_ALL"):
-    FIXTURES = [p for p in FIXTURES if "strategies" not in p]
 
 
 @pytest.mark.parametrize("path", FIXTURES, ids=lambda p: os.path.basename(p)[:-5])
