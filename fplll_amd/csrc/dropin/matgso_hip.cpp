@@ -216,4 +216,43 @@ bool LLLReduction<Z_NR<long>, FP_NR<double>>::lll(int kappa_min, int kappa_start
   return next(this, kappa_min, kappa_start, kappa_end, size_reduction_start);
 }
 
+// ---------------------------------------------------------------------------------------------
+// LLLReduction<Z_NR<long>, FP_NR<double>>::babai (declared fplll/lll.h:83, body lll.cpp:166-224) —
+// the member LLLReduction::size_reduction (inline, lll.h:107-122: compiled into every caller, bkz.cpp's
+// svp_reduction included) calls row by row through the PLT.  Interposed the same way as lll(): on a
+// MatGSOHip, babai(kappa, kappa, 0) — the form size_reduction uses — runs on the device
+// (fphip_gso_size_reduce of the one row: the same multipliers, the same integer row).  Opt-in
+// (FPLLL_HIP_BABAI=1): one row is microseconds of work on the host and a launch plus a mirror
+// refresh on the device — this path exists so that EVERY reduction primitive of the class reaches
+// the device through the reference's unmodified callers (the correctness harness of SURVEY 8(b)(i)),
+// the speed is in the coarse entry points (size_reduction_device, lll_device, the batched C ABI).
+// ---------------------------------------------------------------------------------------------
+typedef bool (*babai_member_fn)(LLLReduction<Z_NR<long>, FP_NR<double>> *, int, int, int);
+
+template <>
+bool LLLReduction<Z_NR<long>, FP_NR<double>>::babai(int kappa, int size_reduction_end, int size_reduction_start)
+{
+  static const bool enabled = getenv("FPLLL_HIP_BABAI") && atoi(getenv("FPLLL_HIP_BABAI")) != 0;
+  fplll_hip::MatGSOHip *h   = enabled ? dynamic_cast<fplll_hip::MatGSOHip *>(&m) : nullptr;
+  if (h && h->on_device() && size_reduction_end == kappa && size_reduction_start == 0 && kappa > 0)
+  {
+    const int st = h->size_reduction_device(kappa, kappa + 1, eta.get_d());
+    if (st == 1)
+      return true;
+    if (st == 0)
+      return set_status(RED_GSO_FAILURE);
+    if (st == -1)
+      return set_status(RED_BABAI_FAILURE);
+    // -2 (a multiplier beyond 63 bits) / device error: nothing was changed, the host path takes over
+  }
+  static babai_member_fn next = (babai_member_fn)dlsym(
+      RTLD_NEXT, "_ZN5fplll12LLLReductionINS_4Z_NRIlEENS_5FP_NRIdEEE5babaiEiii");
+  if (!next)
+  {
+    status = RED_BABAI_FAILURE;
+    return false;
+  }
+  return next(this, kappa, size_reduction_end, size_reduction_start);
+}
+
 FPLLL_END_NAMESPACE

@@ -10,8 +10,16 @@
 #define FPHIP_TRI64 2016   /* 64*63/2 mu entries: rows below 64 (the wave-per-subtree walk) */
 #define FPHIP_TRI128 8128 /* 128*127/2: rows up to 127 (the top walk of blocks larger than 64) */
 
+/* Task queues.  One returning atomic on ONE address costs about 50 ns of that address's L2 channel
+ * (measured on MI355X: a walk launch lasted 62-66 ns per task whatever the tasks held, 180 000 tickets
+ * took 9 ms) — a single ticket counter caps a launch at 2·10^7 tasks/s.  Tickets and emission counters
+ * are therefore spread over FPHIP_NQ queues / regions whose counters sit FPHIP_QS words apart. */
+#define FPHIP_NQ 128
+#define FPHIP_QS 16 /* unsigned words between two counters: 64 bytes */
+
 #define FPHIP_ERR_RING_TIMEOUT 1u
 #define FPHIP_FLAG_TASK_OVERFLOW 2u
+#define FPHIP_FLAG_BFS_OVERFLOW 4u /* a buffer of the breadth-first expansion was too small: the host starts over */
 
 namespace fphip
 {
@@ -52,6 +60,9 @@ struct DevShared
   unsigned int drain[FPHIP_MAX_LAUNCHES];  // set when a launch's task queue ran dry
   double rp[128][2];  // (rdiag[k], pruning[k]) interleaved: one 16-byte scalar load per level
   double mu_tri[FPHIP_TRI128];  // mu_tri[k(k-1)/2 + i] = mu(k,i), i<k
+  // breadth-first expansion of the top of the tree (enum_bfs_kernel): the table of the subtree-size
+  // estimate (scheduling only: never affects which nodes are visited)
+  float bfs_A[64][64];  // [L][k], k < L: log( V_{L-k}(1) / prod_{i=k}^{L-1} sqrt(r_ii) )
 };
 
 // Subtree tasks (structure of arrays; col/x rows are 64 doubles so that a wave loads them coalesced).
@@ -65,6 +76,14 @@ struct TaskBuf
                         //            coefficients of levels 64..127 are kept once, in xhi_root
   unsigned int *count;  // number of tasks written (may exceed cap: overflow handled inline)
   unsigned int cap;
+};
+
+// Queue memory of one enumeration call (device; zeroed at the start of the call).
+struct QueueMem
+{
+  unsigned int head[FPHIP_MAX_LAUNCHES][FPHIP_NQ * FPHIP_QS];  // ticket counters per launch and queue
+  unsigned int bfs[66][FPHIP_NQ * FPHIP_QS];  // breadth-first stage: heavy nodes per level and region
+  unsigned int fin[FPHIP_NQ * FPHIP_QS];      // breadth-first stage: final tasks per region
 };
 
 // Tasks of the top walk of a block larger than 64 (enum_top_kernel): subtree roots at a level > 64.

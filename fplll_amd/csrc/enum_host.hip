@@ -28,13 +28,50 @@ template <bool MU_LDS, bool SUBS, bool DUAL>
 __global__ void enum_phase_kernel(DevShared *g, HostCtl *h, TaskBuf in, TaskBuf out, int d,
                                   int Lmax, int stop, unsigned task_lo, unsigned task_hi,
                                   const unsigned *idxlist, int launch_idx, int count_nodes,
-                                  unsigned budget, const double *xhi_root, double *gstk, int Tsplit);
+                                  unsigned budget, const double *xhi_root, double *gstk, int Tsplit,
+                                  unsigned *qh, const unsigned *rcnt, unsigned rcap,
+                                  unsigned long long bound_init);
 template <bool SUBS, bool DUAL>
 __global__ void enum_top_kernel(DevShared *g, HostCtl *h, TopBuf in, unsigned n_in, TopBuf out_top,
                                 int stop, TaskBuf out, double *xhi_root, int d, double maxdist,
                                 int count_nodes, int launch_idx);
 __global__ void task_key_kernel(TaskBuf in, unsigned n, int d, unsigned long long *keys,
-                                const double *xhi_root);
+                                const double *xhi_root, const unsigned *slots);
+template <bool DUAL>
+__global__ void enum_bfs_kernel(DevShared *g, double maxdist, QueueMem *qm, TaskBuf f0, TaskBuf f1,
+                                TaskBuf fin, int L0, int nlev, int floor_level, float heavy, int count_nodes,
+                                int compact_n);
+// Closes the breadth-first stage: number of final tasks and the error flags into the pinned control
+// block (the host reads them without another device round trip); with `slots` (multi-GPU partition:
+// the host sorts the tasks by content) also the compact list of the occupied slots and their
+// partial distances.
+__global__ void enum_bfs_epilogue(const DevShared *g, HostCtl *h, const QueueMem *qm, unsigned rcap,
+                                  unsigned *slots, double *pdc, const double *pd)
+{
+  __shared__ unsigned base[FPHIP_NQ + 1];
+  if (threadIdx.x == 0)
+  {
+    unsigned tot = 0;
+    for (int q = 0; q < FPHIP_NQ; ++q)
+    {
+      base[q] = tot;
+      const unsigned c = qm->fin[q * FPHIP_QS];
+      tot += c < rcap ? c : rcap;
+    }
+    base[FPHIP_NQ] = tot;
+    h->pad[0]      = tot;
+    h->pad[1]      = g->error_flags;
+    __threadfence_system();
+  }
+  __syncthreads();
+  if (slots)
+    for (int q = 0; q < FPHIP_NQ; ++q)
+      for (unsigned i = threadIdx.x; i < base[q + 1] - base[q]; i += blockDim.x)
+      {
+        slots[base[q] + i] = (unsigned)q * rcap + i;
+        pdc[base[q] + i]   = pd[(size_t)q * rcap + i];
+      }
+}
 }
 using namespace fphip;
 
@@ -87,13 +124,16 @@ struct fphip_ctx
   DevShared *g      = nullptr;  // device
   DevShared *stage  = nullptr;  // pinned host staging copy
   HostCtl *h        = nullptr;  // pinned, coherent; same pointer is valid on the device
-  TaskBuf buf[2];
+  TaskBuf buf[3];  // [0], [1]: task lists of the launches; [2]: second frontier of the breadth-first stage
   unsigned cap                 = 0;
   unsigned long long ring_next = 0;
   unsigned long long *keys     = nullptr;  // device: content key per task (multi-GPU partition)
   unsigned *idxlist            = nullptr;  // device: this rank's task indices, heaviest first
   double *xhi_root             = nullptr;  // device: [cap][64] coefficients of levels 64..127 per
                                            // level-64 ancestor (blocks larger than 64)
+  QueueMem *qm                 = nullptr;  // device: ticket / emission counters of the current call
+  unsigned *slots              = nullptr;  // device: compact list of the occupied slots of a regioned buffer
+  double *pdc                  = nullptr;  // device: their partial distances (multi-GPU partition)
   double *gstk                 = nullptr;  // device: per-wave scratch of the tall stack slots (split stack)
   size_t gstk_doubles          = 0;
   TopBuf top[2] = {};                           // top tasks of blocks larger than 64 (allocated on demand)
@@ -167,8 +207,12 @@ extern "C" int fphip_create(int device, fphip_ctx **out)
   if (!ctx->stage || !ctx->h)
     HIPCHK(ctx, hipErrorOutOfMemory);
   memset(ctx->h, 0, sizeof(HostCtl));
-  ctx->cap = (unsigned)env_int("FPHIP_TASK_CAP", 1 << 19);
-  for (int b = 0; b < 2; ++b)
+  ctx->cap = (unsigned)env_int("FPHIP_TASK_CAP", 1 << 20);
+  ctx->cap = (ctx->cap + FPHIP_NQ - 1) / FPHIP_NQ * FPHIP_NQ;  // regions of cap / FPHIP_NQ slots
+  HIPCHK(ctx, fphip_dev_alloc((void **)&ctx->qm, sizeof(QueueMem), ctx->stream));
+  HIPCHK(ctx, fphip_dev_alloc((void **)&ctx->slots, (size_t)ctx->cap * sizeof(unsigned), ctx->stream));
+  HIPCHK(ctx, fphip_dev_alloc((void **)&ctx->pdc, (size_t)ctx->cap * sizeof(double), ctx->stream));
+  for (int b = 0; b < 3; ++b)
   {
     HIPCHK(ctx, fphip_dev_alloc((void **)&ctx->buf[b].col, (size_t)ctx->cap * 64 * sizeof(double), ctx->stream));
     HIPCHK(ctx, fphip_dev_alloc((void **)&ctx->buf[b].x, (size_t)ctx->cap * 64 * sizeof(double), ctx->stream));
@@ -206,7 +250,7 @@ extern "C" void fphip_destroy(fphip_ctx *ctx)
   fphip_gso_release_all(ctx);
   if (ctx->stream)
     hipStreamSynchronize(ctx->stream);
-  for (int b = 0; b < 2; ++b)
+  for (int b = 0; b < 3; ++b)
   {
     if (ctx->buf[b].col)
       fphip_dev_free(ctx->buf[b].col, ctx->stream);
@@ -238,6 +282,12 @@ extern "C" void fphip_destroy(fphip_ctx *ctx)
     if (ctx->top[b].count)
       fphip_dev_free(ctx->top[b].count, ctx->stream);
   }
+  if (ctx->qm)
+    fphip_dev_free(ctx->qm, ctx->stream);
+  if (ctx->slots)
+    fphip_dev_free(ctx->slots, ctx->stream);
+  if (ctx->pdc)
+    fphip_dev_free(ctx->pdc, ctx->stream);
   if (ctx->keys)
     fphip_dev_free(ctx->keys, ctx->stream);
   if (ctx->idxlist)
@@ -474,6 +524,11 @@ extern "C" int fphip_enum_run(fphip_ctx *ctx, int dim, double maxdist, const dou
   }
 
   HIPCHK(ctx, hipSetDevice(ctx->device));
+  // Breadth-first stage instead of the depth-first split launches (see enum_bfs_kernel): the default;
+  // sub-solution calls keep the split launches (the expansion does not report sub-solutions), and a
+  // call whose expansion overflowed a buffer starts over with them.
+  bool use_bfs = env_int("FPHIP_BFS", 1) != 0 && !subs;
+restart:
   // ---- upload the block: rdiag, pruning, mu rows (triangular) ---------------------------------
   DevShared *st = ctx->stage;
   memset(st, 0, sizeof(DevShared));
@@ -488,13 +543,38 @@ extern "C" int fphip_enum_run(fphip_ctx *ctx, int dim, double maxdist, const dou
   for (int k = 1; k < d; ++k)
     for (int i = 0; i < k; ++i)
       st->mu_tri[(k * (k - 1)) / 2 + i] = mut[(size_t)i * d + k];  // mu(k,i)
+  // table of the subtree-size estimate of the breadth-first stage (levels below 64):
+  // A[L][k] = log V_{L-k}(1) - sum_{i=k}^{L-1} log sqrt(r_ii)
+  float bfs_est0[65];  // estimate for a node of partial distance 0 at level L (the heaviest there is)
+  if (use_bfs)
+  {
+    const int Lh = d < 64 ? d : 64;
+    for (int Lv = 1; Lv <= Lh; ++Lv)
+    {
+      double sumlog = 0.0, tot = 0.0;
+      for (int k = Lv - 1; k >= 0; --k)
+      {
+        sumlog += 0.5 * std::log(rdiag[k]);
+        const int n       = Lv - k;
+        const double logV = 0.5 * n * std::log(M_PI) - std::lgamma(0.5 * n + 1.0);
+        const double A    = logV - sumlog;
+        if (Lv < 64)
+          st->bfs_A[Lv][k] = (float)A;
+        const double R2 = (pruning ? pruning[k] : 1.0) * maxdist;
+        tot += std::exp(std::min(A + 0.5 * n * std::log(R2 > 0 ? R2 : 1e-300), 80.0));
+      }
+      bfs_est0[Lv] = (float)std::min(tot, 1e30);
+    }
+  }
   st->sol_head   = ctx->ring_next;
   st->bound_bits = dbits(maxdist);
   __atomic_store_n(&ctx->h->bound_bits, dbits(maxdist), __ATOMIC_RELEASE);
   __atomic_store_n(&ctx->h->consumed, ctx->ring_next, __ATOMIC_RELEASE);
   HIPCHK(ctx, hipMemcpyAsync(ctx->g, st, sizeof(DevShared), hipMemcpyHostToDevice, ctx->stream));
-  // root task: level d, zero partial sums, zero prefix, zero partial distance
-  int cur = 0;
+  HIPCHK(ctx, hipMemsetAsync(ctx->qm, 0, sizeof(QueueMem), ctx->stream));
+  // root task: level d, zero partial sums, zero prefix, zero partial distance (the breadth-first
+  // stage reads its first frontier from buf[1] and leaves the final task list in buf[0])
+  int cur = use_bfs ? 1 : 0;
   HIPCHK(ctx, hipMemsetAsync(ctx->buf[cur].col, 0, 64 * sizeof(double), ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(ctx->buf[cur].x, 0, 64 * sizeof(double), ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(ctx->buf[cur].pd, 0, sizeof(double), ctx->stream));
@@ -619,6 +699,94 @@ extern "C" int fphip_enum_run(fphip_ctx *ctx, int dim, double maxdist, const dou
   int round           = 0;
   unsigned prevC      = 0;
 
+  // ---- breadth-first stage: root (or the level-64 tasks of the top walk) -> final task list ------
+  bool regioned = false;  // the current task list is a regioned buffer (what the stage leaves in buf[0])
+  unsigned n_slots = 0;   // multi-GPU: length of the compact slot list of the regioned buffer
+  if (use_bfs && C > 0)
+  {
+    const int L0        = L;
+    const unsigned rcap = ctx->cap / FPHIP_NQ;
+    // a subtree counts as heavy above `heavy` estimated nodes: enough final tasks to balance the
+    // walk, few enough to fit the buffers (the estimate runs 2-5x high on pruned trees)
+    const double want_tasks = o.target_tasks > 0 ? o.target_tasks : env_int("FPHIP_BFS_TASKS", 65536);
+    float heavy = (float)std::max((double)env_int("FPHIP_BFS_HEAVY", 256), est_nodes / want_tasks);
+    // levels: down to the first one where even a node of partial distance 0 is light
+    int Lend = 1;
+    for (int Lv = L0 - 1; Lv >= 1; --Lv)
+      if (bfs_est0[Lv] <= heavy)
+      {
+        Lend = Lv;
+        break;
+      }
+    Lend = std::max(Lend, std::min(L0 - 1, env_int("FPHIP_BFS_FLOOR", 4)));
+    const int cnt_bfs = (o.shard_index == 0) ? 1 : 0;  // replicated on every rank: shard 0 counts
+    // the thin top in ONE single-workgroup launch (a barrier between levels), then a launch per level
+    int n_single = 0;
+    for (int Lv = L0; Lv > Lend; --Lv)
+    {
+      const double est_parents = (Lv == L0 ? (double)C : std::exp(std::min(logN[Lv] - logN[L0], 40.0)) * C);
+      if (est_parents > env_int("FPHIP_BFS_SINGLE_MAX", 256))
+        break;
+      ++n_single;
+    }
+    HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    int Lv = L0, par = 0;  // par: which of buf[1] / buf[2] holds the frontier of level Lv
+    int compact_n = (int)C;  // the first frontier is a compact list in buf[1] (root / top-walk tasks)
+    auto bfs_launch = [&](int nlev, unsigned grid, unsigned threads)
+    {
+      const TaskBuf &fa = ctx->buf[1 + par], &fb = ctx->buf[2 - par];
+      if (dual)
+        hipLaunchKernelGGL((enum_bfs_kernel<true>), dim3(grid), dim3(threads), 0, ctx->stream, ctx->g, maxdist,
+                           ctx->qm, fa, fb, ctx->buf[0], Lv, nlev, Lend, heavy, cnt_bfs, compact_n);
+      else
+        hipLaunchKernelGGL((enum_bfs_kernel<false>), dim3(grid), dim3(threads), 0, ctx->stream, ctx->g, maxdist,
+                           ctx->qm, fa, fb, ctx->buf[0], Lv, nlev, Lend, heavy, cnt_bfs, compact_n);
+      Lv -= nlev;
+      par ^= nlev & 1;
+      compact_n = -1;
+      ++launches;
+    };
+    if (n_single > 0)
+      bfs_launch(n_single, 1u, 1024u);
+    // (waves per launch: a multiple of FPHIP_NQ — each wave reads one region)
+    const unsigned bgrid = std::max(32u, ((unsigned)ctx->num_cus * (unsigned)env_int("FPHIP_BFS_WG_PER_CU", 4)) / 32u * 32u);
+    while (Lv > Lend)
+      bfs_launch(1, bgrid, 256u);
+    const bool want_slots = o.shard_count > 1;
+    hipLaunchKernelGGL(enum_bfs_epilogue, dim3(1), dim3(1024), 0, ctx->stream, ctx->g, ctx->h, ctx->qm, rcap,
+                       want_slots ? ctx->slots : nullptr, want_slots ? ctx->pdc : nullptr, ctx->buf[0].pd);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    float bms = 0.f;
+    HIPCHK(ctx, hipEventElapsedTime(&bms, ctx->ev[0], ctx->ev[1]));
+    kernel_ms += bms;
+    const unsigned nfin = (unsigned)__atomic_load_n(&ctx->h->pad[0], __ATOMIC_ACQUIRE);
+    const unsigned flg  = (unsigned)__atomic_load_n(&ctx->h->pad[1], __ATOMIC_ACQUIRE);
+    if (debug)
+      fprintf(stderr, "[fphip s%d] bfs levels %d..%d (%d in one workgroup), heavy > %.0f nodes: %u tasks, "
+                      "%.3f ms%s\n", o.shard_index, L0, Lend, n_single, heavy, nfin, bms,
+              (flg & FPHIP_FLAG_BFS_OVERFLOW) ? " OVERFLOW: starting over with split launches" : "");
+    if (flg & FPHIP_FLAG_BFS_OVERFLOW)
+    {
+      if (d > 64)  // (the top walk cannot be repeated cheaply: such a block stays with the caller)
+      {
+        snprintf(ctx->err, sizeof ctx->err, "breadth-first stage overflowed on a block larger than 64");
+        return FPHIP_UNSUPPORTED;
+      }
+      use_bfs = false;
+      goto restart;
+    }
+    cur         = 0;
+    C           = nfin;
+    L           = L0 - 1;
+    in_final    = true;
+    final_tasks = (int)C;
+    final_L     = L;
+    regioned    = true;
+    n_slots     = want_slots ? nfin : 0u;
+  }
+
   bool others_active = false;  // multi-GPU: some other rank still has tasks
   while (C > 0 || others_active)
   {
@@ -680,7 +848,8 @@ extern "C" int fphip_enum_run(fphip_ctx *ctx, int dim, double maxdist, const dou
     const int nxt     = cur ^ 1;
     // only the first final round is sharded across GPUs; donated tasks stay on their GPU
     const bool shard_now = in_final && round == 0 && o.shard_count > 1;
-    const int chunks     = (in_final && round == 0) ? o.exchange_chunks : 1;
+    // (a regioned task list that is not dealt over ranks is drawn region by region: one launch)
+    const int chunks     = (in_final && round == 0 && !(regioned && !shard_now)) ? o.exchange_chunks : 1;
     const unsigned *idxl = nullptr;
     unsigned n_list      = C;  // number of tasks this rank walks in this round
     if (shard_now)
@@ -692,14 +861,24 @@ extern "C" int fphip_enum_run(fphip_ctx *ctx, int dim, double maxdist, const dou
       // shares are disjoint, complete and of nearly equal weight, and each rank walks its share
       // heaviest-first.
       const unsigned kgrid = std::min<unsigned>((C + 3) / 4, (unsigned)ctx->num_cus * 8u);
+      // (a regioned list — the breadth-first stage's — goes through the compact list of its slots)
+      const bool via_slots = regioned && n_slots == C;
+      if (regioned && !via_slots)
+        return fail(ctx, "internal: regioned task list without its slot list under sharding");
       hipLaunchKernelGGL(task_key_kernel, dim3(kgrid ? kgrid : 1), dim3(256), 0, ctx->stream,
-                         ctx->buf[cur], C, d, ctx->keys, ctx->xhi_root);
+                         ctx->buf[cur], C, d, ctx->keys, ctx->xhi_root, via_slots ? ctx->slots : nullptr);
       HIPCHK(ctx, hipGetLastError());
       HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
       std::vector<unsigned long long> keys(C);
       std::vector<double> pds(C);
+      std::vector<unsigned> slot_of;
       HIPCHK(ctx, hipMemcpy(keys.data(), ctx->keys, (size_t)C * 8, hipMemcpyDeviceToHost));
-      HIPCHK(ctx, hipMemcpy(pds.data(), ctx->buf[cur].pd, (size_t)C * 8, hipMemcpyDeviceToHost));
+      HIPCHK(ctx, hipMemcpy(pds.data(), via_slots ? ctx->pdc : ctx->buf[cur].pd, (size_t)C * 8, hipMemcpyDeviceToHost));
+      if (via_slots)
+      {
+        slot_of.resize(C);
+        HIPCHK(ctx, hipMemcpy(slot_of.data(), ctx->slots, (size_t)C * 4, hipMemcpyDeviceToHost));
+      }
       std::vector<unsigned> order(C);
       for (unsigned i = 0; i < C; ++i)
         order[i] = i;
@@ -716,7 +895,7 @@ extern "C" int fphip_enum_run(fphip_ctx *ctx, int dim, double maxdist, const dou
         const unsigned r = p % (2 * W);
         const unsigned owner = r < W ? r : 2 * W - 1 - r;  // snake: 0..W-1, W-1..0
         if (owner == (unsigned)o.shard_index)
-          mine.push_back(order[p]);
+          mine.push_back(via_slots ? slot_of[order[p]] : order[p]);
       }
       n_list = (unsigned)mine.size();
       if (n_list)
@@ -746,7 +925,9 @@ extern "C" int fphip_enum_run(fphip_ctx *ctx, int dim, double maxdist, const dou
 #define FPHIP_LAUNCH(M, S, D)                                                                       \
   hipLaunchKernelGGL((enum_phase_kernel<M, S, D>), dim3(grid), dim3(wpb * 64), lds, ctx->stream, ctx->g, \
                      ctx->h, ctx->buf[cur], ctx->buf[nxt], d, L, stop, lo, hi, idxl, launch_idx,     \
-                     count_nodes, bud, ctx->xhi_root, ctx->gstk, Ts)
+                     count_nodes, bud, ctx->xhi_root, ctx->gstk, Ts, &ctx->qm->head[launch_idx][0],          \
+                     (regioned && !shard_now) ? &ctx->qm->fin[0] : (const unsigned *)nullptr, ctx->cap / FPHIP_NQ, \
+                     (unsigned long long)__atomic_load_n(&ctx->h->bound_bits, __ATOMIC_ACQUIRE))
         if (dual && mu_lds)
           FPHIP_LAUNCH(true, false, true);
         else if (dual)
@@ -833,8 +1014,9 @@ extern "C" int fphip_enum_run(fphip_ctx *ctx, int dim, double maxdist, const dou
     {
       L = stop;
     }
-    C   = cnt;
-    cur = nxt;
+    C        = cnt;
+    cur      = nxt;
+    regioned = false;  // what a launch emits is a compact list
   }
   const int phases = launches;
 

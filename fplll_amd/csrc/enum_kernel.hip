@@ -169,7 +169,8 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK)
                       int d, int Lmax, int stop, unsigned task_lo, unsigned task_hi,
                       const unsigned *__restrict__ idxlist, int launch_idx, int count_nodes,
                       unsigned budget, const double *__restrict__ xhi_root, double *__restrict__ gstk,
-                      int Tsplit)
+                      int Tsplit, unsigned *__restrict__ qh, const unsigned *__restrict__ rcnt, unsigned rcap,
+                      unsigned long long bound_init)
 {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x & 63;
@@ -217,7 +218,11 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK)
   // The bound lives in two places: the pinned host word the callback thread writes, and a
   // device-memory mirror.  Waves poll the mirror (L2) often and the host word (PCIe) rarely;
   // whoever sees a smaller host value lowers the mirror for everybody.
-  unsigned long long mbits = rfl_u64(load_sys_u64(&h->bound_bits));
+  // A wave STARTS from the bound the host held when it launched the kernel (an argument) and the
+  // mirror: a read of the pinned host word costs a PCIe round trip, and thousands of waves doing one
+  // at their start serialise on it (measured: 0.3 ms per launch of 4096 waves, 0.6 ms of 8192).
+  unsigned long long mbits =
+      rfl_u64(min(bound_init, __hip_atomic_load(&g->bound_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
   double maxdist           = __longlong_as_double((long long)mbits);
   double maxdist_v         = maxdist;  // the same value held in a VGPR pair (see FPHIP_IN_VGPR)
   FPHIP_IN_VGPR(maxdist_v);
@@ -257,26 +262,66 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK)
     }                                                                                             \
   } while (0)
 
+  // Tasks are pulled through FPHIP_NQ ticket counters (qh[q * FPHIP_QS], one per queue, 64 bytes
+  // apart): a wave draws from its home queue and moves on to a queue that still holds tasks when
+  // that one is exhausted.  Two input forms.  Compact list [task_lo, task_hi) (optionally through
+  // the index list of the multi-GPU partition): queue q owns the positions task_lo + q + j NQ.
+  // Regioned buffer (rcnt != null; what the breadth-first stage writes): queue q owns the
+  // rcnt[q * FPHIP_QS] tasks of region q, slots q * rcap + i, drawn from the END — the stage appends
+  // level by level, so the deepest roots, whose ancestors all had small partial distances (the most
+  // promising subtrees: a good radius early), go first.
+  unsigned q = (unsigned)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * nw + wave) % FPHIP_NQ));
+  const unsigned nlist = task_hi - task_lo;
   for (;;)
   {
     // ---- pull a task ------------------------------------------------------------------------
-    unsigned t = 0;
-    if (lane == 0)
-      t = atomicAdd(&g->task_head[launch_idx], 1u);
-    t = (unsigned)__builtin_amdgcn_readfirstlane((int)t);
-    const unsigned long long pos = (unsigned long long)task_lo + t;
-    if (pos >= task_hi)
-    {  // queue empty: tell the waves still walking to shed work for the next launch
+    unsigned t = 0, cq = 0;
+    bool have = false;
+    for (;;)
+    {
+      if (lane == 0)
+        t = atomicAdd(&qh[q * FPHIP_QS], 1u);
+      t  = (unsigned)__builtin_amdgcn_readfirstlane((int)t);
+      cq = rcnt ? min((unsigned)__builtin_amdgcn_readfirstlane((int)rcnt[q * FPHIP_QS]), rcap)
+                : (nlist > q ? (nlist - q + FPHIP_NQ - 1u) / FPHIP_NQ : 0u);
+      if (t < cq)
+      {
+        have = true;
+        break;
+      }
+      // exhausted: the lanes look at the heads of the other queues, 64 at a time
+      bool any = false;
+#pragma unroll
+      for (unsigned hf = 0; hf < FPHIP_NQ / 64; ++hf)
+      {
+        const unsigned qq = (q + 1u + hf * 64u + (unsigned)lane) % FPHIP_NQ;
+        const unsigned hd = __hip_atomic_load(&qh[qq * FPHIP_QS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned cn = rcnt ? min(rcnt[qq * FPHIP_QS], rcap)
+                                 : (nlist > qq ? (nlist - qq + FPHIP_NQ - 1u) / FPHIP_NQ : 0u);
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(hd < cn);
+        if (m != 0ull)
+        {
+          q   = (q + 1u + hf * 64u + (unsigned)__builtin_ctzll(m)) % FPHIP_NQ;
+          any = true;
+          break;
+        }
+      }
+      if (!any)
+        break;
+    }
+    if (!have)
+    {  // every queue is empty: tell the waves still walking to shed work for the next launch
       if (budget != 0u && lane == 0)
         __hip_atomic_store(&g->drain[launch_idx], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       FPHIP_JOIN();
       break;
     }
-
     // multi-GPU: this rank's share of the task list is an explicit index list (built on the host
     // from a content-sorted order, see enum_host.hip), walked heaviest-first
+    const unsigned long long pos = (unsigned long long)task_lo + q + (unsigned long long)t * FPHIP_NQ;
     const unsigned long long ti =
-        idxlist ? (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)idxlist[pos]) : pos;
+        rcnt ? (unsigned long long)q * rcap + (cq - 1u - t)
+             : (idxlist ? (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)idxlist[pos]) : pos);
     const int Lt      = __builtin_amdgcn_readfirstlane(in.level[ti]);  // root level of this task
     const int rid     = __builtin_amdgcn_readfirstlane(in.root[ti]);   // level-64 ancestor (d > 64)
     const double xpre = in.x[ti * 64 + lane];                          // coefficients of levels >= Lt
@@ -654,7 +699,9 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK)
 #define FPHIP_INST(M, S, D)                                                                            \
   template __global__ void enum_phase_kernel<M, S, D>(DevShared *, HostCtl *, TaskBuf, TaskBuf, int,  \
                                                       int, int, unsigned, unsigned, const unsigned *,  \
-                                                      int, int, unsigned, const double *, double *, int);
+                                                      int, int, unsigned, const double *, double *, int, \
+                                                      unsigned *, const unsigned *, unsigned,            \
+                                                      unsigned long long);
 FPHIP_INST(true, false, false)
 FPHIP_INST(false, false, false)
 FPHIP_INST(true, true, false)
@@ -662,6 +709,164 @@ FPHIP_INST(false, true, false)
 FPHIP_INST(true, false, true)
 FPHIP_INST(false, false, true)
 #undef FPHIP_INST
+
+// ---------------------------------------------------------------------------------------------
+// Breadth-first expansion of the TOP of the tree.
+//
+// The wave-per-subtree walk needs tens of thousands of subtree roots before the chip is busy, and a
+// pruned tree is thin at the top: the depth-first split launches that used to produce the roots were
+// a handful of lone waves each walking one dependent chain (100 ns per step when nothing else is
+// resident), and the walk launch that followed ended with its HEAVIEST root — subtree sizes under a
+// level are heavy-tailed.  This kernel instead expands the tree level by level, one wavefront per
+// parent node: all children of a node come from one column (S_{k+1}), so the chain per level is the
+// zig-zag over ONE node's children, the shortest there is; and it decides per child whether the
+// subtree below it is still HEAVY (Gaussian-heuristic size estimate from its own partial distance:
+// lane k evaluates the expected number of descendants at level k, one wave sum) — heavy children
+// form the next level's frontier, light ones are final tasks of the walk at once.  The final task
+// list therefore holds roots of mixed levels and of comparable (estimated) size.
+//
+// Same arithmetic as the walk (centre, round(), zig-zag order, bound test, S_k = S_{k+1} - x mu_k;
+// enumerate_base.cpp:24-118), same counting; the estimate only steers scheduling.  No candidate can
+// be met up here (level 0 is never expanded), so the radius is the call's initial one.
+//
+// One launch expands `nlev` consecutive levels when it is a single workgroup (the thin top: a
+// __syncthreads between levels), otherwise one level (the host enqueues the levels back to back,
+// without waiting: frontier sizes live in g->bfs_count).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum_f32(float v)
+{
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1)
+    v += __shfl_xor(v, off);
+  return v;
+}
+
+template <bool DUAL>
+__global__ void __launch_bounds__(1024)
+    enum_bfs_kernel(DevShared *__restrict__ g, double maxdist, QueueMem *__restrict__ qm,
+                    TaskBuf f0, TaskBuf f1, TaskBuf fin, int L0, int nlev, int floor_level, float heavy,
+                    int count_nodes, int compact_n)
+{
+  // Buffers are REGIONED: region q of a buffer holds the slots [q rcap, (q + 1) rcap), its fill count
+  // sits in qm (64 bytes from the next one): emission counters are spread over FPHIP_NQ addresses
+  // (see enum_device.h).  compact_n >= 0: the parents of the first level are a compact list of that
+  // length instead (the level-64 tasks of the top walk): region q owns its positions q + j NQ.
+  const int lane       = threadIdx.x & 63;
+  const unsigned nwb   = blockDim.x >> 6;
+  const unsigned gw    = blockIdx.x * nwb + (threadIdx.x >> 6);
+  const unsigned nwave = gridDim.x * nwb;
+  const unsigned rcap  = fin.cap / FPHIP_NQ;
+  // (maxdist: the call's radius, an argument — a read of the pinned host word per wave would cost a
+  // PCIe round trip each: 0.3-0.6 ms per launch)
+  const unsigned rstep = nwave < FPHIP_NQ ? nwave : FPHIP_NQ;
+  const unsigned t0    = gw / FPHIP_NQ;
+  const unsigned tstep = nwave < FPHIP_NQ ? 1u : nwave / FPHIP_NQ;
+  unsigned emitted     = gw * 7u;  // children are dealt round-robin over the regions
+  for (int s = 0; s < nlev; ++s)
+  {
+    const int L      = L0 - s;  // level of the parents
+    const int kc     = L - 1;   // level of their children
+    const TaskBuf in = (s & 1) ? f1 : f0, out = (s & 1) ? f0 : f1;
+    const bool compact = s == 0 && compact_n >= 0;
+    const double r    = g->rdiag[kc];
+    const double bnd  = g->pruning[kc] * maxdist;  // partdistbounds[kc], enumerate.cpp:218-228
+    const double mk   = (lane < kc) ? g->mu_tri[tri_off(kc) + lane] : 0.0;  // row kc of mu
+    // estimate of the subtree below a child at level kc: lane k < kc holds the level-k term
+    const float Ak    = (lane < kc) ? g->bfs_A[kc][lane] : 0.f;
+    const float hk    = 0.5f * (float)(kc - lane);
+    const double R2k  = g->pruning[lane] * maxdist;
+    const bool deeper = kc > floor_level;  // at the floor every child is a final task
+    unsigned cnt = 0;
+    for (unsigned rg = gw % FPHIP_NQ; rg < FPHIP_NQ; rg += rstep)
+    {
+      unsigned n;
+      if (compact)
+        n = (unsigned)compact_n > rg ? ((unsigned)compact_n - rg + FPHIP_NQ - 1u) / FPHIP_NQ : 0u;
+      else
+      {
+        n = __hip_atomic_load(&qm->bfs[L][rg * FPHIP_QS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        n = n < rcap ? n : rcap;
+      }
+      n = (unsigned)__builtin_amdgcn_readfirstlane((int)n);
+      for (unsigned t = t0; t < n; t += tstep)
+      {
+        const unsigned long long p = compact ? (unsigned long long)rg + (unsigned long long)t * FPHIP_NQ
+                                             : (unsigned long long)rg * rcap + t;
+        const double col = in.col[p * 64 + lane];
+        const double xp  = in.x[p * 64 + lane];
+        const double pdu = __longlong_as_double((long long)rfl_u64((unsigned long long)__double_as_longlong(in.pd[p])));
+        const int ridu   = __builtin_amdgcn_readfirstlane(in.root[p]);
+        const double c   = rl_f64(col, kc);  // center[kc] = center_partsums[kc][kc + 1]
+        double x = rint(c);                  // roundto(): half away from zero (enumerate_base.h:33-34)
+        double a = x - c;
+        if (fabs(a) == 0.5 && ((a < 0.0) == (c > 0.0)))
+        {
+          x = x - (a + a);
+          a = -a;
+        }
+        double nd = pdu + a * a * r;   // :28-29
+        int dx    = (c >= x) ? 1 : -1;  // :71 (ddx == sign(dx) throughout)
+        const bool zig = pdu != 0.0;    // :80-89: partdist exactly 0 above: x only grows (is_svp)
+        while (nd <= bnd)               // :31 / :93 (NaN fails)
+        {
+          ++cnt;  // ++nodes[kc]
+          // subtree estimate: sum over the levels below of V_{kc-k}(sqrt(R_k^2 - nd)) / prod sqrt(r)
+          bool is_heavy = false;
+          if (deeper)
+          {
+            const float rem = (float)(R2k - nd);
+            float e         = (lane < kc && rem > 0.f) ? __expf(fminf(Ak + hk * __logf(rem), 60.f)) : 0.f;
+            e               = wave_sum_f32(e);
+            is_heavy        = __builtin_amdgcn_readfirstlane((int)(e > heavy)) != 0;
+          }
+          const TaskBuf dst  = is_heavy ? out : fin;
+          const unsigned wr  = (emitted++) % FPHIP_NQ;
+          unsigned *ctr      = is_heavy ? &qm->bfs[kc][wr * FPHIP_QS] : &qm->fin[wr * FPHIP_QS];
+          unsigned oi        = 0;
+          if (lane == 0)
+            oi = atomicAdd(ctr, 1u);
+          oi = (unsigned)__builtin_amdgcn_readfirstlane((int)oi);
+          if (oi < rcap)
+          {
+            const unsigned long long o = (unsigned long long)wr * rcap + oi;
+            // S_kc = S_{kc+1} - x[kc] * mu(kc, .)  (:53-58; dual: alpha instead of x, :57-61)
+            dst.col[o * 64 + lane] = col - (DUAL ? a : x) * mk;
+            dst.x[o * 64 + lane]   = (lane == kc) ? x : xp;
+            if (lane == 0)
+            {
+              dst.pd[o]    = nd;
+              dst.level[o] = kc;
+              dst.root[o]  = ridu;
+            }
+          }
+          else if (lane == 0)
+            atomicOr(&g->error_flags, FPHIP_FLAG_BFS_OVERFLOW);
+          // next sibling, :80-92
+          if (zig)
+          {
+            x += (double)dx;
+            dx = (dx > 0 ? -1 : 1) - dx;
+          }
+          else
+            x += 1.0;
+          a  = x - c;
+          nd = pdu + a * a * r;
+        }
+      }
+    }
+    if (count_nodes && cnt != 0 && lane == 0)
+      atomicAdd(&g->nodes[kc], (unsigned long long)cnt);
+    if (s + 1 < nlev)
+    {  // single-workgroup mode: the next level reads what this one wrote
+      __threadfence();
+      __syncthreads();
+    }
+  }
+}
+template __global__ void enum_bfs_kernel<false>(DevShared *, double, QueueMem *, TaskBuf, TaskBuf, TaskBuf, int, int,
+                                                int, float, int, int);
+template __global__ void enum_bfs_kernel<true>(DevShared *, double, QueueMem *, TaskBuf, TaskBuf, TaskBuf, int, int,
+                                               int, float, int, int);
 
 // ---------------------------------------------------------------------------------------------
 // Blocks larger than 64 (up to 128): the levels 64..d-1.  The TOP of the tree is walked with two
@@ -934,13 +1139,14 @@ template __global__ void enum_top_kernel<false, true>(DevShared *, HostCtl *, To
 // is not deterministic across ranks, the content is.  One wave per task.
 __global__ void __launch_bounds__(256)
     task_key_kernel(TaskBuf in, unsigned n, int d, unsigned long long *__restrict__ keys,
-                    const double *__restrict__ xhi_root)
+                    const double *__restrict__ xhi_root, const unsigned *__restrict__ slots)
 {
   const int lane = threadIdx.x & 63;
   const unsigned w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const unsigned nw = (gridDim.x * blockDim.x) >> 6;
-  for (unsigned ti = w; ti < n; ti += nw)
+  for (unsigned tp = w; tp < n; tp += nw)
   {
+    const unsigned ti = slots ? slots[tp] : tp;  // (regioned buffer: the tp-th occupied slot)
     const int Lt      = in.level[ti];
     const double xpre = in.x[(unsigned long long)ti * 64 + lane];
     const bool on     = lane >= Lt && lane < d;
@@ -958,7 +1164,7 @@ __global__ void __launch_bounds__(256)
       h2 += (unsigned)__shfl_xor((int)h2, off);
     }
     if (lane == 0)
-      keys[ti] = ((unsigned long long)h1 << 32) | h2;
+      keys[tp] = ((unsigned long long)h1 << 32) | h2;
   }
 }
 

@@ -21,7 +21,19 @@
 // Protocol implemented (enumerate_ext.cpp:48-167): call cbfunc once with mutranspose=true to
 // receive mu^T / rdiag / pruning; report candidates through cbsol, which returns the new bound;
 // return per-level node counts, or [0] = ~0 to decline so fplll falls back to its own enumerator
-// (dual, dim > 128, or any device error).
+// (dim > 128, any device error, and dual calls unless FPLLL_HIP_DUAL=1).
+//
+// Dual calls (FPLLL_HIP_DUAL=1).  The reference's adapter hands a plugin the UNTRANSFORMED mu / r of
+// the block for a dual enumeration and does not reverse the solutions afterwards
+// (enumerate_ext.cpp:57-89, against EnumerationDyn::enumerate's enumerate.cpp:100-123,154-158), so
+// the plugin does both itself: r'_{d-1-i} = 1 / r_i, mu'^T[d-1-j][d-1-i] = -mu(j,i), the dualenum
+// walk (alpha instead of x in the centre sums), every solution reversed before it reaches fplll's
+// evaluator.  It is opt-in because the adapter's radius is only right when the caller's radius
+// exponent is zero: it scales by 2^(normexp - fmaxdistexpo) (enumerate_ext.cpp:75) where
+// EnumerationDyn::enumerate scales by 2^(fmaxdistexpo + normexp) (enumerate.cpp:100-106) — the same
+// number for fmaxdistexpo = 0 (a MatGSO without GSO_ROW_EXPO), a radius off by 4^fmaxdistexpo
+// otherwise (BKZ in double precision runs WITH row exponents, bkz.cpp:816-820; the reference's own
+// plugin declines every dual call, enum-parallel/enumlib.cpp:99).
 
 #include <array>
 #include <cstdint>
@@ -68,6 +80,7 @@ struct Trampoline
   std::function<cb_process_subsol_t> *cbsubsol;
   int dim;
   long delivered;  // candidates handed to fplll's evaluator so far
+  bool dual;       // reverse every solution (enumerate.cpp:154-158 does it after the run)
 };
 
 void subsol_trampoline(void *user, double dist, const double *subsol, int offset)
@@ -91,7 +104,7 @@ double sol_trampoline(void *user, double dist, const double *sol)
   ++t->delivered;
   double buf[FPHIP_ENUM_MAX_DIM];
   for (int i = 0; i < t->dim; ++i)
-    buf[i] = sol[i];
+    buf[i] = t->dual ? sol[t->dim - 1 - i] : sol[i];
   try
   {
     return (*t->cbsol)(dist, buf);
@@ -206,6 +219,7 @@ struct MultiShared
   std::function<cb_process_sol_t> *cbsol;
   std::function<cb_process_subsol_t> *cbsubsol;
   int dim;
+  bool dual = false;
   long delivered = 0;
   const std::vector<fphip_ctx *> *ctxs;
   HostExchange ex;
@@ -234,7 +248,8 @@ double multi_sol(void *user, double dist, const double *sol)
 {
   ShardUser *u = static_cast<ShardUser *>(user);
   double buf[FPHIP_ENUM_MAX_DIM];
-  memcpy(buf, sol, sizeof(double) * u->sh->dim);
+  for (int i = 0; i < u->sh->dim; ++i)
+    buf[i] = u->sh->dual ? sol[u->sh->dim - 1 - i] : sol[i];
   double nb = 0.0;
   {
     std::lock_guard<std::mutex> lk(u->sh->cb_mutex);
@@ -281,8 +296,17 @@ nodes_array_t fplll_hip_extenum(const int dim, enumf maxdist, std::function<cb_s
 {
   nodes_array_t out{};
   out[0] = ~std::uint64_t(0);
-  if (dim < 2 || dim > FPHIP_ENUM_MAX_DIM || dual)
+  if (dim < 2 || dim > FPHIP_ENUM_MAX_DIM)
     return out;
+  if (dual)
+  {
+    const char *dv = getenv("FPLLL_HIP_DUAL");
+    if (!dv || atoi(dv) == 0 || findsubsols)
+    {
+      g_totals.declined++;
+      return out;
+    }
+  }
   std::lock_guard<std::mutex> lock(g_mutex);
   const std::vector<fphip_ctx *> &multi = multi_contexts();
   fphip_ctx *ctx                        = multi.empty() ? context() : multi[0];
@@ -291,8 +315,20 @@ nodes_array_t fplll_hip_extenum(const int dim, enumf maxdist, std::function<cb_s
 
   std::vector<double> mu((size_t)dim * dim, 0.0), rdiag(dim, 0.0), pruning(dim, 0.0);
   cbfunc(mu.data(), (size_t)dim, true, rdiag.data(), pruning.data());
+  if (dual)
+  {  // EnumerationDyn::enumerate's transformation (enumerate.cpp:107-123) of the primal inputs
+    std::vector<double> mu2((size_t)dim * dim, 0.0), r2(dim, 0.0);
+    for (int i = 0; i < dim; ++i)
+      r2[dim - 1 - i] = 1.0 / rdiag[i];
+    for (int i = 0; i < dim; ++i)
+      for (int j = i + 1; j < dim; ++j)  // mu[i*dim + j] = mu(j,i)
+        mu2[(size_t)(dim - 1 - j) * dim + (dim - 1 - i)] = -mu[(size_t)i * dim + j];
+    mu.swap(mu2);
+    rdiag.swap(r2);
+  }
 
   fphip_enum_opts opts{};
+  opts.dual = dual ? 1 : 0;
   const char *mn         = getenv("FPLLL_HIP_MIN_NODES");
   opts.min_nodes_decline = mn ? atoi(mn) : 0;
   opts.findsubsols       = findsubsols ? 1 : 0;
@@ -303,6 +339,7 @@ nodes_array_t fplll_hip_extenum(const int dim, enumf maxdist, std::function<cb_s
     sh.cbsol       = &cbsol;
     sh.cbsubsol    = &cbsubsol;
     sh.dim         = dim;
+    sh.dual        = dual;
     sh.ctxs        = &multi;
     sh.ex.expected = W;
     std::vector<ShardUser> users(W);
@@ -365,7 +402,7 @@ nodes_array_t fplll_hip_extenum(const int dim, enumf maxdist, std::function<cb_s
         out[k] += nodes[i][k];
     return out;
   }
-  Trampoline tr{&cbsol, &cbsubsol, dim, 0};
+  Trampoline tr{&cbsol, &cbsubsol, dim, 0, dual};
   std::vector<std::uint64_t> nodes(dim + 1, 0);
   fphip_enum_stats stats{};
   const auto t0 = std::chrono::steady_clock::now();

@@ -9,11 +9,16 @@
  *
  *   dropin_driver bkz <basisfile> <beta> hip|cpu [max_loops] [plugin.so]
  *   dropin_driver lll <basisfile> hip|cpu
+ *   dropin_driver sizered <basisfile> hip|cpu     LLLReduction::size_reduction(0, d) (lll.h:107-122; with
+ *                                                 FPLLL_HIP_BABAI=1 every babai() of it runs on the device)
+ *   dropin_driver hlll <basisfile> hip|cpu        HLLLReduction::hlll() on MatHouseholder(Hip), the way
+ *                                                 hlll_reduction_zf does it (wrapper.cpp:790-806)
  * prints one JSON line: status, seconds, device calls / seconds, the output basis.
  */
 #include <fplll/fplll.h>
 
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <dlfcn.h>
@@ -22,6 +27,7 @@
 #include <memory>
 
 #include "../fplll_amd/csrc/dropin/matgso_hip.h"
+#include "../fplll_amd/csrc/dropin/mathouseholder_hip.h"
 
 using namespace fplll;
 
@@ -33,7 +39,7 @@ int main(int argc, char **argv)
 {
   if (argc < 4)
   {
-    fprintf(stderr, "usage: dropin_driver bkz basisfile beta hip|cpu [max_loops] [plugin.so] | lll basisfile hip|cpu\n");
+    fprintf(stderr, "usage: dropin_driver bkz basisfile beta hip|cpu [max_loops] [plugin.so] | lll|sizered|hlll basisfile hip|cpu\n");
     return 2;
   }
   const std::string cmd = argv[1];
@@ -73,6 +79,47 @@ int main(int argc, char **argv)
   }
   typedef Z_NR<long> ZT;
   typedef FP_NR<double> FT;
+  if (cmd == "hlll")
+  {
+    // hlll_reduction_zf<long, double> with LM_FAST: MatHouseholder(ROW_EXPO) + HLLLReduction::hlll
+    // (wrapper.cpp:790-806) — with the device-backed object in place of the host one
+    std::unique_ptr<MatHouseholder<ZT, FT>> mh;
+    fplll_hip::MatHouseholderHip *hh = nullptr;
+    if (w == "hip")
+    {
+      hh = new fplll_hip::MatHouseholderHip(bl, ul, ul_inv, HOUSEHOLDER_ROW_EXPO);
+      mh.reset(hh);
+      if (!hh->on_device())
+      {
+        fprintf(stderr, "MatHouseholderHip has no device: %s\n", hh->last_error());
+        return 3;
+      }
+    }
+    else
+      mh.reset(new MatHouseholder<ZT, FT>(bl, ul, ul_inv, HOUSEHOLDER_ROW_EXPO));
+    HLLLReduction<ZT, FT> hlll_obj(*mh, LLL_DEF_DELTA, LLL_DEF_ETA, HLLL_DEF_THETA, HLLL_DEF_C, LLL_DEFAULT);
+    auto t0 = std::chrono::steady_clock::now();
+    hlll_obj.hlll();
+    const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    // the host members after the call: R(i,i) of the object, as a later host caller would read them
+    double rsum = 0.0;
+    for (int i = 0; i < bl.get_rows(); ++i)
+    {
+      FT f;
+      long e;
+      mh->get_R(f, i, i, e);
+      rsum += std::log(std::fabs(f.get_d())) + e * std::log(2.0);
+    }
+    printf("{\"what\":\"hlll\",\"gso\":\"%s\",\"status\":%d,\"seconds\":%.3f,\"nodes\":0,\"n_swaps\":%ld,"
+           "\"device_calls\":%ld,\"device_seconds\":%.3f,\"log_abs_det_R\":%.12g,\"d\":%d,\"n\":%d,\"b_out\":[",
+           w.c_str(), hlll_obj.get_status(), secs, hh ? hh->n_swaps : -1L, hh ? hh->n_device_calls : 0L,
+           hh ? hh->device_seconds : 0.0, rsum, bl.get_rows(), bl.get_cols());
+    for (int i = 0; i < bl.get_rows(); ++i)
+      for (int j = 0; j < bl.get_cols(); ++j)
+        printf("%s%ld", (i || j) ? "," : "", bl(i, j).get_si());
+    printf("]}\n");
+    return 0;
+  }
   std::unique_ptr<MatGSO<ZT, FT>> gso;
   fplll_hip::MatGSOHip *hip = nullptr;
   if (w == "hip")
@@ -105,6 +152,11 @@ int main(int argc, char **argv)
     bkz_obj.bkz();
     status = bkz_obj.status;
     nodes  = bkz_obj.nodes;
+  }
+  else if (cmd == "sizered")
+  {
+    lll_obj.size_reduction(0, bl.get_rows());
+    status = lll_obj.status;
   }
   else
   {

@@ -336,12 +336,17 @@ struct EnumOut
 };
 
 static EnumOut run_enum(MatGSO<ZT, FT> &M, int first, int d, const vector<double> &pruning,
-                        double rfac, size_t max_sols, int strategy)
+                        double rfac, size_t max_sols, int strategy, bool dual = false)
 {
   long expo;
-  FT max_dist = M.get_r_exp(first, first, expo);
+  FT max_dist = M.get_r_exp(dual ? first + d - 1 : first, dual ? first + d - 1 : first, expo);
+  if (dual)
+  {  // the radius of svp_reduction(dual = true), bkz.cpp:308-318
+    max_dist.pow_si(max_dist, -1, GMP_RNDU);
+    expo *= -1;
+  }
   max_dist *= rfac;
-  if (d > 30 && rfac <= 1.0)
+  if (!dual && d > 30 && rfac <= 1.0)
   {
     FT root_det = M.get_root_det(first, first + d);
     adjust_radius_to_gh_bound(max_dist, expo, d, root_det, 1.1);
@@ -351,7 +356,7 @@ static EnumOut run_enum(MatGSO<ZT, FT> &M, int first, int d, const vector<double
   FastEvaluator<FT> ev(max_sols, (EvaluatorStrategy)strategy, false);
   Enumeration<ZT, FT> E(M, ev);
   auto t0 = std::chrono::steady_clock::now();
-  E.enumerate(first, first + d, max_dist, expo, vector<FT>(), vector<enumxt>(), pruning);
+  E.enumerate(first, first + d, max_dist, expo, vector<FT>(), vector<enumxt>(), pruning, dual);
   EnumOut o;
   o.secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   auto na = E.get_nodes_array();
@@ -391,22 +396,42 @@ static int cmd_plugin(int argc, char **argv)
 
   ZZ_mat<mpz_t> A, U, UT;
   make_basis(A, n, k, bits, seed, bkz_pre);
-  MatGSO<ZT, FT> M(A, U, UT, GSO_ROW_EXPO);
+  // REFDRV_PLUGIN_DUAL=1: a DUAL call through the hook, on a MatGSO WITHOUT row exponents — the only
+  // configuration in which the reference's adapter hands a plugin the right radius for a dual call
+  // (enumerate_ext.cpp:75 against enumerate.cpp:100-106; see extenum_shim.cpp)
+  const bool pdual = getenv("REFDRV_PLUGIN_DUAL") != nullptr;
+  MatGSO<ZT, FT> M(A, U, UT, pdual ? 0 : GSO_ROW_EXPO);
   M.update_gso();
   vector<double> pruning = make_pruning(prspec, d);
 
   set_external_enumerator(nullptr);
-  EnumOut ref = run_enum(M, first, d, pruning, rfac, max_sols, strategy);
+  EnumOut ref = run_enum(M, first, d, pruning, rfac, max_sols, strategy, pdual);
   extenum_fn *fn = load_plugin(so);
   set_external_enumerator(fn);
-  EnumOut ours = run_enum(M, first, d, pruning, rfac, max_sols, strategy);
+  EnumOut ours = run_enum(M, first, d, pruning, rfac, max_sols, strategy, pdual);
   // warm second run for timing
-  EnumOut ours2 = run_enum(M, first, d, pruning, rfac, max_sols, strategy);
+  EnumOut ours2 = run_enum(M, first, d, pruning, rfac, max_sols, strategy, pdual);
+  bool dual_vec_ok = true;
+  if (pdual && ref.found && ours.found)
+  {  // the ORIENTATION of the solution is part of the contract (the adapter does not reverse it)
+    vector<double> neg(ref.x);
+    for (auto &v : neg)
+      v = -v;
+    dual_vec_ok = (ours.x == ref.x) || (ours.x == neg);
+  }
 
   bool ok = (ref.found == ours.found) && (!ref.found || ref.dist == ours.dist);
+  if (pdual && ref.found && ours.found)
+  {  // the adapter leaves the evaluator's exponent at +normexp for a dual call (enumerate_ext.cpp:79;
+     // EnumerationDyn::enumerate sets -normexp, enumerate.cpp:100-106): the de-normalised distance it
+     // records is the internal one times a power of four — same vector, same normalised norm
+    int e2;
+    ok = std::frexp(ours.dist / ref.dist, &e2) == 0.5 && ((e2 - 1) % 2 == 0);
+  }
   bool counts_equal = ref.nodes == ours.nodes;
   if (max_sols >= 1000000 && strategy == 0)
     ok = ok && counts_equal;
+  ok = ok && dual_vec_ok;
   printf("{\"ok\":%s,\"counts_equal\":%s,\"ref_found\":%d,\"ours_found\":%d,\"ref_dist\":%.17g,"
          "\"ours_dist\":%.17g,\"ref_nodes\":%llu,\"ours_nodes\":%llu,\"ref_secs\":%.6f,"
          "\"ours_secs\":%.6f,\"ours_secs_warm\":%.6f}\n",

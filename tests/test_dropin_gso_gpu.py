@@ -67,3 +67,60 @@ def test_config2_reference_bkz_driver_on_device_gso():
     assert j["status"] == 0 and j["device_calls"] > 1000
     assert j["nodes"] == f["nodes"] == 10252068
     assert np.array_equal(j["b_out"], f["b_out"])
+
+
+def _run_env(args, env):
+    assert os.path.exists(DRV), "oracle/_ref/dropin_driver is not built (python __graft_entry__.py)"
+    r = subprocess.run([DRV] + args, capture_output=True, text=True, timeout=1100, env=dict(os.environ, **env))
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = json.loads(r.stdout)
+    j["b_out"] = np.array(j["b_out"], dtype=np.int64).reshape(j["d"], j["n"])
+    return j
+
+
+@pytest.mark.parametrize("name", ["gso_q48_p3", "gso_q64_p5"])
+def test_reference_size_reduction_reaches_the_device_row_by_row(name):
+    """LLLReduction::size_reduction(0, d) (lll.h:107-122 — inline, so it is the CALLER's code) calls
+    babai() row by row through the PLT; with FPLLL_HIP_BABAI=1 the interposed babai
+    (csrc/dropin/matgso_hip.cpp) runs each row's size reduction on the device.  Output basis = the
+    reference's (the fixture's b after size_reduction), d - 1 device calls."""
+    f = C.load_gso_fixture(os.path.join(C.GOLDEN, name + ".json"))
+    path = _write_basis(f["b_in"])
+    try:
+        j = _run_env(["sizered", path, "hip"], {"FPLLL_HIP_BABAI": "1"})
+        jc = _run_env(["sizered", path, "cpu"], {})
+    finally:
+        os.unlink(path)
+    assert j["status"] == 0 and jc["status"] == 0
+    assert j["device_calls"] == f["d"] - 1, j["device_calls"]
+    assert np.array_equal(j["b_out"], jc["b_out"])
+    assert np.array_equal(j["b_out"], f["b_out"]), "size_reduction through the device differs from the golden"
+    # without the opt-in the same object size-reduces on the host (no device call)
+    path = _write_basis(f["b_in"])
+    try:
+        j0 = _run_env(["sizered", path, "hip"], {})
+    finally:
+        os.unlink(path)
+    assert j0["device_calls"] == 0 and np.array_equal(j0["b_out"], f["b_out"])
+
+
+@pytest.mark.parametrize("name", ["hlll_q40", "hlll_q72", "hlll_r30", "hlll_u24"])
+def test_reference_hlll_object_runs_on_the_device(name):
+    """HLLLReduction(m, delta, eta, theta, c, LLL_DEFAULT).hlll() with m a MatHouseholderHip
+    (csrc/dropin/mathouseholder_hip.h): the interposed hlll() runs the whole loop on the device
+    (fphip_hh_hlll) and leaves the host members — b, and R / V / sigma / bf recomputed by the
+    reference's own refresh_R_bf + update_R — in line.  The reference's reduced basis and status; the
+    host object's diagonal of R equals the plain host run's."""
+    f = C.load_hlll_fixture(os.path.join(C.GOLDEN, name + ".json"))
+    path = _write_basis(f["b_in"])
+    try:
+        j = _run(["hlll", path, "hip"])
+        jc = _run(["hlll", path, "cpu"])
+    finally:
+        os.unlink(path)
+    assert j["status"] == jc["status"] == 0 and j["device_calls"] == 1
+    assert np.array_equal(j["b_out"], f["b_out"])
+    assert np.array_equal(jc["b_out"], f["b_out"])
+    assert j["log_abs_det_R"] == jc["log_abs_det_R"], (j["log_abs_det_R"], jc["log_abs_det_R"])
+    print("%s through HLLLReduction on MatHouseholderHip: %d swaps, %.3f s (%.3f s on the device); host object %.3f s"
+          % (name, j["n_swaps"], j["seconds"], j["device_seconds"], jc["seconds"]))

@@ -8,6 +8,7 @@ inputs.  Contract:
   * shrinking bound, pruned   → identical final norm unless the reference's vector is provably cut
     by the pruning bound under the (smaller) radius the device had already reached.
 """
+import json
 import os
 
 import numpy as np
@@ -310,6 +311,35 @@ def test_plugin_axis_with_reference_build():
         out = subprocess.run([drv, "plugin", so] + c.split(), capture_output=True, text=True,
                              timeout=600, env=env)
         assert out.returncode == 0, (c, out.stdout, out.stderr)
+
+
+def test_plugin_dual_call_through_the_hook():
+    """A DUAL enumeration through fplll's plugin hook (FPLLL_HIP_DUAL=1): the reference's adapter hands
+    a plugin the untransformed mu / r and never reverses the solutions (enumerate_ext.cpp:57-89), so
+    the shim does EnumerationDyn::enumerate's transformation itself (enumerate.cpp:107-123, 154-158).
+    Driven by the reference (ref_driver plugin, REFDRV_PLUGIN_DUAL=1: svp_reduction's dual radius,
+    enumerate(..., dual = true)) on a MatGSO without row exponents — the configuration in which the
+    adapter's radius is right (see extenum_shim.cpp) — against fplll's internal enumerator: per-level
+    node counts at fixed radius, and the solution VECTOR (orientation included) in every case."""
+    import subprocess
+    drv = os.path.join(C.ROOT, "oracle", "_ref", "ref_driver")
+    so = os.path.join(C.ROOT, "fplll_amd", "lib", "libfplll_hip_extenum.so")
+    assert os.path.exists(drv) and os.path.exists(so), "oracle/_ref/ref_driver or the plugin shim is missing"
+    env = dict(os.environ, FPLLL_HIP_DUAL="1", REFDRV_PLUGIN_DUAL="1")
+    for c in ("80 40 12 1 0 0 32 none 100000000 0 0.99",       # fixed radius: counts identical
+              "80 40 12 1 0 3 36 linear:18 1 0 0.99",          # pruned, shrinking radius
+              "100 50 14 2 20 10 40 linear:20 1 0 0.99"):
+        out = subprocess.run([drv, "plugin", so] + c.split(), capture_output=True, text=True,
+                             timeout=600, env=env)
+        assert out.returncode == 0, (c, out.stdout, out.stderr)
+        j = json.loads(out.stdout.strip().splitlines()[-1])
+        assert j["ours_nodes"] > 0 and j["ours_found"] == 1, j   # it ran on the device, not declined
+    # without the opt-in the shim declines a dual call and fplll's own enumerator answers
+    env2 = dict(os.environ, REFDRV_PLUGIN_DUAL="1", FPLLL_HIP_STATS="1")
+    out = subprocess.run([drv, "plugin", so] + "80 40 12 1 0 0 32 none 100000000 0 0.99".split(),
+                         capture_output=True, text=True, timeout=600, env=env2)
+    assert out.returncode == 0, (out.stdout, out.stderr)
+    assert "declined" in out.stderr and " 0 enumerations on the device" in out.stderr, out.stderr
 
 
 def test_plugin_in_process_multi_device():
