@@ -667,6 +667,7 @@ bkzs_body(GsoBatch P, BkzStrat S, BkzMail *mailbox, int *abort_flag, int block_s
         }
         int prune       = -1;
         double expct    = 1.0;  // PruningParams(): no pruning, expectation 1
+        bool hand       = false;  // the host walks this block on the multi-wave enumerator (hand-off mode)
         if (has_strat || ((F.flags & 0x80) && bs > 30) || dualb)
         {
           if (in)
@@ -690,6 +691,7 @@ bkzs_body(GsoBatch P, BkzStrat S, BkzMail *mailbox, int *abort_flag, int block_s
           md    = mail_load_f64(&mail->max_dist);
           prune = uni(mail_load_i32(&mail->prune));
           expct = mail_load_f64(&mail->expectation);
+          hand  = P.enum_mu_h != nullptr && uni(mail_load_i32(&mail->handoff)) != 0;
         }
         // ---- normalisation, enumerate.cpp:88-141 ------------------------------------------------
         int ne = in ? (int)min((long long)e2 + fexponent(rr), (long long)INT_MAX) : INT_MIN;
@@ -748,6 +750,42 @@ bkzs_body(GsoBatch P, BkzStrat S, BkzMail *mailbox, int *abort_flag, int block_s
         // ---- the walk (bkz_kernel.hip) with per-level bounds -----------------------------------
         double best_x = 0.0;
         bool have_sol = false;
+        if (hand)
+        {
+          // Hand-off (opt-in, FPHIP_BKZ_HANDOFF): this block's tree is large — one wave walks
+          // 3·10^6 nodes a second, the multi-wave enumerator (enum_kernel.hip) 10^9 and more — so the
+          // host runs fphip_enum_run on it (a second context of this device; this wave only waits
+          // on its mailbox meanwhile) and returns the vector FastEvaluator(1) would hold.  The
+          // enumerator walks in another order than the reference: with a shrinking pruned radius
+          // the vector, and from there the tour, may differ from the sequential one — as fplll with
+          // its own multi-threaded enumlib differs from fplll alone.
+          const int ntri = (bs * (bs - 1)) >> 1;
+          double *muh    = P.enum_mu_h + (size_t)L * (64 * 63 / 2);
+          for (int idx = lane; idx < ntri; idx += 64)
+            muh[idx] = mu_lds ? mu_blk_l[idx] : mu_blk_g[idx];
+          if (in)
+          {
+            mail->rd[lane]  = rd;
+            mail->prn[lane] = prn;
+          }
+          if (lane == 0)
+          {
+            mail->type     = 3;
+            mail->bs       = bs;
+            mail->maxdist3 = maxdist;
+            mail->dual3    = (DUALS && dualb) ? 1 : 0;
+          }
+          if (!mail_wait())
+          {
+            status = -7;
+            break;
+          }
+          have_sol = uni(mail_load_i32(&mail->have_sol)) != 0;
+          best_x   = in ? mail_load_f64(&mail->sol[lane]) : 0.0;
+          total_nodes += mail_load_u64(&mail->nodes3);
+          ++ncalls;
+        }
+        else
         {
           // The walk of enum_kernel.hip (see the comments there): two hot loops of wave-uniform
           // branches (this file is compiled with -structurizecfg-skip-uniform-regions), ddx =

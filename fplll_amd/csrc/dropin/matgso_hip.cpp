@@ -125,7 +125,20 @@ int MatGSOHip::size_reduction_device(int kappa_min, int kappa_end, double eta)
   const double t0 = now_s();
   upload_basis();
   int st = 0;
-  const int rc = fphip_gso_size_reduce(g_, kappa_min, kappa_end, eta, &st);
+  int rc = FPHIP_OK;
+  if (kappa_min > 0)
+  {  // the sweep of a sub-range reads mu / r of the rows before it (as babai does on the host: the
+     // reference keeps them valid); this object's device calls are stateless, so compute them first
+    rc = fphip_gso_update(g_, &st);
+    if (rc == FPHIP_OK && st != 1)
+    {
+      device_seconds += now_s() - t0;
+      ++n_device_calls;
+      return 0;
+    }
+  }
+  if (rc == FPHIP_OK)
+    rc = fphip_gso_size_reduce(g_, kappa_min, kappa_end, eta, &st);
   if (rc != FPHIP_OK)
     st = -100;
   else if (st == 1)

@@ -98,9 +98,15 @@ void MatHouseholderHip::mirror_from_device(bool basis_changed)
       for (int j = 0; j < n; ++j)
         bref_(i, j) = (long)hb_[(size_t)i * n + j];
   }
+  // (refresh_R_bf only converts the columns below n_known_cols — the widest row SHAPE of the input
+  // discovered so far, householder.cpp:193, captured at construction; the reduced rows are mixtures of
+  // all input rows, so every row counts as discovered first: one pass raises n_known_cols to its
+  // final value, what the host loop reaches when it has visited the last row)
+  invalidate_row(0);
+  for (int i = 0; i < d; ++i)
+    refresh_R_bf(i);
   for (int i = 0; i < d; ++i)
   {
-    invalidate_row(i);
     refresh_R_bf(i);
     update_R(i);
   }

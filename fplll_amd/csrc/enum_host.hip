@@ -319,6 +319,7 @@ hipStream_t fphip_ctx_stream(fphip_ctx *ctx) { return ctx->stream; }
 void **fphip_ctx_gso_slot(fphip_ctx *ctx) { return &ctx->gso; }
 char *fphip_ctx_errbuf(fphip_ctx *ctx) { return ctx->err; }
 int fphip_ctx_num_cus(fphip_ctx *ctx) { return ctx->num_cus; }
+int fphip_ctx_device(fphip_ctx *ctx) { return ctx->device; }
 
 // ---------------------------------------------------------------------------------------------
 // ring consumer
@@ -511,9 +512,10 @@ extern "C" int fphip_enum_run(fphip_ctx *ctx, int dim, double maxdist, const dou
   double gh_nodes = 0;
   for (int k = 0; k < d; ++k)
     gh_nodes += std::exp(std::min(logN[k], 60.0));
-  const double target_final =
+  double target_final =
       o.target_tasks > 0 ? o.target_tasks
                          : env_int("FPHIP_TARGET_TASKS", gh_nodes > 1e8 ? 65536 : 32768);
+  int overflow_retries = 0;  // split-launch overflows under sharding answered by a smaller task target
   if (o.min_nodes_decline > 0)
   {
     double tot = 0;
@@ -709,7 +711,7 @@ restart:
     // a subtree counts as heavy above `heavy` estimated nodes: enough final tasks to balance the
     // walk, few enough to fit the buffers (the estimate runs 2-5x high on pruned trees)
     const double want_tasks = o.target_tasks > 0 ? o.target_tasks : env_int("FPHIP_BFS_TASKS", 65536);
-    float heavy = (float)std::max((double)env_int("FPHIP_BFS_HEAVY", 256), est_nodes / want_tasks);
+    float heavy = (float)std::max((double)env_int("FPHIP_BFS_HEAVY", 1024), est_nodes / want_tasks);
     // levels: down to the first one where even a node of partial distance 0 is light
     int Lend = 1;
     for (int Lv = L0 - 1; Lv >= 1; --Lv)
@@ -749,7 +751,7 @@ restart:
     if (n_single > 0)
       bfs_launch(n_single, 1u, 1024u);
     // (waves per launch: a multiple of FPHIP_NQ — each wave reads one region)
-    const unsigned bgrid = std::max(32u, ((unsigned)ctx->num_cus * (unsigned)env_int("FPHIP_BFS_WG_PER_CU", 4)) / 32u * 32u);
+    const unsigned bgrid = std::max(32u, ((unsigned)ctx->num_cus * (unsigned)env_int("FPHIP_BFS_WG_PER_CU", 1)) / 32u * 32u);
     while (Lv > Lend)
       bfs_launch(1, bgrid, 256u);
     const bool want_slots = o.shard_count > 1;
@@ -767,7 +769,19 @@ restart:
       fprintf(stderr, "[fphip s%d] bfs levels %d..%d (%d in one workgroup), heavy > %.0f nodes: %u tasks, "
                       "%.3f ms%s\n", o.shard_index, L0, Lend, n_single, heavy, nfin, bms,
               (flg & FPHIP_FLAG_BFS_OVERFLOW) ? " OVERFLOW: starting over with split launches" : "");
-    if (flg & FPHIP_FLAG_BFS_OVERFLOW)
+    bool bfs_over = (flg & FPHIP_FLAG_BFS_OVERFLOW) != 0;
+    if (o.exchange)
+    {
+      // multi-GPU: WHICH region of a buffer overflows depends on the order of the atomics, so one
+      // rank may overflow where another does not — and a rank that started over with the split
+      // launches would hold another task set than the others.  One more collective (the bound
+      // cannot have moved yet) makes the decision common: everybody starts over if anybody must.
+      int any = 0;
+      (void)o.exchange(o.exchange_user, bdbl(__atomic_load_n(&ctx->h->bound_bits, __ATOMIC_ACQUIRE)),
+                       bfs_over ? 1 : 0, &any);
+      bfs_over = any != 0;
+    }
+    if (bfs_over)
     {
       if (d > 64)  // (the top walk cannot be repeated cheaply: such a block stays with the caller)
       {
@@ -985,12 +999,21 @@ restart:
       HIPCHK(ctx, hipMemcpy(&cnt, ctx->buf[nxt].count, 4, hipMemcpyDeviceToHost));
     }
     if (!in_final && o.shard_count > 1 && cnt > ctx->cap)
+    {
       // The multi-GPU partition deals the tasks of the replicated split launches by content; that
       // needs every rank to hold the SAME task set.  After an overflow, which tasks made it into
       // the buffer depends on the order of the atomics and differs per rank: a subtree could be
       // walked twice or by nobody.  (A single GPU walks the overflow inline and stays exact.)
-      return fail(ctx, "task buffer overflow in a split launch (%u tasks, capacity %u) under sharding: "
-                       "raise FPHIP_TASK_CAP or lower the task target", cnt, ctx->cap);
+      // The COUNT, however, is a property of the replicated tree — the same on every rank — so every
+      // rank takes the same decision here without talking: start over with an eighth of the task
+      // target (nothing has been reported yet: candidates only appear in the walk launches).
+      if (d > 64 || ++overflow_retries > 3)
+        return fail(ctx, "task buffer overflow in a split launch (%u tasks, capacity %u) under sharding: "
+                         "raise FPHIP_TASK_CAP or lower the task target", cnt, ctx->cap);
+      target_final = std::max(64.0, target_final / 8.0);
+      use_bfs      = false;
+      goto restart;
+    }
     if (cnt > ctx->cap)
       cnt = ctx->cap;
     if (in_final && o.exchange)

@@ -55,6 +55,9 @@ struct GsoBatch
   double *enum_mu;  // BKZ kernel: [batch][64*63/2] scaled mu rows of the block being enumerated
   int *bkz_active;  // BKZ kernel: [batch] 0 = leave this lattice alone (its reduction has ended)
   int *bkz_rows;    // BKZ kernel: [batch] number of rows without the trailing zero rows
+  double *enum_mu_h;  // strategy-BKZ kernel, hand-off mode: [batch][64*63/2] in PINNED HOST memory — the
+                      // scaled mu rows of a block whose enumeration the host runs on the multi-wave
+                      // enumerator (null: every block is walked by the lattice's own wave)
 };
 // ---- BKZ with strategies (bkzs_kernel.hip) ------------------------------------------------------
 #define FPHIP_BKZS_MAX_DEPTH 4  /* nested tour() activations: the BKZ tour + 3 levels of preprocessing */
@@ -96,6 +99,16 @@ struct BkzMail
   unsigned plan[FPHIP_BKZS_PLAN_MAX];
   // mailbox[0] only: bumped by the host on every service sweep (the device's liveness test)
   unsigned long long heartbeat;
+  // ---- hand-off of a large block enumeration to the multi-wave enumerator (type 3) ------------
+  int handoff;    // response of type 1: 1 = this block is large, send a type-3 request for it
+  int dual3;      // type 3 request: the inputs are the dual transformation (dualenum walk)
+  double rd[64];   // type 3 request: normalised r_ii of the block (the walk's rdiag)
+  double prn[64];  //                 pruning coefficient per level
+  double maxdist3; //                 normalised radius
+  double sol[64];  // type 3 response: coefficients of the last solution delivered (FastEvaluator(1))
+  int have_sol;
+  int pad2;
+  unsigned long long nodes3;  // nodes of the call, fplll rule
 };
 // Batched Householder state (MatHouseholder<Z_NR<long>, FP_NR<double>>): b, V, R are [batch][d][ldn]
 // row-major (lane = column), sigma / rexp [batch][d].

@@ -65,6 +65,7 @@ using namespace fphip;
 hipStream_t fphip_ctx_stream(fphip_ctx *ctx);
 char *fphip_ctx_errbuf(fphip_ctx *ctx);
 int fphip_ctx_num_cus(fphip_ctx *ctx);
+int fphip_ctx_device(fphip_ctx *ctx);
 
 struct fphip_gso
 {
@@ -80,6 +81,7 @@ struct fphip_gso
   short *m16;   // 2-byte mirrors: [batch][n*ldd + d*ldn] (bT16 then b16 of each lattice)
   int *flag16;  // [batch][d]
   int sweep_version;  // 2 (default) or 1 (FPHIP_GSO_SWEEP=1: the first-generation kernel)
+  fphip_ctx *ectx;    // hand-off mode of the strategy-BKZ kernel: the enumeration context (same device)
 };
 
 static int gfail(fphip_ctx *ctx, const char *what, hipError_t e)
@@ -203,6 +205,8 @@ extern "C" void fphip_gso_destroy(fphip_gso *g)
 {
   if (!g)
     return;
+  if (g->ectx)
+    fphip_destroy(g->ectx);
   hipStreamSynchronize(fphip_ctx_stream(g->ctx));
   fphip_dev_free(g->P.b, fphip_ctx_stream(g->ctx));
   fphip_dev_free(g->P.bfT, fphip_ctx_stream(g->ctx));
@@ -746,6 +750,9 @@ extern "C" int fphip_gso_bkz(fphip_gso *g, int block_size, double delta, double 
 // roundings) and the rerandomisation plan (drawn from the caller's generator, rnd(user, lattice,
 // n) = gmp_urandomm_ui(state of that lattice, n)).
 #include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 #include <thread>
 static inline void *pinned_get(size_t bytes) { return fphip_pinned_get(bytes); }
 static inline void pinned_put(void *p) { fphip_pinned_put(p); }
@@ -775,7 +782,25 @@ struct BkzsHost
   double gh_factor;
   fphip_rand_fn rnd;
   void *rnd_user;
+  double handoff_nodes;  // > 0: blocks above that many estimated nodes go to the multi-wave enumerator
 };
+
+// Gaussian-heuristic size of the pruned tree of a block (what enum_host.hip's estimate_levels
+// computes, in logarithms: the r_ii carry their row exponents here): sum over the levels k of
+// 1/2 V_{bs-k}(R_k) / prod_{i>=k} sqrt(r_ii), R_k^2 = pruning_k * radius.  Scheduling only.
+double estimate_block_nodes(int bs, const double *logr, double log_radius, const double *prune)
+{
+  double sumlog = 0.0, tot = 0.0;
+  for (int k = bs - 1; k >= 0; --k)
+  {
+    sumlog += 0.5 * logr[k];
+    const int n       = bs - k;
+    const double logV = 0.5 * n * std::log(M_PI) - std::lgamma(0.5 * n + 1.0);
+    const double pr   = prune ? prune[k] : 1.0;
+    tot += std::exp(std::min(std::log(0.5) + logV + 0.5 * n * (std::log(pr > 0 ? pr : 1e-300) + log_radius) - sumlog, 80.0));
+  }
+  return tot;
+}
 
 // type 1: radius (bkz.cpp:309-323) and pruning set (get_pruning :82-98, Strategy::get_pruning
 // bkz_param.cpp:64-80) of the block whose r_ii the wave has written
@@ -827,6 +852,70 @@ void serve_radius(const BkzsHost &H, BkzMail *m)
   m->max_dist    = max_dist;
   m->expectation = expectation;
   m->prune       = best;
+  m->handoff     = 0;
+  if (H.handoff_nodes > 0 && bs >= 24)
+  {
+    // the tree the wave is about to walk: primal block r_ii 2^e2_i, radius max_dist 2^expo; a dual
+    // block is the index-reversed inverse (enumerate.cpp:107-123)
+    double logr[64];
+    for (int i = 0; i < bs; ++i)
+    {
+      const double lr = std::log(m->r[i]) + m->e2[i] * M_LN2;
+      if (dual)
+        logr[bs - 1 - i] = -lr;
+      else
+        logr[i] = lr;
+    }
+    const double *pr = nullptr;
+    if (H.S && best >= 0 && H.S->coeff_off[best + 1] - H.S->coeff_off[best] == bs)
+      pr = H.S->coeff + H.S->coeff_off[best];
+    const double est = estimate_block_nodes(bs, logr, std::log(max_dist) + expo * M_LN2, pr);
+    m->handoff       = est >= H.handoff_nodes ? 1 : 0;
+  }
+}
+
+// type 3: the enumeration of a large block on the multi-wave enumerator (enum_host.hip) with
+// FastEvaluator(1) semantics (evaluator.h:122-156, max_sols = 1: every delivered solution replaces
+// the last one and becomes the radius).  Runs on the hand-off worker thread.
+struct HandoffSol
+{
+  double sol[64];
+  int have;
+  int dim;
+};
+double handoff_cb(void *user, double dist, const double *sol)
+{
+  HandoffSol *h = static_cast<HandoffSol *>(user);
+  for (int i = 0; i < h->dim; ++i)
+    h->sol[i] = sol[i];
+  h->have = 1;
+  return dist;
+}
+int serve_enumeration(fphip_ctx *ectx, BkzMail *m, const double *mu_tri)
+{
+  const int bs = m->bs;
+  std::vector<double> mut((size_t)bs * bs, 0.0);
+  for (int k = 1; k < bs; ++k)
+    for (int l = 0; l < k; ++l)
+      mut[(size_t)l * bs + k] = mu_tri[(k * (k - 1)) / 2 + l];  // mut[i*dim + j] = mu(j, i), j > i
+  HandoffSol hs;
+  hs.have = 0;
+  hs.dim  = bs;
+  fphip_enum_opts o;
+  memset(&o, 0, sizeof o);
+  o.dual = m->dual3;
+  std::vector<uint64_t> nodes(bs + 1, 0);
+  fphip_enum_stats stt;
+  memset(&stt, 0, sizeof stt);
+  const int rc = fphip_enum_run(ectx, bs, m->maxdist3, mut.data(), m->rd, m->prn, &o, handoff_cb, nullptr, &hs,
+                                nodes.data(), &stt);
+  if (rc != FPHIP_OK)
+    return rc;
+  m->have_sol = hs.have;
+  for (int i = 0; i < 64; ++i)
+    m->sol[i] = (i < bs && hs.have) ? hs.sol[i] : 0.0;
+  m->nodes3 = stt.total_nodes;
+  return FPHIP_OK;
 }
 
 // type 2: the random choices of rerandomize_block(min_row, max_row, density), bkz.cpp:43-80 — they
@@ -934,8 +1023,12 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
   // BKZ_GH_BND
   // BKZ_SD_VARIANT (0x100): self-dual BKZ, bkzs_body<NQ, true>
   const bool sd = (flags & 0x100) != 0;
-  if (block_size > 64 || (flags & ~(0x4 | 0x10 | 0x20 | 0x80 | 0x100)))
+  if (block_size > 64 || (flags & ~(0x4 | 0x10 | 0x20 | 0x80 | 0x100 | 0x1000)))
     return FPHIP_UNSUPPORTED;
+  // FPHIP_BKZ_HANDOFF (0x1000, or FPHIP_BKZ_HANDOFF=1 in the environment): blocks whose tree is large
+  // are enumerated by the multi-wave enumerator on a second context instead of by the lattice's wave
+  const bool handoff = (flags & 0x1000) != 0 || (getenv("FPHIP_BKZ_HANDOFF") && atoi(getenv("FPHIP_BKZ_HANDOFF")) != 0);
+  flags &= ~0x1000;
   if (sd && !(flags & (0x4 | 0x20)))
     flags |= 0x20;  // "SD Variant of BKZ requires explicit termination condition", bkz.cpp:548-554
   const int bsz = block_size < g->P.d ? block_size : g->P.d;
@@ -1008,6 +1101,11 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
     fphip_dev_free(d_abort, fphip_ctx_stream(g->ctx));
     if (mail)
       pinned_put(mail);
+    if (g->P.enum_mu_h)
+    {
+      pinned_put(g->P.enum_mu_h);
+      g->P.enum_mu_h = nullptr;
+    }
   };
 #define BCHK(call)                         \
   do                                       \
@@ -1109,7 +1207,33 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
     default: BCHK(hipFuncSetAttribute((const void *)sdv::bkzd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); break;
     }
   }
-  BkzsHost H{S, gh_factor, rnd, rnd_user};
+  BkzsHost H{S, gh_factor, rnd, rnd_user, 0.0};
+  if (handoff)
+  {
+    // hand-off mode: a second context on this device for the enumerations, the blocks' mu rows in
+    // pinned host memory (the wave writes them, the worker thread reads them without a HIP call)
+    if (!g->ectx && fphip_create(fphip_ctx_device(g->ctx), &g->ectx) != FPHIP_OK)
+    {
+      snprintf(fphip_ctx_errbuf(g->ctx), 512, "bkz_strategies: no enumeration context for the hand-off: %s",
+               g->ectx ? fphip_last_error(g->ectx) : "?");
+      if (g->ectx)
+        fphip_destroy(g->ectx);
+      g->ectx = nullptr;
+      cleanup();
+      return FPHIP_ERROR;
+    }
+    g->P.enum_mu_h = (double *)pinned_get(B * (64 * 63 / 2) * sizeof(double));
+    if (!g->P.enum_mu_h)
+    {
+      cleanup();
+      snprintf(fphip_ctx_errbuf(g->ctx), 512, "bkz_strategies: no pinned memory for the hand-off");
+      return FPHIP_ERROR;
+    }
+    const char *hn  = getenv("FPHIP_BKZ_HANDOFF_NODES");
+    H.handoff_nodes = hn ? atof(hn) : 2e5;
+  }
+  unsigned long long handoff_calls = 0;
+  int handoff_rc                   = FPHIP_OK;
   bool rnd_failed              = false;
   unsigned long long heartbeat = 0;
   std::vector<unsigned long long> handled(B, 0);
@@ -1150,6 +1274,40 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
     // (measured: the config-3 tour timed out next to the rest of the GPU test suite).  This thread
     // only waits for the stream.
     std::atomic<bool> stop{false};
+    // hand-off mode: type-3 requests are answered by a worker thread of their own (it makes HIP calls
+    // — launches on the enumeration context's stream — and may take milliseconds per request; the
+    // service thread goes on sweeping, so the heartbeat never stands still)
+    std::mutex hq_m;
+    std::condition_variable hq_cv;
+    std::deque<std::pair<size_t, unsigned long long>> hq;
+    bool hq_stop = false;
+    std::thread worker;
+    if (handoff)
+      worker = std::thread([&]()
+      {
+        for (;;)
+        {
+          std::pair<size_t, unsigned long long> job;
+          {
+            std::unique_lock<std::mutex> lk(hq_m);
+            hq_cv.wait(lk, [&] { return hq_stop || !hq.empty(); });
+            if (hq.empty())
+              return;
+            job = hq.front();
+            hq.pop_front();
+          }
+          BkzMail *m   = &mail[job.first];
+          const int rc = serve_enumeration(g->ectx, m, g->P.enum_mu_h + job.first * (64 * 63 / 2));
+          if (rc != FPHIP_OK)
+          {  // the wave cannot walk the block itself any more: no solution, and the call reports the error
+            m->have_sol = 0;
+            m->nodes3   = 0;
+            handoff_rc  = rc;
+          }
+          ++handoff_calls;
+          __atomic_store_n(&m->rsp_seq, job.second, __ATOMIC_RELEASE);
+        }
+      });
     std::thread server([&]()
     {
       for (;;)
@@ -1161,6 +1319,16 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
           const unsigned long long seq = __atomic_load_n(&m->req_seq, __ATOMIC_ACQUIRE);
           if (seq == handled[L])
             continue;
+          if (m->type == 3 && handoff)
+          {  // to the worker; it stores rsp_seq when the enumeration is done
+            handled[L] = seq;
+            {
+              std::lock_guard<std::mutex> lk(hq_m);
+              hq.emplace_back(L, seq);
+            }
+            hq_cv.notify_one();
+            continue;
+          }
           if (m->type == 1)
             serve_radius(H, m);
           else if (m->type == 2 && serve_plan(H, (int)L, m) < 0)
@@ -1179,6 +1347,15 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
     const hipError_t q = hipStreamSynchronize(s);
     stop.store(true, std::memory_order_release);
     server.join();
+    if (handoff)
+    {
+      {
+        std::lock_guard<std::mutex> lk(hq_m);
+        hq_stop = true;
+      }
+      hq_cv.notify_all();
+      worker.join();
+    }
     if (q != hipSuccess)
       return gfail(g->ctx, "bkzs_kernel", q);
     GCHK(hipEventElapsedTime(ms, g->ev[0], g->ev[1]));
@@ -1234,6 +1411,15 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
   }
 #undef BCHK
   cleanup();  // (run_once's GCHKs return to this function, never past it: nothing leaks on a HIP error)
+  if (handoff && getenv("FPHIP_DEBUG"))
+    fprintf(stderr, "[fphip] bkz_strategies: %llu block enumerations handed to the multi-wave enumerator\n",
+            handoff_calls);
+  if (handoff_rc != FPHIP_OK && rc == FPHIP_OK)
+  {
+    snprintf(fphip_ctx_errbuf(g->ctx), 512, "bkz_strategies: a handed-off enumeration failed: %s",
+             g->ectx ? fphip_last_error(g->ectx) : "?");
+    rc = FPHIP_ERROR;
+  }
   if (rnd_failed && rc == FPHIP_OK)
   {
     snprintf(fphip_ctx_errbuf(g->ctx), 512,

@@ -101,3 +101,50 @@ def run_rounds(exchange, rounds_local, bound0):
         calls += 1
         others = any_active
     return bound, calls
+
+
+def reduce_enumeration(dist, best_dist, best_coords, nodes, dim, device="cpu"):
+    """The three reductions that turn the ranks' shares of ONE sharded enumeration into the result of
+    the call: norm MIN -> the winner's coefficient vector broadcast -> per-level node
+    counts SUM.  All messages are below 4 KB (latency-bound: xGMI bandwidth plays no role).
+
+      best_dist   this rank's shortest squared norm (float; inf if it holds no solution)
+      best_coords its coefficient vector (sequence of dim numbers, ignored when best_dist is inf)
+      nodes       its per-level node counts (dim + 1 integers)
+
+    Returns (dist, coords, nodes) — identical on every rank: the globally shortest norm, the vector of
+    the LOWEST rank that holds it (a deterministic tie rule), and the summed counts.  One all_gather of
+    (norm, vector) = 8 (dim + 1) bytes per rank and one all_reduce of dim + 1 int64."""
+    import math
+    import torch
+    world = dist.get_world_size()
+    mine = torch.zeros(dim + 1, dtype=torch.float64, device=device)
+    mine[0] = float(best_dist)
+    if math.isfinite(float(best_dist)):
+        mine[1:] = torch.as_tensor([float(v) for v in best_coords][:dim], dtype=torch.float64)
+    everyone = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(everyone, mine)
+    norms = [float(t[0]) for t in everyone]
+    win = min(range(world), key=lambda r: (norms[r], r))
+    cnt = torch.as_tensor([int(v) for v in nodes][:dim + 1], dtype=torch.int64).to(device)
+    dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+    coords = [float(v) for v in everyone[win][1:]] if math.isfinite(norms[win]) else None
+    return norms[win], coords, [int(v) for v in cnt.tolist()]
+
+
+def enumerate_block_sharded(ctx, dist, mut, rdiag, pruning, maxdist, evaluator, device="cpu",
+                            exchange_chunks=4, **kw):
+    """One SVP enumeration over all ranks of `dist` (one process per GPU): this rank walks its share of
+    the subtree tasks (fplll_amd.enumeration.enumerate_block with the 16-byte bound exchange), then
+    the reductions above.  Returns (dist, coords, nodes, local_result): the first three identical on
+    every rank.  `evaluator` is this rank's (fplll's evaluator is per process); with BEST-1 semantics
+    its shortest solution is this rank's candidate."""
+    from .enumeration import enumerate_block
+    rank, world = dist.get_rank(), dist.get_world_size()
+    res = enumerate_block(ctx, mut, rdiag, pruning, maxdist, evaluator, shard_index=rank, shard_count=world,
+                          exchange=make_exchange(dist, device), exchange_chunks=exchange_chunks, **kw)
+    sols = sorted(evaluator.solutions, key=lambda s: s[0]) if evaluator.solutions else []
+    bd = sols[0][0] if sols else float("inf")
+    bc = sols[0][1] if sols else None
+    gd, gc, gn = reduce_enumeration(dist, bd, bc, res.nodes, len(rdiag), device)
+    return gd, gc, gn, res

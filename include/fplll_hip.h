@@ -217,6 +217,15 @@ int fphip_gso_bkz(fphip_gso *g, int block_size, double delta, double eta, int fl
 #define FPHIP_BKZ_BOUNDED_LLL 0x10
 #define FPHIP_BKZ_GH_BND 0x80
 #define FPHIP_BKZ_SD_VARIANT 0x100
+/* FPHIP_BKZ_HANDOFF (not a flag of fplll): blocks whose Gaussian-heuristic tree size exceeds
+ * FPHIP_BKZ_HANDOFF_NODES (environment, default 2e5 estimated nodes) are enumerated by the multi-wave
+ * enumerator (fphip_enum_run on a second context of the device, FastEvaluator(1) semantics) instead
+ * of by the lattice's own wave: 10^9 nodes/s instead of 3·10^6.  That enumerator visits the tree in
+ * another order than the reference, so with a shrinking pruned radius it may end on another vector:
+ * the run is no longer bit-identical to BKZReduction::bkz() — it is to fplll what fplll with its
+ * multi-threaded enumlib is to fplll alone.  Accept it by the reference's reducedness predicate
+ * (tests/test_a_configs_at_size_gpu.py). */
+#define FPHIP_BKZ_HANDOFF 0x1000
 typedef struct fphip_strategies
 {
   int max_block_size;

@@ -122,3 +122,46 @@ def test_batch_sharding_replicas_world2():
     assert (res[0][1], res[0][2], res[1][1], res[1][2]) == (0, 6, 6, 11)
     expect = list(range(0, 6)) + [1000 + i for i in range(6, 11)]
     assert res[0][3] == expect and res[1][3] == expect
+
+
+def _reduce_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from fplll_amd.distributed import reduce_enumeration
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dim = 6
+    # case 1: rank 1 holds the shortest vector; rank 2 (if any) holds nothing
+    cand = {0: (3.5, [1, 0, -2, 0, 0, 1]), 1: (2.25, [0, 1, 1, -1, 0, 0])}.get(rank, (float("inf"), None))
+    nodes = [10 * (rank + 1) + k for k in range(dim + 1)]
+    a = reduce_enumeration(dist, cand[0], cand[1], nodes, dim)
+    # case 2: a tie — the lowest rank's vector wins on every rank
+    b = reduce_enumeration(dist, 1.0, [rank + 1] * dim, [1] * (dim + 1), dim)
+    # case 3: nobody found anything
+    c = reduce_enumeration(dist, float("inf"), None, [0] * (dim + 1), dim)
+    q.put((rank, a, b, c))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_library_level_reductions_norm_vector_counts(world):
+    """reduce_enumeration: norm MIN, the winner's vector to every rank, node counts SUM —
+    identical results on all ranks, also with a tie and with no solution at all."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_reduce_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    for p in ps:
+        p.join(120)
+        assert p.exitcode == 0
+    res = sorted(q.get(timeout=10) for _ in range(world))
+    dim = 6
+    want_nodes = [sum(10 * (r + 1) + k for r in range(world)) for k in range(dim + 1)]
+    for rank, a, b, c in res:
+        assert a == (2.25, [0.0, 1.0, 1.0, -1.0, 0.0, 0.0], want_nodes)
+        assert b == (1.0, [1.0] * dim, [world] * (dim + 1))
+        assert c[0] == float("inf") and c[1] is None and c[2] == [0] * (dim + 1)

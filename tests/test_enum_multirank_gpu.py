@@ -73,3 +73,54 @@ def test_two_ranks_partition_the_tree(name, share):
     assert not diff, (str(diff), out[0][2], out[1][2], out[0][4], out[1][4])
     assert min(sum(out[0][1]), sum(out[1][1])) > share * f["total_nodes"]  # both ranks did real work
     assert out[0][2] == out[1][2] >= 3  # identical collective call counts
+
+
+def _worker_lib(rank, world, port, fixture, q):
+    import torch.distributed as dist
+    import fplll_amd
+    from fplll_amd.distributed import enumerate_block_sharded
+    from fplll_amd.enumeration import FastEvaluator
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    f = C.load_fixture(fixture)
+    ctx = fplll_amd.Context(0)
+    ev = FastEvaluator(f["max_sols"], f["strategy"])
+    gd, gc, gn, res = enumerate_block_sharded(ctx, dist, f["mut"], f["rdiag"], f["pruning"], f["maxdist"], ev,
+                                              device="cpu", exchange_chunks=3)
+    q.put((rank, gd, gc, gn, int(res.total_nodes)))
+    dist.barrier()
+    ctx.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,world", [("enum_d48_lin30_fixed", 3), ("enum_d40_lin20_best1", 2),
+                                        ("enum_d48_lin30_best1", 4)])
+def test_sharded_call_with_library_level_reductions(name, world):
+    """enumerate_block_sharded = what bench.py --gpus N times: the sharded walk, then norm MIN -> the
+    winner's vector to every rank -> node counts SUM.  Every rank ends with the SAME
+    result; at a fixed radius the summed per-level counts are the reference's, with a shrinking one the
+    final norm is."""
+    import torch.multiprocessing as mp
+    fixture = os.path.join(C.GOLDEN, name + ".json")
+    f = C.load_fixture(fixture)
+    mpctx = mp.get_context("spawn")
+    q = mpctx.Queue()
+    port = _free_port()
+    ps = [mpctx.Process(target=_worker_lib, args=(r, world, port, fixture, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    out = sorted(q.get(timeout=300) for _ in range(world))
+    for p in ps:
+        p.join(120)
+        assert p.exitcode == 0
+    for r in range(1, world):
+        assert out[r][1:4] == out[0][1:4], "ranks disagree on the reduced result"
+    gd, gc, gn = out[0][1:4]
+    assert sum(o[4] for o in out) == sum(gn)
+    ref_best = min([s[0] for s in f["sol_log"]] or [float("inf")])
+    if "fixed" in name:
+        assert gn == [int(v) for v in f["nodes"]], "summed per-level counts differ from the reference's"
+        assert gd <= ref_best  # (the evaluator keeps every solution here: the shortest is among them)
+    else:
+        assert gd == ref_best and gc is not None and len(gc) == f["d"]

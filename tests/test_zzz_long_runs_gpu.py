@@ -35,3 +35,29 @@ def test_config3_bkz60_tour_and_config5_hlll_match_reference():
     assert c3["expect"][1] == 1224293770 and all(c3["basis_ok"])
     assert c5["st"] == [c5["expect"]] * 2 == [1, 1] and c5["swaps"] == [146491] * 2
     assert all(c5["basis_ok"])
+
+
+def test_config3_bkz60_tour_with_handoff_meets_the_reducedness_predicate():
+    """config 3's tour on the device in hand-off mode (large blocks on the multi-wave enumerator): the
+    output is judged by the reference's own predicates — LLL-reduced (is_lll_reduced at 256 bits), same
+    lattice volume, first vector not longer and slope of log r_ii not worse (within 1 %) than the
+    reference tour's output — and it must be at least twice as fast as the wave-only tour."""
+    if "thread_c3h" not in C.LONG_RUNS:
+        import test_a_configs_at_size_gpu as A
+        A.start_long_runs()
+    C.LONG_RUNS["thread_c3h"].join(1100)
+    assert not C.LONG_RUNS["thread_c3h"].is_alive(), "the hand-off run did not finish"
+    assert "c3h_error" not in C.LONG_RUNS, C.LONG_RUNS.get("c3h_error")
+    h = C.LONG_RUNS["c3h"]
+    s, r, i = h["stat"], h["ref_stat"], h["in_stat"]
+    print("config 3 tour with hand-off: %.1f s on the device (wave-only: see the other test; reference %.1f s), "
+          "%d nodes in %d enumerations (reference %d nodes); slope %.6f (reference %.6f, input %.6f), "
+          "r00 %.6g (reference %.6g)" % (h["wall"], h["ref_s"], h["nodes"], h["calls"], h["ref_nodes"],
+                                         s["slope"], r["slope"], i["slope"], s["r00"], r["r00"]))
+    assert h["st"] == h["expect_status"]
+    assert s["is_lll_reduced"] == 1 and r["is_lll_reduced"] == 1
+    assert abs(s["log_volume"] - r["log_volume"]) < 1e-6 * abs(r["log_volume"])
+    assert s["slope"] >= r["slope"] * 1.01          # slopes are negative: not steeper by more than 1 %
+    assert s["slope"] > i["slope"]                  # the tour improved the basis
+    assert s["r00"] <= i["r00"]
+    assert h["wall"] < 450
