@@ -343,7 +343,11 @@ bkzs_body(GsoBatch P, BkzStrat S, BkzMail *mailbox, int *abort_flag, int block_s
     auto cur_dual = [&]() -> bool
     {
       if constexpr (DUALS)
+      {
+        if (F.flags & 0x200)  // slide frame: the ops behind the checkpoint (op == p) are the dual blocks
+          return F.op > (F.max_row - F.min_row + F.bsz - 1) / F.bsz;
         return (F.flags & 0x100) && F.op < max(F.max_row - F.bsz - F.min_row, 0);
+      }
       else
         return false;
     };
@@ -360,33 +364,49 @@ bkzs_body(GsoBatch P, BkzStrat S, BkzMail *mailbox, int *abort_flag, int block_s
         if (rc != 1)
           status = rc;
       }
-      if ((top_flags & 0x100) && !(run_mode & 2))
+      if ((top_flags & 0x300) && !(run_mode & 2))
         running = false;  // this launch only runs the prelude and / or the closing hkz
     }
-    constexpr int NSTAGE = DUALS ? 2 : 1;
-    for (int stage = 0; stage < NSTAGE; ++stage)
+    // closing passes: SD-BKZ one (the last window), slide reduction one per block
+    const int sld_p  = (num_rows + max(block_size, 1) - 1) / max(block_size, 1);
+    const int nstage = DUALS ? 1 + ((top_flags & 0x200) ? sld_p : 1) : 1;
+    int status_before = status;
+    for (int stage = 0; stage < nstage; ++stage)
     {
     if constexpr (DUALS)
     {
-      if (stage == 1)
+      if (stage >= 1)
       {
         // closing pass of SD-BKZ: hkz(num_rows - block_size, num_rows), bkz.cpp:627-641 — it also
-        // runs after RED_BKZ_LOOPS_LIMIT
-        if (!((top_flags & 0x100) && (run_mode & 4) && block_size >= 2 && (status == 1 || status == 8)))
+        // runs after RED_BKZ_LOOPS_LIMIT.  Slide reduction: hkz of every block, kappa = j bs + 1 to
+        // min(num_rows, kappa + bs - 1), bkz.cpp:643-660 (the blocks are otherwise only SVP and dual
+        // SVP reduced).
+        if (!((top_flags & 0x300) && (run_mode & 4) && block_size >= 2 &&
+              (in_post ? status == 1 : (status == 1 || status == 8))))
           break;
+        if (!in_post)
+          status_before = status;
         in_post     = true;
         running     = true;
         depth       = 0;
-        F.bsz       = block_size;
-        F.flags     = top_flags & ~0x100 & ~0x40000000;
-        F.min_row   = num_rows - block_size;
-        F.max_row   = num_rows;
+        F.flags     = top_flags & ~0x300 & ~0x40000000;
+        if (top_flags & 0x200)
+        {
+          F.min_row = (stage - 1) * block_size + 1;
+          F.max_row = min(num_rows, F.min_row + block_size - 1);
+          F.bsz     = max(F.max_row - F.min_row, 0);  // hkz() takes its window from its arguments
+        }
+        else
+        {
+          F.bsz     = block_size;
+          F.min_row = num_rows - block_size;
+          F.max_row = num_rows;
+        }
         F.op        = 0;
         F.phase     = PH_OP_BEGIN;
         F.clean     = 1;
       }
     }
-    const int status_before = status;
     if constexpr (DUALS)
     {
       if (in_post)
@@ -407,12 +427,22 @@ bkzs_body(GsoBatch P, BkzStrat S, BkzMail *mailbox, int *abort_flag, int block_s
         const int n_hkz   = max(F.max_row - 1 - hkz_lo, 0);
         int nops          = n_trunc + n_hkz + 1;
         bool sd_frame     = false;
+        bool sld_frame    = false;
+        int sld_np        = 0;
         if constexpr (DUALS)
         {
           // sd_tour: n_trunc dual blocks from the top down, then the n_trunc primal blocks; no hkz
           sd_frame = (F.flags & 0x100) != 0;
           if (sd_frame)
             nops = 2 * n_trunc;
+          // slide_tour, bkz.cpp:465-520: passes of p primal blocks (stride bsz) until one leaves them
+          // all unchanged — op == p is the end-of-pass checkpoint — then the p - 1 dual blocks
+          sld_frame = (F.flags & 0x200) != 0;
+          if (sld_frame)
+          {
+            sld_np = (F.max_row - F.min_row + F.bsz - 1) / F.bsz;
+            nops   = 2 * sld_np;
+          }
         }
         if (F.op >= nops)
         {  // the tour is over
@@ -429,6 +459,16 @@ bkzs_body(GsoBatch P, BkzStrat S, BkzMail *mailbox, int *abort_flag, int block_s
               break;
           }
           ++tours;
+          if constexpr (DUALS)
+          {
+            if (sld_frame)
+            {  // one slide tour per launch: the potential test (bkz.cpp:512-518, host libm) decides
+               // on the host whether another one follows
+              if (block_size < num_rows)
+                status = 8;
+              break;
+            }
+          }
           if (F.clean || block_size >= num_rows)
             break;
           ++loop;
@@ -441,7 +481,35 @@ bkzs_body(GsoBatch P, BkzStrat S, BkzMail *mailbox, int *abort_flag, int block_s
           F.clean = 1;
           continue;
         }
-        if (!sd_frame && F.op == nops - 1)
+        if constexpr (DUALS)
+        {
+          if (sld_frame && F.op == sld_np)
+          {  // end of a primal pass: the bounded LLL (bkz.cpp:482-493), then again unless clean
+            if (F.flags & 0x10)
+            {
+              int fk, ns, zs;
+              long long it;
+              const int rc = lll_run(T, C, M, ring, F.min_row, F.min_row, F.max_row, delta, eta, logdelta, fk, ns,
+                                     zs, it, vp);
+              if (rc != 1)
+              {
+                status = rc;
+                break;
+              }
+              if (ns > 0)
+                F.clean = 0;
+            }
+            if (!F.clean)
+            {
+              F.op    = 0;
+              F.clean = 1;
+            }
+            else
+              ++F.op;
+            continue;
+          }
+        }
+        if (!sd_frame && !sld_frame && F.op == nops - 1)
         {  // lll_obj.size_reduction(max_row - 1, max_row, max_row - 2), bkz.cpp:437
           ++F.op;
           if (F.max_row >= 2)
@@ -454,7 +522,23 @@ bkzs_body(GsoBatch P, BkzStrat S, BkzMail *mailbox, int *abort_flag, int block_s
           }
           continue;
         }
-        if (sd_frame)
+        if (sld_frame)
+        {
+          if constexpr (DUALS)
+          {
+            if (F.op < sld_np)
+            {
+              F.kappa = F.min_row + F.op * F.bsz;
+              F.bs    = min(F.max_row - F.kappa, F.bsz);
+            }
+            else
+            {
+              F.kappa = F.min_row + (F.op - sld_np - 1) * F.bsz + 1;
+              F.bs    = F.bsz;
+            }
+          }
+        }
+        else if (sd_frame)
         {
           if constexpr (DUALS)
           {
@@ -1252,12 +1336,12 @@ bkzs_body(GsoBatch P, BkzStrat S, BkzMail *mailbox, int *abort_flag, int block_s
         F.phase = PH_OP_BEGIN;
       }
     }
+    }  // stage
     if constexpr (DUALS)
     {
       if (in_post && status == 1)
-        status = status_before;  // the closing pass keeps RED_SUCCESS / RED_BKZ_LOOPS_LIMIT
+        status = status_before;  // the closing passes keep RED_SUCCESS / RED_BKZ_LOOPS_LIMIT
     }
-    }  // stage
     lll_write_ordered<NQ>(T, M, P.b2 + (size_t)L * d * ldn);
     if (lane == 0)
     {

@@ -19,6 +19,7 @@
 
 #include "../../include/fplll_hip.h"
 #include "dev_mem.h"
+#include "trace.h"
 #include "enum_device.h"
 
 
@@ -459,6 +460,7 @@ extern "C" int fphip_enum_run(fphip_ctx *ctx, int dim, double maxdist, const dou
                               fphip_subsol_cb subcb, void *user, uint64_t *nodes_out,
                               fphip_enum_stats *stats)
 {
+  FPHIP_RANGE("fphip_enum_run");
   if (!ctx)
     return FPHIP_ERROR;
   if (!ctx->g)
@@ -706,6 +708,7 @@ restart:
   unsigned n_slots = 0;   // multi-GPU: length of the compact slot list of the regioned buffer
   if (use_bfs && C > 0)
   {
+    FPHIP_RANGE("enum: breadth-first stage");
     const int L0        = L;
     const unsigned rcap = ctx->cap / FPHIP_NQ;
     // a subtree counts as heavy above `heavy` estimated nodes: enough final tasks to balance the
@@ -934,6 +937,7 @@ restart:
         return fail(ctx, "too many launches");
       if (hi > lo)
       {
+        FPHIP_RANGE(in_final ? "enum: walk launch" : "enum: split launch");
         HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
         const unsigned bud = (in_final && round < max_rounds) ? budget : 0u;
 #define FPHIP_LAUNCH(M, S, D)                                                                       \

@@ -19,6 +19,7 @@
 #include "gso_device.h"
 #include "gso_sweep2.h"
 #include "dev_mem.h"
+#include "trace.h"
 #include "ftx.h"
 
 #ifndef FPHIP_GSO_RING
@@ -422,6 +423,7 @@ extern "C" int fphip_gso_get_basis(fphip_gso *g, int first, int count, int64_t *
 // (re)float every row from the integer basis: MatGSO::update_bf for all rows, gso.cpp:24-48
 extern "C" int fphip_gso_refresh(fphip_gso *g)
 {
+  FPHIP_RANGE("fphip_gso_refresh");
   if (!g)
     return FPHIP_ERROR;
   return launch(g, 0, g->P.d, 0.0, 2);
@@ -430,6 +432,7 @@ extern "C" int fphip_gso_refresh(fphip_gso *g)
 // MatGSOInterface::update_gso(), gso_interface.h:767-775, for every lattice of the batch
 extern "C" int fphip_gso_update(fphip_gso *g, int *status)
 {
+  FPHIP_RANGE("fphip_gso_update");
   if (!g)
     return FPHIP_ERROR;
   int rc = launch(g, 0, g->P.d, 0.0, 0);
@@ -442,6 +445,7 @@ extern "C" int fphip_gso_update(fphip_gso *g, int *status)
 extern "C" int fphip_gso_size_reduce(fphip_gso *g, int kappa_min, int kappa_end, double eta,
                                      int *status)
 {
+  FPHIP_RANGE("fphip_gso_size_reduce");
   if (!g)
     return FPHIP_ERROR;
   if (kappa_end < 0)
@@ -463,6 +467,7 @@ static int ensure_lll_buffers(fphip_gso *g);
 extern "C" int fphip_gso_lll(fphip_gso *g, int kappa_min, int kappa_start, int kappa_end,
                              double delta, double eta, int *status, int *info)
 {
+  FPHIP_RANGE("fphip_gso_lll");
   if (!g)
     return FPHIP_ERROR;
   if (kappa_end < 0)
@@ -605,10 +610,14 @@ static void accumulate_info(int *inf, const int *one, size_t L)
 // get_current_slope, gso_interface.cpp:198-218) needs the host's log(), the one the reference calls.
 // run_tour(loop, &ms, s1, one) launches exactly one tour for the lattices with active[L] != 0 and
 // leaves the identity-layout GSO (r_ii, row exponents) of the new bases on the device.
+// slope_test: BKZ_AUTO_ABORT (the slope test between the tours).  slide: BKZ_SLD_RED — a launch is one
+// slide_tour, and the tour's own progress test runs here: get_slide_potential (gso_interface.cpp:230-258:
+// sum over the blocks of (p - i) log det, the host's log) of the new basis against the previous one,
+// bkz.cpp:512-518 — "clean" (no progress) ends the loop with RED_SUCCESS like any clean tour.
 template <class RunTour>
 static int auto_abort_loop(fphip_gso *g, int block_size, bool use_loops, int max_loops, std::vector<int> &active,
                            std::vector<int> &st, std::vector<int> &inf, std::vector<int> &rows, float &total_ms,
-                           RunTour run_tour)
+                           RunTour run_tour, bool slope_test = true, bool slide = false)
 {
   const size_t B = (size_t)g->P.batch, d = (size_t)g->P.d;
   int rc = launch(g, 0, g->P.d, 0.0, 0);  // r_ii of the input bases
@@ -617,6 +626,7 @@ static int auto_abort_loop(fphip_gso *g, int block_size, bool use_loops, int max
   std::vector<double> rdg(B * d), old_slope(B, std::numeric_limits<double>::max());
   std::vector<long long> rex(B * d);
   std::vector<int> no_dec(B, -1), one(4 * B), s1(B);
+  std::vector<double> sld_potential(B, 0.0);
   bool rows_known = false;
   for (int loop = 0;; ++loop)
   {
@@ -643,6 +653,31 @@ static int auto_abort_loop(fphip_gso *g, int block_size, bool use_loops, int max
         active[L] = 0;
         continue;
       }
+      if (slide)
+      {
+        const int n = rows[L];
+        double potential = 0.0;
+        int p            = n / block_size;
+        if (n % block_size == 0)
+          --p;
+        for (int i = 0; i < p; ++i)
+        {
+          double log_det = 0.0;  // get_log_det(i bs, (i + 1) bs)
+          for (int k = i * block_size; k < std::min(n, (i + 1) * block_size); ++k)
+            log_det += std::log(std::ldexp(rdg[L * d + k], (int)(2 * rex[L * d + k])));
+          potential += (p - i) * log_det;
+        }
+        if (loop == 0)
+          sld_potential[L] = potential;  // bkz.cpp:567-571
+        else if (potential >= sld_potential[L] || block_size >= n)
+        {  // slide_tour returned clean (or one tour was all there is): the loop ends, RED_SUCCESS
+          st[L]     = 1;
+          active[L] = 0;
+          continue;
+        }
+        else
+          sld_potential[L] = potential;
+      }
       if (use_loops && loop >= max_loops)
       {
         st[L]     = 8;
@@ -650,6 +685,8 @@ static int auto_abort_loop(fphip_gso *g, int block_size, bool use_loops, int max
         continue;
       }
       const int n = rows[L];
+      if (slope_test)
+      {
       double v1 = 0, v2 = (double)(n + 1) * n * (n - 1) / 12.0, weight = (1.0 - n) / 2.0;
       for (int i = 0; i < n; ++i)
       {
@@ -668,6 +705,7 @@ static int auto_abort_loop(fphip_gso *g, int block_size, bool use_loops, int max
       {
         active[L] = 0;  // abort: status stays RED_SUCCESS
         continue;
+      }
       }
       ++n_active;
     }
@@ -696,6 +734,7 @@ static int auto_abort_loop(fphip_gso *g, int block_size, bool use_loops, int max
 extern "C" int fphip_gso_bkz(fphip_gso *g, int block_size, double delta, double eta, int flags,
                              int max_loops, int *status, int *info)
 {
+  FPHIP_RANGE("fphip_gso_bkz");
   if (!g)
     return FPHIP_ERROR;
   if (block_size > 64 || (flags & ~(0x4 | 0x20)))
@@ -1017,13 +1056,18 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
                                         const fphip_strategies *S, fphip_rand_fn rnd, void *rnd_user,
                                         int *status, int *info)
 {
+  FPHIP_RANGE("fphip_gso_bkz_strategies");
   if (!g)
     return FPHIP_ERROR;
   // one wavefront enumerates a block: sizes up to 64; BKZ_MAX_LOOPS, BKZ_BOUNDED_LLL, BKZ_AUTO_ABORT,
   // BKZ_GH_BND
   // BKZ_SD_VARIANT (0x100): self-dual BKZ, bkzs_body<NQ, true>
-  const bool sd = (flags & 0x100) != 0;
-  if (block_size > 64 || (flags & ~(0x4 | 0x10 | 0x20 | 0x80 | 0x100 | 0x1000)))
+  const bool sd  = (flags & 0x100) != 0;
+  const bool sld = (flags & 0x200) != 0;  // BKZ_SLD_RED: slide reduction (slide_tour, bkz.cpp:465-520)
+  if (block_size > 64 || (flags & ~(0x4 | 0x10 | 0x20 | 0x80 | 0x100 | 0x200 | 0x1000)) || (sd && sld))
+    return FPHIP_UNSUPPORTED;
+  // (a last block of one row — d = k bs + 1 — would be an svp_reduction of block size 1: not offered)
+  if (sld && block_size >= 2 && g->P.d % block_size == 1)
     return FPHIP_UNSUPPORTED;
   // FPHIP_BKZ_HANDOFF (0x1000, or FPHIP_BKZ_HANDOFF=1 in the environment): blocks whose tree is large
   // are enumerated by the multi-wave enumerator on a second context instead of by the lattice's wave
@@ -1197,7 +1241,7 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
     default: BCHK(hipFuncSetAttribute((const void *)bkzs_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); break;
     }
   }
-  if (sd && lds > 64 * 1024)
+  if ((sd || sld) && lds > 64 * 1024)
   {
     switch (nq)
     {
@@ -1230,7 +1274,7 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
       return FPHIP_ERROR;
     }
     const char *hn  = getenv("FPHIP_BKZ_HANDOFF_NODES");
-    H.handoff_nodes = hn ? atof(hn) : 2e5;
+    H.handoff_nodes = hn ? atof(hn) : 1e4;
   }
   unsigned long long handoff_calls = 0;
   int handoff_rc                   = FPHIP_OK;
@@ -1248,14 +1292,14 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
       return rc1;
     GCHK(hipMemsetAsync(d_abort, 0, sizeof(int), s));  // one launch's timeout must not poison the next
     GCHK(hipEventRecord(g->ev[0], s));
-    if (sd)
+    if (sd || sld)
     {
       switch (nq)
       {
-      case 1: hipLaunchKernelGGL(sdv::bkzd_kernel<1>, dim3(grid), dim3(wpb * 64), lds, s, g->P, DS, mail, d_abort, block_size, kflags | 0x100 | mu_lds_flag, delta, eta, logd, kloops, stack_doubles, run_mode); break;
-      case 2: hipLaunchKernelGGL(sdv::bkzd_kernel<2>, dim3(grid), dim3(wpb * 64), lds, s, g->P, DS, mail, d_abort, block_size, kflags | 0x100 | mu_lds_flag, delta, eta, logd, kloops, stack_doubles, run_mode); break;
-      case 3: hipLaunchKernelGGL(sdv::bkzd_kernel<3>, dim3(grid), dim3(wpb * 64), lds, s, g->P, DS, mail, d_abort, block_size, kflags | 0x100 | mu_lds_flag, delta, eta, logd, kloops, stack_doubles, run_mode); break;
-      default: hipLaunchKernelGGL(sdv::bkzd_kernel<4>, dim3(grid), dim3(wpb * 64), lds, s, g->P, DS, mail, d_abort, block_size, kflags | 0x100 | mu_lds_flag, delta, eta, logd, kloops, stack_doubles, run_mode); break;
+      case 1: hipLaunchKernelGGL(sdv::bkzd_kernel<1>, dim3(grid), dim3(wpb * 64), lds, s, g->P, DS, mail, d_abort, block_size, kflags | (sd ? 0x100 : 0) | mu_lds_flag, delta, eta, logd, kloops, stack_doubles, run_mode); break;
+      case 2: hipLaunchKernelGGL(sdv::bkzd_kernel<2>, dim3(grid), dim3(wpb * 64), lds, s, g->P, DS, mail, d_abort, block_size, kflags | (sd ? 0x100 : 0) | mu_lds_flag, delta, eta, logd, kloops, stack_doubles, run_mode); break;
+      case 3: hipLaunchKernelGGL(sdv::bkzd_kernel<3>, dim3(grid), dim3(wpb * 64), lds, s, g->P, DS, mail, d_abort, block_size, kflags | (sd ? 0x100 : 0) | mu_lds_flag, delta, eta, logd, kloops, stack_doubles, run_mode); break;
+      default: hipLaunchKernelGGL(sdv::bkzd_kernel<4>, dim3(grid), dim3(wpb * 64), lds, s, g->P, DS, mail, d_abort, block_size, kflags | (sd ? 0x100 : 0) | mu_lds_flag, delta, eta, logd, kloops, stack_doubles, run_mode); break;
       }
     }
     else
@@ -1372,7 +1416,39 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
   float total_ms = 0, ms = 0;
   const bool use_loops = (flags & 0x4) != 0, auto_abort = (flags & 0x20) != 0;
   const int kbase = flags & (0x10 | 0x80);
-  if (!auto_abort)
+  if (sld)
+  {
+    // slide reduction: one slide_tour per launch (the kernel's 0x200 frame), the potential test on the
+    // host in between; then the closing hkz of every block (run_mode 4)
+    std::vector<int> rows(B, (int)g->P.d);
+    rc = auto_abort_loop(g, block_size, use_loops, max_loops, active, st, inf, rows, total_ms,
+                         [&](int, float *tms, int *s1, int *one)
+                         { return run_once(kbase | 0x4 | 0x200, 1, tms, s1, one, 2); },
+                         auto_abort, true);
+    std::vector<int> one(4 * B), s1(B);
+    if (rc == FPHIP_OK)
+    {
+      for (size_t L = 0; L < B; ++L)
+        active[L] = (st[L] == 1 || st[L] == 8) ? 1 : 0;
+      BCHK(hipMemcpy(g->P.bkz_active, active.data(), sizeof(int) * B, hipMemcpyHostToDevice));
+      rc = run_once(kbase | 0x4 | 0x200, 1, &ms, s1.data(), one.data(), 4);
+      total_ms += ms;
+      for (size_t L = 0; L < B && rc == FPHIP_OK; ++L)
+      {
+        if (!active[L])
+          continue;
+        const unsigned long long a0 = ((unsigned long long)(unsigned)inf[4 * L + 2] << 32) | (unsigned)inf[4 * L + 1];
+        const unsigned long long a1 = ((unsigned long long)(unsigned)one[4 * L + 2] << 32) | (unsigned)one[4 * L + 1];
+        const unsigned long long t  = a0 + a1;
+        inf[4 * L + 1] = (int)(unsigned)(t & 0xffffffffull);
+        inf[4 * L + 2] = (int)(unsigned)(t >> 32);
+        inf[4 * L + 3] += one[4 * L + 3];
+        if (s1[L] <= 0)
+          st[L] = s1[L];
+      }
+    }
+  }
+  else if (!auto_abort)
   {
     rc       = run_once(kbase | (use_loops ? 0x4 : 0), max_loops, &ms, st.data(), inf.data());
     total_ms = ms;
@@ -1638,6 +1714,7 @@ extern "C" int fphip_hh_broadcast_basis(fphip_hh *h, int src)
 // refresh_R_bf() + update_R() for every lattice; status[batch] = 1
 extern "C" int fphip_hh_update_R(fphip_hh *h, int *status)
 {
+  FPHIP_RANGE("fphip_hh_update_R");
   if (!h)
     return FPHIP_ERROR;
   const int nq  = (h->P.n + 63) / 64;
@@ -1672,6 +1749,7 @@ extern "C" int fphip_hh_update_R(fphip_hh *h, int *status)
 // agree with the exact mode to ~1e-13 relative (checked to 1e-9), row exponents and signs identical.
 extern "C" int fphip_hh_update_R_blocked(fphip_hh *h, int *status)
 {
+  FPHIP_RANGE("fphip_hh_update_R_blocked");
   if (!h)
     return FPHIP_ERROR;
   const int nq   = (h->P.n + 63) / 64;
@@ -1722,6 +1800,7 @@ extern "C" int fphip_hh_get_basis(fphip_hh *h, int first, int count, int64_t *b)
 extern "C" int fphip_hh_hlll(fphip_hh *h, double delta, double eta, double theta, double c,
                              int *status, int *info)
 {
+  FPHIP_RANGE("fphip_hh_hlll");
   (void)eta;
   (void)c;
   if (!h)
@@ -1842,6 +1921,7 @@ static int hh_hlll_ex(fphip_hh *h, double delta, double theta, int precision, co
 extern "C" int fphip_hh_hlll_ex(fphip_hh *h, double delta, double eta, double theta, double c, int precision,
                                 int *status, int *info)
 {
+  FPHIP_RANGE("fphip_hh_hlll_ex");
   (void)eta;
   (void)c;
   return hh_hlll_ex(h, delta, theta, precision, nullptr, status, info);
@@ -1856,6 +1936,7 @@ extern "C" int fphip_hh_hlll_ex(fphip_hh *h, double delta, double eta, double th
 extern "C" int fphip_hh_hlll_ladder(fphip_hh *h, double delta, double eta, double theta, double c, int *status,
                                     int *info, int *stage)
 {
+  FPHIP_RANGE("fphip_hh_hlll_ladder");
   if (!h)
     return FPHIP_ERROR;
   const size_t B = (size_t)h->P.batch;

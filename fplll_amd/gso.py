@@ -134,7 +134,7 @@ class MatGSOBatch:
 
     def bkz_strategies(self, block_size, strategies, rnd, delta=LLL_DEF_DELTA, eta=LLL_DEF_ETA,
                        max_loops=0, gh_bnd=False, bounded_lll=False, gh_factor=1.1, auto_abort=False,
-                       sd=False, handoff=False):
+                       sd=False, handoff=False, slide=False):
         """BKZReduction::bkz() with a strategies table (preprocessing tours, pruning, GH bound,
         rerandomisation; bkz.cpp:43-124, 274-441, 522-668) on every (LLL-reduced) lattice.
         strategies: dict with the flattened arrays of include/fplll_hip.h's fphip_strategies
@@ -142,6 +142,7 @@ class MatGSOBatch:
         rnd(lattice, n) -> gmp_urandomm_ui of that lattice's generator (fplll: RandGen); a Python
         callable, the address (ctypes.c_void_p) of a C function with fphip_rand_fn's signature, or a
         tuple (address, user pointer).
+        sd / slide: BKZ_SD_VARIANT / BKZ_SLD_RED (self-dual BKZ / slide reduction).
         handoff: FPHIP_BKZ_HANDOFF — large blocks are enumerated by the multi-wave enumerator (another
         visiting order than the reference's: accept the result by the reducedness predicate, not by the
         reference's basis; include/fplll_hip.h).
@@ -186,7 +187,8 @@ class MatGSOBatch:
         st = np.zeros(self.batch, dtype=np.int32)
         info = np.zeros((self.batch, 4), dtype=np.int32)
         flags = ((0x4 if max_loops > 0 else 0) | (0x80 if gh_bnd else 0) | (0x10 if bounded_lll else 0) |
-                 (0x20 if auto_abort else 0) | (0x100 if sd else 0) | (0x1000 if handoff else 0))
+                 (0x20 if auto_abort else 0) | (0x100 if sd else 0) | (0x1000 if handoff else 0) |
+                 (0x200 if slide else 0))
         rc = fn(self.h, block_size, delta, eta, flags, max_loops, gh_factor, sp, cb, rnd_user,
                 st.ctypes.data_as(ctypes.c_void_p), info.ctypes.data_as(ctypes.c_void_p))
         if rc == _lib.FPHIP_UNSUPPORTED:

@@ -217,8 +217,14 @@ int fphip_gso_bkz(fphip_gso *g, int block_size, double delta, double eta, int fl
 #define FPHIP_BKZ_BOUNDED_LLL 0x10
 #define FPHIP_BKZ_GH_BND 0x80
 #define FPHIP_BKZ_SD_VARIANT 0x100
+/* FPHIP_BKZ_SLD_RED: slide reduction (fplll's BKZ_SLD_RED; slide_tour bkz.cpp:465-520, the closing hkz of
+ * every block :643-660): passes of disjoint primal blocks until one leaves them unchanged, then the dual
+ * blocks shifted by one row; the slide potential (gso_interface.cpp:244-258) is evaluated on the host
+ * between the tours (one tour per launch).  Not combined with FPHIP_BKZ_SD_VARIANT; declined when the last
+ * block would hold a single row (d = k block_size + 1). */
+#define FPHIP_BKZ_SLD_RED 0x200
 /* FPHIP_BKZ_HANDOFF (not a flag of fplll): blocks whose Gaussian-heuristic tree size exceeds
- * FPHIP_BKZ_HANDOFF_NODES (environment, default 2e5 estimated nodes) are enumerated by the multi-wave
+ * FPHIP_BKZ_HANDOFF_NODES (environment, default 1e4 estimated nodes) are enumerated by the multi-wave
  * enumerator (fphip_enum_run on a second context of the device, FastEvaluator(1) semantics) instead
  * of by the lattice's own wave: 10^9 nodes/s instead of 3·10^6.  That enumerator visits the tree in
  * another order than the reference, so with a shrinking pruned radius it may end on another vector:

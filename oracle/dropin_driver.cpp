@@ -135,7 +135,12 @@ int main(int argc, char **argv)
   else
     gso.reset(new MatGSO<ZT, FT>(bl, ul, ul_inv, GSO_ROW_EXPO));
 
-  LLLReduction<ZT, FT> lll_obj(*gso, LLL_DEF_DELTA, LLL_DEF_ETA, LLL_DEFAULT);
+  // lll basisfile hip|cpu [siegel|earlyred]: the LLL variants the device does not offer — the interposed
+  // lll() must hand them to the reference's own loop (no device call), on the same object
+  int lll_flags = LLL_DEFAULT;
+  if (!is_bkz && argc > 4)
+    lll_flags = strcmp(argv[4], "siegel") == 0 ? LLL_SIEGEL : (strcmp(argv[4], "earlyred") == 0 ? LLL_EARLY_RED : LLL_DEFAULT);
+  LLLReduction<ZT, FT> lll_obj(*gso, LLL_DEF_DELTA, LLL_DEF_ETA, lll_flags);
   int status = 0;
   long nodes = 0;
   auto t0    = std::chrono::steady_clock::now();

@@ -124,3 +124,20 @@ def test_reference_hlll_object_runs_on_the_device(name):
     assert j["log_abs_det_R"] == jc["log_abs_det_R"], (j["log_abs_det_R"], jc["log_abs_det_R"])
     print("%s through HLLLReduction on MatHouseholderHip: %d swaps, %.3f s (%.3f s on the device); host object %.3f s"
           % (name, j["n_swaps"], j["seconds"], j["device_seconds"], jc["seconds"]))
+
+
+@pytest.mark.parametrize("variant", ["siegel", "earlyred"])
+def test_unsupported_lll_variants_fall_back_to_the_reference_loop(variant):
+    """LLL_SIEGEL / LLL_EARLY_RED (lll.h:125-140, lll.cpp:40,116-122) are not offered by the device
+    kernels: on a MatGSOHip the interposed lll() must pass such a call to the reference's own loop —
+    no device call, the reference's result — instead of silently running plain LLL."""
+    f = C.load_lll_fixture(os.path.join(C.GOLDEN, "lll_q40.json"))
+    path = _write_basis(f["b_in"])
+    try:
+        j = _run(["lll", path, "hip", variant])
+        jc = _run(["lll", path, "cpu", variant])
+    finally:
+        os.unlink(path)
+    assert j["status"] == jc["status"] == 0
+    assert j["device_calls"] == 0
+    assert np.array_equal(j["b_out"], jc["b_out"]) and j["n_swaps"] == jc["n_swaps"]

@@ -94,7 +94,7 @@ def _worker_lib(rank, world, port, fixture, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name,world", [("enum_d48_lin30_fixed", 3), ("enum_d40_lin20_best1", 2),
+@pytest.mark.parametrize("name,world", [("enum_d48_lin30_fixed", 3), ("enum_d36_lin18_best1", 2),
                                         ("enum_d48_lin30_best1", 4)])
 def test_sharded_call_with_library_level_reductions(name, world):
     """enumerate_block_sharded = what bench.py --gpus N times: the sharded walk, then norm MIN -> the
@@ -122,5 +122,7 @@ def test_sharded_call_with_library_level_reductions(name, world):
     if "fixed" in name:
         assert gn == [int(v) for v in f["nodes"]], "summed per-level counts differ from the reference's"
         assert gd <= ref_best  # (the evaluator keeps every solution here: the shortest is among them)
+    elif ref_best == float("inf"):  # (the reference finds nothing inside this radius)
+        assert gd == ref_best and gc is None
     else:
         assert gd == ref_best and gc is not None and len(gc) == f["d"]
