@@ -12,7 +12,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 
-HIP_SOURCES = ["enum_kernel.hip", "enum_host.hip", "gso_kernel.hip", "gso_sweep2.hip", "lll_kernel.hip", "hlll_kernel.hip", "hh_blocked.hip", "hlll_x.hip", "bkz_kernel.hip", "bkzs_kernel.hip", "gso_host.hip"]
+HIP_SOURCES = ["enum_kernel.hip", "enum_host.hip", "gso_kernel.hip", "gso_sweep2.hip", "lll_kernel.hip", "hlll_kernel.hip", "hh_blocked.hip", "hlll_x.hip", "lll_x.hip", "bkz_kernel.hip", "bkzs_kernel.hip", "gso_host.hip"]
 HIP_HEADERS = ["dev_mem.h", "trace.h", "enum_device.h", "gso_device.h", "gso_wave.h", "gso_sweep2.h", "ftx.h", "lll_wave.h", os.path.join(ROOT, "include", "fplll_hip.h")]
 HIPCC_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17",
@@ -28,6 +28,13 @@ HIPCC_FLAGS = [
 PER_FILE_FLAGS = {
     "enum_kernel.hip": ["-mllvm", "-structurizecfg-skip-uniform-regions=1"],
     "bkzs_kernel.hip": ["-mllvm", "-structurizecfg-skip-uniform-regions=1"],
+    # the one-wavefront-per-lattice reduction kernels: their loops still hold lane-masked branches, so
+    # the option only spares the regions that are uniform already — measured +4 % on the batched LLL
+    # (100.5 -> 104.6 lattices/s at d = 120, batch 1024), outputs unchanged (parity tests)
+    "lll_kernel.hip": ["-mllvm", "-structurizecfg-skip-uniform-regions=1"],
+    "bkz_kernel.hip": ["-mllvm", "-structurizecfg-skip-uniform-regions=1"],
+    "hlll_kernel.hip": ["-mllvm", "-structurizecfg-skip-uniform-regions=1"],
+    "gso_kernel.hip": ["-mllvm", "-structurizecfg-skip-uniform-regions=1"],
 }
 
 

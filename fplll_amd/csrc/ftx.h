@@ -162,6 +162,8 @@ __device__ __forceinline__ double f_shfl_xor(double v, int m) { return __shfl_xo
 __device__ __forceinline__ DD f_shfl_xor(DD v, int m) { return DD{__shfl_xor(v.hi, m), __shfl_xor(v.lo, m)}; }
 __device__ __forceinline__ double f_bcast(double v, int lane) { return __shfl(v, lane); }
 __device__ __forceinline__ DD f_bcast(DD v, int lane) { return DD{__shfl(v.hi, lane), __shfl(v.lo, lane)}; }
+__device__ __forceinline__ double f_shfl_up(double v, int d) { return __shfl_up(v, d); }
+__device__ __forceinline__ DD f_shfl_up(DD v, int d) { return DD{__shfl_up(v.hi, d), __shfl_up(v.lo, d)}; }
 template <class FT> __device__ __forceinline__ FT f_wave_sum(FT v)
 {
 #pragma unroll

@@ -55,6 +55,21 @@ struct HlllX
   const int *only_failed;
 };
 template <int NQ, class FT> __global__ void hlll_x_kernel(HhBatch P, HlllX X);
+struct LllX
+{
+  int batch, d, n, ldn, ldd, row_expo;
+  long long *b, *b2;
+  double *bf;
+  double *mu_hi, *mu_lo;
+  double *r_hi, *r_lo;
+  double *gf_hi, *gf_lo;
+  long long *rexp;
+  int *status, *info;
+  const int *only_failed;
+  int kmin, kstart, kend;
+  double delta, eta;
+};
+template <int NQ, class FT> __global__ void lll_x_kernel(LllX A);
 __global__ void dd_op_kernel(const double *ahi, const double *alo, const double *bhi, const double *blo,
                              double *ohi, double *olo, int op, int count);
 template <int NQ>
@@ -83,6 +98,7 @@ struct fphip_gso
   int *flag16;  // [batch][d]
   int sweep_version;  // 2 (default) or 1 (FPHIP_GSO_SWEEP=1: the first-generation kernel)
   fphip_ctx *ectx;    // hand-off mode of the strategy-BKZ kernel: the enumeration context (same device)
+  double *xbuf;       // lll_x.hip workspace: bf rows [B][d][ldn], then the low planes of mu, r, gf [B][d][ldd] each
 };
 
 static int gfail(fphip_ctx *ctx, const char *what, hipError_t e)
@@ -208,6 +224,8 @@ extern "C" void fphip_gso_destroy(fphip_gso *g)
     return;
   if (g->ectx)
     fphip_destroy(g->ectx);
+  if (g->xbuf)
+    fphip_dev_free(g->xbuf, fphip_ctx_stream(g->ctx));
   hipStreamSynchronize(fphip_ctx_stream(g->ctx));
   fphip_dev_free(g->P.b, fphip_ctx_stream(g->ctx));
   fphip_dev_free(g->P.bfT, fphip_ctx_stream(g->ctx));
@@ -504,6 +522,163 @@ extern "C" int fphip_gso_lll(fphip_gso *g, int kappa_min, int kappa_start, int k
   if (status)
     memcpy(status, st.data(), sizeof(int) * B);
   return rc;
+}
+
+// LLLReduction::lll in a selectable floating-point type (lll_x.hip): precision 106 = double-double on
+// the device (the stand-in for FP_NR<dd_real>: Wrapper::lll's fast_lll<dd_real>, wrapper.cpp:322-330),
+// 53 = plain double with the same (per-lane) summation order.  Same statuses / info as fphip_gso_lll.
+static int gso_lll_ex(fphip_gso *g, int kappa_min, int kappa_start, int kappa_end, double delta, double eta,
+                      int precision, const int *d_only_failed, int *status, int *info)
+{
+  if (!g || (precision != 53 && precision != 106))
+    return FPHIP_ERROR;
+  if (kappa_end < 0)
+    kappa_end = g->P.d;
+  if (kappa_min < 0 || kappa_min > kappa_start || kappa_start >= kappa_end || kappa_end > g->P.d || g->P.d > 256)
+  {
+    snprintf(fphip_ctx_errbuf(g->ctx), 512, "fphip_gso_lll_ex: need 0 <= kappa_min <= kappa_start < kappa_end <= d <= 256");
+    return FPHIP_ERROR;
+  }
+  int rc = ensure_lll_buffers(g);
+  if (rc != FPHIP_OK)
+    return rc;
+  const size_t B = (size_t)g->P.batch, d = g->P.d, ldd = g->P.ldd, ldn = g->P.ldn;
+  hipStream_t s = fphip_ctx_stream(g->ctx);
+  const size_t n_bf = B * d * ldn, n_pl = B * d * ldd;
+  if (!g->xbuf)
+    GCHK(fphip_dev_alloc((void **)&g->xbuf, (n_bf + 3 * n_pl) * sizeof(double) + 4096, s));
+  GCHK(hipMemsetAsync(g->xbuf, 0, (n_bf + 3 * n_pl) * sizeof(double), s));
+  LllX A;
+  A.batch    = g->P.batch;
+  A.d        = g->P.d;
+  A.n        = g->P.n;
+  A.ldn      = g->P.ldn;
+  A.ldd      = g->P.ldd;
+  A.row_expo = g->P.row_expo;
+  A.b        = g->P.b;
+  A.b2       = g->P.b2;
+  A.bf       = g->xbuf;
+  A.mu_hi    = g->P.mu;
+  A.mu_lo    = precision == 106 ? g->xbuf + n_bf : nullptr;
+  A.r_hi     = g->P.r;
+  A.r_lo     = precision == 106 ? g->xbuf + n_bf + n_pl : nullptr;
+  A.gf_hi    = g->P.gf;
+  A.gf_lo    = precision == 106 ? g->xbuf + n_bf + 2 * n_pl : nullptr;
+  A.rexp     = g->P.rexp;
+  A.status   = g->P.status;
+  A.info     = g->P.lll_info;
+  A.only_failed = d_only_failed;
+  A.kmin     = kappa_min;
+  A.kstart   = kappa_start;
+  A.kend     = kappa_end;
+  A.delta    = delta;
+  A.eta      = eta;
+  if (d_only_failed)  // the lattices that are skipped keep their rows: b2 := b first
+    GCHK(hipMemcpyAsync(g->P.b2, g->P.b, B * d * ldn * sizeof(long long), hipMemcpyDeviceToDevice, s));
+  const int need = (g->P.d > g->P.n ? g->P.d : g->P.n);
+  const int nq   = (need + 63) / 64;
+  int grid       = g->P.batch;
+  if (grid > fphip_ctx_num_cus(g->ctx) * 8)
+    grid = fphip_ctx_num_cus(g->ctx) * 8;
+  GCHK(hipEventRecord(g->ev[0], s));
+  if (precision == 106)
+    switch (nq)
+    {
+    case 1: hipLaunchKernelGGL((lll_x_kernel<1, DD>), dim3(grid), dim3(64), 0, s, A); break;
+    case 2: hipLaunchKernelGGL((lll_x_kernel<2, DD>), dim3(grid), dim3(64), 0, s, A); break;
+    case 3: hipLaunchKernelGGL((lll_x_kernel<3, DD>), dim3(grid), dim3(64), 0, s, A); break;
+    default: hipLaunchKernelGGL((lll_x_kernel<4, DD>), dim3(grid), dim3(64), 0, s, A); break;
+    }
+  else
+    switch (nq)
+    {
+    case 1: hipLaunchKernelGGL((lll_x_kernel<1, double>), dim3(grid), dim3(64), 0, s, A); break;
+    case 2: hipLaunchKernelGGL((lll_x_kernel<2, double>), dim3(grid), dim3(64), 0, s, A); break;
+    case 3: hipLaunchKernelGGL((lll_x_kernel<3, double>), dim3(grid), dim3(64), 0, s, A); break;
+    default: hipLaunchKernelGGL((lll_x_kernel<4, double>), dim3(grid), dim3(64), 0, s, A); break;
+    }
+  GCHK(hipGetLastError());
+  GCHK(hipEventRecord(g->ev[1], s));
+  GCHK(hipStreamSynchronize(s));
+  float ms = 0;
+  GCHK(hipEventElapsedTime(&ms, g->ev[0], g->ev[1]));
+  std::swap(g->P.b, g->P.b2);  // the kernel wrote the rows in position order into b2
+  if (status)
+    GCHK(hipMemcpy(status, g->P.status, sizeof(int) * B, hipMemcpyDeviceToHost));
+  if (info)
+    GCHK(hipMemcpy(info, g->P.lll_info, sizeof(int) * 4 * B, hipMemcpyDeviceToHost));
+  // identity-layout double GSO of the new bases for the getters (its values are functions of b; on a
+  // lattice that needs more than 53 bits they are as good as doubles get)
+  rc = launch(g, 0, g->P.d, 0.0, 2);
+  if (rc == FPHIP_OK)
+    rc = launch(g, 0, g->P.d, 0.0, 0);
+  g->last_ms = ms;
+  return rc;
+}
+
+extern "C" int fphip_gso_lll_ex(fphip_gso *g, int kappa_min, int kappa_start, int kappa_end, double delta,
+                                double eta, int precision, int *status, int *info)
+{
+  FPHIP_RANGE("fphip_gso_lll_ex");
+  return gso_lll_ex(g, kappa_min, kappa_start, kappa_end, delta, eta, precision, nullptr, status, info);
+}
+
+// The LLL-side precision ladder of the reference's wrapper (Wrapper::lll, wrapper.cpp:281-359:
+// fast_lll<double>, then the wider types, each on the basis the failed attempt left) with both
+// stages on the device: the exact-order double kernel (lll_kernel.hip) for the whole batch, then
+// double-double (lll_x.hip) for the lattices that stopped with RED_GSO_FAILURE (0), RED_BABAI_FAILURE
+// (-1) or RED_LLL_FAILURE (-3).  stage[batch] (nullable): 53 or 106.  A lattice that fails at 106 bits
+// keeps its status: the caller's MPFR stage (fplll's CPU path) is next.
+extern "C" int fphip_gso_lll_ladder(fphip_gso *g, int kappa_min, int kappa_start, int kappa_end, double delta,
+                                    double eta, int *status, int *info, int *stage)
+{
+  FPHIP_RANGE("fphip_gso_lll_ladder");
+  if (!g)
+    return FPHIP_ERROR;
+  const size_t B = (size_t)g->P.batch;
+  std::vector<int> st(B, 0), inf(4 * B, 0), stg(B, 53);
+  int rc = fphip_gso_lll(g, kappa_min, kappa_start, kappa_end, delta, eta, st.data(), inf.data());
+  if (rc != FPHIP_OK)
+    return rc;
+  float ms = g->last_ms;
+  bool any = false;
+  std::vector<int> mask(B);
+  for (size_t L = 0; L < B; ++L)
+  {
+    const bool failed = (st[L] == 0 || st[L] == -1 || st[L] == -3);
+    mask[L]           = failed ? 0 : 1;
+    any |= failed;
+  }
+  if (any)
+  {
+    std::vector<int> st2(B, 0), inf2(4 * B, 0);
+    int *d_mask = nullptr;
+    GCHK(fphip_dev_alloc((void **)&d_mask, B * sizeof(int), fphip_ctx_stream(g->ctx)));
+    hipError_t e = hipMemcpy(d_mask, mask.data(), B * sizeof(int), hipMemcpyHostToDevice);
+    // (the wider stage restarts the loop from the top of the range, like a fresh fast_lll<dd_real>)
+    rc = (e == hipSuccess) ? gso_lll_ex(g, kappa_min, kappa_min, kappa_end, delta, eta, 106, d_mask, st2.data(), inf2.data())
+                           : FPHIP_ERROR;
+    fphip_dev_free(d_mask, fphip_ctx_stream(g->ctx));
+    if (rc != FPHIP_OK)
+      return rc;
+    ms += g->last_ms;
+    for (size_t L = 0; L < B; ++L)
+      if (!mask[L])
+      {
+        st[L]  = st2[L];
+        stg[L] = 106;
+        for (int t = 0; t < 4; ++t)
+          inf[4 * L + t] = (t == 0 || t == 2) ? inf2[4 * L + t] : inf[4 * L + t] + inf2[4 * L + t];
+      }
+  }
+  g->last_ms = ms;
+  if (status)
+    memcpy(status, st.data(), B * sizeof(int));
+  if (info)
+    memcpy(info, inf.data(), 4 * B * sizeof(int));
+  if (stage)
+    memcpy(stage, stg.data(), B * sizeof(int));
+  return FPHIP_OK;
 }
 
 static int ensure_lll_buffers(fphip_gso *g)

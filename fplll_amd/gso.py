@@ -117,6 +117,35 @@ class MatGSOBatch:
                                          info.ctypes.data_as(ctypes.c_void_p)), "lll")
         return st, info
 
+    def lll_ex(self, precision=106, kappa_min=0, kappa_start=0, kappa_end=-1, delta=LLL_DEF_DELTA,
+               eta=LLL_DEF_ETA):
+        """LLLReduction::lll in double-double (precision 106) or plain double (53) — lll_x.hip; the
+        second stage of the LLL-side precision ladder.  Returns (status[batch], info[batch][4])."""
+        st = np.zeros(self.batch, dtype=np.int32)
+        info = np.zeros((self.batch, 4), dtype=np.int32)
+        fn = self.lib.fphip_gso_lll_ex
+        fn.restype = ctypes.c_int
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double,
+                       ctypes.c_double, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        self._chk(fn(self.h, kappa_min, kappa_start, kappa_end, delta, eta, precision,
+                     st.ctypes.data_as(ctypes.c_void_p), info.ctypes.data_as(ctypes.c_void_p)), "lll_ex")
+        return st, info
+
+    def lll_ladder(self, kappa_min=0, kappa_start=0, kappa_end=-1, delta=LLL_DEF_DELTA, eta=LLL_DEF_ETA):
+        """Wrapper::lll's precision ladder on the device (wrapper.cpp:281-359): the exact double kernel,
+        then double-double for the lattices that fail in double.  Returns (status, info, stage)."""
+        st = np.zeros(self.batch, dtype=np.int32)
+        info = np.zeros((self.batch, 4), dtype=np.int32)
+        stage = np.zeros(self.batch, dtype=np.int32)
+        fn = self.lib.fphip_gso_lll_ladder
+        fn.restype = ctypes.c_int
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double,
+                       ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        self._chk(fn(self.h, kappa_min, kappa_start, kappa_end, delta, eta,
+                     st.ctypes.data_as(ctypes.c_void_p), info.ctypes.data_as(ctypes.c_void_p),
+                     stage.ctypes.data_as(ctypes.c_void_p)), "lll_ladder")
+        return st, info, stage
+
     def bkz(self, block_size, delta=LLL_DEF_DELTA, eta=LLL_DEF_ETA, max_loops=0, auto_abort=False):
         """BKZReduction::bkz() with empty strategies on every (LLL-reduced) lattice
         (bkz.cpp:522-668).  Returns (status[batch], info[batch][4] = tours, nodes lo, nodes hi,

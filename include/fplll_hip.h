@@ -247,6 +247,24 @@ typedef unsigned long (*fphip_rand_fn)(void *user, int lattice, unsigned long n)
 int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double delta, double eta, int flags,
                              int max_loops, double gh_factor, const fphip_strategies *strategies,
                              fphip_rand_fn rnd, void *rnd_user, int *status, int *info);
+/* LLLReduction::lll in a selectable floating-point type (lll_x.hip): precision 106 = double-double
+ * arithmetic on the device (the stand-in for FP_NR<dd_real>: what Wrapper::lll's fast_lll<dd_real>
+ * runs, wrapper.cpp:322-330; libqd's algorithms restated, csrc/ftx.h), 53 = plain double.  Same
+ * algorithm (lll.cpp:44-224), statuses and info as fphip_gso_lll; sums are accumulated per lane, not in
+ * the reference's order, so results are the reference's up to rounding (at 106 bits the decisions carry
+ * ~50 bits of slack).  d <= 256. */
+int fphip_gso_lll_ex(fphip_gso *g, int kappa_min, int kappa_start, int kappa_end, double delta, double eta,
+                     int precision, int *status, int *info);
+/* The LLL-side precision ladder of the reference's wrapper (Wrapper::lll, wrapper.cpp:281-359: double
+ * first, then the wider types, each on the basis the failed attempt left) with both stages on the
+ * device: the exact-order double kernel for the whole batch, then double-double for the lattices that
+ * stopped with RED_GSO_FAILURE (0), RED_BABAI_FAILURE (-1) or RED_LLL_FAILURE (-3) — BASELINE config
+ * 5's 256-dim NTRU-like lattice is such a case ("infinite loop in babai" in double, in the reference
+ * and here).  stage[batch] (nullable): 53 or 106.  A lattice that fails at 106 bits too keeps its
+ * status — the caller's MPFR stage is next. */
+int fphip_gso_lll_ladder(fphip_gso *g, int kappa_min, int kappa_start, int kappa_end, double delta, double eta,
+                         int *status, int *info, int *stage);
+
 /* raw stored values, d×d row-major; true values carry the row exponents exactly as
  * get_mu/get_r do (gso_interface.h:694-732): mu·2^(e_i-e_j), r·2^(e_i+e_j) */
 int fphip_gso_get_mu(fphip_gso *g, int lattice, double *mu);

@@ -1012,14 +1012,10 @@ static int cmd_basisstat(int argc, char **argv)
   ZZ_mat<mpz_t> A;
   if (!read_basis(argv[2], A))
     return 2;
-  ZZ_mat<mpz_t> U, UT;
-  MatGSO<ZT, FT> M(A, U, UT, GSO_ROW_EXPO);
-  M.update_gso();
-  FT r0;
-  M.get_r(r0, 0, 0);
-  double slope = M.get_current_slope(0, A.get_rows());
+  // everything at 256 bits: a lattice whose GSO is beyond plain doubles (BASELINE config 5's) must not
+  // turn the figures into NaN
   int lll_red;
-  double logvol = 0.0;
+  double logvol = 0.0, r00 = 0.0, slope = 0.0;
   int old_prec  = FP_NR<mpfr_t>::set_prec(256);
   {
     ZZ_mat<mpz_t> U2, UT2;
@@ -1029,13 +1025,16 @@ static int cmd_basisstat(int argc, char **argv)
     for (int i = 0; i < A.get_rows(); ++i)
     {
       M2.get_r(f, i, i);
+      if (i == 0)
+        r00 = f.get_d();
       f.log(f);
       logvol += f.get_d();
     }
+    slope = M2.get_current_slope(0, A.get_rows());
   }
   FP_NR<mpfr_t>::set_prec(old_prec);
   printf("{\"d\":%d,\"r00\":%.17g,\"slope\":%.9f,\"is_lll_reduced\":%d,\"log_volume\":%.12g}\n",
-         A.get_rows(), r0.get_d(), slope, lll_red, logvol);
+         A.get_rows(), r00, slope, lll_red, logvol);
   return 0;
 }
 

@@ -141,7 +141,7 @@ def start_long_runs():
     import threading
     if "thread_c3" in C.LONG_RUNS:
         return
-    for name, fn in (("c3", _run_config3_tour), ("c5", _run_config5_hlll), ("c3h", _run_config3_tour_handoff)):
+    for name, fn in (("c3", _run_config3_tour), ("c5", _run_config5_hlll)):
         th = threading.Thread(target=fn, args=(C.LONG_RUNS,), name="long-" + name, daemon=True)
         th.start()
         C.LONG_RUNS["thread_" + name] = th
@@ -154,7 +154,7 @@ def test_00_start_the_config3_tour_and_the_config5_hlll(ctx):
     another xdist worker: the comparison is never skipped)."""
     start_long_runs()
     assert all(C.LONG_RUNS["thread_" + n].is_alive() or n in C.LONG_RUNS or n + "_error" in C.LONG_RUNS
-               for n in ("c3", "c5", "c3h"))
+               for n in ("c3", "c5"))
 
 
 # ---------------------------------------------------------------------------------------------

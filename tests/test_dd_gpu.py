@@ -12,6 +12,7 @@ import ctypes
 import gzip
 import json
 import os
+import time
 
 import numpy as np
 import pytest
@@ -222,3 +223,100 @@ def test_precision_ladder_double_then_double_double(ctx, monkeypatch):
     assert list(st) == [1] * 4 and list(stage) == [53, 106, 53, 106]
     assert all(np.array_equal(b, f["b_out"]) for b in h.get_basis(0, 4))
     h.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# LLL in double-double (lll_x.hip, fphip_gso_lll_ex) — the second stage of the LLL-side precision
+# ladder (Wrapper::lll, wrapper.cpp:281-359)
+# ---------------------------------------------------------------------------------------------
+def _basisstat(b):
+    """ref_driver basisstat: the reference's is_lll_reduced (lll.cpp:226-257) at 256 bits, volume, slope."""
+    import subprocess
+    import tempfile
+    drv = os.path.join(C.ROOT, "oracle", "_ref", "ref_driver")
+    assert os.path.exists(drv), "oracle/_ref/ref_driver is not built"
+    with tempfile.NamedTemporaryFile("w", suffix=".txt", delete=False) as t:
+        t.write("[" + "\n".join("[" + " ".join(str(int(x)) for x in row) + "]" for row in b) + "]\n")
+    try:
+        r = subprocess.run([drv, "basisstat", t.name], capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-300:]
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    finally:
+        os.unlink(t.name)
+
+
+@pytest.mark.parametrize("name", ["lll_q40", "lll_q72", "lll_u24", "lll_r30", "lll_q40_zero2", "lll_q40_dup2"])
+def test_lll_in_double_double_and_plain_double_tree_order(ctx, name):
+    """fphip_gso_lll_ex at 106 and 53 bits on the LLL fixtures (q-ary, uniform, integer relation, with
+    zero and duplicated rows): RED_SUCCESS, the output is LLL-reduced by the REFERENCE's predicate
+    (is_lll_reduced, delta 0.99 / eta 0.51, evaluated at 256 bits) and spans the input's lattice; on
+    these well-conditioned inputs the double-double run also returns the reference's own basis."""
+    from fplll_amd.gso import MatGSOBatch
+    f = C.load_lll_fixture(os.path.join(C.GOLDEN, name + ".json"))
+    g = MatGSOBatch(ctx, 2, f["d"], f["n"])
+    for prec in (106, 53):
+        g.set_basis(np.stack([f["b_in"]] * 2))
+        st, info = g.lll_ex(prec, f["kmin"], f["kstart"], f["kend"], f["delta"], f["eta"])
+        out = g.get_basis(0, 2)
+        assert list(st) == [1, 1], (prec, st, info)
+        assert np.array_equal(out[0], out[1])
+        nz = out[0][np.any(out[0] != 0, axis=1)]
+        if f["kmin"] == 0 and f["kend"] in (-1, f["d"]):
+            s = _basisstat(nz)
+            assert s["is_lll_reduced"] == 1, (name, prec, s)
+            ref = _basisstat(f["b_out"][np.any(f["b_out"] != 0, axis=1)])
+            assert abs(s["log_volume"] - ref["log_volume"]) < 1e-9 * max(1.0, abs(ref["log_volume"]))
+        same = np.array_equal(out[0], f["b_out"])
+        print("%s at %d bits: %d swaps (reference %d), %.1f ms, basis %s the reference's"
+              % (name, prec, int(info[0][1]), f["n_swaps"], g.last_kernel_ms, "==" if same else "!="))
+        if prec == 106 and name in ("lll_q40", "lll_q72", "lll_u24"):
+            assert same and int(info[0][1]) == f["n_swaps"]
+    g.close()
+
+
+def _rows_in_qary_lattice(b_in, b_out):
+    """b_in = [[I, H], [0, q I]] (q-ary / NTRU-like generator): every row (x, y) of b_out lies in its
+    lattice iff y = x H (mod q).  With equal volumes (basisstat) that is lattice equality."""
+    d = b_in.shape[0]
+    k = d // 2
+    assert np.array_equal(b_in[:k, :k], np.eye(k, dtype=np.int64)) and not b_in[k:, :k].any()
+    q = int(b_in[k, k])
+    assert np.array_equal(b_in[k:, k:], q * np.eye(d - k, dtype=np.int64))
+    H = b_in[:k, k:].astype(object)
+    x, y = b_out[:, :k].astype(object), b_out[:, k:].astype(object)
+    return bool(np.all((y - x.dot(H)) % q == 0))
+
+
+def test_config5_lattice_lll_ladder_escalates_to_double_double(ctx):
+    """A GENUINE escalation of the LLL-side precision ladder (Wrapper::lll, wrapper.cpp:281-359), on
+    BASELINE config 5's own lattice (`latticegen n 128 12 b`, 256-dim NTRU-like): LLLReduction in double
+    stops with RED_BABAI_FAILURE on it — the reference (`fplll -a lll -m fast -f double`: "infinite loop
+    in babai") and the exact-order device kernel alike — and fphip_gso_lll_ladder carries on in
+    double-double on the device (lll_x.hip) to RED_SUCCESS.  The reference has no dd_real here and its
+    long double / 106-bit MPFR runs return DIFFERENT reduced bases of this lattice (exact ties), so the
+    output is judged by the reference's own predicate: is_lll_reduced (delta 0.99, eta 0.51, at 256
+    bits), plus lattice equality (every row in the input's lattice, same volume)."""
+    from fplll_amd.gso import MatGSOBatch
+    f = C.load_hlll_fixture(os.path.join(C.GOLDEN, "c5_hlll_n256_double.json.gz"))
+    b = f["b_in"]
+    assert b.shape == (256, 256)
+    g = MatGSOBatch(ctx, 1, 256, 256)
+    g.set_basis(np.stack([b]))
+    t = time.time()
+    st, _ = g.lll()
+    t_double = time.time() - t
+    assert int(st[0]) == -1, "double LLL is expected to fail with RED_BABAI_FAILURE on this lattice (%r)" % (st,)
+    g.set_basis(np.stack([b]))
+    t = time.time()
+    st, info, stage = g.lll_ladder()
+    t_ladder = time.time() - t
+    out = g.get_basis(0, 1)[0]
+    g.close()
+    assert int(st[0]) == 1 and int(stage[0]) == 106, (st, stage, info)
+    s_out, s_in = _basisstat(out), _basisstat(b)
+    print("config 5 LLL: double stops with RED_BABAI_FAILURE after %.1f s; ladder (double -> double-double) %.1f s, "
+          "%d swaps in all; is_lll_reduced %d, slope %.6f (input %.6f)"
+          % (t_double, t_ladder, int(info[0][1]), s_out["is_lll_reduced"], s_out["slope"], s_in["slope"]))
+    assert s_out["is_lll_reduced"] == 1 and s_in["is_lll_reduced"] == 0
+    assert abs(s_out["log_volume"] - s_in["log_volume"]) < 1e-9 * abs(s_in["log_volume"])
+    assert _rows_in_qary_lattice(b, out)

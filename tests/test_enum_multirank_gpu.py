@@ -126,3 +126,28 @@ def test_sharded_call_with_library_level_reductions(name, world):
         assert gd == ref_best and gc is None
     else:
         assert gd == ref_best and gc is not None and len(gc) == f["d"]
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_bench_py_multi_rank_protocol_on_one_device(world):
+    """bench.py exactly as the driver launches it for N GPUs (torch.distributed.run, one rank per
+    process) — with the collectives on gloo and every rank on the ONE GPU of this box
+    (FPHIP_BENCH_BACKEND=gloo, FPHIP_BENCH_ONE_DEVICE=1): the sharded call, the bound exchange, the
+    library-level reductions and the max-over-ranks timing.  Every timed step must end on the
+    reference's final norm, like the N = 1 line; nodes are the whole job's."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, FPHIP_BENCH_BACKEND="gloo", FPHIP_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(C.ROOT, "bench.py"), "--gpus", str(world), "--steps", "3", "--warmup", "1",
+           "--no-cpu", "--no-gso", "--no-tour", "--no-pmc"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=C.ROOT)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "rank 0 prints ONE json line"
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == world and j["steps"] == 3 and j["scaling"] == "strong"
+    assert j["parity"]["final_norm_equal_to_reference"] == 3, j["parity"]
+    assert j["nodes"] > 3 * 10**9 and j["value"] > 0

@@ -41,12 +41,12 @@ def test_config3_bkz60_tour_with_handoff_meets_the_reducedness_predicate():
     """config 3's tour on the device in hand-off mode (large blocks on the multi-wave enumerator): the
     output is judged by the reference's own predicates — LLL-reduced (is_lll_reduced at 256 bits), same
     lattice volume, first vector not longer and slope of log r_ii not worse (within 1 %) than the
-    reference tour's output — and it must be at least twice as fast as the wave-only tour."""
-    if "thread_c3h" not in C.LONG_RUNS:
-        import test_a_configs_at_size_gpu as A
-        A.start_long_runs()
-    C.LONG_RUNS["thread_c3h"].join(1100)
-    assert not C.LONG_RUNS["thread_c3h"].is_alive(), "the hand-off run did not finish"
+    reference tour's output — in less than 300 s (the wave-only tour: 620 s)."""
+    # (run here, after the two background runs have been joined by the test above: its worker thread
+    # makes HIP calls, and beside two other busy contexts of the same process they stall — 675 s instead
+    # of 80-110 s when it shared the device with them)
+    import test_a_configs_at_size_gpu as A
+    A._run_config3_tour_handoff(C.LONG_RUNS)
     assert "c3h_error" not in C.LONG_RUNS, C.LONG_RUNS.get("c3h_error")
     h = C.LONG_RUNS["c3h"]
     s, r, i = h["stat"], h["ref_stat"], h["in_stat"]
@@ -60,4 +60,4 @@ def test_config3_bkz60_tour_with_handoff_meets_the_reducedness_predicate():
     assert s["slope"] >= r["slope"] * 1.01          # slopes are negative: not steeper by more than 1 %
     assert s["slope"] > i["slope"]                  # the tour improved the basis
     assert s["r00"] <= i["r00"]
-    assert h["wall"] < 450
+    assert h["wall"] < 300
