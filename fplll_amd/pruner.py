@@ -1,0 +1,79 @@
+"""ctypes mirror of the pruner's C ABI (include/fplll_hip.h: fphip_pruner_*): the reference's names
+(prune, svp_probability, Pruner.single_enum_cost / measure_metric; fplll/pruner/pruner.h).  Host code, no
+device involved; contains no arithmetic."""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+PRUNER_METRIC_PROBABILITY_OF_SHORTEST = 0
+PRUNER_METRIC_EXPECTED_SOLUTIONS = 1
+PRUNER_CVP, PRUNER_START_FROM_INPUT, PRUNER_GRADIENT, PRUNER_HALF, PRUNER_SINGLE = 0x1, 0x2, 0x4, 0x20, 0x40
+
+
+class PruningParams:
+    """fplll's PruningParams (pruner.h:36-58): gh_factor, coefficients, expectation, metric, detailed_cost."""
+
+    def __init__(self, gh_factor, coefficients, expectation, metric, detailed_cost):
+        self.gh_factor, self.coefficients, self.expectation = gh_factor, coefficients, expectation
+        self.metric, self.detailed_cost = metric, detailed_cost
+
+
+def _dp(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def prune(enumeration_radius, preproc_cost, gso_r, target=0.9, metric=PRUNER_METRIC_PROBABILITY_OF_SHORTEST,
+          flags=PRUNER_GRADIENT, start=None):
+    """prune<FP_NR<double>>(pruning, radius, preproc_cost, gso_r, target, metric, flags)."""
+    lib = _lib.load()
+    r = np.ascontiguousarray(gso_r, dtype=np.float64)
+    n = r.size
+    co = np.zeros(n, dtype=np.float64)
+    if start is not None:
+        co[:] = np.asarray(start, dtype=np.float64)
+    dc = np.zeros(n, dtype=np.float64)
+    ex, gh = ctypes.c_double(0), ctypes.c_double(0)
+    fn = lib.fphip_pruner_prune
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_int,
+                   ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
+                   ctypes.c_void_p]
+    rc = fn(n, _dp(r), float(enumeration_radius), float(preproc_cost), float(target), int(metric), int(flags),
+            _dp(co), ctypes.byref(ex), ctypes.byref(gh), _dp(dc))
+    if rc == _lib.FPHIP_UNSUPPORTED:
+        raise NotImplementedError("PRUNER_NELDER_MEAD / PRUNER_VERBOSE are not offered")
+    if rc != _lib.FPHIP_OK:
+        raise RuntimeError("prune failed (the reference throws here: NaN / inf in a cost value, or a bad target)")
+    return PruningParams(gh.value, co, ex.value, metric, dc)
+
+
+def svp_probability(pr):
+    """svp_probability<FP_NR<double>>(pr)."""
+    lib = _lib.load()
+    p = np.ascontiguousarray(pr, dtype=np.float64)
+    out = ctypes.c_double(0)
+    fn = lib.fphip_pruner_svp_probability
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)]
+    if fn(p.size, _dp(p), ctypes.byref(out)) != _lib.FPHIP_OK:
+        raise RuntimeError("svp_probability failed")
+    return out.value
+
+
+def enum_cost(enumeration_radius, gso_r, pr, metric=PRUNER_METRIC_PROBABILITY_OF_SHORTEST):
+    """(Pruner.single_enum_cost(pr), Pruner.measure_metric(pr), detailed_cost) for the block gso_r."""
+    lib = _lib.load()
+    r = np.ascontiguousarray(gso_r, dtype=np.float64)
+    p = np.ascontiguousarray(pr, dtype=np.float64)
+    dc = np.zeros(r.size, dtype=np.float64)
+    c, m = ctypes.c_double(0), ctypes.c_double(0)
+    fn = lib.fphip_pruner_enum_cost
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_double, ctypes.c_void_p, ctypes.c_int,
+                   ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.c_void_p]
+    if fn(r.size, _dp(r), float(enumeration_radius), _dp(p), int(metric), ctypes.byref(c), ctypes.byref(m),
+          _dp(dc)) != _lib.FPHIP_OK:
+        raise RuntimeError("enum_cost failed")
+    return c.value, m.value, dc

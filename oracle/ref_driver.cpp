@@ -1002,6 +1002,71 @@ static int cmd_bkztour(int argc, char **argv)
   return (status == RED_SUCCESS || status == RED_BKZ_LOOPS_LIMIT) ? 0 : 1;
 }
 
+/* prunefix basisfile first d gh_factor preproc_cost target metric flags
+ *   → JSON: the reference's prune<FP_NR<double>> (pruner/pruner.cpp:190-203) on the r-profile of block
+ *   [first, first + d) of the basis, radius = gh_factor x Gaussian heuristic of the block (the way the
+ *   survey built its strategies); plus svp_probability<FP_NR<double>> and Pruner::single_enum_cost /
+ *   measure_metric of the result AND of LinearPruningParams(d, d/2) through the public API.  Doubles in
+ *   hex: the pruner of the product (fplll_amd/csrc/pruner_host.hip) is compared bit for bit. */
+static void put_hex(const char *name, const vector<double> &v, bool last = false)
+{
+  printf("\"%s\":[", name);
+  for (size_t i = 0; i < v.size(); ++i)
+    printf("%s\"%a\"", i ? "," : "", v[i]);
+  printf("]%s", last ? "" : ",");
+}
+static int cmd_prunefix(int argc, char **argv)
+{
+  if (argc < 10)
+  {
+    fprintf(stderr, "usage: prunefix basisfile first d gh_factor preproc_cost target metric flags\n");
+    return 2;
+  }
+  ZZ_mat<mpz_t> A, U, UT;
+  if (!read_basis(argv[2], A))
+    return 2;
+  const int first = atoi(argv[3]), d = atoi(argv[4]);
+  const double ghf = atof(argv[5]), preproc = atof(argv[6]), target = atof(argv[7]);
+  const int metric = atoi(argv[8]), flags = atoi(argv[9]);
+  MatGSO<ZT, FT> M(A, U, UT, GSO_ROW_EXPO);
+  M.update_gso();
+  vector<double> r;
+  for (int i = 0; i < d; ++i)
+  {
+    FT t;
+    M.get_r(t, first + i, first + i);
+    r.push_back(t.get_d());
+  }
+  long expo;
+  FT max_dist = M.get_r_exp(first, first, expo);
+  max_dist *= 1e10;  // a huge radius: the Gaussian-heuristic bound decides
+  FT root_det = M.get_root_det(first, first + d);
+  adjust_radius_to_gh_bound(max_dist, expo, d, root_det, ghf);
+  const double radius = max_dist.get_d() * std::pow(2.0, (double)expo);
+  PruningParams pp;
+  auto t0 = std::chrono::steady_clock::now();
+  prune<FT>(pp, radius, preproc, r, target, (PrunerMetric)metric, flags);
+  const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  printf("{\"d\":%d,\"radius\":\"%a\",\"preproc_cost\":\"%a\",\"target\":\"%a\",\"metric\":%d,\"flags\":%d,"
+         "\"ref_seconds\":%.6f,\"expectation\":\"%a\",\"gh_factor\":\"%a\",",
+         d, radius, preproc, target, metric, flags, secs, pp.expectation, pp.gh_factor);
+  put_hex("gso_r", r);
+  put_hex("coefficients", pp.coefficients);
+  put_hex("detailed_cost", pp.detailed_cost);
+  // the evaluation functions on a second coefficient vector, through the public API
+  vector<double> lin = PruningParams::LinearPruningParams(d, d / 2).coefficients;
+  Pruner<FT> ev(radius, preproc, r, target, (PrunerMetric)metric, 0);
+  vector<double> lin_detail;
+  const double lin_cost = ev.single_enum_cost(lin, &lin_detail);
+  const double lin_metric = ev.measure_metric(lin);
+  const double lin_svp    = svp_probability<FT>(lin).get_d();
+  printf("\"lin_cost\":\"%a\",\"lin_metric\":\"%a\",\"lin_svp_probability\":\"%a\",", lin_cost, lin_metric, lin_svp);
+  put_hex("lin", lin);
+  put_hex("lin_detailed_cost", lin_detail, true);
+  printf("}\n");
+  return 0;
+}
+
 /* basisstat basisfile  → JSON: the reference's is_lll_reduced (256-bit GSO), slope of log r_ii
  * (gso_interface.cpp:198-218), log-volume, r_00 — the acceptance test of a tour whose enumerations
  * ran in another order than the reference's (a pruned shrinking-radius walk is order dependent) */
@@ -1310,6 +1375,8 @@ int main(int argc, char **argv)
     return cmd_bkztour(argc, argv);
   if (cmd == "basisstat")
     return cmd_basisstat(argc, argv);
+  if (cmd == "prunefix")
+    return cmd_prunefix(argc, argv);
   fprintf(stderr, "unknown command %s\n", cmd.c_str());
   return 2;
 }

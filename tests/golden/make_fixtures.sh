@@ -126,3 +126,11 @@ done
 # hlll_{q40,n64,q72}.json: golden values for the double-double device path (ref_driver hhmp; the
 # python wrapper that adds the basis to the JSON is in the commit that introduced these files)
 #   $D hhmp <basis.txt> 106  ->  tests/golden/hhmp106_{q40,n64,q72}.json.gz
+
+# ---- pruner fixtures (round 3): prune<FP_NR<double>> of the real reference on blocks of the C3 basis ----
+# ref_driver prunefix basisfile first d gh_factor preproc_cost target metric flags
+B=basis_q180_seed0_lll_bkz20.txt
+$DRV prunefix $B 60 60 1.1 1e7 0.5 0 4   > prune_q180_k60_b60_p05.json             # PRUNER_GRADIENT
+$DRV prunefix $B 10 45 1.2 1e7 0.3 0 4   > prune_q180_k10_b45_p03.json             # odd block size
+$DRV prunefix $B 60 50 1.1 1e7 1.0 1 68  > prune_q180_k60_b50_single_expsol.json   # PRUNER_SINGLE, expected solutions
+$DRV prunefix $B 100 31 1.0 1e5 0.9 0 36 > prune_q180_k100_b31_half.json           # PRUNER_HALF
