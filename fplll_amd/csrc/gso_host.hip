@@ -1083,8 +1083,25 @@ void serve_radius(const BkzsHost &H, BkzMail *m)
     const double *pr = nullptr;
     if (H.S && best >= 0 && H.S->coeff_off[best + 1] - H.S->coeff_off[best] == bs)
       pr = H.S->coeff + H.S->coeff_off[best];
-    const double est = estimate_block_nodes(bs, logr, std::log(max_dist) + expo * M_LN2, pr);
-    m->handoff       = est >= H.handoff_nodes ? 1 : 0;
+    // expected number of nodes of this enumeration: the pruner's cost function (pruner_host.hip:
+    // Pruner::single_enum_cost, volumes of the cylinder intersections — what the reference's pruner
+    // optimises); the plain Gaussian-heuristic sum (2-5x high on pruned trees) only if it fails
+    double est = -1.0;
+    {
+      double rr[64], ones[64], cost = 0.0;
+      for (int i = 0; i < bs; ++i)
+      {
+        rr[i]   = std::exp(logr[i]);
+        ones[i] = 1.0;
+      }
+      const double radius = std::exp(std::log(max_dist) + expo * M_LN2);
+      if (std::isfinite(radius) && fphip_pruner_enum_cost(bs, rr, radius, pr ? pr : ones, 0, &cost, nullptr, nullptr) == FPHIP_OK &&
+          std::isfinite(cost))
+        est = cost;
+    }
+    if (est < 0.0)
+      est = 0.25 * estimate_block_nodes(bs, logr, std::log(max_dist) + expo * M_LN2, pr);
+    m->handoff = est >= H.handoff_nodes ? 1 : 0;
   }
 }
 
@@ -1449,7 +1466,7 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
       return FPHIP_ERROR;
     }
     const char *hn  = getenv("FPHIP_BKZ_HANDOFF_NODES");
-    H.handoff_nodes = hn ? atof(hn) : 1e4;
+    H.handoff_nodes = hn ? atof(hn) : 2500.0;
   }
   unsigned long long handoff_calls = 0;
   int handoff_rc                   = FPHIP_OK;
