@@ -1466,7 +1466,7 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
       return FPHIP_ERROR;
     }
     const char *hn  = getenv("FPHIP_BKZ_HANDOFF_NODES");
-    H.handoff_nodes = hn ? atof(hn) : 2500.0;
+    H.handoff_nodes = hn ? atof(hn) : 800.0;
   }
   unsigned long long handoff_calls = 0;
   int handoff_rc                   = FPHIP_OK;

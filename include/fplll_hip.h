@@ -224,7 +224,7 @@ int fphip_gso_bkz(fphip_gso *g, int block_size, double delta, double eta, int fl
  * block would hold a single row (d = k block_size + 1). */
 #define FPHIP_BKZ_SLD_RED 0x200
 /* FPHIP_BKZ_HANDOFF (not a flag of fplll): blocks whose Gaussian-heuristic tree size exceeds
- * FPHIP_BKZ_HANDOFF_NODES expected nodes (environment, default 2500; the pruner's cost function,
+ * FPHIP_BKZ_HANDOFF_NODES expected nodes (environment, default 800; the pruner's cost function,
  * fphip_pruner_enum_cost, on the block's r-profile, radius and pruning set) are enumerated by the multi-wave
  * enumerator (fphip_enum_run on a second context of the device, FastEvaluator(1) semantics) instead
  * of by the lattice's own wave: 10^9 nodes/s instead of 3·10^6.  That enumerator visits the tree in
