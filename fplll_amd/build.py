@@ -26,8 +26,12 @@ HIPCC_FLAGS = [
 # live register per iteration) because the surrounding function has lane-masked branches — the
 # option makes StructurizeCFG leave regions of uniform branches alone (see the kernel's header).
 PER_FILE_FLAGS = {
-    "enum_kernel.hip": ["-mllvm", "-structurizecfg-skip-uniform-regions=1"],
-    "bkzs_kernel.hip": ["-mllvm", "-structurizecfg-skip-uniform-regions=1"],
+    # (-disable-lifetime-markers: with lifetime markers every `break` out of a loop body that declares
+    #  locals goes through the front end's cleanup block — ONE block shared with the loop latch, a
+    #  "continue" flag and a phi per live value: 4 scalar + 2 branch instructions per iteration of the
+    #  walk loops, which are bound by the scalar / branch issue port)
+    "enum_kernel.hip": ["-mllvm", "-structurizecfg-skip-uniform-regions=1", "-Xclang", "-disable-lifetime-markers"],
+    "bkzs_kernel.hip": ["-mllvm", "-structurizecfg-skip-uniform-regions=1", "-Xclang", "-disable-lifetime-markers"],
     # the one-wavefront-per-lattice reduction kernels: their loops still hold lane-masked branches, so
     # the option only spares the regions that are uniform already — measured +4 % on the batched LLL
     # (100.5 -> 104.6 lattices/s at d = 120, batch 1024), outputs unchanged (parity tests)
@@ -77,7 +81,7 @@ def build_hip(force=False):
     for src in srcs:
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
         objs.append(obj)
-        if force or _newer(obj, [src] + hdrs):
+        if force or _newer(obj, [src, os.path.abspath(__file__)] + hdrs):  # (the flags live in this file)
             _run([hipcc()] + HIPCC_FLAGS + extra + PER_FILE_FLAGS.get(os.path.basename(src), []) +
                  ["-c", "-o", obj, src])
             relink = True

@@ -14,6 +14,9 @@
  * (measured on MI355X: a walk launch lasted 62-66 ns per task whatever the tasks held, 180 000 tickets
  * took 9 ms) — a single ticket counter caps a launch at 2·10^7 tasks/s.  Tickets and emission counters
  * are therefore spread over FPHIP_NQ queues / regions whose counters sit FPHIP_QS words apart. */
+// doubles behind the LDS column stack of a wave (enum_phase_kernel): where the lanes beyond a short
+// row land when a 64-lane push is not masked
+#define FPHIP_STACK_PAD 64
 #define FPHIP_NQ 128
 #define FPHIP_QS 16 /* unsigned words between two counters: 64 bytes */
 
@@ -63,6 +66,10 @@ struct DevShared
   // breadth-first expansion of the top of the tree (enum_bfs_kernel): the table of the subtree-size
   // estimate (scheduling only: never affects which nodes are visited)
   float bfs_A[64][64];  // [L][k], k < L: log( V_{L-k}(1) / prod_{i=k}^{L-1} sqrt(r_ii) )
+  // rows 0..63 of mu once more, one 512-byte row per level (mu_sq[k][i] = mu(k,i), i < k, zero
+  // beyond): what the big walk launches read — the row address is a scalar add, the lane offset a
+  // loop-invariant register, no clamp (the packed rows above cost three VALU instructions per load)
+  double mu_sq[64][64];
 };
 
 // Subtree tasks (structure of arrays; col/x rows are 64 doubles so that a wave loads them coalesced).

@@ -546,7 +546,11 @@ restart:
   }
   for (int k = 1; k < d; ++k)
     for (int i = 0; i < k; ++i)
+    {
       st->mu_tri[(k * (k - 1)) / 2 + i] = mut[(size_t)i * d + k];  // mu(k,i)
+      if (k < 64)
+        st->mu_sq[k][i] = mut[(size_t)i * d + k];
+    }
   // table of the subtree-size estimate of the breadth-first stage (levels below 64):
   // A[L][k] = log V_{L-k}(1) - sum_{i=k}^{L-1} log sqrt(r_ii)
   float bfs_est0[65];  // estimate for a node of partial distance 0 at level L (the heaviest there is)
@@ -832,18 +836,18 @@ restart:
                         L < env_int("FPHIP_MU_GLOBAL_MIN_LEVEL", 47);
     // Split stack: the slots k < Ts of the column stack stay in LDS, the tall ones go to a per-wave
     // scratch in global memory.  Ts is the largest level whose LDS part still lets 32 waves (8 per
-    // SIMD) reside on a CU in the big walk launches (tri_off(36) = 630 doubles = 5 KB per wave); the
+    // SIMD) reside on a CU in the big walk launches (tri_off(34) + 64 = 625 doubles = 5 KB per wave); the
     // split launches and small trees keep the whole stack in LDS.
     int Ts = L + 1;
     if (in_final && C >= 1024 && !mu_lds)
     {
-      const int want = env_int("FPHIP_STACK_SPLIT", 36);
+      const int want = env_int("FPHIP_STACK_SPLIT", 34);
       if (want > 1 && want < Ts)
         Ts = want;
     }
     const int ldsRow = (Ts * (Ts - 1)) / 2;
-    // (+ one spare double per wave: the slot the lanes beyond a stack row write to)
-    const size_t lds  = ((size_t)(mu_lds ? triL : 0) + (size_t)wpb * ldsRow + (size_t)wpb) * sizeof(double);
+    // (+ the pad per wave the lanes beyond a short stack row write to)
+    const size_t lds  = ((size_t)(mu_lds ? triL : 0) + (size_t)wpb * (ldsRow + FPHIP_STACK_PAD)) * sizeof(double);
     if (lds > 160 * 1024)
       return fail(ctx, "LDS request too large (%zu)", lds);
     int blocks_per_cu = (int)std::max<size_t>(1, std::min<size_t>(32 / wpb, (160 * 1024) / lds));

@@ -72,6 +72,20 @@ __device__ __forceinline__ double ld_off(const double *row, unsigned off8)
 {
   return *(const double *)((const char *)row + off8);
 }
+// Row `row8 / 8` (512 bytes each) of the square mu table, element `lane`, as a raw buffer load: the
+// row offset rides in the instruction's scalar offset operand, the lane offset is a loop-invariant
+// register — no address arithmetic on the vector unit (a global_load needs one v_add per row, the
+// packed rows three).  Reads beyond the table return zero.
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t mu_rsrc(const double *tab, unsigned bytes)
+{
+  return __builtin_amdgcn_make_buffer_rsrc((void *)tab, 0, bytes, 0x00020000);  // (untyped 32-bit data)
+}
+__device__ __forceinline__ double ld_row(__amdgpu_buffer_rsrc_t tab, unsigned row8, unsigned lane8)
+{
+  const v2u v = __builtin_amdgcn_raw_buffer_load_b64(tab, lane8, row8 << 6, 0);
+  return __hiloint2double((int)v.y, (int)v.x);
+}
 // (r_ii, pruning_i) of one level straight into SGPRs through the scalar cache: the table is read-only
 // for the whole enumeration, the index is wave-uniform.  Issue early (rp_issue), wait right before
 // the first use (rp_wait: s_waitcnt through the value, so that the compiler keeps the order).
@@ -110,7 +124,35 @@ __device__ __forceinline__ unsigned long long rfl_u64(unsigned long long v)
   unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
   return ((unsigned long long)hi << 32) | lo;
 }
+// The lane mask of ONE level built on the scalar unit (s_lshl_b64) and consumed as the select / carry
+// operand of VOP3 instructions: `lane == k ? a : b` without the v_cmp, `cnt += (lane == k)` as one
+// v_addc_co (the compiler's form is v_cmp + v_cndmask 0/1 + v_add).  The walk is VALU-issue bound.
+__device__ __forceinline__ unsigned long long lane_bit(int k) { return 1ull << (k & 63); }
+__device__ __forceinline__ int sel_i32(unsigned long long m, int a, int b)
+{
+  int r;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
+  return r;
+}
+__device__ __forceinline__ double sel_f64(unsigned long long m, double a, double b)
+{
+  return __hiloint2double(sel_i32(m, __double2hiint(a), __double2hiint(b)),
+                          sel_i32(m, __double2loint(a), __double2loint(b)));
+}
+__device__ __forceinline__ unsigned add_bit(unsigned long long m, unsigned c)
+{
+  unsigned long long co;
+  asm("v_addc_co_u32_e64 %0, %1, 0, %0, %2" : "+v"(c), "=s"(co) : "s"(m));
+  return c;
+}
 __device__ __forceinline__ int tri_off(int k) { return (k * (k - 1)) >> 1; }  // slot k starts here
+__device__ __forceinline__ unsigned tri8(int k)
+{  // 8 * tri_off(k) on the scalar unit, opaque to the optimiser (which otherwise folds the sign of a
+   // subtraction into the product: four instructions instead of three)
+  unsigned t = (unsigned)(k * (k - 1)) << 2;
+  asm("" : "+s"(t));
+  return t;
+}
 
 __device__ __forceinline__ unsigned long long load_sys_u64(const unsigned long long *p)
 {
@@ -163,8 +205,9 @@ __device__ __forceinline__ unsigned long long load_sys_u64(const unsigned long l
 // DUAL: the dualenum instantiation of the recursion (enumerate_base.cpp:57-61, 103-105): the centre
 // partial sums are driven by alpha = x - c instead of x; the inputs are then the transformed mu / r
 // EnumerationDyn::enumerate builds for a dual call (enumerate.cpp:107-123).
+// (8 waves per SIMD = at most 64 VGPRs: the walk is issue-bound and loses a tenth of its rate at 7)
 template <bool MU_LDS, bool SUBS, bool DUAL>
-__global__ void __launch_bounds__(FPHIP_MAX_BLOCK)
+__global__ void __launch_bounds__(FPHIP_MAX_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8)))
     enum_phase_kernel(DevShared *__restrict__ g, HostCtl *__restrict__ h, TaskBuf in, TaskBuf out,
                       int d, int Lmax, int stop, unsigned task_lo, unsigned task_hi,
                       const unsigned *__restrict__ idxlist, int launch_idx, int count_nodes,
@@ -189,15 +232,19 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK)
   // against 4 with the whole stack of a 50-level task in LDS).
   const int nw     = (int)(blockDim.x >> 6);
   const int Ts     = min(Tsplit, Lmax + 1);
-  const int ldsRow = tri_off(Ts);  // doubles of LDS stack per wave
-  double *stk;                     // slot k < Ts at stk + tri_off(k)
-  int dummy_slot;  // (relative to stk) one spare double per wave behind all the LDS stacks: the
-                   // lanes beyond a slot write there (no exec-masked branch in the hot loop)
+  const int ldsRow = tri_off(Ts);  // doubles of LDS stack slots per wave
+  // The LDS slots are laid out in DESCENDING level order: slot k (k doubles) starts
+  // tri_off(Ts) - tri_off(k + 1) doubles into the wave's region, slot k - 1 right behind it.  A push
+  // of S_k is then ONE unmasked 64-lane store: the lanes beyond the row land in the slots of the
+  // levels below k — dead at that moment, each is rewritten by the descent that reaches it — and, for
+  // k < 11, in the 64-double pad behind slot 1.  (Neither a select to a dummy slot nor an
+  // exec-masked branch in the hot loop; reads need no clamp for the same reason.)
+  const int ldsWave = ldsRow + FPHIP_STACK_PAD;
+  double *stk;  // this wave's region
   if constexpr (MU_LDS)
   {
     double *mu_l = smem;
-    stk          = smem + triL + wave * ldsRow;
-    dummy_slot   = nw * ldsRow - wave * ldsRow + wave;
+    stk          = smem + triL + wave * ldsWave;
     const int nmu = (Lmax * (Lmax - 1)) >> 1;
     for (int i = threadIdx.x; i < nmu; i += blockDim.x)
       mu_l[i] = g->mu_tri[i];
@@ -206,12 +253,18 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK)
   }
   else
   {
-    mu_s       = g->mu_tri;
-    stk        = smem + wave * ldsRow;
-    dummy_slot = nw * ldsRow - wave * ldsRow + wave;
+    mu_s       = &g->mu_sq[0][0];
+    stk        = smem + wave * ldsWave;
   }
+  const __amdgpu_buffer_rsrc_t mu_b = mu_rsrc(&g->mu_sq[0][0], (unsigned)sizeof(g->mu_sq));  // (!MU_LDS)
+  // LDS slot k of this lane: stk_top - tri8(k + 1).  The offset comes out of a lane-indexed table
+  // with one v_readlane (tri8tab lane j = tri8(j + 2)): computing it from k costs four scalar
+  // instructions, and since the address arithmetic left the vector unit the walk is bound by the
+  // scalar / branch issue port (PMC: 47 VALU against 46 SALU + 15 branch per node); an incrementally
+  // kept offset ends up as a VECTOR induction variable, one v_add per update.
+  char *stk_top      = (char *)stk + (((unsigned)ldsRow << 3) + lane8);
+  const int tri8tab  = ((lane + 2) * (lane + 1)) << 2;
   // slot k >= Ts at gst + tri_off(k); one spare double behind the last slot (index triL)
-  const unsigned dummy8 = (unsigned)dummy_slot << 3;
   double *gst = gstk + (size_t)(blockIdx.x * nw + wave) * (size_t)(triL - ldsRow + 1) - ldsRow;
 
   const double *rptab = &g->rp[0][0];  // (r_ii, pruning_i) pairs, read through the scalar cache
@@ -329,7 +382,6 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK)
     const double pd0  = in.pd[ti];
     int donate        = 1 << 20;
     const unsigned iter0 = iter;  // (iterations of this task = iter - iter0)
-    unsigned tk8         = (unsigned)tri_off(Lt) << 3;  // 8 * tri_off(k), kept incrementally
     FPHIP_REFRESH_BOUND((t & 63u) == 0u);
 
     // the task root is a surviving node at level Lt whose column and distance are given
@@ -433,12 +485,30 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK)
     // a step were that).  FPHIP_OPAQUE on the event code behind a loop keeps the loop's exits on
     // one successor block.  The scalar unit issues as slowly as the vector unit here (one
     // instruction per SIMD turn), so scalar work is counted like vector work.
-    enum : int { EV_CHILD = 0, EV_EMIT = 1, EV_REPORT = 2, EV_DONE = 3, EV_RESTEP = 4, EV_OK = 5, EV_REFRESH = 6 };
+    enum : int { EV_CHILD = 0, EV_EMIT = 1, EV_REPORT = 2, EV_DONE = 3, EV_RESTEP = 4, EV_OK = 5, EV_REFRESH = 6,
+                 EV_SPECIAL = 7, EV_FAIL = 8 };
     // Levels whose surviving first children are handed to the next launch: [elo, elo + erng].  The
     // split launches (stop >= 0, no budget) emit at level `stop` only; the walk launches (stop < 0)
     // emit at every level >= donate once the task sheds work.
     unsigned elo  = (stop >= 0 && stop < Lt) ? (unsigned)stop : (unsigned)donate;
     unsigned erng = (stop >= 0 && stop < Lt) ? 0u : 0x7fffffffu;
+    // What the CHILD chain tests instead: ONE bit of a scalar mask (bit k - 1 for level k, 1 <= k <= 64)
+    // that holds every level which leaves the chain for the general path behind it — the emission
+    // levels and level 1.  The general path sorts out which it is.
+    unsigned long long smask;
+    auto hot_range = [&]()
+    {
+      const auto from = [](unsigned lvl) { return lvl > 64u ? 0ull : (lvl <= 1u ? ~0ull : ~0ull << (lvl - 1u)); };
+      unsigned long long m = from(elo);               // levels >= elo ...
+      if (erng < 64u)
+        m &= ~from(elo + erng + 1u);                  // ... up to elo + erng
+      // ... and level 1: the descent to the leaves (a handful of nodes in 10^10) goes through the
+      // general path, so that the chain has no exit BEHIND the state updates of a descent — exits in
+      // front of and behind them keep the old and the new level registers alive across the loop (a
+      // copy of each per iteration)
+      smask = rfl_u64(m | 1ull);
+    };
+    hot_range();
     bool buffer_full         = false;
     bool resume_step         = false;  // re-enter the STEP loop at level k (after a report / refresh)
     // (par, mk) = (S_{k+1}, row k of mu): what a step at level k needs to rebuild S_k.  Both are in
@@ -452,80 +522,110 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK)
       // (state: a surviving, already counted node at level k with column S = S_k, distance nd)
       if (!resume_step)
       {
+        int kc;
+        double mk1, c1, x1, a1, n1;
+        // S_k -> slot k (LDS: all 64 lanes store, `lds8` = 8 tri_off(k + 1), see the layout above; global
+        // part: the lanes beyond the row write the spare double — a select, no lane-masked branch, and
+        // its operands are computed in front of it so that it stays one)
+#define FPHIP_PUSH(lds8)                                                          \
+  if (k < Ts)                                                                     \
+    *(double *)(stk_top - (lds8)) = S;                                            \
+  else                                                                            \
+  {                                                                               \
+    const unsigned gk8 = ((unsigned)(k * (k - 1)) << 2) + lane8;                  \
+    *(double *)((char *)gst + ((lane < k) ? gk8 : (unsigned)triL << 3)) = S;      \
+  }
+// descent to level kc (the first child survived): PUSH stores S_k for the steps of level kc
+#define FPHIP_DESCEND(PUSH)                                                                                   \
+  do                                                                                                          \
+  {                                                                                                           \
+    PUSH;                                                                                                     \
+    const int s1                = (c1 >= x1) ? 1 : -1; /* :71 / :114 (dx = ddx = s1; ddx stays sign(dx)) */    \
+    const unsigned long long me = lane_bit(kc);                                                               \
+    cs                          = wl_f64(c1, kc, cs);                                                         \
+    xs                          = sel_f64(me, x1, xs);                                                        \
+    pds                         = sel_f64(me, nd, pds);                                                       \
+    dxs                         = wl_i32(s1, kc, dxs);                                                        \
+    cnt32                       = add_bit(me, cnt32); /* ++nodes[kk-1] */                                     \
+    if constexpr (SUBS)                                                                                       \
+    {                                                                                                         \
+      if (n1 < rl_f64(sb, kc) && n1 != 0.0)                                                                   \
+        sub_report(kc, n1);                                                                                   \
+    }                                                                                                         \
+    par = S; /* (S_{kc+1}, row kc): what a step at the new level needs */                                     \
+    mk  = mk1;                                                                                                \
+    k   = kc;                                                                                                 \
+    nd  = n1;                                                                                                 \
+    /* S_k = S_{k+1} - x[k]*mu(k,.), :53-58 (mk1 is row k; at k == 0 a dead value) */                         \
+    S = S - (DUAL ? a1 : x1) * mk1;                                                                           \
+  } while (0)
         for (;;)
         {
-          const int kc       = k - 1;
+          kc                 = k - 1;
           const unsigned kc8 = (unsigned)kc << 3;
           v4i q1             = rp_issue2(rptab, kc8);
           // speculative load for the descending case: row kc of mu is needed right after the test
-          // (its latency overlaps the test).  tk8 = 8 * tri_off(k) is kept incrementally: row kc
+          // (its latency overlaps the test).  tri8(k) = 8 * tri_off(k) comes from the scalar unit: row kc
           // starts kc elements before row k.  At kc == 0 the clamp wraps and the lanes read the
           // head of the table (valid, unused).
-          const unsigned tkc8 = tk8 - kc8;
-          const double mk1    = ld_off(mu_s, tkc8 + min(lane8, kc8 - 8u));
-          const double c1  = rl_f64(S, kc);  // center[kk-1] = center_partsums[kk-1][kk]
+          if constexpr (MU_LDS)
+            mk1 = ld_off(mu_s, tri8(kc) + min(lane8, kc8 - 8u));
+          else  // (the square copy: scalar row address, zero beyond the row)
+            mk1 = ld_row(mu_b, kc8, lane8);
+          c1 = rl_f64(S, kc);  // center[kk-1] = center_partsums[kk-1][kk]
           // roundto() = round(): half away from zero (enumerate_base.h:33-34), as round-to-even
           // (one instruction) plus the correction of the ties that went towards zero
-          double x1 = rint(c1);
-          double a1 = x1 - c1;
+          x1 = rint(c1);
+          a1 = x1 - c1;
           if (fabs(a1) == 0.5 && ((a1 < 0.0) == (c1 > 0.0)))
           {
             x1 = x1 - (a1 + a1);
             a1 = -a1;
           }
           rp_wait(q1);
-          const double n1 = nd + a1 * a1 * rp_r(q1);  // :28-29
+          n1 = nd + a1 * a1 * rp_r(q1);  // :28-29
           // :31-32 (partdistbounds = pruning * maxdist); the ballot makes the test wave-uniform for
           // the compiler although maxdist_v went through an asm statement
           if (__builtin_amdgcn_ballot_w64(n1 <= rp_p(q1) * maxdist_v) == 0ull)
           {  // no surviving child: next sibling at level k (the root has none: task done)
-            ev = (k >= Lt) ? EV_DONE : EV_RESTEP;
+            ev = EV_FAIL;
             FPHIP_EXIT();
             break;
           }
-          if ((unsigned)(k - elo) <= erng)
-          {  // hand the subtree below this node to the next launch (outside the loop): k == stop in
-             // the split launches, k >= donate once this task sheds work (never the task root:
-             // donate starts beyond every level and the root is only visited first)
-            ev = EV_EMIT;
+          unsigned sbit = (unsigned)(smask >> kc);
+          asm("" : "+s"(sbit));  // (a 32-bit test of the shifted mask: the compiler's own form adds a 64-bit compare)
+          if (sbit & 1u)
+          {  // an emission level (k == stop in the split launches, k >= donate once this task sheds
+             // work; never the task root: donate starts beyond every level and the root is only
+             // visited first) or a level above the LDS part of the stack: the general path below
+            ev = EV_SPECIAL;
             FPHIP_EXIT();
             break;
           }
-          // descend: level kc becomes the current level.  S is needed again when x[kc] steps to
-          // its next sibling; the lanes beyond the row write a dummy slot (no exec-masked branch)
-          if (k < Ts)
-            *(double *)((char *)stk + ((lane < k) ? tk8 + lane8 : dummy8)) = S;
-          else
-            *(double *)((char *)gst + ((lane < k) ? tk8 + lane8 : (unsigned)triL << 3)) = S;
-          const int s1  = (c1 >= x1) ? 1 : -1;  // :71 / :114 (dx = ddx = s1; ddx stays sign(dx))
-          const bool me = lane == kc;
-          cs            = wl_f64(c1, kc, cs);
-          xs            = me ? x1 : xs;
-          pds           = me ? nd : pds;
-          dxs           = wl_i32(s1, kc, dxs);
-          cnt32 += me ? 1u : 0u;  // ++nodes[kk-1]
-          if constexpr (SUBS)
-          {
-            if (n1 < rl_f64(sb, kc) && n1 != 0.0)
-              sub_report(kc, n1);
-          }
-          par = S;    // (S_{kc+1}, row kc): what a step at the new level needs
-          mk  = mk1;
-          k   = kc;
-          tk8 = tkc8;
-          nd  = n1;
-          // S_k = S_{k+1} - x[k]*mu(k,·), :53-58 (mk1 is row k; at k == 0 a dead value)
-          S = S - (DUAL ? a1 : x1) * mk1;
-          if (k == 0)
-          {  // level 0: process_solution, :42-46; no children
-            ev = (nd > 0.0) ? EV_REPORT : EV_RESTEP;
-            FPHIP_EXIT();
-            break;
-          }
+          // descend: level kc becomes the current level.  S is needed again when x[kc] steps to its
+          // next sibling.  (The global part of the stack is no rare path: a quarter of the nodes of a
+          // 60-dimensional block sit above level 33 — which is why it is handled inside the loop.)
+          FPHIP_DESCEND(FPHIP_PUSH((unsigned)rl_i32(tri8tab, kc)));
         }
         FPHIP_OPAQUE(ev);
+        if (ev == EV_FAIL)
+          ev = (k >= Lt) ? EV_DONE : EV_RESTEP;
         if (ev == EV_DONE)
           break;
+        if (ev == EV_SPECIAL)
+        {
+          if ((unsigned)(k - elo) <= erng)
+            ev = EV_EMIT;  // hand the subtree below this node to the next launch
+          else
+          {  // the descent to level 0 (or a level the mask holds for no reason): one iteration by hand
+            FPHIP_DESCEND(FPHIP_PUSH(tri8(k + 1)));
+            if (k != 0)
+              continue;  // → CHILD chain at the new level
+            ev = (nd > 0.0) ? EV_REPORT : EV_RESTEP;
+          }
+        }
+#undef FPHIP_DESCEND
+#undef FPHIP_PUSH
         if (ev == EV_EMIT)
         {
           unsigned oi = 0;
@@ -555,6 +655,7 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK)
             donate      = 1 << 20;
             elo         = 1u << 20;
             erng        = 0u;
+            hot_range();
             continue;
           }
         }
@@ -569,10 +670,13 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK)
         const unsigned k8  = (unsigned)k << 3;
         const unsigned cl8 = min(lane8, k8 - 8u);  // (k == 0: wraps, the lanes read valid, unused data)
         if (k + 1 < Ts)
-          par = ld_off(stk, tk8 + k8 + cl8);
+          par = *(const double *)(stk_top - tri8(k + 2));  // slot k + 1
         else
-          par = ld_off(gst, tk8 + k8 + cl8);
-        mk = ld_off(mu_s, tk8 + cl8);
+          par = ld_off(gst, tri8(k + 1) + cl8);
+        if constexpr (MU_LDS)
+          mk = ld_off(mu_s, tri8(k) + cl8);
+        else
+          mk = ld_row(mu_b, k8, lane8);
       }
       resume_step = false;
       // ================= STEP loop: next sibling at level k, climbing while they fail ===========
@@ -596,9 +700,8 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK)
         asm volatile("" : "+s"(stepi));  // (keeps the select in front of the int -> double conversion)
         xk += (double)stepi;
         dxk = zig ? ((dxk > 0 ? -1 : 1) - dxk) : dxk;  // ddx = -ddx; dx = ddx - dx, ddx == sign(dx)
-        const bool me = lane == k;
-        xs            = me ? xk : xs;
-        dxs           = wl_i32(dxk, k, dxs);
+        xs  = sel_f64(lane_bit(k), xk, xs);
+        dxs = wl_i32(dxk, k, dxs);
         asm volatile("" : "+v"(xs), "+v"(dxs));  // (the updates stay in front of the test: sunk behind
                                                   //  it they would merge the loop's exits again)
         a             = xk - ck;
@@ -610,20 +713,19 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK)
           FPHIP_EXIT();
           break;
         }
-        // :93-94: the parent steps to its next sibling.  The loads for the surviving case at the
-        // new level are issued now: their latency (mu comes through L1 in the big launches)
-        // overlaps the next test.  Lanes beyond the row read a clamped (valid, unused) address.
-        {
-          const unsigned k8 = (unsigned)k << 3;  // (old k) * 8 = 8 * (new k - 1): the clamp, and
-          tk8 += k8;                             // row k + 1 starts k elements behind row k
-          ++k;
-          const unsigned cl8 = min(lane8, k8);
-          if (k + 1 < Ts)
-            par = ld_off(stk, tk8 + k8 + 8u + cl8);
-          else
-            par = ld_off(gst, tk8 + k8 + 8u + cl8);
-          mk = ld_off(mu_s, tk8 + cl8);
-        }
+        // :93-94: the parent steps to its next sibling.  The loads for the surviving case at the new
+        // level are issued now: their latency (mu comes through L1 in the big launches) overlaps the
+        // next test.
+        ++k;
+        // slot k + 1 (lanes beyond the row: a valid, unused address)
+        if (k + 1 < Ts)
+          par = *(const double *)(stk_top - (unsigned)rl_i32(tri8tab, k));
+        else
+          par = ld_off(gst, tri8(k + 1) + min(lane8, ((unsigned)k << 3) - 8u));
+        if constexpr (MU_LDS)
+          mk = ld_off(mu_s, tri8(k) + min(lane8, ((unsigned)k << 3) - 8u));
+        else
+          mk = ld_row(mu_b, (unsigned)k << 3, lane8);
         if (k >= Lt)
         {
           ev = EV_DONE;
@@ -640,7 +742,7 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK)
       FPHIP_OPAQUE(ev);
       if (ev == EV_OK)
       {
-        cnt32 += (lane == k) ? 1u : 0u;  // ++nodes[kk]
+        cnt32 = add_bit(lane_bit(k), cnt32);  // ++nodes[kk]
         if constexpr (SUBS)
         {
           if (nd < rl_f64(sb, k) && nd != 0.0)
@@ -682,6 +784,7 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK)
           }
         }
         FPHIP_JOIN();
+        hot_range();
         resume_step = true;
       }
     }

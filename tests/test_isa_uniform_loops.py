@@ -33,7 +33,10 @@ def artefacts(tmp_path_factory):
     d = tmp_path_factory.mktemp("isa")
     ll, asm = str(d / "enum.ll"), str(d / "enum.s")
     per_file = build.PER_FILE_FLAGS.get("enum_kernel.hip", [])
-    subprocess.check_call([_hipcc()] + FLAGS + ["-S", "-emit-llvm", "-o", ll, SRC], stderr=subprocess.DEVNULL)
+    # (the IR the uniformity analysis reads is built with the front-end options of the real build; the
+    #  -mllvm ones only act in the code generator)
+    front = [f for i, f in enumerate(per_file) if f != "-mllvm" and (i == 0 or per_file[i - 1] != "-mllvm")]
+    subprocess.check_call([_hipcc()] + FLAGS + front + ["-S", "-emit-llvm", "-o", ll, SRC], stderr=subprocess.DEVNULL)
     subprocess.check_call([_hipcc()] + FLAGS + per_file + ["-S", "-o", asm, SRC], stderr=subprocess.DEVNULL)
     uni = subprocess.run([OPT, "-mtriple=amdgcn-amd-amdhsa", "-mcpu=gfx950", "-passes=print<uniformity>",
                           "-disable-output", ll], stderr=subprocess.PIPE, stdout=subprocess.DEVNULL, check=True)
@@ -43,6 +46,9 @@ def artefacts(tmp_path_factory):
 def test_build_uses_the_skip_uniform_regions_flag():
     from fplll_amd import build
     assert "-structurizecfg-skip-uniform-regions=1" in build.PER_FILE_FLAGS["enum_kernel.hip"]
+    # without it every `break` of the walk loops goes through the front end's cleanup block: a merged
+    # latch with a "continue" flag (4 scalar + 2 branch instructions per iteration)
+    assert "-disable-lifetime-markers" in build.PER_FILE_FLAGS["enum_kernel.hip"]
     assert "-structurizecfg-skip-uniform-regions=1" in build.PER_FILE_FLAGS["bkzs_kernel.hip"]
 
 
@@ -97,7 +103,9 @@ def test_hot_loops_are_free_of_exec_masking_and_copy_storms(artefacts):
     """The CHILD chain (recognised by its v_rndne_f64: roundto) and the STEP loop (v_cvt_f64_i32: the
     zig-zag step) of the big-launch kernel: no exec manipulation, k in an SGPR (no v_readfirstlane
     round trip), at most a handful of register moves, and instruction counts within the budget the
-    measured 58 VALU + 38 SALU per node correspond to."""
+    measured 53 VALU + 41 SALU + 13 branch instructions per node correspond to (static counts of ALL
+    blocks of a loop, the rare tie-rounding and global-stack blocks included); the kernel keeps 8 waves
+    per SIMD (64 VGPRs)."""
     _, asm = artefacts
     body = _kernel_body(asm, WALK)
     found = {}
@@ -114,7 +122,9 @@ def test_hot_loops_are_free_of_exec_masking_and_copy_storms(artefacts):
                           execs=sum(bool(re.match(r"s_\w+\s+exec\b", s)) or "saveexec" in s for s in seg),
                           rfl=sum(s.startswith("v_readfirstlane") for s in seg))
     assert set(found) == {"child", "step"}, found
-    for key, lim in (("child", dict(valu=60, salu=40, mov=8)), ("step", dict(valu=36, salu=34, mov=4))):
+    for key, lim in (("child", dict(valu=44, salu=20, mov=6)), ("step", dict(valu=28, salu=30, mov=3))):
         f = found[key]
         assert f["execs"] == 0 and f["rfl"] == 0, (key, f)
         assert f["valu"] <= lim["valu"] and f["salu"] <= lim["salu"] and f["mov"] <= lim["mov"], (key, f)
+    m = re.search(re.escape(WALK) + r"[^\n]*\n(?:.*\n)*?\s*\.vgpr_count:\s+(\d+)", asm[asm.index(".amdgpu_metadata"):])
+    assert m and int(m.group(1)) <= 64, m and m.group(1)
