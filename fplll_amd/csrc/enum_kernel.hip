@@ -185,8 +185,10 @@ __device__ __forceinline__ unsigned long long load_sys_u64(const unsigned long l
 // walk loops' exit conditions divergent, and the structuriser rewrites them with exit codes in
 // VGPRs and a copy of every level register per iteration.
 #define FPHIP_JOIN() asm volatile("")
-// The same on each `break` of a hot loop: the optimiser otherwise folds the exit paths into the
-// loop latch (one merged block with a "continue" flag and a phi — a register copy — per live value)
+// The same on each `break` of the CHILD chain: the optimiser otherwise merges the exit tests into a
+// flag computed with scalar selects.  (Not in the STEP loop: there the separate exit blocks make the
+// code generator unify the exits through a hub that keeps the requested (par, mk) and the old pair
+// alive side by side — a copy of each, behind a wait for the loads, in the loop latch.)
 #define FPHIP_EXIT() asm volatile("")
 // keeps a wave-uniform double in a VGPR pair: it is the second scalar operand of a VALU instruction
 // whose first one already sits in SGPRs (one constant-bus read per instruction on gfx9).  The
@@ -528,7 +530,7 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK) __attribute__((amdgpu_waves_p
         // part: the lanes beyond the row write the spare double — a select, no lane-masked branch, and
         // its operands are computed in front of it so that it stays one)
 #define FPHIP_PUSH(lds8)                                                          \
-  if (k < Ts)                                                                     \
+  if (__builtin_expect(k < Ts, 1))                                                \
     *(double *)(stk_top - (lds8)) = S;                                            \
   else                                                                            \
   {                                                                               \
@@ -710,7 +712,6 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK) __attribute__((amdgpu_waves_p
         if (__builtin_amdgcn_ballot_w64(nd <= rp_p(qk) * maxdist_v) != 0ull)
         {
           ev = EV_OK;
-          FPHIP_EXIT();
           break;
         }
         // :93-94: the parent steps to its next sibling.  The loads for the surviving case at the new
@@ -718,10 +719,15 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK) __attribute__((amdgpu_waves_p
         // next test.
         ++k;
         // slot k + 1 (lanes beyond the row: a valid, unused address)
-        if (k + 1 < Ts)
+        if (__builtin_expect(k + 1 < Ts, 1))
           par = *(const double *)(stk_top - (unsigned)rl_i32(tri8tab, k));
         else
-          par = ld_off(gst, tri8(k + 1) + min(lane8, ((unsigned)k << 3) - 8u));
+        {  // (the level number hidden from the optimiser: it otherwise carries 4 k and 8 k for this
+           //  block as induction variables, two scalar adds in every iteration of the loop)
+          int kt = k;
+          asm volatile("" : "+s"(kt));
+          par = ld_off(gst, tri8(kt + 1) + min(lane8, ((unsigned)kt << 3) - 8u));
+        }
         if constexpr (MU_LDS)
           mk = ld_off(mu_s, tri8(k) + min(lane8, ((unsigned)k << 3) - 8u));
         else
@@ -729,13 +735,11 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK) __attribute__((amdgpu_waves_p
         if (k >= Lt)
         {
           ev = EV_DONE;
-          FPHIP_EXIT();
           break;
         }
         if (((++iter) & 63u) == 0u)
         {
           ev = EV_REFRESH;
-          FPHIP_EXIT();
           break;
         }
       }
