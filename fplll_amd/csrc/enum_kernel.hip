@@ -488,7 +488,7 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK) __attribute__((amdgpu_waves_p
     // one successor block.  The scalar unit issues as slowly as the vector unit here (one
     // instruction per SIMD turn), so scalar work is counted like vector work.
     enum : int { EV_CHILD = 0, EV_EMIT = 1, EV_REPORT = 2, EV_DONE = 3, EV_RESTEP = 4, EV_OK = 5, EV_REFRESH = 6,
-                 EV_SPECIAL = 7, EV_FAIL = 8 };
+                 EV_SPECIAL = 7, EV_FAIL = 8, EV_LEAF = 9 };
     // Levels whose surviving first children are handed to the next launch: [elo, elo + erng].  The
     // split launches (stop >= 0, no budget) emit at level `stop` only; the walk launches (stop < 0)
     // emit at every level >= donate once the task sheds work.
@@ -517,156 +517,47 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK) __attribute__((amdgpu_waves_p
     // registers whenever the STEP loop is entered: left there by the CHILD descent to level k or by
     // the successful step at level k that preceded a failing first child.
     double par = 0.0, mk = 0.0;
+    double xk = 0.0, a = 0.0;
+    int kc = 0;
+    double mk1 = 0.0, c1 = 0.0, x1 = 0.0, a1 = 0.0, n1 = 0.0;
+    // S_k -> slot k (LDS: all 64 lanes store, `lds8` = 8 tri_off(k + 1), see the layout above; global
+    // part: the lanes beyond the row write the spare double — a select, no lane-masked branch, and
+    // its operands are computed in front of it so that it stays one)
+#define FPHIP_PUSH(lds8)                                                        \
+  if (__builtin_expect(k < Ts, 1))                                              \
+    *(double *)(stk_top - (lds8)) = S;                                          \
+  else                                                                          \
+  {                                                                             \
+    const unsigned gk8 = ((unsigned)(k * (k - 1)) << 2) + lane8;                \
+    *(double *)((char *)gst + ((lane < k) ? gk8 : (unsigned)triL << 3)) = S;    \
+  }
+// descent to level kc (the first child survived): PUSH stores S_k for the steps of level kc
+#define FPHIP_DESCEND(PUSH)                                                                              \
+  do                                                                                                     \
+  {                                                                                                      \
+    PUSH;                                                                                                \
+    const int s1                = (c1 >= x1) ? 1 : -1; /* :71 / :114 (dx = ddx = s1, ddx = sign(dx)) */   \
+    const unsigned long long me = lane_bit(kc);                                                          \
+    cs                          = wl_f64(c1, kc, cs);                                                    \
+    xs                          = sel_f64(me, x1, xs);                                                   \
+    pds                         = sel_f64(me, nd, pds);                                                  \
+    dxs                         = wl_i32(s1, kc, dxs);                                                   \
+    cnt32                       = add_bit(me, cnt32); /* ++nodes[kk-1] */                                \
+    if constexpr (SUBS)                                                                                  \
+    {                                                                                                    \
+      if (n1 < rl_f64(sb, kc) && n1 != 0.0)                                                              \
+        sub_report(kc, n1);                                                                              \
+    }                                                                                                    \
+    par = S; /* (S_{kc+1}, row kc): what a step at the new level needs */                                \
+    mk  = mk1;                                                                                           \
+    k   = kc;                                                                                            \
+    nd  = n1;                                                                                            \
+    /* S_k = S_{k+1} - x[k]*mu(k,.), :53-58 (mk1 is row k; at k == 0 a dead value) */                    \
+    S = S - (DUAL ? a1 : x1) * mk1;                                                                      \
+  } while (0)
     for (;;)
     {
       int ev;
-      // ================= CHILD chain: descend while the first child survives ====================
-      // (state: a surviving, already counted node at level k with column S = S_k, distance nd)
-      if (!resume_step)
-      {
-        int kc;
-        double mk1, c1, x1, a1, n1;
-        // S_k -> slot k (LDS: all 64 lanes store, `lds8` = 8 tri_off(k + 1), see the layout above; global
-        // part: the lanes beyond the row write the spare double — a select, no lane-masked branch, and
-        // its operands are computed in front of it so that it stays one)
-#define FPHIP_PUSH(lds8)                                                          \
-  if (__builtin_expect(k < Ts, 1))                                                \
-    *(double *)(stk_top - (lds8)) = S;                                            \
-  else                                                                            \
-  {                                                                               \
-    const unsigned gk8 = ((unsigned)(k * (k - 1)) << 2) + lane8;                  \
-    *(double *)((char *)gst + ((lane < k) ? gk8 : (unsigned)triL << 3)) = S;      \
-  }
-// descent to level kc (the first child survived): PUSH stores S_k for the steps of level kc
-#define FPHIP_DESCEND(PUSH)                                                                                   \
-  do                                                                                                          \
-  {                                                                                                           \
-    PUSH;                                                                                                     \
-    const int s1                = (c1 >= x1) ? 1 : -1; /* :71 / :114 (dx = ddx = s1; ddx stays sign(dx)) */    \
-    const unsigned long long me = lane_bit(kc);                                                               \
-    cs                          = wl_f64(c1, kc, cs);                                                         \
-    xs                          = sel_f64(me, x1, xs);                                                        \
-    pds                         = sel_f64(me, nd, pds);                                                       \
-    dxs                         = wl_i32(s1, kc, dxs);                                                        \
-    cnt32                       = add_bit(me, cnt32); /* ++nodes[kk-1] */                                     \
-    if constexpr (SUBS)                                                                                       \
-    {                                                                                                         \
-      if (n1 < rl_f64(sb, kc) && n1 != 0.0)                                                                   \
-        sub_report(kc, n1);                                                                                   \
-    }                                                                                                         \
-    par = S; /* (S_{kc+1}, row kc): what a step at the new level needs */                                     \
-    mk  = mk1;                                                                                                \
-    k   = kc;                                                                                                 \
-    nd  = n1;                                                                                                 \
-    /* S_k = S_{k+1} - x[k]*mu(k,.), :53-58 (mk1 is row k; at k == 0 a dead value) */                         \
-    S = S - (DUAL ? a1 : x1) * mk1;                                                                           \
-  } while (0)
-        for (;;)
-        {
-          kc                 = k - 1;
-          const unsigned kc8 = (unsigned)kc << 3;
-          v4i q1             = rp_issue2(rptab, kc8);
-          // speculative load for the descending case: row kc of mu is needed right after the test
-          // (its latency overlaps the test).  tri8(k) = 8 * tri_off(k) comes from the scalar unit: row kc
-          // starts kc elements before row k.  At kc == 0 the clamp wraps and the lanes read the
-          // head of the table (valid, unused).
-          if constexpr (MU_LDS)
-            mk1 = ld_off(mu_s, tri8(kc) + min(lane8, kc8 - 8u));
-          else  // (the square copy: scalar row address, zero beyond the row)
-            mk1 = ld_row(mu_b, kc8, lane8);
-          c1 = rl_f64(S, kc);  // center[kk-1] = center_partsums[kk-1][kk]
-          // roundto() = round(): half away from zero (enumerate_base.h:33-34), as round-to-even
-          // (one instruction) plus the correction of the ties that went towards zero
-          x1 = rint(c1);
-          a1 = x1 - c1;
-          if (fabs(a1) == 0.5 && ((a1 < 0.0) == (c1 > 0.0)))
-          {
-            x1 = x1 - (a1 + a1);
-            a1 = -a1;
-          }
-          rp_wait(q1);
-          n1 = nd + a1 * a1 * rp_r(q1);  // :28-29
-          // :31-32 (partdistbounds = pruning * maxdist); the ballot makes the test wave-uniform for
-          // the compiler although maxdist_v went through an asm statement
-          if (__builtin_amdgcn_ballot_w64(n1 <= rp_p(q1) * maxdist_v) == 0ull)
-          {  // no surviving child: next sibling at level k (the root has none: task done)
-            ev = EV_FAIL;
-            FPHIP_EXIT();
-            break;
-          }
-          unsigned sbit = (unsigned)(smask >> kc);
-          asm("" : "+s"(sbit));  // (a 32-bit test of the shifted mask: the compiler's own form adds a 64-bit compare)
-          if (sbit & 1u)
-          {  // an emission level (k == stop in the split launches, k >= donate once this task sheds
-             // work; never the task root: donate starts beyond every level and the root is only
-             // visited first) or a level above the LDS part of the stack: the general path below
-            ev = EV_SPECIAL;
-            FPHIP_EXIT();
-            break;
-          }
-          // descend: level kc becomes the current level.  S is needed again when x[kc] steps to its
-          // next sibling.  (The global part of the stack is no rare path: a quarter of the nodes of a
-          // 60-dimensional block sit above level 33 — which is why it is handled inside the loop.)
-          FPHIP_DESCEND(FPHIP_PUSH((unsigned)rl_i32(tri8tab, kc)));
-        }
-        FPHIP_OPAQUE(ev);
-        if (ev == EV_FAIL)
-          ev = (k >= Lt) ? EV_DONE : EV_RESTEP;
-        if (ev == EV_DONE)
-          break;
-        if (ev == EV_SPECIAL)
-        {
-          if ((unsigned)(k - elo) <= erng)
-            ev = EV_EMIT;  // hand the subtree below this node to the next launch
-          else
-          {  // the descent to level 0 (or a level the mask holds for no reason): one iteration by hand
-            FPHIP_DESCEND(FPHIP_PUSH(tri8(k + 1)));
-            if (k != 0)
-              continue;  // → CHILD chain at the new level
-            ev = (nd > 0.0) ? EV_REPORT : EV_RESTEP;
-          }
-        }
-#undef FPHIP_DESCEND
-#undef FPHIP_PUSH
-        if (ev == EV_EMIT)
-        {
-          unsigned oi = 0;
-          if (lane == 0)
-            oi = atomicAdd(out.count, 1u);
-          oi = (unsigned)__builtin_amdgcn_readfirstlane((int)oi);
-          if (oi < out.cap)
-          {
-            out.col[(unsigned long long)oi * 64 + lane] = S;
-            const double xf                             = (lane < Lt) ? xs : xpre;
-            out.x[(unsigned long long)oi * 64 + lane]   = xf;
-            if (lane == 0)
-            {
-              out.pd[oi]    = nd;
-              out.level[oi] = k;
-              out.root[oi]  = rid;
-            }
-            FPHIP_JOIN();
-            // → next sibling at level k
-          }
-          else
-          {  // buffer full: walk everything inline from here on (results stay exact)
-            if (lane == 0)
-              atomicOr(&g->error_flags, FPHIP_FLAG_TASK_OVERFLOW);
-            FPHIP_JOIN();
-            buffer_full = true;
-            donate      = 1 << 20;
-            elo         = 1u << 20;
-            erng        = 0u;
-            hot_range();
-            continue;
-          }
-        }
-        else if (ev == EV_REPORT)
-        {
-          report(nd);
-          FPHIP_JOIN();
-        }
-      }
       if (resume_step)
       {  // (par, mk) were lost to the slow path: reload them
         const unsigned k8  = (unsigned)k << 3;
@@ -680,96 +571,219 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK) __attribute__((amdgpu_waves_p
         else
           mk = ld_row(mu_b, k8, lane8);
       }
-      resume_step = false;
-      // ================= STEP loop: next sibling at level k, climbing while they fail ===========
-      double xk, a;
+      bool at_step = resume_step;
+      resume_step  = false;
+      // ---- the hot cycle: CHILD chain -> (no surviving child) -> STEP loop -> (a sibling survives) ->
+      // CHILD chain ...  Uniform branches only, like the two loops in it: the transitions between them
+      // happen once per five nodes, and in a region the structuriser rewrites each one costs a copy of
+      // every level register plus a cascade of flag tests.  Everything else is an event for the code
+      // behind the cycle.
       for (;;)
       {
-        v4i qk           = rp_issue2(rptab, (unsigned)k << 3);
-        xk               = rl_f64(xs, k);
-        const double ck  = rl_f64(cs, k);
-        const int pdlo   = __builtin_amdgcn_readlane(__double2loint(pds), k);
-        const int pdhi   = __builtin_amdgcn_readlane(__double2hiint(pds), k);
-        const double pdk = __hiloint2double(pdhi, pdlo);
-        int dxk          = rl_i32(dxs, k);
-        // :80-89 (is_svp is always true here): zig-zag around the centre unless the partial
-        // distance above is exactly +0 (then x only grows).  pdk is a sum of squares, never -0:
-        // the test and the selection of the step are scalar-unit work.
-        int pdor = pdlo | pdhi;
-        asm volatile("" : "+s"(pdor));  // (one 32-bit OR, not a 64-bit compare of a register pair)
-        const bool zig = pdor != 0;
-        int stepi      = zig ? dxk : 1;
-        asm volatile("" : "+s"(stepi));  // (keeps the select in front of the int -> double conversion)
-        xk += (double)stepi;
-        dxk = zig ? ((dxk > 0 ? -1 : 1) - dxk) : dxk;  // ddx = -ddx; dx = ddx - dx, ddx == sign(dx)
-        xs  = sel_f64(lane_bit(k), xk, xs);
-        dxs = wl_i32(dxk, k, dxs);
-        asm volatile("" : "+v"(xs), "+v"(dxs));  // (the updates stay in front of the test: sunk behind
-                                                  //  it they would merge the loop's exits again)
-        a             = xk - ck;
-        rp_wait(qk);
-        nd = pdk + a * a * rp_r(qk);  // :91-92
-        if (__builtin_amdgcn_ballot_w64(nd <= rp_p(qk) * maxdist_v) != 0ull)
+        if (!at_step)
         {
-          ev = EV_OK;
-          break;
+          // ================= CHILD chain: descend while the first child survives ====================
+          // (state: a surviving, already counted node at level k with column S = S_k, distance nd)
+          for (;;)
+          {
+            kc                 = k - 1;
+            const unsigned kc8 = (unsigned)kc << 3;
+            v4i q1             = rp_issue2(rptab, kc8);
+            // speculative load for the descending case: row kc of mu is needed right after the test
+            // (its latency overlaps the test).  tri8(k) = 8 * tri_off(k) comes from the scalar unit: row kc
+            // starts kc elements before row k.  At kc == 0 the clamp wraps and the lanes read the
+            // head of the table (valid, unused).
+            if constexpr (MU_LDS)
+              mk1 = ld_off(mu_s, tri8(kc) + min(lane8, kc8 - 8u));
+            else  // (the square copy: scalar row address, zero beyond the row)
+              mk1 = ld_row(mu_b, kc8, lane8);
+            c1 = rl_f64(S, kc);  // center[kk-1] = center_partsums[kk-1][kk]
+            // roundto() = round(): half away from zero (enumerate_base.h:33-34), as round-to-even
+            // (one instruction) plus the correction of the ties that went towards zero
+            x1 = rint(c1);
+            a1 = x1 - c1;
+            if (fabs(a1) == 0.5 && ((a1 < 0.0) == (c1 > 0.0)))
+            {
+              x1 = x1 - (a1 + a1);
+              a1 = -a1;
+            }
+            rp_wait(q1);
+            n1 = nd + a1 * a1 * rp_r(q1);  // :28-29
+            // :31-32 (partdistbounds = pruning * maxdist); the ballot makes the test wave-uniform for
+            // the compiler although maxdist_v went through an asm statement
+            if (__builtin_amdgcn_ballot_w64(n1 <= rp_p(q1) * maxdist_v) == 0ull)
+            {  // no surviving child: next sibling at level k (the root has none: task done)
+              ev = EV_FAIL;
+              FPHIP_EXIT();
+              break;
+            }
+            unsigned sbit = (unsigned)(smask >> kc);
+            asm("" : "+s"(sbit));  // (a 32-bit test of the shifted mask: the compiler's own form adds a 64-bit compare)
+            if (sbit & 1u)
+            {  // an emission level (k == stop in the split launches, k >= donate once this task sheds
+               // work; never the task root: donate starts beyond every level and the root is only
+               // visited first) or a level above the LDS part of the stack: the general path below
+              ev = EV_SPECIAL;
+              FPHIP_EXIT();
+              break;
+            }
+            // descend: level kc becomes the current level.  S is needed again when x[kc] steps to its
+            // next sibling.  (The global part of the stack is no rare path: a quarter of the nodes of a
+            // 60-dimensional block sit above level 33 — which is why it is handled inside the loop.)
+            FPHIP_DESCEND(FPHIP_PUSH((unsigned)rl_i32(tri8tab, kc)));
+          }
+          FPHIP_OPAQUE(ev);
+          if (ev != EV_FAIL)
+            break;  // EV_SPECIAL
+          // no surviving child: next sibling at level k (the root has none: task done)
+          if (k >= Lt)
+          {
+            ev = EV_DONE;
+            break;
+          }
         }
-        // :93-94: the parent steps to its next sibling.  The loads for the surviving case at the new
-        // level are issued now: their latency (mu comes through L1 in the big launches) overlaps the
-        // next test.
-        ++k;
-        // slot k + 1 (lanes beyond the row: a valid, unused address)
-        if (__builtin_expect(k + 1 < Ts, 1))
-          par = *(const double *)(stk_top - (unsigned)rl_i32(tri8tab, k));
-        else
-        {  // (the level number hidden from the optimiser: it otherwise carries 4 k and 8 k for this
-           //  block as induction variables, two scalar adds in every iteration of the loop)
-          int kt = k;
-          asm volatile("" : "+s"(kt));
-          par = ld_off(gst, tri8(kt + 1) + min(lane8, ((unsigned)kt << 3) - 8u));
-        }
-        if constexpr (MU_LDS)
-          mk = ld_off(mu_s, tri8(k) + min(lane8, ((unsigned)k << 3) - 8u));
-        else
-          mk = ld_row(mu_b, (unsigned)k << 3, lane8);
-        if (k >= Lt)
+        at_step = false;
+        // ================= STEP loop: next sibling at level k, climbing while they fail ===========
+        for (;;)
         {
-          ev = EV_DONE;
-          break;
+          v4i qk           = rp_issue2(rptab, (unsigned)k << 3);
+          xk               = rl_f64(xs, k);
+          const double ck  = rl_f64(cs, k);
+          const int pdlo   = __builtin_amdgcn_readlane(__double2loint(pds), k);
+          const int pdhi   = __builtin_amdgcn_readlane(__double2hiint(pds), k);
+          const double pdk = __hiloint2double(pdhi, pdlo);
+          int dxk          = rl_i32(dxs, k);
+          // :80-89 (is_svp is always true here): zig-zag around the centre unless the partial
+          // distance above is exactly +0 (then x only grows).  pdk is a sum of squares, never -0:
+          // the test and the selection of the step are scalar-unit work.
+          int pdor = pdlo | pdhi;
+          asm volatile("" : "+s"(pdor));  // (one 32-bit OR, not a 64-bit compare of a register pair)
+          const bool zig = pdor != 0;
+          int stepi      = zig ? dxk : 1;
+          asm volatile("" : "+s"(stepi));  // (keeps the select in front of the int -> double conversion)
+          xk += (double)stepi;
+          dxk = zig ? ((dxk > 0 ? -1 : 1) - dxk) : dxk;  // ddx = -ddx; dx = ddx - dx, ddx == sign(dx)
+          xs  = sel_f64(lane_bit(k), xk, xs);
+          dxs = wl_i32(dxk, k, dxs);
+          asm volatile("" : "+v"(xs), "+v"(dxs));  // (the updates stay in front of the test: sunk behind
+                                                    //  it they would merge the loop's exits again)
+          a             = xk - ck;
+          rp_wait(qk);
+          nd = pdk + a * a * rp_r(qk);  // :91-92
+          if (__builtin_amdgcn_ballot_w64(nd <= rp_p(qk) * maxdist_v) != 0ull)
+          {
+            ev = EV_OK;
+            break;
+          }
+          // :93-94: the parent steps to its next sibling.  The loads for the surviving case at the new
+          // level are issued now: their latency (mu comes through L1 in the big launches) overlaps the
+          // next test.
+          ++k;
+          // slot k + 1 (lanes beyond the row: a valid, unused address)
+          if (__builtin_expect(k + 1 < Ts, 1))
+            par = *(const double *)(stk_top - (unsigned)rl_i32(tri8tab, k));
+          else
+          {  // (the level number hidden from the optimiser: it otherwise carries 4 k and 8 k for this
+             //  block as induction variables, two scalar adds in every iteration of the loop)
+            int kt = k;
+            asm volatile("" : "+s"(kt));
+            par = ld_off(gst, tri8(kt + 1) + min(lane8, ((unsigned)kt << 3) - 8u));
+          }
+          if constexpr (MU_LDS)
+            mk = ld_off(mu_s, tri8(k) + min(lane8, ((unsigned)k << 3) - 8u));
+          else
+            mk = ld_row(mu_b, (unsigned)k << 3, lane8);
+          if (k >= Lt)
+          {
+            ev = EV_DONE;
+            break;
+          }
+          if (((++iter) & 63u) == 0u)
+          {
+            ev = EV_REFRESH;
+            break;
+          }
         }
-        if (((++iter) & 63u) == 0u)
-        {
-          ev = EV_REFRESH;
-          break;
-        }
-      }
-      FPHIP_OPAQUE(ev);
-      if (ev == EV_OK)
-      {
+        FPHIP_OPAQUE(ev);
+        if (ev != EV_OK)
+          break;  // EV_DONE / EV_REFRESH
         cnt32 = add_bit(lane_bit(k), cnt32);  // ++nodes[kk]
         if constexpr (SUBS)
         {
           if (nd < rl_f64(sb, k) && nd != 0.0)
             sub_report(k, nd);
         }
-        if (k != 0)
+        if (k == 0)
         {
-          S = par - (DUAL ? a : xk) * mk;  // :104-110
-          continue;                        // → CHILD chain
+          ev = EV_LEAF;
+          break;
         }
-        // level 0, :97-101: report (nd > 0), then the next sibling of level 0
+        S = par - (DUAL ? a : xk) * mk;  // :104-110
+      }
+      // ---- events
+      FPHIP_OPAQUE(ev);
+      if (ev == EV_DONE)
+        break;
+      if (ev == EV_SPECIAL)
+      {  // EV_SPECIAL
+        if ((unsigned)(k - elo) <= erng)
+          ev = EV_EMIT;  // hand the subtree below this node to the next launch
+        else
+        {  // the descent to level 0 (or a level the mask holds for no reason): one iteration by hand
+          FPHIP_DESCEND(FPHIP_PUSH(tri8(k + 1)));
+          if (k != 0)
+            continue;  // → CHILD chain at the new level
+          ev = (nd > 0.0) ? EV_REPORT : EV_RESTEP;
+        }
+      }
+      if (ev == EV_EMIT)
+      {
+        unsigned oi = 0;
+        if (lane == 0)
+          oi = atomicAdd(out.count, 1u);
+        oi = (unsigned)__builtin_amdgcn_readfirstlane((int)oi);
+        if (oi < out.cap)
+        {
+          out.col[(unsigned long long)oi * 64 + lane] = S;
+          const double xf                             = (lane < Lt) ? xs : xpre;
+          out.x[(unsigned long long)oi * 64 + lane]   = xf;
+          if (lane == 0)
+          {
+            out.pd[oi]    = nd;
+            out.level[oi] = k;
+            out.root[oi]  = rid;
+          }
+          FPHIP_JOIN();
+          // → next sibling at level k
+        }
+        else
+        {  // buffer full: walk everything inline from here on (results stay exact)
+          if (lane == 0)
+            atomicOr(&g->error_flags, FPHIP_FLAG_TASK_OVERFLOW);
+          FPHIP_JOIN();
+          buffer_full = true;
+          donate      = 1 << 20;
+          elo         = 1u << 20;
+          erng        = 0u;
+          hot_range();
+          continue;
+        }
+      }
+      else if (ev == EV_REPORT)
+      {
+        report(nd);
+        FPHIP_JOIN();
+      }
+      else if (ev == EV_LEAF)
+      {  // level 0, :97-101: report (nd > 0), then the next sibling of level 0
         if (nd > 0.0)
         {
           report(nd);
           FPHIP_JOIN();
         }
-        resume_step = true;
-        continue;
       }
-      if (ev == EV_DONE)
-        break;
-      // EV_REFRESH (every 64 failed steps)
-      {
+      else if (ev == EV_REFRESH)
+      {  // every 64 failed steps
         cnt += cnt32;  // the per-level counters of the hot loops are 32 bits wide
         cnt32 = 0u;
         FPHIP_REFRESH_BOUND((iter & 16383u) == 0u);
@@ -789,9 +803,12 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK) __attribute__((amdgpu_waves_p
         }
         FPHIP_JOIN();
         hot_range();
-        resume_step = true;
       }
+      // next sibling at level k (the slow paths lost (par, mk): reloaded at the top)
+      resume_step = true;
     }
+#undef FPHIP_DESCEND
+#undef FPHIP_PUSH
     cnt += cnt32;
     cnt32 = 0u;
   }
