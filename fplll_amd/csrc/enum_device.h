@@ -17,6 +17,7 @@
 // doubles behind the LDS column stack of a wave (enum_phase_kernel): where the lanes beyond a short
 // row land when a 64-lane push is not masked
 #define FPHIP_STACK_PAD 64
+#define FPHIP_MUROW 66 /* doubles per row of DevShared::mu_sq */
 #define FPHIP_NQ 128
 #define FPHIP_QS 16 /* unsigned words between two counters: 64 bytes */
 
@@ -66,10 +67,12 @@ struct DevShared
   // breadth-first expansion of the top of the tree (enum_bfs_kernel): the table of the subtree-size
   // estimate (scheduling only: never affects which nodes are visited)
   float bfs_A[64][64];  // [L][k], k < L: log( V_{L-k}(1) / prod_{i=k}^{L-1} sqrt(r_ii) )
-  // rows 0..63 of mu once more, one 512-byte row per level (mu_sq[k][i] = mu(k,i), i < k, zero
-  // beyond): what the big walk launches read — the row address is a scalar add, the lane offset a
-  // loop-invariant register, no clamp (the packed rows above cost three VALU instructions per load)
-  double mu_sq[64][64];
+  // rows 0..63 of mu once more, one row of FPHIP_MUROW doubles per level: mu_sq[k][i] = mu(k,i) for
+  // i < k, zero up to 63, then (r_kk, pruning_k).  What the walk launches read per level: the mu row
+  // as a buffer load (row offset in the scalar operand, lane offset a loop-invariant register, no
+  // clamp: the packed rows above cost three VALU instructions per load) and the pair as one scalar
+  // load — both with the SAME byte offset, one scalar induction variable per loop.
+  double mu_sq[64][FPHIP_MUROW];
 };
 
 // Subtree tasks (structure of arrays; col/x rows are 64 doubles so that a wave loads them coalesced).

@@ -540,8 +540,13 @@ restart:
   {
     st->rdiag[i]   = rdiag[i];
     st->pruning[i] = pruning ? pruning[i] : 1.0;
-    st->rp[i][0]   = st->rdiag[i];  // the walk kernel reads (r_ii, pruning_i) as one scalar load
+    st->rp[i][0]   = st->rdiag[i];  // the walk kernels read (r_ii, pruning_i) as one scalar load
     st->rp[i][1]   = st->pruning[i];
+    if (i < 64)
+    {
+      st->mu_sq[i][64] = st->rdiag[i];
+      st->mu_sq[i][65] = st->pruning[i];
+    }
     st->sub_bits[i] = dbits(rdiag[i]);  // subsoldists = rdiag, enumerate.cpp:143
   }
   for (int k = 1; k < d; ++k)

@@ -72,7 +72,7 @@ __device__ __forceinline__ double ld_off(const double *row, unsigned off8)
 {
   return *(const double *)((const char *)row + off8);
 }
-// Row `row8 / 8` (512 bytes each) of the square mu table, element `lane`, as a raw buffer load: the
+// The row at byte offset `rowoff` of DevShared::mu_sq, element `lane`, as a raw buffer load: the
 // row offset rides in the instruction's scalar offset operand, the lane offset is a loop-invariant
 // register — no address arithmetic on the vector unit (a global_load needs one v_add per row, the
 // packed rows three).  Reads beyond the table return zero.
@@ -81,9 +81,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t mu_rsrc(const double *tab, uns
 {
   return __builtin_amdgcn_make_buffer_rsrc((void *)tab, 0, bytes, 0x00020000);  // (untyped 32-bit data)
 }
-__device__ __forceinline__ double ld_row(__amdgpu_buffer_rsrc_t tab, unsigned row8, unsigned lane8)
+__device__ __forceinline__ double ld_row(__amdgpu_buffer_rsrc_t tab, unsigned rowoff, unsigned lane8)
 {
-  const v2u v = __builtin_amdgcn_raw_buffer_load_b64(tab, lane8, row8 << 6, 0);
+  const v2u v = __builtin_amdgcn_raw_buffer_load_b64(tab, lane8, rowoff, 0);
   return __hiloint2double((int)v.y, (int)v.x);
 }
 // (r_ii, pruning_i) of one level straight into SGPRs through the scalar cache: the table is read-only
@@ -96,10 +96,10 @@ __device__ __forceinline__ v4i rp_issue(const double *tab, int level)
   asm volatile("s_load_dwordx4 %0, %1, %2" : "=s"(q) : "s"(tab), "s"(level << 4));
   return q;
 }
-__device__ __forceinline__ v4i rp_issue2(const double *tab, unsigned level8)
-{  // (level8 = 8 * level: the byte offset of the 16-byte pair is twice that)
+__device__ __forceinline__ v4i rp_issue2(const double *tab, unsigned off)
+{  // (off = byte offset of the level's row in DevShared::mu_sq; tab points at the pair of row 0)
   v4i q;
-  asm volatile("s_load_dwordx4 %0, %1, %2" : "=s"(q) : "s"(tab), "s"(level8 << 1));
+  asm volatile("s_load_dwordx4 %0, %1, %2" : "=s"(q) : "s"(tab), "s"(off));
   return q;
 }
 __device__ __forceinline__ void rp_wait(v4i &q) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(q)); }
@@ -220,6 +220,7 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK) __attribute__((amdgpu_waves_p
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
+  constexpr unsigned MUROW8 = FPHIP_MUROW * 8u;  // bytes per row of DevShared::mu_sq
   const unsigned lane8 = (unsigned)lane << 3;  // byte offset of this lane's element in a row
   const int triL = (Lmax * (Lmax + 1)) >> 1;  // doubles for slots 1..Lmax
   // mu rows 1..Lmax-1 (packed like the stack slots).  MU_LDS: one copy per workgroup in LDS (lowest
@@ -234,6 +235,7 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK) __attribute__((amdgpu_waves_p
   // against 4 with the whole stack of a 50-level task in LDS).
   const int nw     = (int)(blockDim.x >> 6);
   const int Ts     = min(Tsplit, Lmax + 1);
+  const int Tsm1   = Ts - 1;
   const int ldsRow = tri_off(Ts);  // doubles of LDS stack slots per wave
   // The LDS slots are laid out in DESCENDING level order: slot k (k doubles) starts
   // tri_off(Ts) - tri_off(k + 1) doubles into the wave's region, slot k - 1 right behind it.  A push
@@ -269,7 +271,7 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK) __attribute__((amdgpu_waves_p
   // slot k >= Ts at gst + tri_off(k); one spare double behind the last slot (index triL)
   double *gst = gstk + (size_t)(blockIdx.x * nw + wave) * (size_t)(triL - ldsRow + 1) - ldsRow;
 
-  const double *rptab = &g->rp[0][0];  // (r_ii, pruning_i) pairs, read through the scalar cache
+  const double *rptab = &g->mu_sq[0][64];  // (r_ii, pruning_i) behind each mu row, read through the scalar cache
   // The bound lives in two places: the pinned host word the callback thread writes, and a
   // device-memory mirror.  Waves poll the mirror (L2) often and the host word (PCIe) rarely;
   // whoever sees a smaller host value lowers the mirror for everybody.
@@ -287,7 +289,8 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK) __attribute__((amdgpu_waves_p
   int dxs = 0;  // (ddx is always sign(dx): not stored)
   unsigned long long cnt = 0;
   unsigned cnt32         = 0;
-  unsigned iter          = 0;
+  unsigned iter          = 0;   // failed steps, in units the refresh events add (64 at a time)
+  int left               = 63;  // failed steps until the next refresh event
   // findsubsols (enumerate_base.cpp:36-40): lane = level, this wave's view of the best sub-solution
   // distance per level (subsoldists); the device-wide value in g->sub_bits is authoritative
   double sb = SUBS ? __longlong_as_double((long long)g->sub_bits[lane]) : 0.0;
@@ -383,7 +386,7 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK) __attribute__((amdgpu_waves_p
     const double col0 = in.col[ti * 64 + lane];  // S_Lt rows (lane < Lt)
     const double pd0  = in.pd[ti];
     int donate        = 1 << 20;
-    const unsigned iter0 = iter;  // (iterations of this task = iter - iter0)
+    const unsigned iter0 = iter + (unsigned)(63 - left);  // (iterations of this task = iter + (63 - left) - iter0)
     FPHIP_REFRESH_BOUND((t & 63u) == 0u);
 
     // the task root is a surviving node at level Lt whose column and distance are given
@@ -523,16 +526,19 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK) __attribute__((amdgpu_waves_p
     // S_k -> slot k (LDS: all 64 lanes store, `lds8` = 8 tri_off(k + 1), see the layout above; global
     // part: the lanes beyond the row write the spare double — a select, no lane-masked branch, and
     // its operands are computed in front of it so that it stays one)
-#define FPHIP_PUSH(lds8)                                                        \
-  if (__builtin_expect(k < Ts, 1))                                              \
+#define FPHIP_PUSH(in_lds, kk, lds8)                                            \
+  if (__builtin_expect(in_lds, 1))                                              \
     *(double *)(stk_top - (lds8)) = S;                                          \
   else                                                                          \
-  {                                                                             \
-    const unsigned gk8 = ((unsigned)(k * (k - 1)) << 2) + lane8;                \
-    *(double *)((char *)gst + ((lane < k) ? gk8 : (unsigned)triL << 3)) = S;    \
+  { /* (the level hidden from the optimiser: no induction variable for this block in the loop) */ \
+    int kt = (kk);                                                              \
+    asm volatile("" : "+s"(kt));                                                \
+    const unsigned gk8 = ((unsigned)(kt * (kt - 1)) << 2) + lane8;              \
+    *(double *)((char *)gst + ((lane < kt) ? gk8 : (unsigned)triL << 3)) = S;   \
   }
-// descent to level kc (the first child survived): PUSH stores S_k for the steps of level kc
-#define FPHIP_DESCEND(PUSH)                                                                              \
+// descent to level kc (the first child survived): PUSH stores S_k for the steps of level kc, NEXT
+// moves the level variable of the caller
+#define FPHIP_DESCEND(PUSH, NEXT)                                                                              \
   do                                                                                                     \
   {                                                                                                      \
     PUSH;                                                                                                \
@@ -550,7 +556,7 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK) __attribute__((amdgpu_waves_p
     }                                                                                                    \
     par = S; /* (S_{kc+1}, row kc): what a step at the new level needs */                                \
     mk  = mk1;                                                                                           \
-    k   = kc;                                                                                            \
+    NEXT;                                                                                                \
     nd  = n1;                                                                                            \
     /* S_k = S_{k+1} - x[k]*mu(k,.), :53-58 (mk1 is row k; at k == 0 a dead value) */                    \
     S = S - (DUAL ? a1 : x1) * mk1;                                                                      \
@@ -569,7 +575,7 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK) __attribute__((amdgpu_waves_p
         if constexpr (MU_LDS)
           mk = ld_off(mu_s, tri8(k) + cl8);
         else
-          mk = ld_row(mu_b, k8, lane8);
+          mk = ld_row(mu_b, (unsigned)k * MUROW8, lane8);
       }
       bool at_step = resume_step;
       resume_step  = false;
@@ -584,11 +590,13 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK) __attribute__((amdgpu_waves_p
         {
           // ================= CHILD chain: descend while the first child survives ====================
           // (state: a surviving, already counted node at level k with column S = S_k, distance nd)
+          // (the loop carries kc = k - 1: one scalar register and one decrement per descent)
+          kc = k - 1;
           for (;;)
           {
-            kc                 = k - 1;
+            asm volatile("" : "+s"(kc));  // (keeps kc itself the carried value, decremented in place)
             const unsigned kc8 = (unsigned)kc << 3;
-            v4i q1             = rp_issue2(rptab, kc8);
+            v4i q1             = rp_issue2(rptab, (unsigned)kc * MUROW8);
             // speculative load for the descending case: row kc of mu is needed right after the test
             // (its latency overlaps the test).  tri8(k) = 8 * tri_off(k) comes from the scalar unit: row kc
             // starts kc elements before row k.  At kc == 0 the clamp wraps and the lanes read the
@@ -596,7 +604,7 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK) __attribute__((amdgpu_waves_p
             if constexpr (MU_LDS)
               mk1 = ld_off(mu_s, tri8(kc) + min(lane8, kc8 - 8u));
             else  // (the square copy: scalar row address, zero beyond the row)
-              mk1 = ld_row(mu_b, kc8, lane8);
+              mk1 = ld_row(mu_b, (unsigned)kc * MUROW8, lane8);
             c1 = rl_f64(S, kc);  // center[kk-1] = center_partsums[kk-1][kk]
             // roundto() = round(): half away from zero (enumerate_base.h:33-34), as round-to-even
             // (one instruction) plus the correction of the ties that went towards zero
@@ -630,9 +638,9 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK) __attribute__((amdgpu_waves_p
             // descend: level kc becomes the current level.  S is needed again when x[kc] steps to its
             // next sibling.  (The global part of the stack is no rare path: a quarter of the nodes of a
             // 60-dimensional block sit above level 33 — which is why it is handled inside the loop.)
-            FPHIP_DESCEND(FPHIP_PUSH((unsigned)rl_i32(tri8tab, kc)));
+            FPHIP_DESCEND(FPHIP_PUSH(kc < Ts - 1, kc + 1, (unsigned)rl_i32(tri8tab, kc)), --kc);
           }
-          FPHIP_OPAQUE(ev);
+          k = kc + 1;
           if (ev != EV_FAIL)
             break;  // EV_SPECIAL
           // no surviving child: next sibling at level k (the root has none: task done)
@@ -646,7 +654,7 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK) __attribute__((amdgpu_waves_p
         // ================= STEP loop: next sibling at level k, climbing while they fail ===========
         for (;;)
         {
-          v4i qk           = rp_issue2(rptab, (unsigned)k << 3);
+          v4i qk           = rp_issue2(rptab, (unsigned)k * MUROW8);
           xk               = rl_f64(xs, k);
           const double ck  = rl_f64(cs, k);
           const int pdlo   = __builtin_amdgcn_readlane(__double2loint(pds), k);
@@ -680,7 +688,7 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK) __attribute__((amdgpu_waves_p
           // next test.
           ++k;
           // slot k + 1 (lanes beyond the row: a valid, unused address)
-          if (__builtin_expect(k + 1 < Ts, 1))
+          if (__builtin_expect(k < Tsm1, 1))
             par = *(const double *)(stk_top - (unsigned)rl_i32(tri8tab, k));
           else
           {  // (the level number hidden from the optimiser: it otherwise carries 4 k and 8 k for this
@@ -692,19 +700,18 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK) __attribute__((amdgpu_waves_p
           if constexpr (MU_LDS)
             mk = ld_off(mu_s, tri8(k) + min(lane8, ((unsigned)k << 3) - 8u));
           else
-            mk = ld_row(mu_b, (unsigned)k << 3, lane8);
+            mk = ld_row(mu_b, (unsigned)k * MUROW8, lane8);
           if (k >= Lt)
           {
             ev = EV_DONE;
             break;
           }
-          if (((++iter) & 63u) == 0u)
-          {
+          if (--left < 0)
+          {  // (every 64 failed steps; a countdown: one scalar instruction less than a masked counter)
             ev = EV_REFRESH;
             break;
           }
         }
-        FPHIP_OPAQUE(ev);
         if (ev != EV_OK)
           break;  // EV_DONE / EV_REFRESH
         cnt32 = add_bit(lane_bit(k), cnt32);  // ++nodes[kk]
@@ -730,7 +737,8 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK) __attribute__((amdgpu_waves_p
           ev = EV_EMIT;  // hand the subtree below this node to the next launch
         else
         {  // the descent to level 0 (or a level the mask holds for no reason): one iteration by hand
-          FPHIP_DESCEND(FPHIP_PUSH(tri8(k + 1)));
+          kc = k - 1;
+          FPHIP_DESCEND(FPHIP_PUSH(k < Ts, k, tri8(k + 1)), k = kc);
           if (k != 0)
             continue;  // → CHILD chain at the new level
           ev = (nd > 0.0) ? EV_REPORT : EV_RESTEP;
@@ -786,6 +794,8 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK) __attribute__((amdgpu_waves_p
       {  // every 64 failed steps
         cnt += cnt32;  // the per-level counters of the hot loops are 32 bits wide
         cnt32 = 0u;
+        iter += 64u;
+        left = 63;
         FPHIP_REFRESH_BOUND((iter & 16383u) == 0u);
         const unsigned titer = iter - iter0;
         if (budget != 0u && titer >= 256u && !buffer_full)
@@ -817,7 +827,7 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK) __attribute__((amdgpu_waves_p
   if (count_nodes && cnt != 0)
     atomicAdd(&g->nodes[lane], cnt);
   if (lane == 0)
-    atomicAdd(&g->iters, (unsigned long long)iter);
+    atomicAdd(&g->iters, (unsigned long long)(iter + (unsigned)(63 - left)));
 }
 
 #define FPHIP_INST(M, S, D)                                                                            \
