@@ -66,6 +66,23 @@ __device__ __forceinline__ double rl_f64(double v, int lane)
   return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ int rl_i32(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+// The same value through the LDS crossbar (ds_bpermute_b32: every lane reads lane `addr4 / 4`; no LDS
+// memory involved): v_readlane_b32 occupies the vector ALU for TWO issue slots (measured:
+// tests/perf/micro/valu_rates.hip), and the walk is bound by exactly that port while the LDS port idles.
+// The result sits in a VGPR (wave-uniform in value, lane-varying for the compiler): fine where it feeds
+// vector arithmetic; conditions derived from it go through a ballot.
+__device__ __forceinline__ int bp_i32(int v, int addr4) { return __builtin_amdgcn_ds_bpermute(addr4, v); }
+__device__ __forceinline__ double bp_f64(double v, int addr4)
+{
+  return __hiloint2double(bp_i32(__double2hiint(v), addr4), bp_i32(__double2loint(v), addr4));
+}
+// 4 * level in a VGPR: the address operand of the bpermutes of one level
+__device__ __forceinline__ int lane_addr(int level)
+{
+  int a = level << 2;
+  asm("" : "+v"(a));
+  return a;
+}
 // element `off8 / 8` of the row at the wave-uniform pointer `row`: scalar base + 32-bit lane offset
 // (the global_load saddr form / one v_add for LDS) instead of a 64-bit address per lane
 __device__ __forceinline__ double ld_off(const double *row, unsigned off8)
@@ -542,9 +559,9 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK) __attribute__((amdgpu_waves_p
   do                                                                                                     \
   {                                                                                                      \
     PUSH;                                                                                                \
-    const int s1                = (c1 >= x1) ? 1 : -1; /* :71 / :114 (dx = ddx = s1, ddx = sign(dx)) */   \
+    const int s1 = __builtin_amdgcn_ballot_w64(c1 >= x1) != 0ull ? 1 : -1; /* :71 / :114 (dx = ddx) */    \
     const unsigned long long me = lane_bit(kc);                                                          \
-    cs                          = wl_f64(c1, kc, cs);                                                    \
+    cs                          = sel_f64(me, c1, cs);                                                   \
     xs                          = sel_f64(me, x1, xs);                                                   \
     pds                         = sel_f64(me, nd, pds);                                                  \
     dxs                         = wl_i32(s1, kc, dxs);                                                   \
@@ -605,15 +622,19 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK) __attribute__((amdgpu_waves_p
               mk1 = ld_off(mu_s, tri8(kc) + min(lane8, kc8 - 8u));
             else  // (the square copy: scalar row address, zero beyond the row)
               mk1 = ld_row(mu_b, (unsigned)kc * MUROW8, lane8);
-            c1 = rl_f64(S, kc);  // center[kk-1] = center_partsums[kk-1][kk]
+            const int ka = lane_addr(kc);
+            c1           = bp_f64(S, ka);  // center[kk-1] = center_partsums[kk-1][kk]
             // roundto() = round(): half away from zero (enumerate_base.h:33-34), as round-to-even
             // (one instruction) plus the correction of the ties that went towards zero
             x1 = rint(c1);
             a1 = x1 - c1;
-            if (fabs(a1) == 0.5 && ((a1 < 0.0) == (c1 > 0.0)))
-            {
-              x1 = x1 - (a1 + a1);
-              a1 = -a1;
+            if (__builtin_amdgcn_ballot_w64(fabs(a1) == 0.5) != 0ull)
+            {  // (a tie: rare; the correction itself is a pair of selects — the empty statement keeps the
+               //  optimiser from flattening the block into eleven instructions executed for every node)
+              asm volatile("");
+              const bool fix = (a1 < 0.0) == (c1 > 0.0);
+              x1             = fix ? x1 - (a1 + a1) : x1;
+              a1             = fix ? -a1 : a1;
             }
             rp_wait(q1);
             n1 = nd + a1 * a1 * rp_r(q1);  // :28-29
@@ -638,7 +659,7 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK) __attribute__((amdgpu_waves_p
             // descend: level kc becomes the current level.  S is needed again when x[kc] steps to its
             // next sibling.  (The global part of the stack is no rare path: a quarter of the nodes of a
             // 60-dimensional block sit above level 33 — which is why it is handled inside the loop.)
-            FPHIP_DESCEND(FPHIP_PUSH(kc < Ts - 1, kc + 1, (unsigned)rl_i32(tri8tab, kc)), --kc);
+            FPHIP_DESCEND(FPHIP_PUSH(kc < Ts - 1, kc + 1, (unsigned)bp_i32(tri8tab, ka)), --kc);
           }
           k = kc + 1;
           if (ev != EV_FAIL)
@@ -652,11 +673,14 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK) __attribute__((amdgpu_waves_p
         }
         at_step = false;
         // ================= STEP loop: next sibling at level k, climbing while they fail ===========
+        int ka = lane_addr(k);  // (4 k in a VGPR, carried: the address of this level's bpermutes)
         for (;;)
         {
           v4i qk           = rp_issue2(rptab, (unsigned)k * MUROW8);
-          xk               = rl_f64(xs, k);
-          const double ck  = rl_f64(cs, k);
+          // x[k] and its centre feed vector arithmetic only: through the LDS crossbar; the partial
+          // distance above and the step select the zig-zag on the scalar unit: v_readlane
+          xk               = bp_f64(xs, ka);
+          const double ck  = bp_f64(cs, ka);
           const int pdlo   = __builtin_amdgcn_readlane(__double2loint(pds), k);
           const int pdhi   = __builtin_amdgcn_readlane(__double2hiint(pds), k);
           const double pdk = __hiloint2double(pdhi, pdlo);
@@ -688,8 +712,9 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK) __attribute__((amdgpu_waves_p
           // next test.
           ++k;
           // slot k + 1 (lanes beyond the row: a valid, unused address)
+          ka += 4;
           if (__builtin_expect(k < Tsm1, 1))
-            par = *(const double *)(stk_top - (unsigned)rl_i32(tri8tab, k));
+            par = *(const double *)(stk_top - (unsigned)bp_i32(tri8tab, ka));
           else
           {  // (the level number hidden from the optimiser: it otherwise carries 4 k and 8 k for this
              //  block as induction variables, two scalar adds in every iteration of the loop)
@@ -741,7 +766,7 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK) __attribute__((amdgpu_waves_p
           FPHIP_DESCEND(FPHIP_PUSH(k < Ts, k, tri8(k + 1)), k = kc);
           if (k != 0)
             continue;  // → CHILD chain at the new level
-          ev = (nd > 0.0) ? EV_REPORT : EV_RESTEP;
+          ev = (__builtin_amdgcn_ballot_w64(nd > 0.0) != 0ull) ? EV_REPORT : EV_RESTEP;
         }
       }
       if (ev == EV_EMIT)
@@ -784,7 +809,7 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK) __attribute__((amdgpu_waves_p
       }
       else if (ev == EV_LEAF)
       {  // level 0, :97-101: report (nd > 0), then the next sibling of level 0
-        if (nd > 0.0)
+        if (__builtin_amdgcn_ballot_w64(nd > 0.0) != 0ull)
         {
           report(nd);
           FPHIP_JOIN();

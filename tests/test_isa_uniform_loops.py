@@ -103,9 +103,8 @@ def test_hot_loops_are_free_of_exec_masking_and_copy_storms(artefacts):
     """The CHILD chain (recognised by its v_rndne_f64: roundto) and the STEP loop (v_cvt_f64_i32: the
     zig-zag step) of the big-launch kernel: no exec manipulation, k in an SGPR (no v_readfirstlane
     round trip), at most a handful of register moves, and instruction counts within the budget the
-    measured 53 VALU + 41 SALU + 13 branch instructions per node correspond to (static counts of ALL
-    blocks of a loop, the rare tie-rounding and global-stack blocks included); the kernel keeps 8 waves
-    per SIMD (64 VGPRs)."""
+    per-node PMC figures of DESIGN.md section 3 correspond to (static counts of ALL blocks of a loop, the
+    rare tie-rounding and global-stack blocks included); the kernel keeps 8 waves per SIMD (64 VGPRs)."""
     _, asm = artefacts
     body = _kernel_body(asm, WALK)
     found = {}
@@ -120,11 +119,15 @@ def test_hot_loops_are_free_of_exec_masking_and_copy_storms(artefacts):
         found[key] = dict(valu=valu, salu=salu, mov=sum(s.startswith("v_mov") for s in seg),
                           # writes of the exec mask (reading it to form vcc / scc is the uniform-branch idiom)
                           execs=sum(bool(re.match(r"s_\w+\s+exec\b", s)) or "saveexec" in s for s in seg),
-                          rfl=sum(s.startswith("v_readfirstlane") for s in seg))
+                          rfl=sum(s.startswith("v_readfirstlane") for s in seg),
+                          # v_readlane_b32 occupies the vector ALU for two issue slots
+                          # (tests/perf/micro/valu_rates.hip): broadcasts that feed vector arithmetic go
+                          # through ds_bpermute_b32 instead
+                          rl=sum(s.startswith("v_readlane") for s in seg))
     assert set(found) == {"child", "step"}, found
-    for key, lim in (("child", dict(valu=44, salu=20, mov=6)), ("step", dict(valu=28, salu=30, mov=3))):
+    for key, lim in (("child", dict(valu=44, salu=18, mov=8, rl=0)), ("step", dict(valu=22, salu=28, mov=1, rl=3))):
         f = found[key]
         assert f["execs"] == 0 and f["rfl"] == 0, (key, f)
-        assert f["valu"] <= lim["valu"] and f["salu"] <= lim["salu"] and f["mov"] <= lim["mov"], (key, f)
+        assert all(f[q] <= lim[q] for q in lim), (key, f)
     m = re.search(re.escape(WALK) + r"[^\n]*\n(?:.*\n)*?\s*\.vgpr_count:\s+(\d+)", asm[asm.index(".amdgpu_metadata"):])
     assert m and int(m.group(1)) <= 64, m and m.group(1)
