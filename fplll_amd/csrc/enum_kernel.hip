@@ -26,18 +26,22 @@
 // * Backtracking needs S_{k+1} again when the next sibling x[k] is tried, so each wave keeps a
 //   triangular stack of columns S_1..S_L (slot k holds k doubles, lane i touches only row i →
 //   conflict-free ds_read_b64/ds_write_b64, no cross-lane traffic through LDS).  In the big walk
-//   launches the stack is SPLIT: slots below level 36 (where 9 nodes out of 10 of a pruned tree
-//   live) in LDS, the tall, rarely touched ones in a per-wave scratch in global memory — 5 KB of
-//   LDS per wave instead of 10, i.e. 8 resident waves per SIMD instead of 4.  mu rows (row k =
-//   mu(k,0..k-1), same triangular packing) are staged per workgroup in LDS in the small launches
-//   and read through L1 in the big ones.
-// * The walk is issue-bound, and on this machine the scalar unit issues as slowly as the vector
-//   unit (one instruction per SIMD turn): the two hot loops are written for the SUM of both —
-//   wave-uniform branches only (the file is compiled with -structurizecfg-skip-uniform-regions,
-//   see the comment at the loops), incremental triangular offsets, the step's column / mu row
-//   kept in registers across the CHILD → STEP hand-over, 32-bit level counters.  PMC, round 2:
-//   58 VALU + 38 SALU + 14 branch instructions per counted node (round 1: 92 + 49; the first
-//   uniform-loop version 51 + 87 — scalar-bound), 83 % of the vector issue slots used.
+//   launches the stack is SPLIT: slots below level 34 in LDS — laid out in DESCENDING level order, so
+//   that a push is one unmasked 64-lane store (see the kernel) — the tall ones (a quarter of the
+//   nodes of a 60-dimensional block) in a per-wave scratch in global memory: 5 KB of LDS per wave
+//   instead of 10, i.e. 8 resident waves per SIMD instead of 4.  mu rows are staged per workgroup
+//   in LDS in the small launches (triangular packing) and read through L1 in the big ones (one
+//   padded row per level, the (r, pruning) pair behind it: a buffer load and a scalar load with
+//   the same scalar offset).
+// * The walk is issue-bound on TWO ports that cost the same per instruction (one issue per SIMD
+//   turn of four cycles): the vector ALU, and the scalar ALU + branch unit together.  The hot
+//   loops are written for both: wave-uniform branches only (-structurizecfg-skip-uniform-regions,
+//   no front-end cleanup blocks: -disable-lifetime-markers), the CHILD chain and the STEP loop
+//   inside ONE cycle of uniform branches, lane masks built on the scalar unit, addresses as scalar
+//   offsets of buffer loads, and — v_readlane_b32 occupies the vector ALU for two issue slots
+//   (tests/perf/micro/valu_rates.hip) — broadcasts that feed vector arithmetic through
+//   ds_bpermute_b32 on the otherwise idle LDS port.  PMC per counted node, round 3: 40.6 VALU +
+//   28.6 SALU + 10.2 branch + 8.4 LDS instructions (round 2: 58 + 38 + 14 + 1.5; round 1: 92 + 49).
 // * The tree is split level-wise into phases: a phase walks every input task (a subtree root at
 //   level L) down to a stop level and emits each surviving node there as a task for the next
 //   phase (root column S, partial distance, coefficient prefix).  The final phase walks to the
@@ -498,15 +502,15 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK) __attribute__((amdgpu_waves_p
         __hip_atomic_store(&r->seq, idx + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     };
 
-    // The walk is two hot loops (CHILD chain, STEP loop) inside an outer event loop.  The hot loops
-    // hold wave-uniform branches only — everything that needs a lane-masked branch (emitting a
-    // task, reporting a candidate, refreshing the bound) happens BETWEEN them — and this file is
+    // The walk is two hot loops (CHILD chain, STEP loop) inside one hot cycle inside an outer event
+    // loop.  The cycle holds wave-uniform branches only — everything that needs a lane-masked branch
+    // (emitting a task, reporting a candidate, refreshing the bound) happens BEHIND it — and this file is
     // compiled with -structurizecfg-skip-uniform-regions: the AMDGPU backend otherwise rewrites
     // every region that holds one divergent branch with exit codes, flag registers and a copy of
     // every live register per iteration (16 of the 45 VALU and most of the 49 SALU instructions of
     // a step were that).  FPHIP_OPAQUE on the event code behind a loop keeps the loop's exits on
-    // one successor block.  The scalar unit issues as slowly as the vector unit here (one
-    // instruction per SIMD turn), so scalar work is counted like vector work.
+    // one successor block.  Scalar and branch instructions share one issue port that is as slow as
+    // the vector ALU's (one instruction per SIMD turn): scalar work is counted like vector work.
     enum : int { EV_CHILD = 0, EV_EMIT = 1, EV_REPORT = 2, EV_DONE = 3, EV_RESTEP = 4, EV_OK = 5, EV_REFRESH = 6,
                  EV_SPECIAL = 7, EV_FAIL = 8, EV_LEAF = 9 };
     // Levels whose surviving first children are handed to the next launch: [elo, elo + erng].  The
