@@ -17,7 +17,7 @@
 // Every expression keeps the reference's operation order (the coefficients come out of thousands of
 // comparisons of floating-point cost values: the parity bar is bit-identical coefficients,
 // tests/test_pruner_cpu.py against the real reference), including its integer divisions and float casts.
-// Not offered: PRUNER_NELDER_MEAD, several bases at once, FT other than double.
+// Not offered: PRUNER_VERBOSE, FT other than double.
 //
 // Why it lives in this library: the strategy-BKZ host service uses single_enum_cost as its measure of a
 // block's tree when it decides which enumerations go to the multi-wave enumerator (gso_host.hip), and a
@@ -72,7 +72,21 @@ struct Pruner
   Pruner(double radius, double preproc, const vec &gso_r, double target_, int metric_, int flags_)
       : enumeration_radius(radius), preproc_cost(preproc), target(target_), metric(metric_), flags(flags_)
   {
-    n = (int)gso_r.size();
+    check_and_size((int)gso_r.size());
+    load_basis_shape(gso_r);
+  }
+  // several bases at once (pruner.h:325-331): the cost is averaged over their shapes
+  Pruner(double radius, double preproc, const std::vector<vec> &gso_rs, double target_, int metric_, int flags_)
+      : enumeration_radius(radius), preproc_cost(preproc), target(target_), metric(metric_), flags(flags_)
+  {
+    if (gso_rs.empty())
+      throw std::invalid_argument("no basis");
+    check_and_size((int)gso_rs[0].size());
+    load_basis_shapes(gso_rs);
+  }
+  void check_and_size(int n_)
+  {
+    n = n_;
     d = n / 2;
     if (flags & PR_CVP)
       symmetry_factor = 1;
@@ -95,11 +109,10 @@ struct Pruner
     }
     else
       throw std::invalid_argument("unknown metric");
-    load_basis_shape(gso_r);
   }
 
   // ---- pruner_util.cpp ------------------------------------------------------------------------
-  void load_basis_shape(const vec &gso_r)
+  void load_basis_shape(const vec &gso_r, bool reset_normalization = true)
   {
     shape_loaded = true;
     double tmp;
@@ -113,8 +126,11 @@ struct Pruner
       r_old[i] = gso_r[i];
       logvol += std::log(r[i]);
     }
-    normalization_factor = std::exp(logvol / ((float)(-n)));
-    normalized_radius    = std::sqrt(enumeration_radius * normalization_factor);
+    if (reset_normalization)
+    {
+      normalization_factor = std::exp(logvol / ((float)(-n)));
+      normalized_radius    = std::sqrt(enumeration_radius * normalization_factor);
+    }
     for (int i = 0; i < n; ++i)
       r[i] *= normalization_factor;
     tmp = 1.;
@@ -123,6 +139,23 @@ struct Pruner
       tmp *= std::sqrt(r[i]);
       ipv[i] = 1.0 / tmp;
     }
+  }
+  // pruner_util.cpp:66-92: every basis is loaded in turn — normalised by the FIRST one's volume — and
+  // the inverse partial volumes are averaged; r / r_old / logvol stay those of the last basis loaded
+  void load_basis_shapes(const std::vector<vec> &gso_rs)
+  {
+    vec sum_ipv(n, 0.);
+    const int count = (int)gso_rs.size();
+    for (int k = 0; k < count; ++k)
+    {
+      if ((int)gso_rs[k].size() != n)
+        throw std::runtime_error("loading several bases with different dimensions");
+      load_basis_shape(gso_rs[k], k == 0);
+      for (int i = 0; i < n; ++i)
+        sum_ipv[i] += ipv[i];
+    }
+    for (int i = 0; i < n; ++i)
+      ipv[i] = sum_ipv[i] / (1.0 * count);
   }
   double gaussian_heuristic() const
   {
@@ -481,12 +514,130 @@ struct Pruner
     min_step = old_min_step;
     return 0;
   }
+  // PRUNER_NELDER_MEAD (pruner_optimize_tc.cpp:581-825): one run of the downhill-simplex search from b,
+  // returns whether the cost went down by the factor min_cf_decrease (the caller repeats while it does).
+  // The search is ordinary Nelder-Mead (reflection 1, expansion 2, contraction 1/2, shrink 1/2); what
+  // has to match the reference for identical coefficients are its particulars: the start simplex
+  // (b and, per coordinate, b with that coordinate moved by 0.01 towards 1/2), `enforce` after every
+  // move, the way worst / second worst / best are picked (the worst is compared with the CURRENT best
+  // while the best is still being searched), and the stop rule (every dim + 1 steps: stop unless the
+  // worst vertex improved by min_cf_decrease since the last check).
+  int nelder_mead_step(vec &b)
+  {
+    const int dn = (int)b.size(), nv = dn + 1;
+    std::vector<vec> vert(nv);
+    vec val(nv);
+    for (int i = 0; i < nv; ++i)
+    {
+      vert[i] = b;
+      if (i < dn)
+        vert[i][i] += (vert[i][i] < .5) ? 0.01 : -0.01;
+      enforce(vert[i]);
+      val[i] = target_function(vert[i]);
+    }
+    const double start_value = val[nv - 1];
+    vec centre(dn), moved(dn);
+    double worst_at_last_check = val[0];
+    unsigned steps             = 0;
+    int best = 0, worst = 0, second = 0;
+    for (;;)
+    {
+      best = worst = second = 0;
+      for (int i = 0; i < dn; ++i)
+        centre[i] = vert[0][i];
+      for (int i = 1; i < nv; ++i)
+      {
+        best  = (val[i] < val[best]) ? i : best;
+        worst = (val[i] > val[best]) ? i : worst;
+        for (int j = 0; j < dn; ++j)
+          centre[j] += vert[i][j];
+      }
+      const double count = nv;
+      for (int i = 0; i < dn; ++i)
+        centre[i] /= count;  // (of ALL vertices, the worst included: the reference's centroid)
+      if (!steps)
+        worst_at_last_check = val[worst];
+      second += (!worst);
+      for (int i = 1; i < nv; ++i)
+        second = ((val[i] > val[second]) && (i != worst)) ? i : second;
+      if (enforce(centre))
+        throw std::runtime_error("Concavity says that should not happen.");
+      ++steps;
+      if (!(steps % (unsigned)nv))
+      {
+        if (val[worst] > worst_at_last_check * min_cf_decrease)
+          break;
+        worst_at_last_check = val[worst];
+      }
+      for (int i = 0; i < nv; ++i)
+        if ((val[i] > val[second]) && (i != worst))
+          second = i;
+      // reflection of the worst vertex through the centroid
+      for (int i = 0; i < dn; ++i)
+        moved[i] = centre[i] + 1.0 * (centre[i] - vert[worst][i]);
+      enforce(moved);
+      const double reflected = target_function(moved);
+      if ((val[best] <= reflected) && (reflected < val[second]))
+      {
+        vert[worst] = moved;
+        val[worst]  = reflected;
+        continue;
+      }
+      if (reflected < val[best])
+      {  // expansion: twice as far; keep the better of the two
+        vec farther(dn);
+        for (int i = 0; i < dn; ++i)
+          farther[i] = centre[i] + 2.0 * (moved[i] - centre[i]);
+        enforce(farther);
+        const double expanded = target_function(farther);
+        if (expanded < reflected)
+        {
+          vert[worst] = farther;
+          val[worst]  = expanded;
+        }
+        else
+        {
+          vert[worst] = moved;
+          val[worst]  = reflected;
+        }
+        continue;
+      }
+      if (!(reflected >= val[second]))
+        throw std::runtime_error("Something certain is false in Nelder-Mead.");
+      // contraction towards the worst vertex
+      vec nearer(dn);
+      for (int i = 0; i < dn; ++i)
+        nearer[i] = centre[i] + 0.5 * (vert[worst][i] - centre[i]);
+      enforce(nearer);
+      const double contracted = target_function(nearer);
+      if (contracted < val[worst])
+      {
+        vert[worst] = nearer;
+        val[worst]  = contracted;
+        continue;
+      }
+      // shrink every vertex towards the best one
+      for (int j = 0; j < nv; ++j)
+      {
+        for (int i = 0; i < dn; ++i)
+          vert[j][i] = vert[best][i] + 0.5 * (vert[j][i] - vert[best][i]);
+        enforce(vert[j]);
+        val[j] = target_function(vert[j]);
+      }
+    }
+    b = vert[best];
+    return (start_value * min_cf_decrease) > val[best];
+  }
   void optimize_coefficients_evec_core(vec &pr)
   {
     vec b(d);
     load_coefficients(b, pr);
     if (flags & PR_GRADIENT)
       gradient_descent(b);
+    if (flags & PR_NELDER_MEAD)
+      while (nelder_mead_step(b))
+      {
+      }
     save_coefficients(pr, b);
   }
   void optimize_coefficients_full_core(vec &pr)
@@ -495,6 +646,10 @@ struct Pruner
     load_coefficients(b, pr);
     if (flags & PR_GRADIENT)
       gradient_descent(b);
+    if (flags & PR_NELDER_MEAD)
+      while (nelder_mead_step(b))
+      {
+      }
     save_coefficients(pr, b);
   }
   void optimize_coefficients_preparation(vec &pr)
@@ -880,7 +1035,7 @@ extern "C" int fphip_pruner_prune(int n, const double *gso_r, double enumeration
 {
   if (n < 2 || n >= FPHIP_PRUNER_TABLE_N || !gso_r || !coefficients)
     return FPHIP_ERROR;
-  if (flags & (PR_NELDER_MEAD | 0x10 /* PRUNER_VERBOSE */))
+  if (flags & 0x10 /* PRUNER_VERBOSE */)
     return FPHIP_UNSUPPORTED;
   try
   {
@@ -906,6 +1061,44 @@ extern "C" int fphip_pruner_prune(int n, const double *gso_r, double enumeration
   catch (const std::exception &)
   {
     return FPHIP_ERROR;  // (the reference throws on NaN / inf: "using a higher precision sometimes helps")
+  }
+}
+
+extern "C" int fphip_pruner_prune_multi(int n, int count, const double *gso_rs, double enumeration_radius,
+                                        double preproc_cost, double target, int metric, int flags,
+                                        double *coefficients, double *expectation, double *gh_factor,
+                                        double *detailed_cost)
+{
+  if (n < 2 || n >= FPHIP_PRUNER_TABLE_N || count < 1 || !gso_rs || !coefficients)
+    return FPHIP_ERROR;
+  if (flags & 0x10 /* PRUNER_VERBOSE */)
+    return FPHIP_UNSUPPORTED;
+  try
+  {
+    std::vector<vec> rs;
+    for (int c = 0; c < count; ++c)
+      rs.emplace_back(gso_rs + (size_t)c * n, gso_rs + (size_t)(c + 1) * n);
+    Pruner pruner(enumeration_radius, preproc_cost, rs, target, metric, flags);
+    vec pr;
+    if (flags & PR_START_FROM_INPUT)
+      pr.assign(coefficients, coefficients + n);
+    pruner.optimize_coefficients(pr);
+    vec dc;
+    pruner.single_enum_cost_pr(pr, &dc);
+    for (int i = 0; i < n; ++i)
+      coefficients[i] = pr[i];
+    if (detailed_cost)
+      for (int i = 0; i < n; ++i)
+        detailed_cost[i] = i < (int)dc.size() ? dc[i] : 0.0;
+    if (gh_factor)
+      *gh_factor = enumeration_radius / pruner.gaussian_heuristic();
+    if (expectation)
+      *expectation = pruner.measure_metric_pr(pr);
+    return FPHIP_OK;
+  }
+  catch (const std::exception &)
+  {
+    return FPHIP_ERROR;
   }
 }
 

@@ -10,6 +10,8 @@ from . import _lib
 PRUNER_METRIC_PROBABILITY_OF_SHORTEST = 0
 PRUNER_METRIC_EXPECTED_SOLUTIONS = 1
 PRUNER_CVP, PRUNER_START_FROM_INPUT, PRUNER_GRADIENT, PRUNER_HALF, PRUNER_SINGLE = 0x1, 0x2, 0x4, 0x20, 0x40
+PRUNER_NELDER_MEAD = 0x8
+PRUNER_ZEALOUS = PRUNER_GRADIENT | PRUNER_NELDER_MEAD
 
 
 class PruningParams:
@@ -26,9 +28,12 @@ def _dp(a):
 
 def prune(enumeration_radius, preproc_cost, gso_r, target=0.9, metric=PRUNER_METRIC_PROBABILITY_OF_SHORTEST,
           flags=PRUNER_GRADIENT, start=None):
-    """prune<FP_NR<double>>(pruning, radius, preproc_cost, gso_r, target, metric, flags)."""
+    """prune<FP_NR<double>>(pruning, radius, preproc_cost, gso_r, target, metric, flags); gso_r may be one
+    profile or a list of profiles of equal length (the reference's overload for several bases)."""
     lib = _lib.load()
     r = np.ascontiguousarray(gso_r, dtype=np.float64)
+    if r.ndim == 2:
+        return _prune_multi(lib, enumeration_radius, preproc_cost, r, target, metric, flags, start)
     n = r.size
     co = np.zeros(n, dtype=np.float64)
     if start is not None:
@@ -43,7 +48,28 @@ def prune(enumeration_radius, preproc_cost, gso_r, target=0.9, metric=PRUNER_MET
     rc = fn(n, _dp(r), float(enumeration_radius), float(preproc_cost), float(target), int(metric), int(flags),
             _dp(co), ctypes.byref(ex), ctypes.byref(gh), _dp(dc))
     if rc == _lib.FPHIP_UNSUPPORTED:
-        raise NotImplementedError("PRUNER_NELDER_MEAD / PRUNER_VERBOSE are not offered")
+        raise NotImplementedError("PRUNER_VERBOSE is not offered")
+    if rc != _lib.FPHIP_OK:
+        raise RuntimeError("prune failed (the reference throws here: NaN / inf in a cost value, or a bad target)")
+    return PruningParams(gh.value, co, ex.value, metric, dc)
+
+
+def _prune_multi(lib, enumeration_radius, preproc_cost, rs, target, metric, flags, start):
+    count, n = rs.shape
+    co = np.zeros(n, dtype=np.float64)
+    if start is not None:
+        co[:] = np.asarray(start, dtype=np.float64)
+    dc = np.zeros(n, dtype=np.float64)
+    ex, gh = ctypes.c_double(0), ctypes.c_double(0)
+    fn = lib.fphip_pruner_prune_multi
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                   ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_double),
+                   ctypes.POINTER(ctypes.c_double), ctypes.c_void_p]
+    rc = fn(n, count, _dp(rs), float(enumeration_radius), float(preproc_cost), float(target), int(metric),
+            int(flags), _dp(co), ctypes.byref(ex), ctypes.byref(gh), _dp(dc))
+    if rc == _lib.FPHIP_UNSUPPORTED:
+        raise NotImplementedError("PRUNER_VERBOSE is not offered")
     if rc != _lib.FPHIP_OK:
         raise RuntimeError("prune failed (the reference throws here: NaN / inf in a cost value, or a bad target)")
     return PruningParams(gh.value, co, ex.value, metric, dc)

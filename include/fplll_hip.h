@@ -270,19 +270,26 @@ int fphip_gso_lll_ladder(fphip_gso *g, int kappa_min, int kappa_start, int kappa
  * fphip_pruner_prune = prune<FP_NR<double>>(pruning, enumeration_radius, preproc_cost, gso_r, target,
  * metric, flags) (pruner/pruner.h:187-193, pruner.cpp:190-203): searches pruning coefficients that
  * minimise (cost of one enumeration x trials + preproc_cost x (trials - 1)) for the block whose squared
- * Gram-Schmidt lengths are gso_r[0..n) — greedy start, gradient descent on the even-indexed
- * coefficients, local tuning, gradient descent on all of them (pruner_optimize*.cpp) — bit-identical
- * coefficients to the reference's (every expression in its operation order; host libm).
+ * Gram-Schmidt lengths are gso_r[0..n) — greedy start, gradient descent and / or the Nelder-Mead search
+ * (pruner_optimize_tc.cpp:581-825) on the even-indexed coefficients, local tuning, the same searches on
+ * all of them (pruner_optimize*.cpp) — bit-identical coefficients to the reference's (every expression
+ * in its operation order; host libm).
  *   metric 0 = PRUNER_METRIC_PROBABILITY_OF_SHORTEST (0 < target < 1), 1 = PRUNER_METRIC_EXPECTED_SOLUTIONS
  *   flags: fplll's PRUNER_CVP 0x1, PRUNER_START_FROM_INPUT 0x2 (coefficients is then an input too),
- *          PRUNER_GRADIENT 0x4, PRUNER_HALF 0x20, PRUNER_SINGLE 0x40; PRUNER_NELDER_MEAD 0x8 and
- *          PRUNER_VERBOSE 0x10 → FPHIP_UNSUPPORTED
+ *          PRUNER_GRADIENT 0x4, PRUNER_NELDER_MEAD 0x8 (both = PRUNER_ZEALOUS), PRUNER_HALF 0x20,
+ *          PRUNER_SINGLE 0x40; PRUNER_VERBOSE 0x10 → FPHIP_UNSUPPORTED
  *   coefficients[n] (out), expectation = the metric of the result, gh_factor = radius / Gaussian
  *   heuristic, detailed_cost[n] (nullable) = expected nodes per level — the fields of PruningParams.
  * FPHIP_ERROR where the reference throws (NaN / inf in a cost value, bad target). */
 int fphip_pruner_prune(int n, const double *gso_r, double enumeration_radius, double preproc_cost, double target,
                        int metric, int flags, double *coefficients, double *expectation, double *gh_factor,
                        double *detailed_cost);
+/* The overload for SEVERAL bases (pruner.h:200-221, pruner.cpp:214-227; Pruner::load_basis_shapes,
+ * pruner_util.cpp:66-92): gso_rs = count profiles of n values each, row-major; the cost is averaged
+ * over their shapes (normalised by the volume of the first). */
+int fphip_pruner_prune_multi(int n, int count, const double *gso_rs, double enumeration_radius, double preproc_cost,
+                             double target, int metric, int flags, double *coefficients, double *expectation,
+                             double *gh_factor, double *detailed_cost);
 /* svp_probability<FP_NR<double>>(pr) (pruner.cpp:166-176): probability that the enumeration pruned with
  * pr[0..n) still contains the shortest vector. */
 int fphip_pruner_svp_probability(int n, const double *pr, double *probability);

@@ -1067,6 +1067,60 @@ static int cmd_prunefix(int argc, char **argv)
   return 0;
 }
 
+/* prunemulti basisfile first d count stride gh_factor preproc_cost target metric flags
+ *   → JSON: the reference's prune<FP_NR<double>> over SEVERAL bases (pruner/pruner.cpp:214-227,
+ *   Pruner::load_basis_shapes pruner_util.cpp:66-92): the r-profiles of the `count` blocks
+ *   [first + i stride, first + i stride + d), radius from the first block as in prunefix. */
+static int cmd_prunemulti(int argc, char **argv)
+{
+  if (argc < 12)
+  {
+    fprintf(stderr, "usage: prunemulti basisfile first d count stride gh_factor preproc_cost target metric flags\n");
+    return 2;
+  }
+  ZZ_mat<mpz_t> A, U, UT;
+  if (!read_basis(argv[2], A))
+    return 2;
+  const int first = atoi(argv[3]), d = atoi(argv[4]), count = atoi(argv[5]), stride = atoi(argv[6]);
+  const double ghf = atof(argv[7]), preproc = atof(argv[8]), target = atof(argv[9]);
+  const int metric = atoi(argv[10]), flags = atoi(argv[11]);
+  MatGSO<ZT, FT> M(A, U, UT, GSO_ROW_EXPO);
+  M.update_gso();
+  vector<vector<double>> rs;
+  for (int c = 0; c < count; ++c)
+  {
+    vector<double> r;
+    for (int i = 0; i < d; ++i)
+    {
+      FT t;
+      M.get_r(t, first + c * stride + i, first + c * stride + i);
+      r.push_back(t.get_d());
+    }
+    rs.push_back(r);
+  }
+  long expo;
+  FT max_dist = M.get_r_exp(first, first, expo);
+  max_dist *= 1e10;
+  FT root_det = M.get_root_det(first, first + d);
+  adjust_radius_to_gh_bound(max_dist, expo, d, root_det, ghf);
+  const double radius = max_dist.get_d() * std::pow(2.0, (double)expo);
+  PruningParams pp;
+  prune<FT>(pp, radius, preproc, rs, target, (PrunerMetric)metric, flags);
+  printf("{\"d\":%d,\"count\":%d,\"radius\":\"%a\",\"preproc_cost\":\"%a\",\"target\":\"%a\",\"metric\":%d,"
+         "\"flags\":%d,\"expectation\":\"%a\",\"gh_factor\":\"%a\",",
+         d, count, radius, preproc, target, metric, flags, pp.expectation, pp.gh_factor);
+  for (int c = 0; c < count; ++c)
+  {
+    char name[32];
+    snprintf(name, sizeof name, "gso_r_%d", c);
+    put_hex(name, rs[c]);
+  }
+  put_hex("coefficients", pp.coefficients);
+  put_hex("detailed_cost", pp.detailed_cost, true);
+  printf("}\n");
+  return 0;
+}
+
 /* basisstat basisfile  → JSON: the reference's is_lll_reduced (256-bit GSO), slope of log r_ii
  * (gso_interface.cpp:198-218), log-volume, r_00 — the acceptance test of a tour whose enumerations
  * ran in another order than the reference's (a pruned shrinking-radius walk is order dependent) */
@@ -1377,6 +1431,8 @@ int main(int argc, char **argv)
     return cmd_basisstat(argc, argv);
   if (cmd == "prunefix")
     return cmd_prunefix(argc, argv);
+  if (cmd == "prunemulti")
+    return cmd_prunemulti(argc, argv);
   fprintf(stderr, "unknown command %s\n", cmd.c_str());
   return 2;
 }

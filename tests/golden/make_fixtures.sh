@@ -134,3 +134,9 @@ $DRV prunefix $B 60 60 1.1 1e7 0.5 0 4   > prune_q180_k60_b60_p05.json          
 $DRV prunefix $B 10 45 1.2 1e7 0.3 0 4   > prune_q180_k10_b45_p03.json             # odd block size
 $DRV prunefix $B 60 50 1.1 1e7 1.0 1 68  > prune_q180_k60_b50_single_expsol.json   # PRUNER_SINGLE, expected solutions
 $DRV prunefix $B 100 31 1.0 1e5 0.9 0 36 > prune_q180_k100_b31_half.json           # PRUNER_HALF
+$DRV prunefix $B 60 40 1.1 1e7 0.5 0 12  > prune_q180_k60_b40_zealous.json         # PRUNER_ZEALOUS = GRADIENT | NELDER_MEAD
+$DRV prunefix $B 20 30 1.0 1e6 0.7 0 8   > prune_q180_k20_b30_neldermead.json      # PRUNER_NELDER_MEAD alone
+$DRV prunefix $B 90 37 1.2 1e6 1.5 1 12  > prune_q180_k90_b37_zealous_expsol.json  # odd size, expected solutions
+# ref_driver prunemulti basisfile first d count stride gh_factor preproc_cost target metric flags
+$DRV prunemulti $B 30 40 3 20 1.1 1e7 0.5 0 4  > prunemulti_q180_k30_b40_x3.json   # three bases, gradient
+$DRV prunemulti $B 10 33 2 50 1.0 1e6 0.6 0 12 > prunemulti_q180_k10_b33_x2_zealous.json
