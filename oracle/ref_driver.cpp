@@ -1067,6 +1067,56 @@ static int cmd_prunefix(int argc, char **argv)
   return 0;
 }
 
+/* stratdump strategies.json  → JSON: the strategies as load_strategies_json (bkz_param.cpp:82-157) holds
+ * them, flattened like the "strategies" member of the BKZ fixtures (block sizes the file skips get the
+ * empty strategy with one default PruningParams) — what fplll_amd.strategies.load_strategies_json is
+ * compared with. */
+static int cmd_stratdump(int argc, char **argv)
+{
+  if (argc < 3)
+    return 2;
+  vector<Strategy> loaded = load_strategies_json(argv[2]);
+  auto hx = [](double v) { char b[64]; snprintf(b, sizeof b, "\"%a\"", v); return std::string(b); };
+  std::ostringstream po, pv, ro, rg, re, co, cv;
+  int np = 0, npr = 0, nc = 0;
+  for (size_t bs = 0; bs < loaded.size(); ++bs)
+  {
+    po << (bs ? "," : "") << np;
+    ro << (bs ? "," : "") << npr;
+    for (int pb : loaded[bs].preprocessing_block_sizes)
+      pv << (np++ ? "," : "") << pb;
+    for (const PruningParams &pp : loaded[bs].pruning_parameters)
+    {
+      rg << (npr ? "," : "") << hx(pp.gh_factor);
+      re << (npr ? "," : "") << hx(pp.expectation);
+      co << (npr ? "," : "") << nc;
+      for (double c : pp.coefficients)
+        cv << (nc++ ? "," : "") << hx(c);
+      ++npr;
+    }
+  }
+  po << "," << np;
+  ro << "," << npr;
+  co << (npr ? "," : "") << nc;
+  printf("{\"max_block_size\":%d,\"pre_off\":[%s],\"pre\":[%s],\"prune_off\":[%s],\"prune_gh\":[%s],"
+         "\"prune_exp\":[%s],\"coeff_off\":[%s],\"coeff\":[%s]",
+         (int)loaded.size() - 1, po.str().c_str(), pv.str().c_str(), ro.str().c_str(), rg.str().c_str(),
+         re.str().c_str(), co.str().c_str(), cv.str().c_str());
+  // Strategy::get_pruning (bkz_param.cpp:62-79) on a few (radius, gh) pairs per block size
+  printf(",\"get_pruning\":[");
+  bool first = true;
+  const double ratios[] = {0.5, 0.97, 1.0, 1.05, 1.12, 1.27, 1.6, 3.0};
+  for (size_t bs = 0; bs < loaded.size(); ++bs)
+    for (double q : ratios)
+    {
+      const PruningParams &pp = loaded[bs].get_pruning(q * 1234.5, 1234.5);
+      printf("%s[%d,%s,%d]", first ? "" : ",", (int)bs, hx(q).c_str(), (int)(&pp - &loaded[bs].pruning_parameters[0]));
+      first = false;
+    }
+  printf("]}\n");
+  return 0;
+}
+
 /* prunemulti basisfile first d count stride gh_factor preproc_cost target metric flags
  *   → JSON: the reference's prune<FP_NR<double>> over SEVERAL bases (pruner/pruner.cpp:214-227,
  *   Pruner::load_basis_shapes pruner_util.cpp:66-92): the r-profiles of the `count` blocks
@@ -1433,6 +1483,8 @@ int main(int argc, char **argv)
     return cmd_prunefix(argc, argv);
   if (cmd == "prunemulti")
     return cmd_prunemulti(argc, argv);
+  if (cmd == "stratdump")
+    return cmd_stratdump(argc, argv);
   fprintf(stderr, "unknown command %s\n", cmd.c_str());
   return 2;
 }

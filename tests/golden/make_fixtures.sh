@@ -140,3 +140,7 @@ $DRV prunefix $B 90 37 1.2 1e6 1.5 1 12  > prune_q180_k90_b37_zealous_expsol.jso
 # ref_driver prunemulti basisfile first d count stride gh_factor preproc_cost target metric flags
 $DRV prunemulti $B 30 40 3 20 1.1 1e7 0.5 0 4  > prunemulti_q180_k30_b40_x3.json   # three bases, gradient
 $DRV prunemulti $B 10 33 2 50 1.0 1e6 0.6 0 12 > prunemulti_q180_k10_b33_x2_zealous.json
+
+# ---- strategies loader (round 3): what load_strategies_json holds after reading a file ----
+$DRV stratdump strategies_q180_b60.json > stratdump_q180_b60.json
+$DRV stratdump strategies_handmade.json > stratdump_handmade.json   # (strategies_handmade.json is written by hand)
