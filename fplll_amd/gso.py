@@ -251,6 +251,27 @@ class MatGSOBatch:
         return float(np.ldexp(self.get_r_matrix(lattice)[i, j], int(e[i] + e[j])))
 
     @property
+    # ---- host-side members of MatGSOInterface that BKZ callers use between reductions
+    # (gso_interface.cpp:197-276; C ABI fphip_gso_util_*): evaluated on the downloaded diagonal of r
+    def _diag(self, lattice):
+        return np.ascontiguousarray(np.diag(self.get_r_matrix(lattice))), self.row_expo(lattice)
+
+    def get_current_slope(self, lattice, start_row, stop_row):
+        r, e = self._diag(lattice)
+        return current_slope(r, e, start_row, stop_row)
+
+    def get_log_det(self, lattice, start_row, end_row):
+        r, e = self._diag(lattice)
+        return log_det(r, e, start_row, end_row)
+
+    def get_root_det(self, lattice, start_row, end_row):
+        r, e = self._diag(lattice)
+        return root_det(r, e, start_row, end_row)
+
+    def get_slide_potential(self, lattice, start_row, end_row, block_size):
+        r, e = self._diag(lattice)
+        return slide_potential(r, e, start_row, end_row, block_size)
+
     def last_kernel_ms(self):
         return float(self.lib.fphip_gso_last_kernel_ms(self.h))
 
@@ -268,6 +289,58 @@ class MatGSOBatch:
 
 
 # ---------------------------------------------------------------------------------------------
+def _util(name, restype=ctypes.c_double):
+    fn = getattr(_lib.load(), name)
+    fn.restype = restype
+    return fn
+
+
+def _re(r_diag, row_expo):
+    r = np.ascontiguousarray(r_diag, dtype=np.float64)
+    e = None if row_expo is None else np.ascontiguousarray(row_expo, dtype=np.int64)
+    return r, e, r.ctypes.data_as(ctypes.c_void_p), (None if e is None else e.ctypes.data_as(ctypes.c_void_p))
+
+
+def current_slope(r_diag, row_expo, start_row, stop_row):
+    """MatGSOInterface::get_current_slope (gso_interface.cpp:197-218) on the STORED diagonal of r and the
+    row exponents (None: GSO without row exponents)."""
+    r, e, rp, ep = _re(r_diag, row_expo)
+    fn = _util("fphip_gso_util_current_slope")
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    return fn(rp, ep, int(start_row), int(stop_row))
+
+
+def log_det(r_diag, row_expo, start_row, end_row):
+    """get_log_det (gso_interface.cpp:230-242)."""
+    r, e, rp, ep = _re(r_diag, row_expo)
+    fn = _util("fphip_gso_util_log_det")
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    return fn(rp, ep, r.size, int(start_row), int(end_row))
+
+
+def root_det(r_diag, row_expo, start_row, end_row):
+    """get_root_det (gso_interface.cpp:220-228)."""
+    r, e, rp, ep = _re(r_diag, row_expo)
+    fn = _util("fphip_gso_util_root_det")
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    return fn(rp, ep, r.size, int(start_row), int(end_row))
+
+
+def slide_potential(r_diag, row_expo, start_row, end_row, block_size):
+    """get_slide_potential (gso_interface.cpp:244-258)."""
+    r, e, rp, ep = _re(r_diag, row_expo)
+    fn = _util("fphip_gso_util_slide_potential")
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    return fn(rp, ep, r.size, int(start_row), int(end_row), int(block_size))
+
+
+def adjust_radius_to_gh_bound(max_dist, max_dist_expo, block_size, root_det_, gh_factor):
+    """adjust_radius_to_gh_bound (gso_interface.cpp:260-276): returns the new max_dist."""
+    fn = _util("fphip_gso_util_adjust_radius_to_gh_bound")
+    fn.argtypes = [ctypes.c_double, ctypes.c_long, ctypes.c_int, ctypes.c_double, ctypes.c_double]
+    return fn(float(max_dist), int(max_dist_expo), int(block_size), float(root_det_), float(gh_factor))
+
+
 def sweep_bytes_8d(d, n):
     """ALGORITHMIC bytes of one size-reduction sweep of a d x n lattice as SURVEY.md 8(d) /
     BASELINE.md 3.6 define them: per row kappa ONE babai iteration with every X_j != 0,

@@ -301,6 +301,20 @@ int fphip_pruner_enum_cost(int n, const double *gso_r, double enumeration_radius
                            double *cost, double *metric_value, double *detailed_cost);
 
 
+/* ---- host-side members of MatGSOInterface that BKZ callers use between reductions (csrc/gso_util_host.hip;
+ * gso_interface.cpp:197-276), stateless over downloaded values: r_diag[i] = the STORED r(i,i) (the diagonal of
+ * fphip_gso_get_r), row_expo = fphip_gso_get_row_expo's array (NULL: no row exponents), d = number of rows.
+ * Bit for bit the reference's numbers (its operation order, the host's libm). */
+double fphip_gso_util_current_slope(const double *r_diag, const int64_t *row_expo, int start_row, int stop_row);
+double fphip_gso_util_log_det(const double *r_diag, const int64_t *row_expo, int d, int start_row, int end_row);
+double fphip_gso_util_root_det(const double *r_diag, const int64_t *row_expo, int d, int start_row, int end_row);
+double fphip_gso_util_slide_potential(const double *r_diag, const int64_t *row_expo, int d, int start_row,
+                                      int end_row, int block_size);
+/* adjust_radius_to_gh_bound(max_dist, max_dist_expo, block_size, root_det, gh_factor): returns the new
+ * max_dist (unchanged when the bound is not smaller) */
+double fphip_gso_util_adjust_radius_to_gh_bound(double max_dist, long max_dist_expo, int block_size,
+                                                double root_det, double gh_factor);
+
 /* raw stored values, d×d row-major; true values carry the row exponents exactly as
  * get_mu/get_r do (gso_interface.h:694-732): mu·2^(e_i-e_j), r·2^(e_i+e_j) */
 int fphip_gso_get_mu(fphip_gso *g, int lattice, double *mu);

@@ -1067,6 +1067,69 @@ static int cmd_prunefix(int argc, char **argv)
   return 0;
 }
 
+/* gsoutil basisfile  → JSON: stored r(i,i) and row_expo of MatGSO<long,double> (GSO_ROW_EXPO) after
+ * update_gso, and the reference's get_current_slope / get_log_det / get_root_det / get_slide_potential
+ * (gso_interface.cpp:197-258) on a list of ranges, plus adjust_radius_to_gh_bound (:260-276) — what
+ * fphip_gso_util_* (fplll_amd/csrc/gso_util_host.hip) is compared with, bit for bit. */
+static int cmd_gsoutil(int argc, char **argv)
+{
+  if (argc < 3)
+    return 2;
+  ZZ_mat<mpz_t> A;
+  if (!read_basis(argv[2], A))
+    return 2;
+  ZZ_mat<long> b, u, ut;
+  b.resize(A.get_rows(), A.get_cols());
+  for (int i = 0; i < A.get_rows(); ++i)
+    for (int j = 0; j < A.get_cols(); ++j)
+      b(i, j) = A(i, j).get_si();
+  MatGSO<Z_NR<long>, FP_NR<double>> M(b, u, ut, GSO_ROW_EXPO);
+  M.update_gso();
+  const int d = M.d;
+  printf("{\"d\":%d,\"r_diag\":[", d);
+  for (int i = 0; i < d; ++i)
+  {
+    long e;
+    const FP_NR<double> &f = M.get_r_exp(i, i, e);
+    printf("%s\"%a\"", i ? "," : "", f.get_d());
+  }
+  printf("],\"row_expo\":[");
+  for (int i = 0; i < d; ++i)
+  {
+    long e;
+    M.get_r_exp(i, i, e);
+    printf("%s%ld", i ? "," : "", e / 2);
+  }
+  printf("],\"queries\":[");
+  const int ranges[][3] = {{0, d, 10}, {0, d, 20}, {5, d - 3, 7}, {d / 2, d, 12}, {0, 30, 30}, {10, 11, 1},
+                           {3, 60, 19}, {0, d, d}, {-4, d + 9, 25}};
+  bool first = true;
+  for (auto &q : ranges)
+  {
+    const int a = q[0], e = q[1], bs = q[2];
+    const int ca = std::max(0, a), ce = std::min(d, e);
+    const double slope = (ce - ca >= 2) ? M.get_current_slope(ca, ce) : 0.0;
+    const double ld    = M.get_log_det(a, e).get_d();
+    const double rd    = M.get_root_det(a, e).get_d();
+    const double pot   = M.get_slide_potential(ca, ce, bs).get_d();
+    long expo;
+    FP_NR<double> max_dist = M.get_r_exp(ca, ca, expo);
+    FP_NR<double> root     = M.get_root_det(a, e);
+    FP_NR<double> adj      = max_dist;
+    adjust_radius_to_gh_bound(adj, expo, ce - ca, root, 1.1);
+    FP_NR<double> big = max_dist;
+    big *= 1e10;
+    adjust_radius_to_gh_bound(big, expo, ce - ca, root, 1.05);
+    printf("%s{\"start\":%d,\"end\":%d,\"block_size\":%d,\"slope\":\"%a\",\"log_det\":\"%a\",\"root_det\":\"%a\","
+           "\"slide_potential\":\"%a\",\"max_dist\":\"%a\",\"expo\":%ld,\"adjusted_1.1\":\"%a\","
+           "\"adjusted_big_1.05\":\"%a\"}",
+           first ? "" : ",", a, e, bs, slope, ld, rd, pot, max_dist.get_d(), expo, adj.get_d(), big.get_d());
+    first = false;
+  }
+  printf("]}\n");
+  return 0;
+}
+
 /* stratdump strategies.json  → JSON: the strategies as load_strategies_json (bkz_param.cpp:82-157) holds
  * them, flattened like the "strategies" member of the BKZ fixtures (block sizes the file skips get the
  * empty strategy with one default PruningParams) — what fplll_amd.strategies.load_strategies_json is
@@ -1485,6 +1548,8 @@ int main(int argc, char **argv)
     return cmd_prunemulti(argc, argv);
   if (cmd == "stratdump")
     return cmd_stratdump(argc, argv);
+  if (cmd == "gsoutil")
+    return cmd_gsoutil(argc, argv);
   fprintf(stderr, "unknown command %s\n", cmd.c_str());
   return 2;
 }

@@ -144,3 +144,7 @@ $DRV prunemulti $B 10 33 2 50 1.0 1e6 0.6 0 12 > prunemulti_q180_k10_b33_x2_zeal
 # ---- strategies loader (round 3): what load_strategies_json holds after reading a file ----
 $DRV stratdump strategies_q180_b60.json > stratdump_q180_b60.json
 $DRV stratdump strategies_handmade.json > stratdump_handmade.json   # (strategies_handmade.json is written by hand)
+
+# ---- GSO host utilities (round 3): get_current_slope / get_log_det / get_root_det / get_slide_potential /
+# adjust_radius_to_gh_bound of the reference on the stored r diagonal of MatGSO<long,double>
+$DRV gsoutil basis_q180_seed0_lll_bkz20.txt > gsoutil_q180.json
