@@ -88,3 +88,28 @@ extern "C" double fphip_gso_util_adjust_radius_to_gh_bound(double max_dist, long
   f        = f * gh_factor;
   return f < max_dist ? f : max_dist;
 }
+// is_lll_reduced<ZT, FT = double>(m, delta, eta) (lll.cpp:226-258) on the STORED mu / r (d x d row-major,
+// as fphip_gso_get_mu / fphip_gso_get_r hand them out) and the row exponents: every |mu(i,j)| <= eta, then
+// r(i,i) >= (delta - mu(i,i-1)^2) r(i-1,i-1) for every row — in the precision of the GSO itself, like the
+// reference's predicate (which is why the test infrastructure judges a 180-dimensional tour at 256 bits).
+extern "C" int fphip_gso_util_is_lll_reduced(const double *mu, const double *r, const int64_t *row_expo, int d,
+                                             double delta, double eta)
+{
+  auto ex    = [&](int i) { return row_expo ? (int)row_expo[i] : 0; };
+  auto get_mu = [&](int i, int j) { return std::ldexp(mu[(size_t)i * d + j], ex(i) - ex(j)); };
+  auto get_r  = [&](int i, int j) { return std::ldexp(r[(size_t)i * d + j], ex(i) + ex(j)); };
+  for (int i = 0; i < d; i++)
+    for (int j = 0; j < i; j++)
+      if (std::fabs(get_mu(i, j)) > eta)
+        return 0;
+  for (int i = 1; i < d; i++)
+  {
+    double t = get_mu(i, i - 1);
+    t        = t * t;
+    t        = delta - t;
+    t        = get_r(i - 1, i - 1) * t;
+    if (get_r(i, i) < t)
+      return 0;
+  }
+  return 1;
+}

@@ -272,6 +272,12 @@ class MatGSOBatch:
         r, e = self._diag(lattice)
         return slide_potential(r, e, start_row, end_row, block_size)
 
+    def is_lll_reduced(self, lattice, delta=LLL_DEF_DELTA, eta=LLL_DEF_ETA):
+        """is_lll_reduced(m, delta, eta) (lll.cpp:226-258) on the lattice's current mu / r (call update_gso
+        first: the predicate reads the GSO, it does not recompute it)."""
+        return is_lll_reduced(self.get_mu_matrix(lattice), self.get_r_matrix(lattice), self.row_expo(lattice),
+                              delta, eta)
+
     def last_kernel_ms(self):
         return float(self.lib.fphip_gso_last_kernel_ms(self.h))
 
@@ -339,6 +345,17 @@ def adjust_radius_to_gh_bound(max_dist, max_dist_expo, block_size, root_det_, gh
     fn = _util("fphip_gso_util_adjust_radius_to_gh_bound")
     fn.argtypes = [ctypes.c_double, ctypes.c_long, ctypes.c_int, ctypes.c_double, ctypes.c_double]
     return fn(float(max_dist), int(max_dist_expo), int(block_size), float(root_det_), float(gh_factor))
+
+
+def is_lll_reduced(mu, r, row_expo, delta=LLL_DEF_DELTA, eta=LLL_DEF_ETA):
+    """is_lll_reduced<ZT, double> (lll.cpp:226-258) on stored mu / r (d x d) and the row exponents (or None)."""
+    m = np.ascontiguousarray(mu, dtype=np.float64)
+    rr = np.ascontiguousarray(r, dtype=np.float64)
+    e = None if row_expo is None else np.ascontiguousarray(row_expo, dtype=np.int64)
+    fn = _util("fphip_gso_util_is_lll_reduced", ctypes.c_int)
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_double]
+    return bool(fn(m.ctypes.data_as(ctypes.c_void_p), rr.ctypes.data_as(ctypes.c_void_p),
+                   None if e is None else e.ctypes.data_as(ctypes.c_void_p), m.shape[0], float(delta), float(eta)))
 
 
 def sweep_bytes_8d(d, n):

@@ -310,6 +310,10 @@ double fphip_gso_util_log_det(const double *r_diag, const int64_t *row_expo, int
 double fphip_gso_util_root_det(const double *r_diag, const int64_t *row_expo, int d, int start_row, int end_row);
 double fphip_gso_util_slide_potential(const double *r_diag, const int64_t *row_expo, int d, int start_row,
                                       int end_row, int block_size);
+/* is_lll_reduced<ZT, double>(m, delta, eta) (lll.cpp:226-258) on the stored mu / r matrices (d x d row-major:
+ * fphip_gso_get_mu / fphip_gso_get_r of a lattice whose GSO is up to date) and the row exponents: 1 / 0. */
+int fphip_gso_util_is_lll_reduced(const double *mu, const double *r, const int64_t *row_expo, int d, double delta,
+                                  double eta);
 /* adjust_radius_to_gh_bound(max_dist, max_dist_expo, block_size, root_det, gh_factor): returns the new
  * max_dist (unchanged when the bound is not smaller) */
 double fphip_gso_util_adjust_radius_to_gh_bound(double max_dist, long max_dist_expo, int block_size,

@@ -1100,7 +1100,27 @@ static int cmd_gsoutil(int argc, char **argv)
     M.get_r_exp(i, i, e);
     printf("%s%ld", i ? "," : "", e / 2);
   }
-  printf("],\"queries\":[");
+  printf("],\"is_lll_reduced\":%d,\"is_lll_reduced_d0999_e0501\":%d", (int)is_lll_reduced<Z_NR<long>, FP_NR<double>>(M, LLL_DEF_DELTA, LLL_DEF_ETA),
+         (int)is_lll_reduced<Z_NR<long>, FP_NR<double>>(M, 0.999, 0.501));
+  if (d <= 64)
+  {  // the stored matrices (what fphip_gso_get_mu / _get_r hand out): mu(i,j), r(i,j) for j <= i, else 0
+    printf(",\"mu\":[");
+    for (int i = 0; i < d; ++i)
+      for (int j = 0; j < d; ++j)
+      {
+        long e;
+        printf("%s\"%a\"", (i || j) ? "," : "", j < i ? M.get_mu_exp(i, j, e).get_d() : 0.0);
+      }
+    printf("],\"r\":[");
+    for (int i = 0; i < d; ++i)
+      for (int j = 0; j < d; ++j)
+      {
+        long e;
+        printf("%s\"%a\"", (i || j) ? "," : "", j <= i ? M.get_r_exp(i, j, e).get_d() : 0.0);
+      }
+    printf("]");
+  }
+  printf(",\"queries\":[");
   const int ranges[][3] = {{0, d, 10}, {0, d, 20}, {5, d - 3, 7}, {d / 2, d, 12}, {0, 30, 30}, {10, 11, 1},
                            {3, 60, 19}, {0, d, d}, {-4, d + 9, 25}};
   bool first = true;

@@ -148,3 +148,6 @@ $DRV stratdump strategies_handmade.json > stratdump_handmade.json   # (strategie
 # ---- GSO host utilities (round 3): get_current_slope / get_log_det / get_root_det / get_slide_potential /
 # adjust_radius_to_gh_bound of the reference on the stored r diagonal of MatGSO<long,double>
 $DRV gsoutil basis_q180_seed0_lll_bkz20.txt > gsoutil_q180.json
+# (40-dim bases written from bkz_q40_b10.json's b_in / reversed rows / b_out: basis_q40_*.txt; their dumps carry
+#  the stored mu / r matrices and the reference's is_lll_reduced verdicts)
+for f in q40_lll q40_lll_rows_reversed q40_bkz10; do $DRV gsoutil basis_$f.txt > gsoutil_$f.json; done

@@ -37,9 +37,45 @@ def _check(j):
             float.fromhex(q["adjusted_big_1.05"]), q
 
 
+def _check_predicate(j):
+    from fplll_amd import gso as G
+    d = j["d"]
+    mu = np.array([float.fromhex(x) for x in j["mu"]]).reshape(d, d)
+    r = np.array([float.fromhex(x) for x in j["r"]]).reshape(d, d)
+    e = np.array(j["row_expo"], dtype=np.int64)
+    assert G.is_lll_reduced(mu, r, e) == bool(j["is_lll_reduced"])
+    assert G.is_lll_reduced(mu, r, e, 0.999, 0.501) == bool(j["is_lll_reduced_d0999_e0501"])
+
+
+SMALL = ["q40_lll", "q40_lll_rows_reversed", "q40_bkz10"]
+
+
 def test_gso_utilities_match_reference_fixture():
     with open(os.path.join(C.GOLDEN, "gsoutil_q180.json")) as f:
         _check(json.load(f))
+
+
+@pytest.mark.parametrize("name", SMALL)
+def test_is_lll_reduced_and_utilities_match_reference_on_small_bases(name):
+    """40-dimensional bases (the stored mu / r matrices are part of the fixture): an LLL-reduced one, the same
+    rows in reverse order (not reduced) and a BKZ-10 reduced one; the predicate also at delta 0.999 / eta
+    0.501, which none of them meets."""
+    with open(os.path.join(C.GOLDEN, "gsoutil_%s.json" % name)) as f:
+        j = json.load(f)
+    _check(j)
+    _check_predicate(j)
+
+
+@pytest.mark.parametrize("name", SMALL)
+def test_is_lll_reduced_matches_reference_live(name):
+    if not os.path.exists(DRV):
+        pytest.skip("oracle/_ref is not built on this machine (the committed fixtures cover the predicate)")
+    r = subprocess.run([DRV, "gsoutil", os.path.join(C.GOLDEN, "basis_%s.txt" % name)], capture_output=True,
+                       text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-300:]
+    j = json.loads(r.stdout)
+    _check(j)
+    _check_predicate(j)
 
 
 def test_gso_utilities_match_reference_live():
