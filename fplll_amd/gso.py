@@ -403,13 +403,49 @@ def _dense_unreduced(b, kmax=3, seed=1):
 
 
 def load_basis_txt(path):
-    """fplll's matrix text format ([[a b ...] [...]]), plain or gzipped."""
+    """fplll's matrix text format ([[a b ...] [...]]), plain or gzipped; rows need not be as long as the
+    matrix is high (the knapsack bases of `latticegen r` are d x (d + 1))."""
     import gzip
     op = gzip.open if path.endswith(".gz") else open
     with op(path, "rt") as f:
-        vals = np.array([int(t) for t in f.read().replace("[", " ").replace("]", " ").split()], dtype=np.int64)
-    d = int(round(len(vals) ** 0.5))
-    return vals.reshape(d, d)
+        text = f.read()
+    rows = [r for r in text.replace("[[", "[").split("[") if r.strip(" ]\n\t")]
+    mat = [[int(t) for t in r.replace("]", " ").split()] for r in rows]
+    mat = [r for r in mat if r]
+    if len({len(r) for r in mat}) != 1:
+        raise ValueError("rows of different lengths in " + path)
+    return np.array(mat, dtype=np.int64)
+
+
+def save_basis_txt(path, b):
+    """The text form Matrix<T>::print writes in compact mode (nr/matrix.cpp:136-161: `[[a b c]` newline
+    `[d e f]]`) and fplll's readers (operator>>, the `fplll` command line) accept."""
+    b = np.asarray(b)
+    with open(path, "w") as f:
+        f.write("[")
+        for i, row in enumerate(b):
+            f.write(("" if i == 0 else "\n") + "[" + " ".join(str(int(v)) for v in row) + "]")
+        f.write("]\n")
+
+
+class BKZAutoAbort:
+    """fplll's BKZAutoAbort (bkz.h:33-79, bkz.cpp:800-809) over one lattice of a MatGSOBatch (or anything with
+    get_current_slope(lattice, start_row, stop_row)): test_abort() is True once the slope of log r_ii has
+    not improved for max_no_dec consecutive calls."""
+
+    def __init__(self, m, num_rows, start_row=0, lattice=0):
+        self.m, self.num_rows, self.start_row, self.lattice = m, int(num_rows), int(start_row), int(lattice)
+        self.old_slope = float(np.finfo(np.float64).max)
+        self.no_dec = -1
+
+    def test_abort(self, scale=1.0, max_no_dec=5):
+        new_slope = -self.m.get_current_slope(self.lattice, self.start_row, self.num_rows)
+        if self.no_dec == -1 or new_slope < scale * self.old_slope:
+            self.no_dec = 0
+        else:
+            self.no_dec += 1
+        self.old_slope = min(self.old_slope, new_slope)
+        return self.no_dec >= max_no_dec
 
 
 def bench_inputs(distinct=64, kmax=3):
