@@ -250,7 +250,6 @@ class MatGSOBatch:
         e = self.row_expo(lattice)
         return float(np.ldexp(self.get_r_matrix(lattice)[i, j], int(e[i] + e[j])))
 
-    @property
     # ---- host-side members of MatGSOInterface that BKZ callers use between reductions
     # (gso_interface.cpp:197-276; C ABI fphip_gso_util_*): evaluated on the downloaded diagonal of r
     def _diag(self, lattice):
@@ -278,6 +277,7 @@ class MatGSOBatch:
         return is_lll_reduced(self.get_mu_matrix(lattice), self.get_r_matrix(lattice), self.row_expo(lattice),
                               delta, eta)
 
+    @property
     def last_kernel_ms(self):
         return float(self.lib.fphip_gso_last_kernel_ms(self.h))
 
