@@ -62,14 +62,14 @@ def shard_batch(batch, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def gather_status(dist, local_status, batch, rank, world):
+def gather_status(dist, local_status, batch, rank, world, device="cpu"):
     """Collect the per-lattice status words of every rank's slice on all ranks (one all_gather of
     `batch` int32 at the end of a batched reduction — the only communication of that path)."""
     import torch
     lo, hi = shard_batch(batch, rank, world)
     width = -(-batch // world)
-    buf = torch.full((width,), -99, dtype=torch.int32)
-    buf[: hi - lo] = torch.as_tensor(local_status, dtype=torch.int32)
+    buf = torch.full((width,), -99, dtype=torch.int32, device=device)
+    buf[: hi - lo] = torch.as_tensor(local_status, dtype=torch.int32).to(device)
     out = [torch.empty_like(buf) for _ in range(world)]
     dist.all_gather(out, buf)
     res = []

@@ -21,6 +21,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
 
 
+def note(make):
+    """Timing / progress line of a GPU test.  `make` is a callable returning the print arguments: it
+    is evaluated HERE, inside a try, so that a formatting problem in a perf line can never fail a
+    parity test whose assertions passed (round 3 ended red on exactly that)."""
+    try:
+        print(*make())
+    except Exception as e:  # noqa: never part of the assertion path
+        print("note unavailable: %r" % (e,))
+
+
 def hexvec(a):
     return np.array([float.fromhex(s) for s in a], dtype=np.float64)
 

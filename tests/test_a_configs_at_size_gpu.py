@@ -200,7 +200,7 @@ def test_nq4_lll_matches_oracle(ctx):
     assert int(info[0][1]) == int(info_o[1]) > 0, (info[0], info_o)
     for L in range(2):
         assert np.array_equal(g.get_basis(L, 1)[0], o.b)
-    print("NQ=4 LLL: %d swaps, kernel %.1f ms" % (int(info[0][1]), g.last_kernel_ms))
+    C.note(lambda: ("NQ=4 LLL: %d swaps, kernel %.1f ms" % (int(info[0][1]), g.last_kernel_ms),))
     o.close()
     g.close()
 
@@ -236,8 +236,8 @@ def test_config2_bkz20_q120_matches_reference(ctx):
     st, info = g.bkz(f["block_size"], f["delta"], f["eta"], f["max_loops"])
     wall = time.time() - t
     out = g.get_basis()
-    print("config 2: %d tours, %d nodes, %.1f s on the device (reference %.2f s on one core)"
-          % (int(info[0][0]), _nodes(info[0]), wall, f["ref_seconds"]))
+    C.note(lambda: ("config 2: %d tours, %d nodes, %.1f s on the device (reference %.2f s on one core)"
+          % (int(info[0][0]), _nodes(info[0]), wall, f["ref_seconds"]),))
     for L in range(B):
         assert st[L] == f["status"] == 1
         assert _nodes(info[L]) == f["nodes"] == 10252068
@@ -297,8 +297,8 @@ def test_config3_pruner_block_matches_reference(ctx, k):
     # reference's 0.68177 in most runs, the reference's own value in others) — validity and
     # completeness at the device's own final radius are what _check_pruned_result asserts
     assert 0 < res.total_nodes < 2 * f["total_nodes"]
-    print("C3 block %d (pruner): %d nodes (reference %d), norm %r (reference %r), %.2f ms" %
-          (k, res.total_nodes, f["total_nodes"], ev.solutions[0][0], ref_best, res.stats.kernel_ms))
+    C.note(lambda: ("C3 block %d (pruner): %d nodes (reference %d), norm %r (reference %r), %.2f ms" %
+          (k, res.total_nodes, f["total_nodes"], ev.solutions[0][0], ref_best, res.stats.kernel_ms),))
 
 
 @pytest.mark.parametrize("k", [0, 1, 2])
@@ -313,8 +313,8 @@ def test_config3_linear_block_matches_reference(ctx, k):
     res = enumerate_block(ctx, f["mut"], f["rdiag"], f["pruning"], f["maxdist"], ev)
     ref_best = min(s[0] for s in f["sol_log"])
     assert len(ev.solutions) == 1 and ev.solutions[0][0] == ref_best
-    print("C3 block %d (linear30): %d nodes (reference %d), %.1f ms" %
-          (k, res.total_nodes, f["total_nodes"], res.stats.kernel_ms))
+    C.note(lambda: ("C3 block %d (linear30): %d nodes (reference %d), %.1f ms" %
+          (k, res.total_nodes, f["total_nodes"], res.stats.kernel_ms),))
 
 
 @pytest.mark.parametrize("precision", [106, 53])
@@ -333,7 +333,7 @@ def test_config5_hlll_in_double_double_matches_reference(ctx, precision):
     st, info = h.hlll(f["delta"], f["eta"], f["theta"], f["c"], precision=precision)
     wall = time.time() - t
     out = h.get_basis(0, 2)
-    print("config 5 at precision %d: %d swaps, %.1f s on the device" % (precision, int(info[0][0]), wall))
+    C.note(lambda: ("config 5 at precision %d: %d swaps, %.1f s on the device" % (precision, int(info[0][0]), wall),))
     assert list(st) == [1, 1] and [int(i[0]) for i in info] == [146491, 146491]
     assert np.array_equal(out[0], f["b_out"]) and np.array_equal(out[1], f["b_out"])
     h.close()

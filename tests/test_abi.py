@@ -93,3 +93,16 @@ def test_header_is_plain_c(tmp_path):
     cpp.write_text('#include "%s"\nint main() { return FPHIP_OK; }\n' % hdr)
     subprocess.run(["g++", "-std=c++11", "-Wall", "-Werror", "-fsyntax-only", str(cpp)], check=True)
     assert 'extern "C"' in open(hdr).read()
+
+
+def test_timing_accessors_are_properties():
+    """`last_kernel_ms` is read as an attribute everywhere (bench.py, smoke, the tests): a decorator that
+    slips onto a neighbouring method turns every such read into a bound method (round 3's regression)."""
+    import ast
+    for mod, cls in (("gso.py", "MatGSOBatch"), ("householder.py", "MatHouseholderBatch")):
+        tree = ast.parse(open(os.path.join(C.ROOT, "fplll_amd", mod)).read())
+        c = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == cls][0]
+        props = {f.name for f in c.body if isinstance(f, ast.FunctionDef)
+                 and any(isinstance(d, ast.Name) and d.id == "property" for d in f.decorator_list)}
+        assert "last_kernel_ms" in props, (mod, props)
+        assert not any(p.startswith("_") or p.startswith("get_") for p in props), (mod, props)

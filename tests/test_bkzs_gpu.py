@@ -40,8 +40,8 @@ def test_bkz_strategies_matches_reference(ctx, path):
                                 auto_abort=bool(f["flags"] & 0x20))
     out = g.get_basis()
     nodes = [(int(i[1]) & 0xffffffff) | (int(i[2]) << 32) for i in info]
-    print("status", st, "expected", f["status"], "tours/calls", info[:, 0], info[:, 3], "nodes", nodes,
-          "expected", f["nodes"], "kernel ms", g.last_kernel_ms, "rng draws", draws())
+    C.note(lambda: ("status", st, "expected", f["status"], "tours/calls", info[:, 0], info[:, 3], "nodes", nodes,
+          "expected", f["nodes"], "kernel ms", g.last_kernel_ms, "rng draws", draws(),))
     for L in range(batch):
         bad = np.nonzero((out[L] != f["b_out"]).any(axis=1))[0]
         assert st[L] == f["status"], (L, st, info)
@@ -91,7 +91,7 @@ def test_heterogeneous_batch_vs_oracle(ctx, d, beta, which):
     rnd, draws = C.gmp_streams_native(B, seed)
     st, info = g.bkz_strategies(beta, S, rnd, max_loops=max_loops, gh_bnd=True)
     out = g.get_basis(0, B)
-    print("rerandomisations (oracle)", [w[2] for w in want], "rng draws", draws(), "kernel ms", g.last_kernel_ms)
+    C.note(lambda: ("rerandomisations (oracle)", [w[2] for w in want], "rng draws", draws(), "kernel ms", g.last_kernel_ms,))
     for L in range(B):
         nodes = (int(info[L][1]) & 0xffffffff) | (int(info[L][2]) << 32)
         assert st[L] == want[L][0]

@@ -69,7 +69,7 @@ def test_double_double_arithmetic_against_mpmath(ctx):
             err = abs(got - want) / scale if scale != 0 else abs(got - want)
             worst = max(worst, err)
         assert worst <= tol * eps, (name, mp.nstr(worst, 5))
-        print("dd %s: worst error %s (in units of 2^-104)" % (name, mp.nstr(worst / eps, 4)))
+        C.note(lambda: ("dd %s: worst error %s (in units of 2^-104)" % (name, mp.nstr(worst / eps, 4)),))
     # nint: exact
     q = _rand_dd(rng, n, 0, 60)
     q[::7, 0] = np.round(q[::7, 0])  # integral high words: the low word decides
@@ -119,8 +119,8 @@ def test_r_factor_in_double_double_against_mpfr106(ctx, name):
             for ref, got in row:
                 w = max(w, abs(got - ref) / rown)
         worst[prec] = w
-    print("R-factor %s (%dx%d) vs MPFR-106: double-double %s, double %s (relative to the row norm)"
-          % (name, d, n, mp.nstr(worst[106], 4), mp.nstr(worst[53], 4)))
+    C.note(lambda: ("R-factor %s (%dx%d) vs MPFR-106: double-double %s, double %s (relative to the row norm)"
+          % (name, d, n, mp.nstr(worst[106], 4), mp.nstr(worst[53], 4)),))
     assert worst[106] <= mp.mpf(2) ** -92   # ~1e-28: double-double accuracy with d*n roundings of slack
     assert worst[53] <= mp.mpf(2) ** -40
     assert worst[106] * 2 ** 30 < worst[53] or worst[53] == 0
@@ -195,8 +195,8 @@ def test_hlll_in_double_double_on_reference_fixtures(ctx, path):
         out = h.get_basis(0, 2)
         assert np.array_equal(out[0], out[1])
         same = np.array_equal(out[0], f["b_out"])
-        print("%s precision %d: %d swaps, %.1f ms, output %s the reference's" %
-              (os.path.basename(path), prec, int(info[0][0]), h.last_kernel_ms, "==" if same else "!="))
+        C.note(lambda: ("%s precision %d: %d swaps, %.1f ms, output %s the reference's" %
+              (os.path.basename(path), prec, int(info[0][0]), h.last_kernel_ms, "==" if same else "!="),))
         if ntru:
             assert _reference_says_hlll_reduced(out[0]) and _same_lattice(f["b_in"], out[0])
         elif prec == 106:
@@ -267,8 +267,8 @@ def test_lll_in_double_double_and_plain_double_tree_order(ctx, name):
             ref = _basisstat(f["b_out"][np.any(f["b_out"] != 0, axis=1)])
             assert abs(s["log_volume"] - ref["log_volume"]) < 1e-9 * max(1.0, abs(ref["log_volume"]))
         same = np.array_equal(out[0], f["b_out"])
-        print("%s at %d bits: %d swaps (reference %d), %.1f ms, basis %s the reference's"
-              % (name, prec, int(info[0][1]), f["n_swaps"], g.last_kernel_ms, "==" if same else "!="))
+        C.note(lambda: ("%s at %d bits: %d swaps (reference %d), %.1f ms, basis %s the reference's"
+              % (name, prec, int(info[0][1]), f["n_swaps"], g.last_kernel_ms, "==" if same else "!="),))
         if prec == 106 and name in ("lll_q40", "lll_q72", "lll_u24"):
             assert same and int(info[0][1]) == f["n_swaps"]
     g.close()
@@ -314,9 +314,9 @@ def test_config5_lattice_lll_ladder_escalates_to_double_double(ctx):
     g.close()
     assert int(st[0]) == 1 and int(stage[0]) == 106, (st, stage, info)
     s_out, s_in = _basisstat(out), _basisstat(b)
-    print("config 5 LLL: double stops with RED_BABAI_FAILURE after %.1f s; ladder (double -> double-double) %.1f s, "
+    C.note(lambda: ("config 5 LLL: double stops with RED_BABAI_FAILURE after %.1f s; ladder (double -> double-double) %.1f s, "
           "%d swaps in all; is_lll_reduced %d, slope %.6f (input %.6f)"
-          % (t_double, t_ladder, int(info[0][1]), s_out["is_lll_reduced"], s_out["slope"], s_in["slope"]))
+          % (t_double, t_ladder, int(info[0][1]), s_out["is_lll_reduced"], s_out["slope"], s_in["slope"]),))
     assert s_out["is_lll_reduced"] == 1 and s_in["is_lll_reduced"] == 0
     assert abs(s_out["log_volume"] - s_in["log_volume"]) < 1e-9 * abs(s_in["log_volume"])
     assert _rows_in_qary_lattice(b, out)

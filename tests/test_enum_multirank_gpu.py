@@ -151,3 +151,52 @@ def test_bench_py_multi_rank_protocol_on_one_device(world):
     assert j["n_gpus"] == world and j["steps"] == 3 and j["scaling"] == "strong"
     assert j["parity"]["final_norm_equal_to_reference"] == 3, j["parity"]
     assert j["nodes"] > 3 * 10**9 and j["value"] > 0
+
+
+def _worker_rccl(port, fixture, q):
+    import torch
+    import torch.distributed as dist
+    import fplll_amd
+    from fplll_amd.distributed import enumerate_block_sharded, gather_status
+    from fplll_amd.enumeration import FastEvaluator
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    f = C.load_fixture(fixture)
+    ctx = fplll_amd.Context(0)
+    ev = FastEvaluator(f["max_sols"], f["strategy"])
+    gd, gc, gn, res = enumerate_block_sharded(ctx, dist, f["mut"], f["rdiag"], f["pruning"], f["maxdist"], ev,
+                                              device="cuda:0", exchange_chunks=3)
+    st = gather_status(dist, [1, 1, 1], 3, 0, 1, device="cuda:0")
+    q.put((gd, gc, gn, int(res.total_nodes), st, dist.get_backend()))
+    dist.barrier()
+    ctx.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["enum_d48_lin30_fixed", "enum_d36_lin18_best1"])
+def test_sharded_call_on_rccl_world_size_one(name):
+    """The RCCL code path itself, executed on hardware: backend "nccl" (= RCCL on ROCm),
+    world size 1 — process-group initialisation on the GPU, the 16-byte all_reduce(MIN) of the bound
+    exchange on a DEVICE tensor at every chunk / round boundary, and the three result reductions
+    (all_gather of (norm, vector), all_reduce(SUM) of the counts) — around the same sharded call the
+    gloo tests run.  Counts / final norm are the reference's."""
+    import torch.multiprocessing as mp
+    fixture = os.path.join(C.GOLDEN, name + ".json")
+    f = C.load_fixture(fixture)
+    mpctx = mp.get_context("spawn")
+    q = mpctx.Queue()
+    p = mpctx.Process(target=_worker_rccl, args=(_free_port(), fixture, q))
+    p.start()
+    gd, gc, gn, total, st, backend = q.get(timeout=600)
+    p.join(120)
+    assert p.exitcode == 0
+    assert backend == "nccl" and st == [1, 1, 1]
+    assert total == sum(gn)
+    ref_best = min([s[0] for s in f["sol_log"]] or [float("inf")])
+    if "fixed" in name:
+        assert gn == [int(v) for v in f["nodes"]]
+        assert gd <= ref_best
+    else:
+        assert gd == ref_best

@@ -206,3 +206,40 @@ def test_upload_without_explicit_refresh(ctx):
     assert np.array_equal(g.get_basis(0, 1)[0], f["b_out"])
     assert np.array_equal(g.get_mu_matrix(1), f["mu1"])
     g.close()
+
+
+# ---- the host-side MatGSOInterface members ON a device batch (round 3 ended red because nothing
+# ---- ever called them on a real MatGSOBatch) ----------------------------------------------------
+@pytest.mark.parametrize("name", ["q40_lll", "q40_lll_rows_reversed", "q40_bkz10"])
+def test_batch_members_match_reference_gsoutil(name):
+    """get_current_slope / get_log_det / get_root_det / get_slide_potential / is_lll_reduced called on a
+    MatGSOBatch whose mu / r come from the device (fplll/gso_interface.cpp:197-258, lll.cpp:226-258),
+    against `ref_driver gsoutil` of the real reference on the same basis — bit for bit; and
+    last_kernel_ms is a number."""
+    import json
+    import fplll_amd
+    from fplll_amd.gso import MatGSOBatch, load_basis_txt
+    with open(os.path.join(C.GOLDEN, "gsoutil_%s.json" % name)) as f:
+        j = json.load(f)
+    b = load_basis_txt(os.path.join(C.GOLDEN, "basis_%s.txt" % name))
+    d, n = b.shape
+    ctx = fplll_amd.Context(0)
+    g = MatGSOBatch(ctx, 2, d, n)
+    g.set_basis(np.stack([b] * 2))
+    assert list(g.update_gso()) == [1, 1]
+    assert isinstance(type(g).last_kernel_ms, property) and isinstance(g.last_kernel_ms, float)
+    for L in (0, 1):
+        assert [x.hex() for x in np.diag(g.get_r_matrix(L))] == j["r_diag"]
+        assert list(g.row_expo(L)) == j["row_expo"]
+    for q in j["queries"]:
+        a, e, bs = q["start"], q["end"], q["block_size"]
+        ca, cb = max(0, a), min(d, e)
+        if cb - ca >= 2:
+            assert g.get_current_slope(1, ca, cb) == float.fromhex(q["slope"]), q
+        assert g.get_log_det(1, a, e) == float.fromhex(q["log_det"]), q
+        assert g.get_root_det(1, a, e) == float.fromhex(q["root_det"]), q
+        assert g.get_slide_potential(1, ca, cb, bs) == float.fromhex(q["slide_potential"]), q
+    assert g.is_lll_reduced(1) == bool(j["is_lll_reduced"])
+    assert g.is_lll_reduced(0, 0.999, 0.501) == bool(j["is_lll_reduced_d0999_e0501"])
+    g.close()
+    ctx.close()

@@ -119,6 +119,6 @@ def test_blocked_mfma_mode_agrees_with_exact_mode(ctx, src, d):
                 scale = np.maximum(np.abs(r_e), np.outer(de, de))
                 assert np.all(np.abs(r_b - r_e) <= 1e-9 * scale)
                 worst = max(worst, float(np.max(np.abs(mu_b - mu_e))))
-        print("blocked vs exact R-factor %s %dx%d row_expo=%d: max |dmu| %.2e; kernel %.2f ms vs %.2f ms (batch 5)"
-              % (src, d, n, row_expo, worst, ms_blk, ms_exact))
+        C.note(lambda: ("blocked vs exact R-factor %s %dx%d row_expo=%d: max |dmu| %.2e; kernel %.2f ms vs %.2f ms (batch 5)"
+              % (src, d, n, row_expo, worst, ms_blk, ms_exact),))
         h.close()

@@ -33,8 +33,8 @@ def test_slide_reduction_matches_reference(ctx, path):
                                 auto_abort=bool(f["flags"] & 0x20), slide=True)
     out = g.get_basis()
     nodes = [(int(i[1]) & 0xffffffff) | ((int(i[2]) & 0xffffffff) << 32) for i in info]
-    print("status", st, "expected", f["status"], "tours/calls", info[:, 0], info[:, 3], "nodes", nodes,
-          "expected", f["nodes"], "kernel ms", g.last_kernel_ms, "rng draws", draws())
+    C.note(lambda: ("status", st, "expected", f["status"], "tours/calls", info[:, 0], info[:, 3], "nodes", nodes,
+          "expected", f["nodes"], "kernel ms", g.last_kernel_ms, "rng draws", draws(),))
     for L in range(batch):
         bad = np.nonzero((out[L] != f["b_out"]).any(axis=1))[0]
         assert st[L] == f["status"], (L, st, info)

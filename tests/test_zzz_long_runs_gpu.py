@@ -28,9 +28,9 @@ def test_config3_bkz60_tour_and_config5_hlll_match_reference():
         assert not C.LONG_RUNS["thread_" + n].is_alive(), "the %s run did not finish" % n
         assert n + "_error" not in C.LONG_RUNS, C.LONG_RUNS.get(n + "_error")
     c3, c5 = C.LONG_RUNS["c3"], C.LONG_RUNS["c5"]
-    print("config 3 tour: %.1f s on the device (reference %.1f s on one core), %d nodes; "
+    C.note(lambda: ("config 3 tour: %.1f s on the device (reference %.1f s on one core), %d nodes; "
           "config 5 HLLL (double, exact order): %.1f s (reference %.1f s), %d swaps"
-          % (c3["wall"], c3["ref_s"], c3["nodes"][0], c5["wall"], c5["ref_s"], c5["swaps"][0]))
+          % (c3["wall"], c3["ref_s"], c3["nodes"][0], c5["wall"], c5["ref_s"], c5["swaps"][0]),))
     assert c3["st"] == [c3["expect"][0]] * 2 and c3["nodes"] == [c3["expect"][1]] * 2
     assert c3["expect"][1] == 1224293770 and all(c3["basis_ok"])
     assert c5["st"] == [c5["expect"]] * 2 == [1, 1] and c5["swaps"] == [146491] * 2
@@ -50,10 +50,10 @@ def test_config3_bkz60_tour_with_handoff_meets_the_reducedness_predicate():
     assert "c3h_error" not in C.LONG_RUNS, C.LONG_RUNS.get("c3h_error")
     h = C.LONG_RUNS["c3h"]
     s, r, i = h["stat"], h["ref_stat"], h["in_stat"]
-    print("config 3 tour with hand-off: %.1f s on the device (wave-only: see the other test; reference %.1f s), "
+    C.note(lambda: ("config 3 tour with hand-off: %.1f s on the device (wave-only: see the other test; reference %.1f s), "
           "%d nodes in %d enumerations (reference %d nodes); slope %.6f (reference %.6f, input %.6f), "
           "r00 %.6g (reference %.6g)" % (h["wall"], h["ref_s"], h["nodes"], h["calls"], h["ref_nodes"],
-                                         s["slope"], r["slope"], i["slope"], s["r00"], r["r00"]))
+                                         s["slope"], r["slope"], i["slope"], s["r00"], r["r00"]),))
     assert h["st"] == h["expect_status"]
     assert s["is_lll_reduced"] == 1 and r["is_lll_reduced"] == 1
     assert abs(s["log_volume"] - r["log_volume"]) < 1e-6 * abs(r["log_volume"])
