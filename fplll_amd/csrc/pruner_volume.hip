@@ -1,0 +1,281 @@
+// pruner_volume.hip — batched even-simplex volumes: the device kernel of the pruner
+// and the host loop that computes the same doubles.
+//
+// V_k(y) (fplll: Pruner::relative_volume, pruner/pruner_simplex.h:6-46) is built by k rounds of
+// "integrate the polynomial, evaluate it at y_i / y_k, make minus that value the new constant term",
+// i = k-1 .. 0.  Round s (degree s -> s+1) touches every coefficient once, so the integration
+// (c_j / (j+1) -> c_{j+1}) and the Horner evaluation (which consumes the NEW coefficients from the top
+// down) are ONE descending pass here: read c_j, divide, store as c_{j+1}, multiply-then-add into the
+// accumulator.  The operations each value goes through — and their order — are the reference's
+// (eval_poly starts from 0 and ends by adding the zero constant term: both kept), so the volumes are
+// its doubles on any IEEE machine without contraction (-ffp-contract=off; f64 division and the
+// products are correctly rounded on gfx950).
+//
+// Device mapping: ONE LANE PER JOB (bound vector, k).  The lanes of a wave run the same round structure
+// (round s has s + 1 steps whatever k is; a lane is finished after k rounds and idles), the host sorts
+// the jobs by k so that a wave holds equal depths, and a lane's polynomial is a COLUMN of LDS
+// (c_j at [j][lane]: 64 consecutive doubles per row — conflict-free, no cross-lane traffic at all).
+// A gradient of a 60-dimensional block is ~7 400 jobs = 116 waves of at most 465 steps.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "dev_mem.h"
+#include "pruner_engine.h"
+
+namespace fphip_pruner
+{
+// ---------------------------------------------------------------------------------------------
+// host form
+// ---------------------------------------------------------------------------------------------
+double simplex_volume(const double *y, int k, double *c)
+{
+  c[0]             = 1.0;
+  const double top = y[k - 1];
+  for (int s = 0; s < k; ++s)
+  {
+    const double x = y[k - 1 - s] / top;
+    double acc     = 0.0;
+    for (int j = s; j >= 0; --j)
+    {
+      const double t = c[j] / (j + 1.0);
+      c[j + 1]       = t;
+      acc            = acc * x;
+      acc            = acc + t;
+    }
+    acc  = acc * x;
+    acc  = acc + 0.0;  // (the constant term of an integrated polynomial)
+    c[0] = -1.0 * acc;
+  }
+  return c[0];  // signed and without the k! — see finish()
+}
+
+// the sign and the factorial (pruner_simplex.h:44-45) are applied on the host for both engines
+extern const double *factorial_table();
+static inline double finish(double raw, int k)
+{
+  const double res = raw * factorial_table()[k];
+  return (k & 1) ? -res : res;
+}
+
+namespace
+{
+class HostEngine : public VolumeEngine
+{
+public:
+  bool run(const double *bounds, int nvec, int m, const VolumeJob *jobs, int njobs, double *out) override
+  {
+    (void)nvec;
+    std::vector<double> scratch((size_t)m + 2);
+    for (int j = 0; j < njobs; ++j)
+      out[j] = finish(simplex_volume(bounds + (size_t)jobs[j].vec * m, jobs[j].k, scratch.data()), jobs[j].k);
+    host_jobs += (unsigned long long)njobs;
+    return true;
+  }
+  int lookahead() const override { return 1; }
+};
+}  // namespace
+
+VolumeEngine *host_volume_engine()
+{
+  static HostEngine e;  // (stateless but for its job counter)
+  return &e;
+}
+
+// ---------------------------------------------------------------------------------------------
+// device form
+// ---------------------------------------------------------------------------------------------
+// jobs[] is sorted by k descending; job = vec | k << 20.  One wave per workgroup; LDS: (m + 1) rows of
+// 64 doubles.
+__global__ __launch_bounds__(64) void pruner_volume_kernel(const double *__restrict__ bounds, int m,
+                                                           const unsigned *__restrict__ jobs, int njobs,
+                                                           double *__restrict__ raw)
+{
+  extern __shared__ double lds[];
+  const int lane  = threadIdx.x;
+  const int idx   = blockIdx.x * 64 + lane;
+  const bool live = idx < njobs;
+  const unsigned w = live ? jobs[idx] : 0u;
+  const int k      = (int)(w >> 20);
+  const double *y  = bounds + (size_t)(w & 0xfffffu) * m;
+  const int kmax   = __builtin_amdgcn_readfirstlane(k);  // lane 0 holds the deepest job of the wave
+  double *c        = lds + lane;
+  c[0]             = 1.0;
+  const double top = live ? y[k - 1] : 1.0;
+  for (int s = 0; s < kmax; ++s)
+  {
+    const bool on  = s < k;
+    const double x = on ? y[k - 1 - s] / top : 0.0;
+    double acc     = 0.0;
+    for (int j = s; j >= 0; --j)
+    {
+      const double t  = c[j * 64] / (double)(j + 1);
+      c[(j + 1) * 64] = t;
+      acc             = acc * x;
+      acc             = acc + t;
+    }
+    acc = acc * x;
+    acc = acc + 0.0;
+    if (on)
+      c[0] = -1.0 * acc;
+  }
+  if (live)
+    raw[idx] = c[0];
+}
+
+namespace
+{
+class DeviceEngine : public VolumeEngine
+{
+public:
+  int device         = 0;
+  hipStream_t stream = nullptr;
+  char *pin          = nullptr;  // pinned staging: bounds | jobs | results
+  size_t pin_bytes   = 0;
+  char *dev          = nullptr;
+  size_t dev_bytes   = 0;
+  int min_jobs       = 24;  // smaller batches are cheaper inline (a k = 30 volume is ~1 400 flops)
+  int lds_opt_in     = 0;
+  char err[256]      = {0};
+  std::vector<double> scratch;
+  std::vector<unsigned> order;
+
+  ~DeviceEngine() override
+  {
+    if (stream)
+    {
+      (void)hipSetDevice(device);
+      (void)hipStreamSynchronize(stream);
+      fphip_dev_free(dev, stream);
+      (void)hipStreamSynchronize(stream);
+      (void)hipStreamDestroy(stream);
+    }
+    if (pin)
+      fphip_pinned_put(pin);
+  }
+  const char *error() const override { return err; }
+  int lookahead() const override { return 32; }
+
+  bool fail(const char *what, hipError_t e)
+  {
+    snprintf(err, sizeof err, "pruner volume engine: %s: %s", what, hipGetErrorString(e));
+    return false;
+  }
+
+  bool run(const double *bounds, int nvec, int m, const VolumeJob *jobs, int njobs, double *out) override
+  {
+    if (njobs <= 0)
+      return true;
+    if (njobs < min_jobs || nvec >= (1 << 20) || m > 255)
+    {
+      if ((int)scratch.size() < m + 2)
+        scratch.resize(m + 2);
+      for (int j = 0; j < njobs; ++j)
+        out[j] = finish(simplex_volume(bounds + (size_t)jobs[j].vec * m, jobs[j].k, scratch.data()), jobs[j].k);
+      host_jobs += (unsigned long long)njobs;
+      return true;
+    }
+    // counting sort of the job indices by k, deepest first
+    order.resize(njobs);
+    {
+      std::vector<int> head(m + 2, 0);
+      for (int j = 0; j < njobs; ++j)
+        ++head[m - jobs[j].k + 1];
+      for (int k = 1; k <= m + 1; ++k)
+        head[k] += head[k - 1];
+      for (int j = 0; j < njobs; ++j)
+        order[head[m - jobs[j].k]++] = (unsigned)j;
+    }
+    const size_t b_bytes = (size_t)nvec * m * sizeof(double);
+    const size_t j_bytes = ((size_t)njobs * sizeof(unsigned) + 63) & ~(size_t)63;
+    const size_t o_bytes = (size_t)njobs * sizeof(double);
+    const size_t need    = b_bytes + j_bytes + o_bytes;
+    hipError_t e         = hipSetDevice(device);
+    if (e != hipSuccess)
+      return fail("hipSetDevice", e);
+    if (need > pin_bytes)
+    {
+      if (pin)
+        fphip_pinned_put(pin);
+      pin_bytes = std::max(need * 2, (size_t)1 << 20);
+      pin       = (char *)fphip_pinned_get(pin_bytes);
+      if (!pin)
+      {
+        pin_bytes = 0;
+        snprintf(err, sizeof err, "pruner volume engine: no pinned memory");
+        return false;
+      }
+    }
+    if (need > dev_bytes)
+    {
+      fphip_dev_free(dev, stream);
+      dev       = nullptr;
+      dev_bytes = std::max(need * 2, (size_t)1 << 20);
+      if ((e = fphip_dev_alloc((void **)&dev, dev_bytes, stream)) != hipSuccess)
+      {
+        dev_bytes = 0;
+        return fail("device allocation", e);
+      }
+    }
+    memcpy(pin, bounds, b_bytes);
+    unsigned *pj = (unsigned *)(pin + b_bytes);
+    for (int j = 0; j < njobs; ++j)
+      pj[j] = (unsigned)jobs[order[j]].vec | ((unsigned)jobs[order[j]].k << 20);
+    const size_t lds = (size_t)(m + 1) * 64 * sizeof(double);
+    if (lds > 64 * 1024 && !lds_opt_in)
+    {
+      if ((e = hipFuncSetAttribute((const void *)pruner_volume_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   160 * 1024)) != hipSuccess)
+        return fail("hipFuncSetAttribute", e);
+      lds_opt_in = 1;
+    }
+    if ((e = hipMemcpyAsync(dev, pin, b_bytes + j_bytes, hipMemcpyHostToDevice, stream)) != hipSuccess)
+      return fail("upload", e);
+    double *d_raw = (double *)(dev + b_bytes + j_bytes);
+    hipLaunchKernelGGL(pruner_volume_kernel, dim3((njobs + 63) / 64), dim3(64), lds, stream, (const double *)dev, m,
+                       (const unsigned *)(dev + b_bytes), njobs, d_raw);
+    if ((e = hipGetLastError()) != hipSuccess)
+      return fail("launch", e);
+    double *praw = (double *)(pin + b_bytes + j_bytes);
+    if ((e = hipMemcpyAsync(praw, d_raw, o_bytes, hipMemcpyDeviceToHost, stream)) != hipSuccess)
+      return fail("download", e);
+    if ((e = hipStreamSynchronize(stream)) != hipSuccess)
+      return fail("synchronize", e);
+    for (int j = 0; j < njobs; ++j)
+      out[order[j]] = finish(praw[j], jobs[order[j]].k);
+    device_jobs += (unsigned long long)njobs;
+    ++launches;
+    return true;
+  }
+};
+}  // namespace
+
+VolumeEngine *create_device_volume_engine(int device, char *err, size_t errlen)
+{
+  DeviceEngine *e = new DeviceEngine;
+  e->device       = device;
+  hipError_t rc   = hipSetDevice(device);
+  if (rc == hipSuccess)
+    rc = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+  if (rc != hipSuccess)
+  {
+    if (err)
+      snprintf(err, errlen, "pruner volume engine: %s", hipGetErrorString(rc));
+    e->stream = nullptr;
+    delete e;
+    return nullptr;
+  }
+  if (const char *v = getenv("FPHIP_PRUNER_MIN_DEVICE_JOBS"))
+    e->min_jobs = atoi(v);
+  return e;
+}
+
+void destroy_volume_engine(VolumeEngine *e)
+{
+  if (e && e != host_volume_engine())
+    delete e;
+}
+}  // namespace fphip_pruner

@@ -266,14 +266,19 @@ int fphip_gso_lll_ex(fphip_gso *g, int kappa_min, int kappa_start, int kappa_end
 int fphip_gso_lll_ladder(fphip_gso *g, int kappa_min, int kappa_start, int kappa_end, double delta, double eta,
                          int *status, int *info, int *stage);
 
-/* ---- the pruner (host code, like the reference's; csrc/pruner_host.hip) -----------------------------
+/* ---- the pruner (csrc/pruner_search.hip, pruner_volume.hip) ----------------------------
+ * The searches are written against BATCHES of candidate coefficient vectors; a batch is scored by a
+ * volume engine: the O(k^2)-per-value even-simplex volumes of every (bound vector, k) of the batch — one
+ * lane per job on the device (pruner_volume_kernel), the same recurrence as a host loop without an
+ * engine — and the O(n) rest with the host libm.  Both engines produce the same doubles.
+ *
  * fphip_pruner_prune = prune<FP_NR<double>>(pruning, enumeration_radius, preproc_cost, gso_r, target,
  * metric, flags) (pruner/pruner.h:187-193, pruner.cpp:190-203): searches pruning coefficients that
  * minimise (cost of one enumeration x trials + preproc_cost x (trials - 1)) for the block whose squared
  * Gram-Schmidt lengths are gso_r[0..n) — greedy start, gradient descent and / or the Nelder-Mead search
  * (pruner_optimize_tc.cpp:581-825) on the even-indexed coefficients, local tuning, the same searches on
- * all of them (pruner_optimize*.cpp) — bit-identical coefficients to the reference's (every expression
- * in its operation order; host libm).
+ * all of them (pruner_optimize*.cpp) — bit-identical coefficients to the reference's (every value goes
+ * through the reference's sequence of IEEE operations; host libm).
  *   metric 0 = PRUNER_METRIC_PROBABILITY_OF_SHORTEST (0 < target < 1), 1 = PRUNER_METRIC_EXPECTED_SOLUTIONS
  *   flags: fplll's PRUNER_CVP 0x1, PRUNER_START_FROM_INPUT 0x2 (coefficients is then an input too),
  *          PRUNER_GRADIENT 0x4, PRUNER_NELDER_MEAD 0x8 (both = PRUNER_ZEALOUS), PRUNER_HALF 0x20,
@@ -299,6 +304,25 @@ int fphip_pruner_svp_probability(int n, const double *pr, double *probability);
  * solutions. */
 int fphip_pruner_enum_cost(int n, const double *gso_r, double enumeration_radius, const double *pr, int metric,
                            double *cost, double *metric_value, double *detailed_cost);
+
+/* A DEVICE volume engine: its own stream (it makes progress beside a persistent reduction kernel on the
+ * context's stream), pinned staging, device buffers.  One per host thread.  fphip_pruner_prune_on is
+ * fphip_pruner_prune / _prune_multi (count profiles) with the batches of the searches scored on that
+ * engine (NULL: the host loop) — the same coefficients either way.  fphip_pruner_volumes exposes the
+ * primitive: out[j] = V_{job_k[j]}(row job_vec[j] of bounds[nvec][m]), the volume of the even simplex
+ * cut by that bound vector (Pruner::relative_volume, pruner_simplex.h:34-46), 1 <= k <= m <= 255.
+ * fphip_pruner_engine_stats: jobs evaluated by kernels / inline on the host (batches below
+ * FPHIP_PRUNER_MIN_DEVICE_JOBS = 24 are cheaper than a launch), number of launches. */
+typedef struct fphip_pruner_engine fphip_pruner_engine;
+int fphip_pruner_engine_create(int device, fphip_pruner_engine **out);
+void fphip_pruner_engine_destroy(fphip_pruner_engine *e);
+int fphip_pruner_engine_stats(const fphip_pruner_engine *e, unsigned long long *device_jobs,
+                              unsigned long long *host_jobs, unsigned long long *launches);
+int fphip_pruner_volumes(fphip_pruner_engine *e, int m, int nvec, const double *bounds, int njobs,
+                         const int *job_vec, const int *job_k, double *out);
+int fphip_pruner_prune_on(fphip_pruner_engine *e, int n, int count, const double *gso_rs, double enumeration_radius,
+                          double preproc_cost, double target, int metric, int flags, double *coefficients,
+                          double *expectation, double *gh_factor, double *detailed_cost);
 
 
 /* ---- host-side members of MatGSOInterface that BKZ callers use between reductions (csrc/gso_util_host.hip;
