@@ -831,6 +831,8 @@ bkzs_body(GsoBatch P, BkzStrat S, BkzMail *mailbox, int *abort_flag, int block_s
           if (c1 > c0 && in)
             prn = S.coeff[c0 + lane];
         }
+        else if (prune == -2 && in)  // in-loop pruning: the host pruned THIS block (gso_host.hip, serve_radius)
+          prn = mail_load_f64(&mail->prn[lane]);
         // ---- the walk (bkz_kernel.hip) with per-level bounds -----------------------------------
         double best_x = 0.0;
         bool have_sol = false;

@@ -21,6 +21,15 @@
 #include "dev_mem.h"
 #include "trace.h"
 #include "ftx.h"
+#include "pruner_engine.h"
+namespace fphip_pruner
+{
+// pruner_search.hip: prune<FP_NR<double>> of one block under PRUNER_METRIC_PROBABILITY_OF_SHORTEST on the
+// given volume engine (nullptr: the host loop)
+__attribute__((visibility("hidden"))) int prune_block(VolumeEngine *eng, int n, const double *gso_r, double radius,
+                                                      double preproc, double target, int flags,
+                                                      double *coefficients, double *expectation);
+}  // namespace fphip_pruner
 
 #ifndef FPHIP_GSO_RING
 #define FPHIP_GSO_RING 6
@@ -99,6 +108,10 @@ struct fphip_gso
   int sweep_version;  // 2 (default) or 1 (FPHIP_GSO_SWEEP=1: the first-generation kernel)
   fphip_ctx *ectx;    // hand-off mode of the strategy-BKZ kernel: the enumeration context (same device)
   double *xbuf;       // lll_x.hip workspace: bf rows [B][d][ldn], then the low planes of mu, r, gf [B][d][ldd] each
+  // in-loop pruning of the strategy-BKZ service (FPHIP_BKZ_PRUNE_IN_LOOP; fphip_gso_bkz_inloop_pruning)
+  double il_preproc = 1e6, il_target = 0.5;
+  int il_min_block = 24, il_flags = 0x4 /* PRUNER_GRADIENT */, il_device = 1;
+  unsigned long long il_calls = 0, il_device_jobs = 0, il_host_jobs = 0, il_launches = 0;
 };
 
 static int gfail(fphip_ctx *ctx, const char *what, hipError_t e)
@@ -139,6 +152,7 @@ extern "C" int fphip_gso_create(fphip_ctx *ctx, int batch, int d, int n, int row
   }
   fphip_gso *g = new fphip_gso();
   memset(g, 0, sizeof *g);
+  g->il_preproc = 1e6, g->il_target = 0.5, g->il_min_block = 24, g->il_flags = 0x4, g->il_device = 1;
   g->ctx        = ctx;
   g->P.batch    = batch;
   g->P.d        = d;
@@ -997,7 +1011,18 @@ struct BkzsHost
   fphip_rand_fn rnd;
   void *rnd_user;
   double handoff_nodes;  // > 0: blocks above that many estimated nodes go to the multi-wave enumerator
+  // in-loop pruning: blocks of the top-level tour of at least il_min_block rows get coefficients from
+  // prune() on their own r-profile instead of a set of the strategies table
+  int inloop           = 0;
+  double il_preproc    = 0, il_target = 0;
+  int il_min_block     = 0, il_flags = 0;
 };
+// the blocks in-loop pruning applies to: primal blocks of the top-level tour (not of a preprocessing
+// tour: 0x10000, not dual: 0x20000)
+static inline bool inloop_block(const BkzsHost &H, const BkzMail *m)
+{
+  return H.inloop && m->type == 1 && !(m->flags & 0x30000) && m->bs >= H.il_min_block && m->bs >= 4;
+}
 
 // Gaussian-heuristic size of the pruned tree of a block (what enum_host.hip's estimate_levels
 // computes, in logarithms: the r_ii carry their row exponents here): sum over the levels k of
@@ -1018,7 +1043,7 @@ double estimate_block_nodes(int bs, const double *logr, double log_radius, const
 
 // type 1: radius (bkz.cpp:309-323) and pruning set (get_pruning :82-98, Strategy::get_pruning
 // bkz_param.cpp:64-80) of the block whose r_ii the wave has written
-void serve_radius(const BkzsHost &H, BkzMail *m)
+void serve_radius(const BkzsHost &H, BkzMail *m, fphip_pruner::VolumeEngine *engine = nullptr)
 {
   const int bs      = m->bs;
   const bool dual   = (m->flags & 0x20000) != 0;  // a dual block of self-dual BKZ (bkzs_kernel.hip, DUALS)
@@ -1063,6 +1088,27 @@ void serve_radius(const BkzsHost &H, BkzMail *m)
       }
     expectation = H.S->prune_exp[best];
   }
+  const double *inloop_pr = nullptr;
+  if (inloop_block(H, m))
+  {
+    // Pruning chosen where the reference chooses it (bkz.cpp:325, after the preprocessing and the radius)
+    // — but computed for THIS block: prune<FP_NR<double>>(radius, preproc_cost, r_ii of the block, target,
+    // PROBABILITY_OF_SHORTEST, flags) (pruner.h:187-193) on the profile the wave has just sent; the
+    // strategies' set stays in force if the pruner fails (a degenerate profile)
+    double rr[64], co[64], ex = 1.0;
+    for (int i = 0; i < bs; ++i)
+      rr[i] = std::ldexp(m->r[i], m->e2[i]);
+    const double radius = max_dist * pow(2, expo);
+    if (std::isfinite(radius) && radius > 0 &&
+        fphip_pruner::prune_block(engine, bs, rr, radius, H.il_preproc, H.il_target, H.il_flags, co, &ex) == FPHIP_OK)
+    {
+      for (int i = 0; i < bs; ++i)
+        m->prn[i] = co[i];
+      best        = -2;  // "the coefficients are in the mailbox"
+      expectation = ex;
+      inloop_pr   = m->prn;
+    }
+  }
   m->max_dist    = max_dist;
   m->expectation = expectation;
   m->prune       = best;
@@ -1080,7 +1126,7 @@ void serve_radius(const BkzsHost &H, BkzMail *m)
       else
         logr[i] = lr;
     }
-    const double *pr = nullptr;
+    const double *pr = inloop_pr;
     if (H.S && best >= 0 && H.S->coeff_off[best + 1] - H.S->coeff_off[best] == bs)
       pr = H.S->coeff + H.S->coeff_off[best];
     // expected number of nodes of this enumeration: the pruner's cost function (pruner_host.hip:
@@ -1243,6 +1289,35 @@ extern "C" int fphip_debug_bkz_plan(fphip_rand_fn rnd, void *rnd_user, int latti
   return FPHIP_OK;
 }
 
+extern "C" int fphip_gso_bkz_inloop_pruning(fphip_gso *g, double preproc_cost, double target, int min_block_size,
+                                            int pruner_flags, int on_device)
+{
+  if (!g || !(target > 0.0 && target < 1.0) || !(preproc_cost >= 0.0) || (pruner_flags & 0x10))
+    return FPHIP_ERROR;
+  g->il_preproc   = preproc_cost;
+  g->il_target    = target;
+  g->il_min_block = min_block_size;
+  g->il_flags     = pruner_flags;
+  g->il_device    = on_device ? 1 : 0;
+  return FPHIP_OK;
+}
+extern "C" int fphip_gso_bkz_inloop_stats(const fphip_gso *g, unsigned long long *prune_calls,
+                                          unsigned long long *device_jobs, unsigned long long *host_jobs,
+                                          unsigned long long *launches)
+{
+  if (!g)
+    return FPHIP_ERROR;
+  if (prune_calls)
+    *prune_calls = g->il_calls;
+  if (device_jobs)
+    *device_jobs = g->il_device_jobs;
+  if (host_jobs)
+    *host_jobs = g->il_host_jobs;
+  if (launches)
+    *launches = g->il_launches;
+  return FPHIP_OK;
+}
+
 extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double delta, double eta,
                                         int flags, int max_loops, double gh_factor,
                                         const fphip_strategies *S, fphip_rand_fn rnd, void *rnd_user,
@@ -1256,8 +1331,11 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
   // BKZ_SD_VARIANT (0x100): self-dual BKZ, bkzs_body<NQ, true>
   const bool sd  = (flags & 0x100) != 0;
   const bool sld = (flags & 0x200) != 0;  // BKZ_SLD_RED: slide reduction (slide_tour, bkz.cpp:465-520)
-  if (block_size > 64 || (flags & ~(0x4 | 0x10 | 0x20 | 0x80 | 0x100 | 0x200 | 0x1000)) || (sd && sld))
+  if (block_size > 64 || (flags & ~(0x4 | 0x10 | 0x20 | 0x80 | 0x100 | 0x200 | 0x1000 | 0x2000)) || (sd && sld))
     return FPHIP_UNSUPPORTED;
+  // FPHIP_BKZ_PRUNE_IN_LOOP (0x2000): pruning per block from the mailbox service (serve_radius)
+  const bool inloop = (flags & 0x2000) != 0;
+  flags &= ~0x2000;
   // (a last block of one row — d = k bs + 1 — would be an svp_reduction of block size 1: not offered)
   if (sld && block_size >= 2 && g->P.d % block_size == 1)
     return FPHIP_UNSUPPORTED;
@@ -1444,6 +1522,27 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
     }
   }
   BkzsHost H{S, gh_factor, rnd, rnd_user, 0.0};
+  fphip_pruner::VolumeEngine *il_engine = nullptr;
+  if (inloop)
+  {
+    H.inloop       = 1;
+    H.il_preproc   = g->il_preproc;
+    H.il_target    = g->il_target;
+    H.il_min_block = g->il_min_block;
+    H.il_flags     = g->il_flags;
+    if (g->il_device)
+    {
+      char why[256] = {0};
+      il_engine     = fphip_pruner::create_device_volume_engine(fphip_ctx_device(g->ctx), why, sizeof why);
+      if (!il_engine)
+      {
+        cleanup();
+        snprintf(fphip_ctx_errbuf(g->ctx), 512, "bkz_strategies: %s", why);
+        return FPHIP_ERROR;
+      }
+    }
+  }
+  unsigned long long il_calls = 0;
   if (handoff)
   {
     // hand-off mode: a second context on this device for the enumerations, the blocks' mu rows in
@@ -1518,7 +1617,7 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
     std::deque<std::pair<size_t, unsigned long long>> hq;
     bool hq_stop = false;
     std::thread worker;
-    if (handoff)
+    if (handoff || inloop)
       worker = std::thread([&]()
       {
         for (;;)
@@ -1533,6 +1632,13 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
             hq.pop_front();
           }
           BkzMail *m   = &mail[job.first];
+          if (m->type == 1)
+          {  // in-loop pruning: radius, prune() on the block's profile (its batches on the engine's stream)
+            serve_radius(H, m, il_engine);
+            ++il_calls;
+            __atomic_store_n(&m->rsp_seq, job.second, __ATOMIC_RELEASE);
+            continue;
+          }
           const int rc = serve_enumeration(g->ectx, m, g->P.enum_mu_h + job.first * (64 * 63 / 2));
           if (rc != FPHIP_OK)
           {  // the wave cannot walk the block itself any more: no solution, and the call reports the error
@@ -1555,8 +1661,8 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
           const unsigned long long seq = __atomic_load_n(&m->req_seq, __ATOMIC_ACQUIRE);
           if (seq == handled[L])
             continue;
-          if (m->type == 3 && handoff)
-          {  // to the worker; it stores rsp_seq when the enumeration is done
+          if ((m->type == 3 && handoff) || inloop_block(H, m))
+          {  // to the worker; it stores rsp_seq when the enumeration (or the block's prune()) is done
             handled[L] = seq;
             {
               std::lock_guard<std::mutex> lk(hq_m);
@@ -1583,7 +1689,7 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
     const hipError_t q = hipStreamSynchronize(s);
     stop.store(true, std::memory_order_release);
     server.join();
-    if (handoff)
+    if (handoff || inloop)
     {
       {
         std::lock_guard<std::mutex> lk(hq_m);
@@ -1679,6 +1785,17 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
   }
 #undef BCHK
   cleanup();  // (run_once's GCHKs return to this function, never past it: nothing leaks on a HIP error)
+  if (inloop)
+  {
+    g->il_calls += il_calls;
+    if (il_engine)
+    {
+      g->il_device_jobs += il_engine->device_jobs;
+      g->il_host_jobs += il_engine->host_jobs;
+      g->il_launches += il_engine->launches;
+      fphip_pruner::destroy_volume_engine(il_engine);
+    }
+  }
   if (handoff && getenv("FPHIP_DEBUG"))
     fprintf(stderr, "[fphip] bkz_strategies: %llu block enumerations handed to the multi-wave enumerator\n",
             handoff_calls);

@@ -163,7 +163,7 @@ class MatGSOBatch:
 
     def bkz_strategies(self, block_size, strategies, rnd, delta=LLL_DEF_DELTA, eta=LLL_DEF_ETA,
                        max_loops=0, gh_bnd=False, bounded_lll=False, gh_factor=1.1, auto_abort=False,
-                       sd=False, handoff=False, slide=False):
+                       sd=False, handoff=False, slide=False, prune_in_loop=None):
         """BKZReduction::bkz() with a strategies table (preprocessing tours, pruning, GH bound,
         rerandomisation; bkz.cpp:43-124, 274-441, 522-668) on every (LLL-reduced) lattice.
         strategies: dict with the flattened arrays of include/fplll_hip.h's fphip_strategies
@@ -175,7 +175,20 @@ class MatGSOBatch:
         handoff: FPHIP_BKZ_HANDOFF — large blocks are enumerated by the multi-wave enumerator (another
         visiting order than the reference's: accept the result by the reducedness predicate, not by the
         reference's basis; include/fplll_hip.h).
+        prune_in_loop: FPHIP_BKZ_PRUNE_IN_LOOP — dict(preproc_cost, target, min_block, pruner_flags,
+        on_device): the primal blocks of the top-level tour of at least min_block rows are pruned one by
+        one by prune() on their own r-profile (on the device's volume kernel with on_device, default)
+        where the reference would pick a set of the strategies (include/fplll_hip.h).
         Returns (status[batch], info[batch][4])."""
+        if prune_in_loop is not None:
+            il = dict(preproc_cost=1e6, target=0.5, min_block=24, pruner_flags=0x4, on_device=True)
+            il.update(prune_in_loop)
+            fn = self.lib.fphip_gso_bkz_inloop_pruning
+            fn.restype = ctypes.c_int
+            fn.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+            self._chk(fn(self.h, float(il["preproc_cost"]), float(il["target"]), int(il["min_block"]),
+                         int(il["pruner_flags"]), 1 if il["on_device"] else 0), "bkz_inloop_pruning")
+
         class Strat(ctypes.Structure):
             _fields_ = [("max_block_size", ctypes.c_int), ("pre_off", ctypes.c_void_p),
                         ("pre", ctypes.c_void_p), ("prune_off", ctypes.c_void_p),
@@ -217,13 +230,22 @@ class MatGSOBatch:
         info = np.zeros((self.batch, 4), dtype=np.int32)
         flags = ((0x4 if max_loops > 0 else 0) | (0x80 if gh_bnd else 0) | (0x10 if bounded_lll else 0) |
                  (0x20 if auto_abort else 0) | (0x100 if sd else 0) | (0x1000 if handoff else 0) |
-                 (0x200 if slide else 0))
+                 (0x200 if slide else 0) | (0x2000 if prune_in_loop is not None else 0))
         rc = fn(self.h, block_size, delta, eta, flags, max_loops, gh_factor, sp, cb, rnd_user,
                 st.ctypes.data_as(ctypes.c_void_p), info.ctypes.data_as(ctypes.c_void_p))
         if rc == _lib.FPHIP_UNSUPPORTED:
             raise NotImplementedError("block sizes above 64 / deeper preprocessing stay on the CPU")
         self._chk(rc, "bkz_strategies")
         return st, info
+
+    def inloop_stats(self):
+        """(prune() calls of the in-loop service, volume jobs on the device, inline on the host, launches)"""
+        v = [ctypes.c_ulonglong(0) for _ in range(4)]
+        fn = self.lib.fphip_gso_bkz_inloop_stats
+        fn.restype = ctypes.c_int
+        fn.argtypes = [ctypes.c_void_p] + [ctypes.POINTER(ctypes.c_ulonglong)] * 4
+        fn(self.h, *[ctypes.byref(x) for x in v])
+        return tuple(x.value for x in v)
 
     def get_mu_matrix(self, lattice=0):
         m = np.empty((self.d, self.d), dtype=np.float64)

@@ -233,6 +233,24 @@ int fphip_gso_bkz(fphip_gso *g, int block_size, double delta, double eta, int fl
  * multi-threaded enumlib is to fplll alone.  Accept it by the reference's reducedness predicate
  * (tests/test_a_configs_at_size_gpu.py). */
 #define FPHIP_BKZ_HANDOFF 0x1000
+/* FPHIP_BKZ_PRUNE_IN_LOOP (not a flag of fplll): at the point where svp_reduction picks a
+ * pruning set of the strategies (bkz.cpp:325, after the preprocessing and the radius), the PRIMAL blocks of
+ * the TOP-LEVEL tour (its closing hkz included) of at least min_block_size rows get coefficients computed
+ * for the block itself: prune<FP_NR<double>>(radius, preproc_cost, r_ii of the block, target,
+ * PRUNER_METRIC_PROBABILITY_OF_SHORTEST, pruner_flags) on the profile the lattice's wave has just sent to
+ * its mailbox, expectation = the pruner's; preprocessing tours and dual blocks keep the strategies' sets.
+ * With on_device the searches' batches are scored by the volume kernel on a stream of its own while the
+ * schedule kernel waits on the mailbox; otherwise by the host loop — same coefficients.  The reference has
+ * no such mode; `oracle/ref_driver bkzprune` drives the reference's own svp_preprocessing / Enumeration /
+ * svp_postprocessing / prune<> the same way, and the device run returns its basis, status and node count
+ * (tests/test_bkzs_gpu.py).  Parameters (defaults 1e6, 0.5, 24, PRUNER_GRADIENT, 1) are per fphip_gso. */
+#define FPHIP_BKZ_PRUNE_IN_LOOP 0x2000
+int fphip_gso_bkz_inloop_pruning(fphip_gso *g, double preproc_cost, double target, int min_block_size,
+                                 int pruner_flags, int on_device);
+/* prune() calls of the service so far, and the volume jobs they evaluated by kernels / inline on the host */
+int fphip_gso_bkz_inloop_stats(const fphip_gso *g, unsigned long long *prune_calls,
+                               unsigned long long *device_jobs, unsigned long long *host_jobs,
+                               unsigned long long *launches);
 typedef struct fphip_strategies
 {
   int max_block_size;

@@ -690,6 +690,159 @@ static int cmd_hlllfix(int argc, char **argv)
 }
 
 
+/* In-loop pruning with the REAL reference (REFDRV_INLOOP="preproc_cost target min_block pruner_flags" of
+ * bkzfix; the product's FPHIP_BKZ_PRUNE_IN_LOOP): the reference has no such mode, so its top-level loop is
+ * driven from here through its PUBLIC members — bkz() (bkz.cpp:522-668, primal, BKZ_MAX_LOOPS / default /
+ * BKZ_AUTO_ABORT), tour = trunc_tour + hkz (:360-441), svp_reduction (:274-358) — with ONE change: where
+ * svp_reduction picks a pruning set of the strategies (:325) a top-level block of at least min_block rows is
+ * pruned by the reference's own prune<FP_NR<double>>() on its current r-profile and radius.  Everything
+ * inside stays the library's: svp_preprocessing (its recursive tours use the strategies' sets),
+ * rerandomize_block, Enumeration, svp_postprocessing, size_reduction. */
+struct InloopBKZ
+{
+  typedef Z_NR<long> ZT;
+  typedef FP_NR<double> FT;
+  MatGSO<ZT, FT> &m;
+  LLLReduction<ZT, FT> &lll_obj;
+  BKZReduction<ZT, FT> &B;
+  const BKZParam &par;
+  double preproc, target;
+  int min_block, pflags;
+  FastEvaluator<FT> evaluator;
+  long prune_calls = 0, prune_failures = 0;
+  int num_rows;
+
+  InloopBKZ(MatGSO<ZT, FT> &m_, LLLReduction<ZT, FT> &l, BKZReduction<ZT, FT> &b, const BKZParam &p, double pc,
+            double tg, int mb, int pf)
+      : m(m_), lll_obj(l), B(b), par(p), preproc(pc), target(tg), min_block(mb), pflags(pf)
+  {
+    for (num_rows = m.d; num_rows > 0 && m.b_row_is_zero(num_rows - 1); num_rows--)
+    {
+    }
+  }
+
+  bool svp_reduction(int kappa, int block_size)
+  {
+    if (block_size < min_block || block_size < 4)
+      return B.svp_reduction(kappa, block_size, par);
+    const int first = kappa;
+    if (!lll_obj.size_reduction(0, first + 1, 0))
+      throw std::runtime_error(RED_STATUS_STR[lll_obj.status]);
+    long old_first_expo;
+    FT old_first                 = FT(m.get_r_exp(first, first, old_first_expo));
+    bool rerandomize             = false;
+    double remaining_probability = 1.0;
+    while (remaining_probability > 1. - par.min_success_probability)
+    {
+      if (rerandomize)
+        B.rerandomize_block(kappa + 1, kappa + block_size, par.rerandomization_density);
+      B.svp_preprocessing(kappa, block_size, par);
+      long max_dist_expo;
+      FT max_dist = m.get_r_exp(first, first, max_dist_expo);
+      FT delta    = par.delta;
+      max_dist *= delta;
+      if ((par.flags & BKZ_GH_BND) && block_size > 30)
+      {
+        FT root_det = m.get_root_det(kappa, kappa + block_size);
+        adjust_radius_to_gh_bound(max_dist, max_dist_expo, block_size, root_det, par.gh_factor);
+      }
+      // ---- the one change: prune THIS block (instead of get_pruning, bkz.cpp:82-98) ----
+      PruningParams pruning;
+      bool pruned = false;
+      {
+        vector<double> r;
+        for (int i = kappa; i < kappa + block_size; ++i)
+        {
+          FT x;
+          m.get_r(x, i, i);
+          r.push_back(x.get_d());
+        }
+        const double radius = max_dist.get_d() * pow(2, max_dist_expo);
+        ++prune_calls;
+        try
+        {
+          if (std::isfinite(radius) && radius > 0)
+          {
+            prune<FT>(pruning, radius, preproc, r, target, PRUNER_METRIC_PROBABILITY_OF_SHORTEST, pflags);
+            pruned = true;
+          }
+        }
+        catch (const std::exception &)
+        {
+        }
+      }
+      if (!pruned)
+      {  // the strategies' choice, bkz.cpp:82-98
+        ++prune_failures;
+        long e2;
+        FT md = m.get_r_exp(kappa, kappa, e2), gh = md, root_det = m.get_root_det(kappa, kappa + block_size);
+        adjust_radius_to_gh_bound(gh, e2, block_size, root_det, 1.0);
+        pruning = par.strategies[block_size].get_pruning(md.get_d() * pow(2, e2), gh.get_d() * pow(2, e2));
+      }
+      evaluator.solutions.clear();
+      Enumeration<ZT, FT> enum_obj(m, evaluator);
+      enum_obj.enumerate(kappa, kappa + block_size, max_dist, max_dist_expo, vector<FT>(), vector<enumxt>(),
+                         pruning.coefficients, false);
+      B.nodes += enum_obj.get_nodes();
+      if (!evaluator.empty())
+      {
+        B.svp_postprocessing(kappa, block_size, evaluator.begin()->second, false);
+        rerandomize = false;
+      }
+      else
+        rerandomize = true;
+      remaining_probability *= (1 - pruning.expectation);
+    }
+    if (!lll_obj.size_reduction(0, first + 1, 0))
+      throw std::runtime_error(RED_STATUS_STR[lll_obj.status]);
+    long new_first_expo;
+    FT new_first = m.get_r_exp(first, first, new_first_expo);
+    new_first.mul_2si(new_first, new_first_expo - old_first_expo);
+    return old_first <= new_first;
+  }
+  bool tour(int min_row, int max_row)
+  {
+    bool clean = true;
+    for (int kappa = min_row; kappa < max_row - par.block_size; ++kappa)  // trunc_tour
+      clean &= svp_reduction(kappa, par.block_size);
+    const int h0 = std::max(max_row - par.block_size, 0);                 // hkz
+    for (int kappa = h0; kappa < max_row - 1; ++kappa)
+      clean &= svp_reduction(kappa, max_row - kappa);
+    lll_obj.size_reduction(max_row - 1, max_row, max_row - 2);
+    return clean;
+  }
+  int run()
+  {
+    B.nodes = 0;
+    if (par.block_size < 2)
+      return RED_SUCCESS;
+    BKZAutoAbort<ZT, FT> auto_abort(m, num_rows);
+    m.discover_all_rows();
+    int final_status = RED_SUCCESS;
+    try
+    {
+      for (int i = 0;; ++i)
+      {
+        if ((par.flags & BKZ_MAX_LOOPS) && i >= par.max_loops)
+        {
+          final_status = RED_BKZ_LOOPS_LIMIT;
+          break;
+        }
+        if ((par.flags & BKZ_AUTO_ABORT) && auto_abort.test_abort(par.auto_abort_scale, par.auto_abort_max_no_dec))
+          break;
+        const bool clean = tour(0, num_rows);
+        if (clean || par.block_size >= num_rows)
+          break;
+      }
+    }
+    catch (const std::runtime_error &)
+    {
+      return lll_obj.status;
+    }
+    return final_status;
+  }
+};
+
 /* bkzfix type d k bits seed block_size max_loops [reps] ; REFDRV_BKZ_AUTO_ABORT=1 adds BKZ_AUTO_ABORT:
  * BKZReduction<Z_NR<long>,FP_NR<double>>::bkz() on MatGSO(GSO_ROW_EXPO) exactly as bkz_reduction_f
  * sets it up after convert<long> (bkz.cpp:813-845), empty strategies (no pruning / preprocessing),
@@ -771,6 +924,8 @@ static int cmd_bkzfix(int argc, char **argv)
   double secs = 0;
   int status = 0;
   long nodes = 0;
+  long inloop_calls = 0, inloop_fails = 0;
+  double inloop_desc[4] = {0, 0, 0, 0};
   for (int rep = 0; rep < reps; ++rep)
   {
     b = b0;
@@ -799,6 +954,17 @@ static int cmd_bkzfix(int argc, char **argv)
         fprintf(stderr, "kappa %d nodes %ld\n", kappa, B.nodes - before);
       }
     }
+    else if (getenv("REFDRV_INLOOP"))
+    {
+      double pc = 1e6, tg = 0.5;
+      int mb = 24, pf = PRUNER_GRADIENT;
+      sscanf(getenv("REFDRV_INLOOP"), "%lf %lf %d %d", &pc, &tg, &mb, &pf);
+      InloopBKZ I(M, L, B, par, pc, tg, mb, pf);
+      B.status       = I.run();
+      inloop_calls   = I.prune_calls;
+      inloop_fails   = I.prune_failures;
+      inloop_desc[0] = pc, inloop_desc[1] = tg, inloop_desc[2] = mb, inloop_desc[3] = pf;
+    }
     else
     B.bkz();
     if (getenv("REFDRV_RECORD"))
@@ -807,6 +973,10 @@ static int cmd_bkzfix(int argc, char **argv)
     status = B.status;
     nodes  = B.nodes;
   }
+  if (getenv("REFDRV_INLOOP"))
+    os << "\"inloop\":{\"preproc_cost\":" << hexd(inloop_desc[0]) << ",\"target\":" << hexd(inloop_desc[1])
+       << ",\"min_block\":" << (int)inloop_desc[2] << ",\"pruner_flags\":" << (int)inloop_desc[3]
+       << ",\"prune_calls\":" << inloop_calls << ",\"prune_failures\":" << inloop_fails << "},\n";
   os << "\"ref_status\":" << status << ",\n\"nodes\":" << nodes << ",\n\"reps\":" << reps
      << ",\n\"ref_seconds\":" << secs << ",\n\"b_out\":[";
   for (int i = 0; i < d; ++i)

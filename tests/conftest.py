@@ -424,6 +424,11 @@ def load_bkz_fixture(path):
         out["gh_factor"] = float.fromhex(j["gh_factor"])
         out["rng_seed"] = j["rng_seed"]
     out["auto_abort"] = bool(j.get("auto_abort", 0))
+    if "inloop" in j:  # in-loop pruning (ref_driver bkzfix with REFDRV_INLOOP)
+        il = j["inloop"]
+        out["inloop"] = dict(preproc_cost=float.fromhex(il["preproc_cost"]), target=float.fromhex(il["target"]),
+                             min_block=il["min_block"], pruner_flags=il["pruner_flags"],
+                             prune_calls=il["prune_calls"], prune_failures=il["prune_failures"])
     out["name"] = os.path.basename(path)[:-5]
     out["ref_seconds"] = j.get("ref_seconds")
     out["status"] = BKZ_REF_STATUS_TO_OURS[j["ref_status"]]

@@ -80,6 +80,11 @@ REFDRV_STRATEGIES=$T/stratB.json REFDRV_BKZ_FLAGS=0x80 REFDRV_RNG_SEED=5 $D bkzf
 REFDRV_STRATEGIES=$T/stratA.json REFDRV_BKZ_FLAGS=0x80 REFDRV_BKZ_AUTO_ABORT=1 REFDRV_RNG_SEED=9 $D bkzfix q 56 28 12 4 36 0 > $G/bkzs_q56_b36_autoabort.json
 REFDRV_STRATEGIES=$T/stratB.json REFDRV_BKZ_FLAGS=0x10 REFDRV_RNG_SEED=11 $D bkzfix q 64 32 14 6 34 1 > $G/bkzs_q64_b34_bounded_lll.json
 REFDRV_STRATEGIES=$T/stratB.json REFDRV_BKZ_FLAGS=0x80 REFDRV_RNG_SEED=13 $D bkzfix r 40 0 40 4 32 2 > $G/bkzs_r40_b32_rerand.json
+# in-loop pruning (REFDRV_INLOOP="preproc_cost target min_block pruner_flags": ref_driver's InloopBKZ drives the
+# reference's public members, prune<>() per top-level block)
+REFDRV_INLOOP="1e5 0.5 24 4" REFDRV_STRATEGIES=$T/stratA.json REFDRV_BKZ_FLAGS=0x80 REFDRV_RNG_SEED=5 $D bkzfix q 64 32 14 3 40 2 > $G/bkzp_q64_b40_inloop.json
+REFDRV_INLOOP="2e4 0.6 20 4" REFDRV_STRATEGIES=$T/stratB.json REFDRV_BKZ_FLAGS=0x80 REFDRV_RNG_SEED=13 $D bkzfix r 40 0 40 4 32 2 > $G/bkzp_r40_b32_inloop_rerand.json
+REFDRV_INLOOP="1e6 0.3 30 36" REFDRV_STRATEGIES=$T/stratA.json REFDRV_BKZ_FLAGS=0x80 REFDRV_BKZ_AUTO_ABORT=1 REFDRV_RNG_SEED=9 $D bkzfix q 56 28 12 4 36 0 > $G/bkzp_q56_b36_inloop_half_autoabort.json
 # --- self-dual BKZ (0x100) and slide reduction (0x200): dual svp_reduction / dual enumeration
 REFDRV_BKZ_FLAGS=0x100 $D bkzfix q 40 20 20 1 10 3 > $G/bkzd_q40_b10_sd_loops3.json
 REFDRV_BKZ_FLAGS=0x200 $D bkzfix q 40 20 20 1 10 0 > $G/bkzd_q40_b10_slide.json

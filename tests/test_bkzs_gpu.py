@@ -98,3 +98,50 @@ def test_heterogeneous_batch_vs_oracle(ctx, d, beta, which):
         assert nodes == want[L][1]
         assert np.array_equal(out[L], want[L][3])
     g.close()
+
+
+# ---- pruning per block, in the loop (FPHIP_BKZ_PRUNE_IN_LOOP) --------------------------
+INLOOP = sorted(__import__("glob").glob(os.path.join(C.GOLDEN, "bkzp_*.json")))
+
+
+@pytest.mark.parametrize("on_device", [True, False], ids=["volume-kernel", "host-loop"])
+@pytest.mark.parametrize("path", INLOOP, ids=lambda p: os.path.basename(p)[:-5])
+def test_bkz_with_inloop_pruning_matches_reference(ctx, path, on_device):
+    """tests/golden/bkzp_*.json: the REAL reference driven block by block (`ref_driver bkzfix` with
+    REFDRV_INLOOP: its own svp_preprocessing / Enumeration / svp_postprocessing, and its own prune<>() on the
+    block's r-profile where svp_reduction would pick a set of the strategies, bkz.cpp:325).  The device tour
+    with the mailbox service pruning every such block — its searches' batches on the volume kernel, or on the
+    host loop — returns the reference's basis, status and node count: every coefficient of every one of the
+    90 / 42 / 459 prune() runs on the way was the reference's."""
+    from fplll_amd.gso import MatGSOBatch
+    f = C.load_bkz_fixture(path)
+    il = f["inloop"]
+    assert il["prune_failures"] == 0
+    batch = 2
+    g = MatGSOBatch(ctx, batch, f["d"], f["n"])
+    g.set_basis(np.stack([f["b_in"]] * batch))
+    rnd, draws = C.gmp_streams_native(batch, f["rng_seed"])
+    st, info = g.bkz_strategies(f["block_size"], f["strategies"], rnd, f["delta"], f["eta"],
+                                max_loops=f["max_loops"], gh_bnd=bool(f["flags"] & 0x80),
+                                bounded_lll=bool(f["flags"] & 0x10), gh_factor=f["gh_factor"],
+                                auto_abort=bool(f["flags"] & 0x20),
+                                prune_in_loop=dict(preproc_cost=il["preproc_cost"], target=il["target"],
+                                                   min_block=il["min_block"], pruner_flags=il["pruner_flags"],
+                                                   on_device=on_device))
+    out = g.get_basis()
+    nodes = [(int(i[1]) & 0xffffffff) | (int(i[2]) << 32) for i in info]
+    calls, dev_jobs, host_jobs, launches = g.inloop_stats()
+    C.note(lambda: ("status", st, "expected", f["status"], "nodes", nodes, "expected", f["nodes"], "kernel ms",
+                    g.last_kernel_ms, "prune calls", calls, "reference", il["prune_calls"], "volume jobs dev/host",
+                    dev_jobs, host_jobs, "launches", launches, "reference s", f["ref_seconds"],))
+    for L in range(batch):
+        bad = np.nonzero((out[L] != f["b_out"]).any(axis=1))[0]
+        assert st[L] == f["status"], (L, st, info)
+        assert bad.size == 0, ("first differing row", int(bad[0]), "of", f["d"], "nodes", nodes[L], f["nodes"])
+        assert nodes[L] == f["nodes"]
+    assert calls == batch * il["prune_calls"]
+    if on_device:
+        assert launches > 0 and dev_jobs > 10 * host_jobs, "the searches' batches must run on the volume kernel"
+    else:
+        assert launches == 0
+    g.close()
