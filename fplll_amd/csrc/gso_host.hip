@@ -102,7 +102,7 @@ struct fphip_gso
   int blocks_per_cu;
   bool dirty;  // the integer basis was uploaded after the last (re)float of the rows
   // planes of mu for gso_sweep2_kernel (low / high words; row-major and transposed), [batch][2][d][ldd]
-  unsigned *muP, *muTP;
+  double *muA;  // anchored transpose of mu for gso_sweep2_kernel's recurrence, [batch][d][ldd] (gso_sweep2.hip)
   short *m16;   // 2-byte mirrors: [batch][n*ldd + d*ldn] (bT16 then b16 of each lattice)
   int *flag16;  // [batch][d]
   int sweep_version;  // 2 (default) or 1 (FPHIP_GSO_SWEEP=1: the first-generation kernel)
@@ -196,11 +196,9 @@ static int gso_allocate(fphip_gso *g)
   GCHK(fphip_dev_alloc((void **)&g->P.bfT32, B * n * ldd * sizeof(float) + pad, fphip_ctx_stream(g->ctx)));
   GCHK(fphip_dev_alloc((void **)&g->P.b32, B * d * ldn * sizeof(int) + pad, fphip_ctx_stream(g->ctx)));
   GCHK(fphip_dev_alloc((void **)&g->P.narrow, B * d * sizeof(int), fphip_ctx_stream(g->ctx)));
-  GCHK(fphip_dev_alloc((void **)&g->muP, B * 2 * d * ldd * sizeof(unsigned) + pad, fphip_ctx_stream(g->ctx)));
-  GCHK(fphip_dev_alloc((void **)&g->muTP, B * 2 * d * ldd * sizeof(unsigned) + pad, fphip_ctx_stream(g->ctx)));
+  GCHK(fphip_dev_alloc((void **)&g->muA, B * d * ldd * sizeof(double) + pad, fphip_ctx_stream(g->ctx)));
   hipStream_t s0 = fphip_ctx_stream(ctx);
-  GCHK(hipMemsetAsync(g->muP, 0, B * 2 * d * ldd * sizeof(unsigned) + pad, s0));
-  GCHK(hipMemsetAsync(g->muTP, 0, B * 2 * d * ldd * sizeof(unsigned) + pad, s0));
+  GCHK(hipMemsetAsync(g->muA, 0, B * d * ldd * sizeof(double) + pad, s0));
   GCHK(fphip_dev_alloc((void **)&g->m16, B * ((size_t)n * ldd + (size_t)d * ldn) * sizeof(short) + pad, fphip_ctx_stream(g->ctx)));
   GCHK(fphip_dev_alloc((void **)&g->flag16, B * d * sizeof(int), fphip_ctx_stream(g->ctx)));
   GCHK(hipMemsetAsync(g->m16, 0, B * ((size_t)n * ldd + (size_t)d * ldn) * sizeof(short) + pad, s0));
@@ -252,8 +250,7 @@ extern "C" void fphip_gso_destroy(fphip_gso *g)
   fphip_dev_free(g->P.bfT32, fphip_ctx_stream(g->ctx));
   fphip_dev_free(g->P.b32, fphip_ctx_stream(g->ctx));
   fphip_dev_free(g->P.narrow, fphip_ctx_stream(g->ctx));
-  fphip_dev_free(g->muP, fphip_ctx_stream(g->ctx));
-  fphip_dev_free(g->muTP, fphip_ctx_stream(g->ctx));
+  fphip_dev_free(g->muA, fphip_ctx_stream(g->ctx));
   fphip_dev_free(g->m16, fphip_ctx_stream(g->ctx));
   fphip_dev_free(g->flag16, fphip_ctx_stream(g->ctx));
   if (g->P.gf)
@@ -315,16 +312,16 @@ static int launch(fphip_gso *g, int kmin, int kend, double eta, int mode, const 
     switch (nq)
     {
     case 1:
-      hipLaunchKernelGGL(s2::gso_sweep2_kernel<1>, dim3(grid), dim3(wpb * 64), lds2, s, g->P, g->muP, g->muTP, g->m16, g->flag16, kmin, kend, eta, mode);
+      hipLaunchKernelGGL(s2::gso_sweep2_kernel<1>, dim3(grid), dim3(wpb * 64), lds2, s, g->P, g->muA, g->m16, g->flag16, kmin, kend, eta, mode);
       break;
     case 2:
-      hipLaunchKernelGGL(s2::gso_sweep2_kernel<2>, dim3(grid), dim3(wpb * 64), lds2, s, g->P, g->muP, g->muTP, g->m16, g->flag16, kmin, kend, eta, mode);
+      hipLaunchKernelGGL(s2::gso_sweep2_kernel<2>, dim3(grid), dim3(wpb * 64), lds2, s, g->P, g->muA, g->m16, g->flag16, kmin, kend, eta, mode);
       break;
     case 3:
-      hipLaunchKernelGGL(s2::gso_sweep2_kernel<3>, dim3(grid), dim3(wpb * 64), lds2, s, g->P, g->muP, g->muTP, g->m16, g->flag16, kmin, kend, eta, mode);
+      hipLaunchKernelGGL(s2::gso_sweep2_kernel<3>, dim3(grid), dim3(wpb * 64), lds2, s, g->P, g->muA, g->m16, g->flag16, kmin, kend, eta, mode);
       break;
     default:
-      hipLaunchKernelGGL(s2::gso_sweep2_kernel<4>, dim3(grid), dim3(wpb * 64), lds2, s, g->P, g->muP, g->muTP, g->m16, g->flag16, kmin, kend, eta, mode);
+      hipLaunchKernelGGL(s2::gso_sweep2_kernel<4>, dim3(grid), dim3(wpb * 64), lds2, s, g->P, g->muA, g->m16, g->flag16, kmin, kend, eta, mode);
       break;
     }
     GCHK(hipGetLastError());
@@ -1522,7 +1519,10 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
     }
   }
   BkzsHost H{S, gh_factor, rnd, rnd_user, 0.0};
-  fphip_pruner::VolumeEngine *il_engine = nullptr;
+  // in-loop pruning: a pool of worker threads (one prune() is tens of milliseconds; the lattices of a batch
+  // ask at about the same time), each with a volume engine of its own (stream, staging, device buffers)
+  std::vector<fphip_pruner::VolumeEngine *> il_engines;
+  int n_workers = 1;
   if (inloop)
   {
     H.inloop       = 1;
@@ -1530,19 +1530,25 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
     H.il_target    = g->il_target;
     H.il_min_block = g->il_min_block;
     H.il_flags     = g->il_flags;
-    if (g->il_device)
+    const char *we = getenv("FPHIP_BKZ_PRUNE_WORKERS");
+    n_workers      = we ? atoi(we) : 8;
+    n_workers      = std::max(1, std::min(n_workers, (int)std::min<size_t>(B, 64)));
+    for (int w = 0; w < n_workers && g->il_device; ++w)
     {
       char why[256] = {0};
-      il_engine     = fphip_pruner::create_device_volume_engine(fphip_ctx_device(g->ctx), why, sizeof why);
-      if (!il_engine)
+      fphip_pruner::VolumeEngine *e = fphip_pruner::create_device_volume_engine(fphip_ctx_device(g->ctx), why, sizeof why);
+      if (!e)
       {
+        for (auto *x : il_engines)
+          fphip_pruner::destroy_volume_engine(x);
         cleanup();
         snprintf(fphip_ctx_errbuf(g->ctx), 512, "bkz_strategies: %s", why);
         return FPHIP_ERROR;
       }
+      il_engines.push_back(e);
     }
   }
-  unsigned long long il_calls = 0;
+  std::atomic<unsigned long long> il_calls{0};
   if (handoff)
   {
     // hand-off mode: a second context on this device for the enumerations, the blocks' mu rows in
@@ -1616,10 +1622,12 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
     std::condition_variable hq_cv;
     std::deque<std::pair<size_t, unsigned long long>> hq;
     bool hq_stop = false;
-    std::thread worker;
-    if (handoff || inloop)
-      worker = std::thread([&]()
+    std::mutex enum_m;  // the hand-off enumerations share ONE context: one at a time
+    std::vector<std::thread> workers;
+    for (int w = 0; w < ((handoff || inloop) ? n_workers : 0); ++w)
+      workers.emplace_back([&, w]()
       {
+        fphip_pruner::VolumeEngine *engine = w < (int)il_engines.size() ? il_engines[w] : nullptr;
         for (;;)
         {
           std::pair<size_t, unsigned long long> job;
@@ -1634,19 +1642,23 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
           BkzMail *m   = &mail[job.first];
           if (m->type == 1)
           {  // in-loop pruning: radius, prune() on the block's profile (its batches on the engine's stream)
-            serve_radius(H, m, il_engine);
+            serve_radius(H, m, engine);
             ++il_calls;
             __atomic_store_n(&m->rsp_seq, job.second, __ATOMIC_RELEASE);
             continue;
           }
-          const int rc = serve_enumeration(g->ectx, m, g->P.enum_mu_h + job.first * (64 * 63 / 2));
-          if (rc != FPHIP_OK)
-          {  // the wave cannot walk the block itself any more: no solution, and the call reports the error
-            m->have_sol = 0;
-            m->nodes3   = 0;
-            handoff_rc  = rc;
+          int rc;
+          {
+            std::lock_guard<std::mutex> lk(enum_m);
+            rc = serve_enumeration(g->ectx, m, g->P.enum_mu_h + job.first * (64 * 63 / 2));
+            if (rc != FPHIP_OK)
+            {  // the wave cannot walk the block itself any more: no solution, and the call reports the error
+              m->have_sol = 0;
+              m->nodes3   = 0;
+              handoff_rc  = rc;
+            }
+            ++handoff_calls;
           }
-          ++handoff_calls;
           __atomic_store_n(&m->rsp_seq, job.second, __ATOMIC_RELEASE);
         }
       });
@@ -1696,7 +1708,8 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
         hq_stop = true;
       }
       hq_cv.notify_all();
-      worker.join();
+      for (auto &t : workers)
+        t.join();
     }
     if (q != hipSuccess)
       return gfail(g->ctx, "bkzs_kernel", q);
@@ -1787,13 +1800,13 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
   cleanup();  // (run_once's GCHKs return to this function, never past it: nothing leaks on a HIP error)
   if (inloop)
   {
-    g->il_calls += il_calls;
-    if (il_engine)
+    g->il_calls += il_calls.load();
+    for (auto *e : il_engines)
     {
-      g->il_device_jobs += il_engine->device_jobs;
-      g->il_host_jobs += il_engine->host_jobs;
-      g->il_launches += il_engine->launches;
-      fphip_pruner::destroy_volume_engine(il_engine);
+      g->il_device_jobs += e->device_jobs;
+      g->il_host_jobs += e->host_jobs;
+      g->il_launches += e->launches;
+      fphip_pruner::destroy_volume_engine(e);
     }
   }
   if (handoff && getenv("FPHIP_DEBUG"))

@@ -23,8 +23,8 @@ template <int NQ> struct Cfg
 };
 
 template <int NQ>
-__global__ void gso_sweep2_kernel(GsoBatch P, unsigned *muP, unsigned *muTP, short *m16, int *flag16, int kmin,
-                                  int kend, double eta, int mode);
+__global__ void gso_sweep2_kernel(GsoBatch P, double *muA, short *m16, int *flag16, int kmin, int kend, double eta,
+                                  int mode);
 }  // namespace s2
 }  // namespace fphip
 #endif

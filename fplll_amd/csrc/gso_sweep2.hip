@@ -13,12 +13,17 @@
 // One wavefront owns one lattice (see gso_kernel.hip for why).  What is new here is the shape of the
 // inner loops — the first kernel spent ~60 issued instructions and half a dozen branches per
 // streamed row and was bound by that, not by HBM:
-//   * EVERYTHING STREAMED IS A ROW OF 4-BYTE ELEMENTS, one LDS-DMA instruction each ("entry"):
-//     the float mirror of bf (Gram pass), the int32 mirror of b (integer AXPY) and mu kept as two
-//     planes of 32-bit words (low / high halves of the doubles; muP row-major for the size-reduction
-//     sweep, muTP transposed for the GSO recurrence).  An entry holds 64*NQ elements (NQ*256 B); a
-//     lane fetches 16 bytes = 4 elements, so a triangular window [lo, hi) is the lane mask
-//     [lo/4, ceil(hi/4)), set with one s_mov exec inside the issue sequence.
+//   * EVERYTHING STREAMED IS A PAIR OF LDS-DMA INSTRUCTIONS INTO ONE PAIR SLOT of the ring (2 entries of
+//     NQ*256 B): two rows of the float / int16 mirror of bf (Gram pass), two rows of the int32 / int16
+//     mirror of b (integer AXPY), or ONE row of mu as doubles (64*NQ doubles = the slot; lanes 0..63 of the
+//     first instruction fetch the first 1024 bytes, the second the rest).  A lane fetches 16 bytes, so a
+//     window of a row is a lane mask set with one s_mov exec inside the issue sequence.
+//   * EVERY mu WINDOW STARTS ON ITS ROW'S FIRST BYTE (round 4; the rows are 128-byte aligned): the
+//     size-reduction sweep reads mu(j, 0..j) straight from the row-major mu array; the GSO recurrence reads
+//     column k of mu from an ANCHORED transposed copy muA[k][p] = mu(k + 1 + p, k) — the entries below the
+//     diagonal pushed to the front of the row — so the window (k, kappa) is bytes [0, 8 (kappa - 1 - k)).
+//     Round 2-3 kept mu as two 4-byte planes with the recurrence window starting at element k + 1: two
+//     partial 128-byte lines more per streamed row, 10 % of the kernel's HBM traffic (tests/perf README).
 //   * THE RING MOVES IN PAIRS of entries: a step consumes one pair (two Gram rows, two AXPY rows,
 //     or the two planes of one mu row) and issues one pair.  INFL entries are ALWAYS in flight —
 //     when a chain of phases has no more rows to request the issue side sends one-lane dummies —
@@ -69,15 +74,13 @@ template <int NQ> struct Stream
   const char *gp;
   long gstride;
   unsigned long long gmask;
-  // recurrence: planes of row k of muTP, elements (k, last]
+  // recurrence: row k of the anchored transpose muA, positions [0, rlast - k) = mu(k+1 .. rlast, k)
   const char *rp;
-  long rstride, rplane;
-  unsigned long long rhimask;
-  int rk;
-  // size-reduction sweep: planes of row j of muP, elements [sr_start, j), j descending
+  long rstride;
+  int rk, rlast;
+  // size-reduction sweep: row j of mu, elements [0, j), j descending
   const char *sp;
-  long sstride, splane;
-  unsigned long long slomask;
+  long sstride;
   int sj;
   // integer AXPY: rows of the int32 mirror whose multiplier is not zero, descending
   const char *ap;
@@ -116,17 +119,40 @@ template <int NQ> struct Stream
     dma_pair(gp, gp + gstride, gmask);
     gp += 2 * gstride;
   }
+  // one row of doubles, elements [0, len) from the row's first byte (len >= 1), into one pair slot:
+  // lanes 0..63 of the first instruction cover the first 1024 bytes, the second instruction the rest —
+  // or, when there is no rest, lane 0 of the first again (same bytes to the same place: the count of
+  // instructions in flight stays two per pair)
+  __device__ __forceinline__ void dma_row8(const char *p, int len)
+  {
+    const int nl                   = (len + 1) >> 1;  // 16-byte lanes
+    const unsigned dst             = base + hoff;
+    const bool two                 = nl > 64;
+    const unsigned long long maskA = uni64(nl >= 64 ? ~0ull : ((1ull << nl) - 1));
+    const unsigned long long maskB = uni64(two ? (nl >= 128 ? ~0ull : ((1ull << (nl - 64)) - 1)) : 1ull);
+    const char *pB                 = two ? p + 1024 : p;
+    const unsigned dstB            = two ? dst + 1024 : dst;
+    asm volatile("s_mov_b32 m0, %2\n\t"
+                 "s_mov_b64 exec, %4\n\t"
+                 "global_load_lds_dwordx4 %6, %0\n\t"
+                 "s_mov_b32 m0, %3\n\t"
+                 "s_mov_b64 exec, %5\n\t"
+                 "global_load_lds_dwordx4 %6, %1\n\t"
+                 "s_mov_b64 exec, -1"
+                 :
+                 : "s"(p), "s"(pB), "s"(dst), "s"(dstB), "s"(maskA), "s"(maskB), "v"(lane16)
+                 : "memory", "m0", "scc");
+    hoff = (hoff + 2 * C::ESZ == (unsigned)C::RING) ? 0u : hoff + 2 * C::ESZ;
+  }
   __device__ __forceinline__ void issue_rec()
   {
-    const unsigned long long m = rhimask & (~0ull << ((rk + 1) >> 2));
-    dma_pair(rp, rp + rplane, m);
+    dma_row8(rp, rlast - rk);
     rp += rstride;
     ++rk;
   }
   __device__ __forceinline__ void issue_sweep()
   {
-    const unsigned long long m = slomask & (~0ull >> (64 - ((sj + 3) >> 2)));
-    dma_pair(sp, sp + splane, m);
+    dma_row8(sp, sj);
     sp -= sstride;
     --sj;
   }
@@ -284,12 +310,10 @@ template <int NQ> struct Stream
   }
 };
 
-// Device-resident planes of mu (one lattice)
+// The kernel's own copies of one lattice's data
 struct Planes
 {
-  unsigned *muP;   // [2][d][ldd]  word p of mu(j,k) at muP[p*pl + j*ldd + k]
-  unsigned *muTP;  // [2][d][ldd]  word p of mu(j,k) at muTP[p*pl + k*ldd + j]
-  size_t pl;       // d * ldd
+  double *muA;     // [d][ldd]  anchored transpose of mu: muA[k*ldd + (j-k-1)] = mu(j,k), j > k
   // 2-byte mirrors: while every entry of a row is below 2^15 in magnitude the Gram pass streams the
   // INTEGER column (bT16[c][j] = b(j,c)) and scales it by 2^-row_expo(j) in registers — bf(j,c) IS
   // b(j,c) * 2^-row_expo(j) exactly (gso.cpp:27-40) — and the AXPY streams b16: half the bytes of
@@ -366,15 +390,17 @@ template <int NQ, int KQ, int QA> struct RecCons
   double (&acc)[NQ];
   int kk;  // row k = 64 KQ + kk
   unsigned lane;
-  unsigned lo[NQ], hi[NQ];
+  double m[NQ];
   __device__ __forceinline__ void load(unsigned w, unsigned lane4)
   {
-    const unsigned a = w + (lane4 >> 2);
+    // position of mu(j, k) in the anchored row: j - k - 1 (the lanes j <= k read position 0: not used)
+    const double *sd = (const double *)s2_smem + (w >> 1);
+    const int p0     = (int)(lane4 >> 2) - kk - 1;
 #pragma unroll
     for (int q = KQ; q < QA; ++q)
     {
-      lo[q] = s2_smem[a + 64 * q];
-      hi[q] = s2_smem[a + 64 * q + Cfg<NQ>::ESZ / 4];
+      const int p = p0 + 64 * (q - KQ);
+      m[q]        = sd[q == KQ ? max(p, 0) : p];
     }
   }
   __device__ __forceinline__ void compute()
@@ -383,8 +409,7 @@ template <int NQ, int KQ, int QA> struct RecCons
 #pragma unroll
     for (int q = KQ; q < QA; ++q)
     {
-      const double m = __hiloint2double((int)hi[q], (int)lo[q]);
-      const double t = m * rk;
+      const double t = m[q] * rk;
       const double u = acc[q] - t;
       if (q == KQ)
         acc[q] = ((int)lane > kk) ? u : acc[q];  // rows j > k only
@@ -412,16 +437,13 @@ template <int NQ, int JQ> struct SweepCons
   int jj;                   // row j = 64 JQ + jj, descending
   int sr_start;
   unsigned lane;
-  unsigned lo[NQ], hi[NQ];
+  double m[NQ];
   __device__ __forceinline__ void load(unsigned w, unsigned lane4)
   {
-    const unsigned a = w + (lane4 >> 2);
+    const double *sd = (const double *)s2_smem + (w >> 1) + (lane4 >> 2);
 #pragma unroll
     for (int q = 0; q <= JQ; ++q)
-    {
-      lo[q] = s2_smem[a + 64 * q];
-      hi[q] = s2_smem[a + 64 * q + Cfg<NQ>::ESZ / 4];
-    }
+      m[q] = sd[64 * q];
   }
   __device__ __forceinline__ void compute()
   {
@@ -435,8 +457,7 @@ template <int NQ, int JQ> struct SweepCons
 #pragma unroll
       for (int q = 0; q <= JQ; ++q)
       {
-        const double m = __hiloint2double((int)hi[q], (int)lo[q]);
-        const double t = X * m;
+        const double t = X * m[q];
         const double u = bm[q] - t;
         // chunks below JQ hold only k < j; the chunk of j itself needs the test
         const bool on = (q < JQ || (int)lane < jj) && (int)(lane + 64 * q) >= sr_start;
@@ -589,7 +610,7 @@ __device__ __forceinline__ void sweep_phase(Stream<NQ> &S, double (&bm)[NQ], dou
       {  // last row: its multiplier only
 #pragma unroll
         for (int q = 0; q <= JQ; ++q)
-          s.lo[q] = s.hi[q] = 0;
+          s.m[q] = 0.0;
         s.compute();
       }
     }
@@ -687,11 +708,10 @@ __device__ __forceinline__ void gso_pass(Lattice<NQ> &T, const Planes &PL, Strea
   const int narrow = (PL.np16 > kappa) ? 2 : (T.np > kappa) ? 1 : 0;
   // recurrence rows k = 0..kappa-2 (row kappa-1 has nothing below it)
   const int nrec = kappa > 0 ? kappa - 1 : 0;
-  S.rp      = (const char *)PL.muTP;
-  S.rstride = (long)ldd * 4;
-  S.rplane  = (long)PL.pl * 4;
+  S.rp      = (const char *)PL.muA;
+  S.rstride = (long)ldd * 8;
   S.rk      = 0;
-  S.rhimask = kappa > 0 ? (~0ull >> (63 - ((kappa - 1) >> 2))) : 0ull;
+  S.rlast   = kappa - 1;
   if (narrow == 2)
   {
     S.gp      = (const char *)PL.bT16;
@@ -763,7 +783,8 @@ __device__ __forceinline__ double finish_diag2(const double (&mu)[NQ], const dou
   return g;
 }
 
-// store the confirmed row kappa: r, mu, the planes (row of muP, column of muTP), r(kappa,kappa)
+// store the confirmed row kappa: r, mu (what the sweep of the later rows streams), its column of the anchored
+// transpose (what their recurrences stream), r(kappa,kappa)
 template <int NQ>
 __device__ __forceinline__ void store_gso_row(Lattice<NQ> &T, const Planes &PL, int kappa, const double (&mu)[NQ],
                                               const double (&rr)[NQ], double rkk)
@@ -777,11 +798,7 @@ __device__ __forceinline__ void store_gso_row(Lattice<NQ> &T, const Planes &PL, 
     {
       T.r[(size_t)kappa * ldd + j]  = rr[q];
       T.mu[(size_t)kappa * ldd + j] = mu[q];
-      const unsigned lo = (unsigned)__double2loint(mu[q]), hi = (unsigned)__double2hiint(mu[q]);
-      PL.muP[(size_t)kappa * ldd + j]          = lo;
-      PL.muP[PL.pl + (size_t)kappa * ldd + j]  = hi;
-      PL.muTP[(size_t)j * ldd + kappa]         = lo;
-      PL.muTP[PL.pl + (size_t)j * ldd + kappa] = hi;
+      PL.muA[(size_t)j * ldd + (kappa - j - 1)] = mu[q];
     }
     else if (j == kappa)
     {
@@ -857,6 +874,46 @@ __device__ __forceinline__ void scale_vector(const Lattice<NQ> &T, int kappa, co
   }
 }
 
+// bf(kappa, c) for lane c.  bfT is column-major (a Gram pass wants the columns): row kappa of it is one
+// 8-byte word out of 180 different 128-byte lines.  While the row carries the 2-byte flag its mirror row is
+// contiguous and bf(kappa, c) = b(kappa, c) 2^-row_expo(kappa) EXACTLY (gso.cpp:27-40; |b| < 2^15): the
+// same doubles from 3 lines instead of 180 (4 MB per 180-dimensional lattice and sweep).
+template <int NQ>
+__device__ __forceinline__ void load_bf_row(const Lattice<NQ> &T, const Planes &PL, int kappa, double (&bk)[NQ])
+{
+  const int n = T.n, lane = T.lane;
+  if (PL.np16 > kappa)
+  {
+    const long long ek = T.rexp[kappa];
+    int v[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+    {
+      const int c = lane + 64 * q;
+      v[q]        = (c < n) ? (int)PL.b16[(size_t)kappa * T.ldn + c] : 0;
+    }
+    const double sck = ldexp(1.0, -(int)ek);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+    {
+      settle(v[q]);
+      bk[q] = (double)v[q] * sck;
+    }
+  }
+  else
+  {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+    {
+      const int c = lane + 64 * q;
+      bk[q]       = (c < n) ? T.bfT[(size_t)c * T.ldd + kappa] : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+      settle(bk[q]);
+  }
+}
+
 // update_gso_row(kappa, kappa) from column 0.  false: RED_GSO_FAILURE.
 template <int NQ>
 __device__ __forceinline__ bool update_full(Lattice<NQ> &T, Planes &PL, Stream<NQ> &S, int kappa)
@@ -864,18 +921,17 @@ __device__ __forceinline__ bool update_full(Lattice<NQ> &T, Planes &PL, Stream<N
   const int n = T.n, lane = T.lane, ldd = T.ldd;
   double bk[NQ], rd[NQ], acc[NQ], mu[NQ], sc[NQ];
   long long rexpj[NQ];
+  load_bf_row<NQ>(T, PL, kappa, bk);
 #pragma unroll
   for (int q = 0; q < NQ; ++q)
   {
     const int c = lane + 64 * q;
-    bk[q]       = (c < n) ? T.bfT[(size_t)c * ldd + kappa] : 0.0;
     rd[q]       = (c < kappa) ? T.rdg[c] : 1.0;
     rexpj[q]    = (c <= kappa) ? T.rexp[c] : 0;
   }
 #pragma unroll
   for (int q = 0; q < NQ; ++q)
   {
-    settle(bk[q]);
     settle(rd[q]);
     settle(rexpj[q]);
   }
@@ -897,11 +953,11 @@ __device__ __forceinline__ int babai2(Lattice<NQ> &T, Planes &PL, Stream<NQ> &S,
   const int sr_start = 0;
   double bk[NQ], rd[NQ], acc[NQ], mu[NQ];
   long long rexpj[NQ];
+  load_bf_row<NQ>(T, PL, kappa, bk);
 #pragma unroll
   for (int q = 0; q < NQ; ++q)
   {
     const int c = lane + 64 * q;
-    bk[q]       = (c < n) ? T.bfT[(size_t)c * ldd + kappa] : 0.0;
     rd[q]       = (c < kappa) ? T.rdg[c] : 1.0;
     rexpj[q]    = (c < kappa) ? T.rexp[c] : 0;
   }
@@ -912,7 +968,6 @@ __device__ __forceinline__ int babai2(Lattice<NQ> &T, Planes &PL, Stream<NQ> &S,
 #pragma unroll
   for (int q = 0; q < NQ; ++q)
   {
-    settle(bk[q]);
     settle(rd[q]);
     settle(rexpj[q]);
   }
@@ -961,11 +1016,9 @@ __device__ __forceinline__ int babai2(Lattice<NQ> &T, Planes &PL, Stream<NQ> &S,
       xs[q] = 0.0;
       nz[q] = 0;
     }
-    S.sp      = (const char *)(PL.muP + (size_t)(kappa - 1) * ldd);
-    S.sstride = (long)ldd * 4;
-    S.splane  = (long)PL.pl * 4;
+    S.sp      = (const char *)(T.mu + (size_t)(kappa - 1) * ldd);
+    S.sstride = (long)ldd * 8;
     S.sj      = kappa - 1;
-    S.slomask = ~0ull << (sr_start >> 2);
     S.begin(K_SWEEP, kappa - 1 - sr_start, K_DUMMY, 0x7fffffff);
     sweep_phase<NQ>(S, bm, xs, e, nz, kappa, sr_start, (unsigned)lane);
     // ---- the multipliers: row_addmul_we(kappa, j, -X, e_j) -> get_si_exp_we, nr_FP_d.inl:46-53
@@ -1045,8 +1098,7 @@ __device__ __forceinline__ int babai2(Lattice<NQ> &T, Planes &PL, Stream<NQ> &S,
 // mode 2: (re)build bfT / row_expo / the narrow mirrors from b for every row (after a basis upload)
 template <int NQ>
 __global__ void __launch_bounds__(256, Cfg<NQ>::WAVES_PER_SIMD)
-    gso_sweep2_kernel(GsoBatch P, unsigned *muP, unsigned *muTP, short *m16, int *flag16, int kmin, int kend,
-                      double eta, int mode)
+    gso_sweep2_kernel(GsoBatch P, double *muA, short *m16, int *flag16, int kmin, int kend, double eta, int mode)
 {
   using C        = Cfg<NQ>;
   const int lane = threadIdx.x & 63;
@@ -1079,9 +1131,7 @@ __global__ void __launch_bounds__(256, Cfg<NQ>::WAVES_PER_SIMD)
     T.narrow_flag = P.narrow + (size_t)L * P.d;
     T.np          = 0;
     Planes PL;
-    PL.pl   = (size_t)P.d * P.ldd;
-    PL.muP  = muP + (size_t)L * 2 * PL.pl;
-    PL.muTP = muTP + (size_t)L * 2 * PL.pl;
+    PL.muA = muA + (size_t)L * P.d * P.ldd;
     // m16: [batch][n*ldd + d*ldn] shorts — bT16 then b16 of each lattice
     PL.bT16   = m16 + (size_t)L * ((size_t)P.n * P.ldd + (size_t)P.d * P.ldn);
     PL.b16    = PL.bT16 + (size_t)P.n * P.ldd;
@@ -1143,10 +1193,10 @@ __global__ void __launch_bounds__(256, Cfg<NQ>::WAVES_PER_SIMD)
   }
 }
 
-template __global__ void gso_sweep2_kernel<1>(GsoBatch, unsigned *, unsigned *, short *, int *, int, int, double, int);
-template __global__ void gso_sweep2_kernel<2>(GsoBatch, unsigned *, unsigned *, short *, int *, int, int, double, int);
-template __global__ void gso_sweep2_kernel<3>(GsoBatch, unsigned *, unsigned *, short *, int *, int, int, double, int);
-template __global__ void gso_sweep2_kernel<4>(GsoBatch, unsigned *, unsigned *, short *, int *, int, int, double, int);
+template __global__ void gso_sweep2_kernel<1>(GsoBatch, double *, short *, int *, int, int, double, int);
+template __global__ void gso_sweep2_kernel<2>(GsoBatch, double *, short *, int *, int, int, double, int);
+template __global__ void gso_sweep2_kernel<3>(GsoBatch, double *, short *, int *, int, int, double, int);
+template __global__ void gso_sweep2_kernel<4>(GsoBatch, double *, short *, int *, int, int, double, int);
 
 }  // namespace s2
 }  // namespace fphip

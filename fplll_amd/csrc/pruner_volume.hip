@@ -137,7 +137,10 @@ public:
   size_t pin_bytes   = 0;
   char *dev          = nullptr;
   size_t dev_bytes   = 0;
-  int min_jobs       = 24;  // smaller batches are cheaper inline (a k = 30 volume is ~1 400 flops)
+  // batches below this many polynomial steps (sum of k (k + 1) / 2 over the jobs) are cheaper inline than
+  // a launch with its two copies (~35 us): one candidate of a 36-dimensional block is 2 000 steps = 6 us
+  // of host arithmetic, the gradient batch of the same block 140 000
+  long long min_steps = 40000;
   int lds_opt_in     = 0;
   char err[256]      = {0};
   std::vector<double> scratch;
@@ -169,7 +172,10 @@ public:
   {
     if (njobs <= 0)
       return true;
-    if (njobs < min_jobs || nvec >= (1 << 20) || m > 255)
+    long long steps = 0;
+    for (int j = 0; j < njobs; ++j)
+      steps += (long long)jobs[j].k * (jobs[j].k + 1) / 2;
+    if (steps < min_steps || nvec >= (1 << 20) || m > 255)
     {
       if ((int)scratch.size() < m + 2)
         scratch.resize(m + 2);
@@ -268,8 +274,8 @@ VolumeEngine *create_device_volume_engine(int device, char *err, size_t errlen)
     delete e;
     return nullptr;
   }
-  if (const char *v = getenv("FPHIP_PRUNER_MIN_DEVICE_JOBS"))
-    e->min_jobs = atoi(v);
+  if (const char *v = getenv("FPHIP_PRUNER_MIN_DEVICE_STEPS"))
+    e->min_steps = atoll(v);
   return e;
 }
 
