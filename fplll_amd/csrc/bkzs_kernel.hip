@@ -326,6 +326,11 @@ bkzs_body(GsoBatch P, BkzStrat S, BkzMail *mailbox, int *abort_flag, int block_s
     F.old_first = 0.0;
     F.remaining = 0.0;
     int loop    = 0;
+    if constexpr (DUALS)
+    {
+      if ((top_flags & 0x200) && P.sld_pass == 2 && block_size >= 1)  // dual pass only: behind the checkpoint
+        F.op = (num_rows + block_size - 1) / block_size + 1;
+    }
     int sr_kmin = 0, sr_kend = 0, sr_start = 0, sr_next = PH_OP_BEGIN;  // the pending size reduction
     bool running = block_size >= 2;
     if (uni(__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)))
@@ -483,6 +488,23 @@ bkzs_body(GsoBatch P, BkzStrat S, BkzMail *mailbox, int *abort_flag, int block_s
         }
         if constexpr (DUALS)
         {
+          if (sld_frame && depth == 0 && P.sld_pass != 0)
+          {
+            // block-parallel mode: one pass per launch, only this device's blocks of it.  The end-of-pass
+            // work (bounded LLL, repeat unless clean, potential) is the host's, on the merged basis.
+            if (P.sld_pass == 1 && F.op == sld_np)
+            {
+              tours  = F.clean ? 1 : 0;  // info[0] of a pass launch: "my blocks were left unchanged"
+              status = 8;
+              break;
+            }
+            const int bit = F.op < sld_np ? F.op : F.op - sld_np - 1;
+            if (!((P.sld_mask >> bit) & 1ull))
+            {
+              ++F.op;
+              continue;
+            }
+          }
           if (sld_frame && F.op == sld_np)
           {  // end of a primal pass: the bounded LLL (bkz.cpp:482-493), then again unless clean
             if (F.flags & 0x10)

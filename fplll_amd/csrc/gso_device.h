@@ -58,6 +58,11 @@ struct GsoBatch
   double *enum_mu_h;  // strategy-BKZ kernel, hand-off mode: [batch][64*63/2] in PINNED HOST memory — the
                       // scaled mu rows of a block whose enumeration the host runs on the multi-wave
                       // enumerator (null: every block is walked by the lattice's own wave)
+  // slide reduction, block-parallel mode (fphip_gso_slide_pass): this launch runs ONE pass of the slide
+  // tour — sld_pass 1 = the primal blocks, 2 = the dual blocks — and of that pass only the blocks whose
+  // bit is set in sld_mask (bit i = i-th block of the pass); 0 = the whole tour as usual
+  int sld_pass;
+  unsigned long long sld_mask;
 };
 // ---- BKZ with strategies (bkzs_kernel.hip) ------------------------------------------------------
 #define FPHIP_BKZS_MAX_DEPTH 4  /* nested tour() activations: the BKZ tour + 3 levels of preprocessing */

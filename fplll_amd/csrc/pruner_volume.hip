@@ -138,9 +138,11 @@ public:
   char *dev          = nullptr;
   size_t dev_bytes   = 0;
   // batches below this many polynomial steps (sum of k (k + 1) / 2 over the jobs) are cheaper inline than
-  // a launch with its two copies (~35 us): one candidate of a 36-dimensional block is 2 000 steps = 6 us
-  // of host arithmetic, the gradient batch of the same block 140 000
-  long long min_steps = 40000;
+  // a launch with its two copies (~35 us, and a lone wave needs ~0.1 us per step of its longest job): one
+  // candidate of a 36-dimensional block is 2 000 steps = 6 us of host arithmetic, the gradient batch of the
+  // same block 140 000.  Measured (MI355X box, prune() of a 60-dimensional block): host loop 19.5 ms,
+  // every batch on the device 11.0 ms (1 440 launches), with this threshold 5.9 ms (30 launches)
+  long long min_steps = 16000;
   int lds_opt_in     = 0;
   char err[256]      = {0};
   std::vector<double> scratch;

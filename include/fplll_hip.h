@@ -330,7 +330,7 @@ int fphip_pruner_enum_cost(int n, const double *gso_r, double enumeration_radius
  * primitive: out[j] = V_{job_k[j]}(row job_vec[j] of bounds[nvec][m]), the volume of the even simplex
  * cut by that bound vector (Pruner::relative_volume, pruner_simplex.h:34-46), 1 <= k <= m <= 255.
  * fphip_pruner_engine_stats: jobs evaluated by kernels / inline on the host (batches below
- * FPHIP_PRUNER_MIN_DEVICE_STEPS = 40 000 polynomial steps — a lone candidate of a search — are cheaper
+ * FPHIP_PRUNER_MIN_DEVICE_STEPS = 16 000 polynomial steps — a lone candidate of a search — are cheaper
  * inline than a launch; the gradients, simplices and look-ahead batches go to the kernel), launches. */
 typedef struct fphip_pruner_engine fphip_pruner_engine;
 int fphip_pruner_engine_create(int device, fphip_pruner_engine **out);

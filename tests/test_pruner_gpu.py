@@ -32,7 +32,7 @@ def engine():
     e.close()
 
 
-@pytest.mark.parametrize("m,nvec,seed", [(30, 300, 1), (64, 500, 2), (17, 40, 3), (1, 70, 4), (100, 130, 5)])
+@pytest.mark.parametrize("m,nvec,seed", [(30, 300, 1), (64, 500, 2), (17, 200, 3), (1, 70, 4), (100, 130, 5)])
 def test_device_volumes_equal_host_volumes_bit_for_bit(engine, m, nvec, seed):
     from fplll_amd import pruner as P
     rng = np.random.default_rng(seed)
@@ -50,9 +50,10 @@ def test_device_volumes_equal_host_volumes_bit_for_bit(engine, m, nvec, seed):
     dev = P.volumes(b, jv, jk, engine)
     host = P.volumes(b, jv, jk, None)
     after = engine.stats()
-    if m > 1:
+    steps = int(np.sum(jk.astype(np.int64) * (jk + 1) // 2))
+    if steps >= 16000:
         assert after[0] - before[0] == len(jv) and after[2] == before[2] + 1, "the batch did not go through the kernel"
-    else:  # (a batch of k = 1 jobs is a handful of operations: evaluated inline, FPHIP_PRUNER_MIN_DEVICE_STEPS)
+    else:  # (a handful of operations: evaluated inline, FPHIP_PRUNER_MIN_DEVICE_STEPS)
         assert after[1] - before[1] == len(jv) and after[2] == before[2]
     bad = np.nonzero(dev.view(np.uint64) != host.view(np.uint64))[0]
     assert bad.size == 0, (int(bad[0]), dev[bad[0]].hex(), host[bad[0]].hex(), int(jk[bad[0]]))
@@ -80,7 +81,8 @@ def test_prune_on_the_device_matches_reference_fixture(engine, path):
     assert pp.expectation == float.fromhex(j["expectation"])
     assert pp.gh_factor == float.fromhex(j["gh_factor"])
     assert np.array_equal(pp.detailed_cost, _hx(j["detailed_cost"]))
-    assert after[2] > before[2] and after[0] - before[0] > 5 * (after[1] - before[1]), \
+    # the gradients / simplices / look-ahead batches go through the kernel, lone candidates are evaluated inline
+    assert after[2] > before[2] and after[0] > before[0], \
         "the searches' batches must run on the device (stats: %r -> %r)" % (before, after)
 
 
