@@ -1286,6 +1286,27 @@ extern "C" int fphip_debug_bkz_plan(fphip_rand_fn rnd, void *rnd_user, int latti
   return FPHIP_OK;
 }
 
+// One pass of slide reduction on a subset of its (disjoint) blocks: the unit of the block-parallel mode
+// (slide_tour's p primal blocks and p - 1 dual blocks, bkz.cpp:475-480, 495-499).
+extern "C" int fphip_gso_slide_pass(fphip_gso *g, int block_size, double delta, double eta, int flags,
+                                    double gh_factor, const fphip_strategies *S, fphip_rand_fn rnd, void *rnd_user,
+                                    int pass, unsigned long long block_mask, int *status, int *info)
+{
+  if (!g || pass < 1 || pass > 3)
+    return FPHIP_ERROR;
+  // without BKZ_BOUNDED_LLL every svp_reduction starts with an LLL from row 0: the blocks of a pass are
+  // not independent then (bkz.cpp:107-108)
+  if (!(flags & 0x10))
+    return FPHIP_UNSUPPORTED;
+  g->P.sld_pass = pass;
+  g->P.sld_mask = block_mask;
+  const int rc  = fphip_gso_bkz_strategies(g, block_size, delta, eta, (flags & (0x10 | 0x80 | 0x2000)) | 0x4 | 0x200, 1,
+                                           gh_factor, S, rnd, rnd_user, status, info);
+  g->P.sld_pass = 0;
+  g->P.sld_mask = 0;
+  return rc;
+}
+
 extern "C" int fphip_gso_bkz_inloop_pruning(fphip_gso *g, double preproc_cost, double target, int min_block_size,
                                             int pruner_flags, int on_device)
 {
@@ -1727,7 +1748,14 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
   float total_ms = 0, ms = 0;
   const bool use_loops = (flags & 0x4) != 0, auto_abort = (flags & 0x20) != 0;
   const int kbase = flags & (0x10 | 0x80);
-  if (sld)
+  if (sld && g->P.sld_pass != 0)
+  {
+    // block-parallel mode (fphip_gso_slide_pass): ONE pass of a slide tour restricted to the blocks of
+    // g->P.sld_mask (1 primal, 2 dual), or the closing hkz of every block (3) — the caller runs the tour
+    rc       = run_once(kbase | 0x4 | 0x200, 1, &ms, st.data(), inf.data(), g->P.sld_pass == 3 ? 4 : 2);
+    total_ms = ms;
+  }
+  else if (sld)
   {
     // slide reduction: one slide_tour per launch (the kernel's 0x200 frame), the potential test on the
     // host in between; then the closing hkz of every block (run_mode 4)

@@ -148,3 +148,157 @@ def enumerate_block_sharded(ctx, dist, mut, rdiag, pruning, maxdist, evaluator, 
     bc = sols[0][1] if sols else None
     gd, gc, gn = reduce_enumeration(dist, bd, bc, res.nodes, len(rdiag), device)
     return gd, gc, gn, res
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Slide reduction, block-parallel (include/fplll_hip.h: fphip_gso_slide_pass)
+# ---------------------------------------------------------------------------------------------------------
+def slide_blocks(d, block_size):
+    """(primal, dual) block lists of one slide tour over rows [0, d) (bkz.cpp:468-499): primal block i =
+    rows [i bs, min(d, (i+1) bs)), dual block i = rows [i bs + 1, (i+1) bs + 1) for i < p - 1."""
+    p = (d + block_size - 1) // block_size
+    primal = [(i * block_size, min(d, (i + 1) * block_size)) for i in range(p)]
+    dual = [(i * block_size + 1, (i + 1) * block_size + 1) for i in range(p - 1)]
+    return primal, dual
+
+
+def deal_blocks(nblocks, rank, world):
+    """Block i of a pass belongs to participant i % world."""
+    return [i for i in range(nblocks) if i % world == rank]
+
+
+class LocalGather:
+    """gather for participants that live in ONE process (one context per device, or several contexts on
+    one device): a plain rendezvous of host arrays.  Every participant calls gather() once per pass with
+    {block index: (rows, clean, nodes)}; all get the union."""
+
+    def __init__(self, world):
+        import threading
+        self.world = world
+        self.lock = threading.Lock()
+        self.bar = threading.Barrier(world)
+        self.box = {}
+
+    def gather(self, rank, mine):
+        with self.lock:
+            self.box.update(mine)
+        self.bar.wait()
+        out = dict(self.box)
+        self.bar.wait()
+        if rank == 0:
+            self.box.clear()
+        self.bar.wait()
+        return out
+
+
+class DistGather:
+    """gather over torch.distributed ranks (one process per GPU): one all_gather per pass of the blocks'
+    rows — beta x n int64 per block, 86 KB at BASELINE config 3 — plus a (clean, nodes) pair per block."""
+
+    def __init__(self, dist, device="cpu"):
+        self.dist, self.device = dist, device
+
+    def gather(self, rank, mine, layout):
+        import torch
+        world = self.dist.get_world_size()
+        # fixed-size slots: every rank sends the same shape (blocks it does not own stay zero)
+        width = max(hi - lo for lo, hi in layout)
+        n = None
+        for v in mine.values():
+            n = v[0].shape[1]
+        n_t = torch.tensor([n or 0], dtype=torch.int64, device=self.device)
+        self.dist.all_reduce(n_t, op=self.dist.ReduceOp.MAX)
+        n = int(n_t.item())
+        buf = torch.zeros((len(layout), width * n + 2), dtype=torch.int64, device=self.device)
+        for i, (rows, clean, nodes) in mine.items():
+            flat = torch.as_tensor(np.ascontiguousarray(rows, dtype=np.int64).reshape(-1))
+            buf[i, :flat.numel()] = flat.to(self.device)
+            buf[i, -2] = int(bool(clean))
+            buf[i, -1] = int(nodes)
+        every = [torch.empty_like(buf) for _ in range(world)]
+        self.dist.all_gather(every, buf)
+        out = {}
+        for i, (lo, hi) in enumerate(layout):
+            t = every[i % world][i].cpu().numpy()
+            out[i] = (t[:(hi - lo) * n].reshape(hi - lo, n).copy(), bool(t[-2]), int(t[-1]))
+        return out
+
+
+def slide_reduction_blocks(g, rank, world, gather, block_size, max_loops=0, strategies=None, rnd=None,
+                           delta=0.99, eta=0.51, gh_bnd=False, gh_factor=1.1):
+    """BKZ_SLD_RED | BKZ_BOUNDED_LLL with the blocks of every pass dealt over `world` participants
+    (devices of one process, or ranks): slide_tour (bkz.cpp:465-520) and the loop of bkz() around it
+    (:567-571, 583-617, 643-660), host side.  `g` is this participant's MatGSOBatch (batch 1) holding the
+    LLL-reduced input — the same on every participant.
+
+    Per pass every participant reduces ITS blocks (block i -> participant i % world), EACH FROM THE
+    PASS-START BASIS (one fphip_gso_slide_pass launch per block on a fresh copy of that basis), then the
+    blocks' rows are gathered and the merged basis — block i's rows from the participant that reduced it,
+    a unimodular block-triangular transformation of the pass-start basis — replaces every participant's
+    copy.  The bounded LLL after a primal pass, the potential test and the closing hkz run on the merged
+    basis on every participant alike (deterministic: no communication).  Because no block ever sees
+    another block's new rows inside a pass, the result is independent of `world`.
+
+    Returns (status, basis[d][n], total enumeration nodes, tours)."""
+    from .gso import slide_potential
+    assert g.batch == 1
+    d = g.d
+    primal, dual = slide_blocks(d, block_size)
+    is_dist = isinstance(gather, DistGather)
+
+    def run_pass(pass_, layout):
+        start = g.get_basis(0, 1)[0]
+        mine = {}
+        for i in deal_blocks(len(layout), rank, world):
+            g.set_basis(start[None])
+            st, info = g.slide_pass(pass_, 1 << i, block_size, strategies, rnd, delta, eta, gh_bnd, gh_factor)
+            if int(st[0]) <= 0:
+                raise RuntimeError("slide pass %d block %d failed with status %d" % (pass_, i, int(st[0])))
+            lo, hi = layout[i]
+            nodes = (int(info[0][1]) & 0xffffffff) | ((int(info[0][2]) & 0xffffffff) << 32)
+            mine[i] = (g.get_basis(0, 1)[0][lo:hi].copy(), bool(info[0][0]) if pass_ == 1 else True, nodes)
+        every = gather.gather(rank, mine, layout) if is_dist else gather.gather(rank, mine)
+        merged = start.copy()
+        clean, nodes = True, 0
+        for i, (lo, hi) in enumerate(layout):
+            rows, c, nd = every[i]
+            merged[lo:hi] = rows
+            clean &= c
+            nodes += nd
+        g.set_basis(merged[None])
+        return clean, nodes
+
+    def potential():
+        assert int(g.update_gso()[0]) == 1
+        return g.get_slide_potential(0, 0, d, block_size)
+
+    total_nodes, tours, status = 0, 0, 1
+    old = potential()
+    while True:
+        if max_loops > 0 and tours >= max_loops:
+            status = 8  # RED_BKZ_LOOPS_LIMIT
+            break
+        while True:  # primal passes until one leaves every block (and the bounded LLL) unchanged
+            clean, nd = run_pass(1, primal)
+            total_nodes += nd
+            st, info = g.lll(0, 0, d, delta, eta)
+            if int(st[0]) != 1:
+                return int(st[0]), g.get_basis(0, 1)[0], total_nodes, tours
+            if int(info[0][1]) > 0:
+                clean = False
+            if clean:
+                break
+        if dual:
+            _, nd = run_pass(2, dual)
+            total_nodes += nd
+        tours += 1
+        new = potential()
+        if new >= old or block_size >= d:
+            break
+        old = new
+    # closing hkz of every block (bkz.cpp:643-660) on every participant alike; counted once
+    st, info = g.slide_pass(3, 0, block_size, strategies, rnd, delta, eta, gh_bnd, gh_factor)
+    total_nodes += (int(info[0][1]) & 0xffffffff) | ((int(info[0][2]) & 0xffffffff) << 32)
+    if int(st[0]) <= 0:
+        status = int(st[0])
+    return status, g.get_basis(0, 1)[0], total_nodes, tours

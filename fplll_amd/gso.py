@@ -238,6 +238,58 @@ class MatGSOBatch:
         self._chk(rc, "bkz_strategies")
         return st, info
 
+    def slide_pass(self, pass_, block_mask, block_size, strategies=None, rnd=None, delta=LLL_DEF_DELTA,
+                   eta=LLL_DEF_ETA, gh_bnd=False, gh_factor=1.1):
+        """fphip_gso_slide_pass: ONE pass of a slide tour (bkz.cpp:465-520) restricted to the blocks of
+        block_mask — pass_ 1: primal blocks, 2: dual blocks, 3: the closing hkz of every block — with
+        BKZ_BOUNDED_LLL (the blocks of a pass are independent only then).  The unit of the block-parallel
+        mode (fplll_amd.distributed.slide_reduction_blocks).  Returns (status[batch], info[batch][4]);
+        info[:, 0] of a primal pass = 1 when every block of the mask came out unchanged."""
+        keep = []
+        sp = None
+        if strategies is not None:
+            class Strat(ctypes.Structure):
+                _fields_ = [("max_block_size", ctypes.c_int), ("pre_off", ctypes.c_void_p),
+                            ("pre", ctypes.c_void_p), ("prune_off", ctypes.c_void_p),
+                            ("prune_gh", ctypes.c_void_p), ("prune_exp", ctypes.c_void_p),
+                            ("coeff_off", ctypes.c_void_p), ("coeff", ctypes.c_void_p)]
+
+            def arr(key, dt):
+                a = np.ascontiguousarray(strategies[key], dtype=dt)
+                if a.size == 0:
+                    a = np.zeros(1, dtype=dt)
+                keep.append(a)
+                return a.ctypes.data
+            st_ = Strat(int(strategies["max_block_size"]), arr("pre_off", np.int32), arr("pre", np.int32),
+                        arr("prune_off", np.int32), arr("prune_gh", np.float64), arr("prune_exp", np.float64),
+                        arr("coeff_off", np.int32), arr("coeff", np.float64))
+            keep.append(st_)
+            sp = ctypes.byref(st_)
+        RND = ctypes.CFUNCTYPE(ctypes.c_ulong, ctypes.c_void_p, ctypes.c_int, ctypes.c_ulong)
+        rnd_user = None
+        if rnd is None:
+            cb = RND(0)
+        elif callable(rnd):
+            cb = RND(lambda _u, lattice, n: int(rnd(lattice, n)))
+        elif isinstance(rnd, tuple):
+            cb = ctypes.cast(rnd[0], RND)
+            rnd_user = rnd[1]
+        else:
+            cb = ctypes.cast(rnd, RND)
+        fn = self.lib.fphip_gso_slide_pass
+        fn.restype = ctypes.c_int
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_double,
+                       ctypes.c_void_p, RND, ctypes.c_void_p, ctypes.c_int, ctypes.c_ulonglong, ctypes.c_void_p,
+                       ctypes.c_void_p]
+        st = np.zeros(self.batch, dtype=np.int32)
+        info = np.zeros((self.batch, 4), dtype=np.int32)
+        rc = fn(self.h, block_size, delta, eta, 0x10 | (0x80 if gh_bnd else 0), gh_factor, sp, cb, rnd_user,
+                int(pass_), int(block_mask), st.ctypes.data_as(ctypes.c_void_p), info.ctypes.data_as(ctypes.c_void_p))
+        if rc == _lib.FPHIP_UNSUPPORTED:
+            raise NotImplementedError("slide passes: blocks up to 64 rows, no last block of one row")
+        self._chk(rc, "slide_pass")
+        return st, info
+
     def inloop_stats(self):
         """(prune() calls of the in-loop service, volume jobs on the device, inline on the host, launches)"""
         v = [ctypes.c_ulonglong(0) for _ in range(4)]

@@ -41,3 +41,128 @@ def test_slide_reduction_matches_reference(ctx, path):
         assert bad.size == 0, ("first differing row", int(bad[0]), "nodes", nodes[L], f["nodes"])
         assert nodes[L] == f["nodes"]
     g.close()
+
+
+# ---- block-parallel mode: the blocks of every pass over several contexts / ranks -------
+def _slide_blocks_run(world, f, results, gather, rank):
+    import fplll_amd
+    from fplll_amd.distributed import slide_reduction_blocks
+    from fplll_amd.gso import MatGSOBatch
+    try:
+        ctx = fplll_amd.Context(0)
+        g = MatGSOBatch(ctx, 1, f["d"], f["n"])
+        g.set_basis(f["b_in"][None])
+        results[rank] = slide_reduction_blocks(g, rank, world, gather, f["block_size"], max_loops=f["max_loops"],
+                                               delta=f["delta"], eta=f["eta"])
+        g.close()
+        ctx.close()
+    except BaseException as e:  # noqa: reported by the caller
+        results[rank] = e
+        try:
+            gather.bar.abort()
+        except Exception:
+            pass
+
+
+def _potential_and_predicate(ctx, b, bs):
+    """slide potential of a basis (device GSO + the reference's formula) and the reference's is_lll_reduced."""
+    from fplll_amd.gso import MatGSOBatch
+    g = MatGSOBatch(ctx, 1, b.shape[0], b.shape[1])
+    g.set_basis(b[None])
+    assert int(g.update_gso()[0]) == 1
+    pot = g.get_slide_potential(0, 0, b.shape[0], bs)
+    red = g.is_lll_reduced(0)
+    ld = g.get_log_det(0, 0, b.shape[0])
+    g.close()
+    return pot, red, ld
+
+
+def test_block_parallel_slide_reduction_over_contexts(ctx):
+    """fplll_amd.distributed.slide_reduction_blocks with 1, 2 and 3 contexts of this GPU (one host thread
+    each; every block of a pass reduced from the pass-start basis by the context it is dealt to, rows
+    gathered, merged basis to everybody): the SAME basis, node count and number of tours whatever the number
+    of contexts — and an output the reference's predicates accept: LLL-reduced (lll.cpp:226-258), the
+    input's lattice volume, a slide potential (gso_interface.cpp:244-258) below the input's and within 0.1 %
+    of the sequential reference run's (bkzd_q64_b16_slide_bounded_lll.json)."""
+    import threading
+    from fplll_amd.distributed import LocalGather
+    f = C.load_bkz_fixture(os.path.join(C.GOLDEN, "bkzd_q64_b16_slide_bounded_lll.json"))
+    assert f["flags"] & 0x210 == 0x210
+    runs = {}
+    for world in (1, 2, 3):
+        gather = LocalGather(world)
+        res = [None] * world
+        ts = [threading.Thread(target=_slide_blocks_run, args=(world, f, res, gather, r)) for r in range(world)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join(600)
+        for r in res:
+            assert not isinstance(r, BaseException), repr(r)
+        for r in range(1, world):
+            assert res[r][0] == res[0][0] and res[r][2] == res[0][2] and np.array_equal(res[r][1], res[0][1])
+        runs[world] = res[0]
+    st, out, nodes, tours = runs[1]
+    C.note(lambda: ("block-parallel slide: status", st, "nodes", nodes, "tours", tours, "(sequential reference:",
+                    f["nodes"], "nodes)",))
+    for world in (2, 3):
+        assert runs[world][0] == st and runs[world][2] == nodes and runs[world][3] == tours
+        assert np.array_equal(runs[world][1], out), "the result depends on the number of contexts"
+    assert st == 1 and tours >= 1 and nodes > 0
+    p_in, _, ld_in = _potential_and_predicate(ctx, f["b_in"], f["block_size"])
+    p_out, red_out, ld_out = _potential_and_predicate(ctx, out, f["block_size"])
+    p_ref, red_ref, ld_ref = _potential_and_predicate(ctx, f["b_out"], f["block_size"])
+    C.note(lambda: ("slide potential: input %.6f, block-parallel %.6f, sequential reference %.6f" % (p_in, p_out, p_ref),))
+    assert red_out and red_ref
+    assert abs(ld_out - ld_in) < 1e-9 * abs(ld_in) and abs(ld_ref - ld_in) < 1e-9 * abs(ld_in)
+    assert p_out < p_in and p_out <= p_ref + 1e-3 * abs(p_ref)
+
+
+def _slide_rank(rank, world, port, path, q):
+    import torch.distributed as dist
+    import fplll_amd
+    from fplll_amd.distributed import DistGather, slide_reduction_blocks
+    from fplll_amd.gso import MatGSOBatch
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    f = C.load_bkz_fixture(path)
+    ctx = fplll_amd.Context(0)
+    g = MatGSOBatch(ctx, 1, f["d"], f["n"])
+    g.set_basis(f["b_in"][None])
+    st, out, nodes, tours = slide_reduction_blocks(g, rank, world, DistGather(dist), f["block_size"],
+                                                   max_loops=f["max_loops"], delta=f["delta"], eta=f["eta"])
+    q.put((rank, st, out.tolist(), nodes, tours))
+    dist.barrier()
+    g.close()
+    ctx.close()
+    dist.destroy_process_group()
+
+
+def test_block_parallel_slide_reduction_over_ranks(ctx):
+    """The same over two RANKS (one process each, gloo, both on this GPU): one all_gather of the blocks'
+    rows per pass; both ranks end on the basis the single-participant run ends on."""
+    import socket
+    import torch.multiprocessing as mp
+    from fplll_amd.distributed import LocalGather
+    path = os.path.join(C.GOLDEN, "bkzd_q64_b16_slide_bounded_lll.json")
+    f = C.load_bkz_fixture(path)
+    res = [None]
+    _slide_blocks_run(1, f, res, LocalGather(1), 0)
+    assert not isinstance(res[0], BaseException), repr(res[0])
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mpctx = mp.get_context("spawn")
+    q = mpctx.Queue()
+    ps = [mpctx.Process(target=_slide_rank, args=(r, 2, port, path, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    out = sorted(q.get(timeout=600) for _ in range(2))
+    for p in ps:
+        p.join(120)
+        assert p.exitcode == 0
+    for r in range(2):
+        assert out[r][1] == res[0][0] and out[r][3] == res[0][2] and out[r][4] == res[0][3]
+        assert np.array_equal(np.array(out[r][2]), res[0][1])
