@@ -245,23 +245,6 @@ int fphip_gso_bkz(fphip_gso *g, int block_size, double delta, double eta, int fl
  * svp_postprocessing / prune<> the same way, and the device run returns its basis, status and node count
  * (tests/test_bkzs_gpu.py).  Parameters (defaults 1e6, 0.5, 24, PRUNER_GRADIENT, 1) are per fphip_gso. */
 #define FPHIP_BKZ_PRUNE_IN_LOOP 0x2000
-/* Slide reduction, BLOCK-PARALLEL (SURVEY 8(e) row 2).  The p primal blocks of a pass of slide_tour
- * (bkz.cpp:475-480) are disjoint, and so are its p - 1 dual blocks (:495-499); with BKZ_BOUNDED_LLL (flag
- * 0x10, required: otherwise every svp_reduction starts with an LLL from row 0) a block's svp_reduction
- * rewrites only its own rows — it reads the rows above them for the size reduction.  fphip_gso_slide_pass
- * runs ONE pass restricted to the blocks whose bit is set in block_mask (pass 1: primal block i = rows
- * [i bs, min(d, (i+1) bs)); pass 2: dual block i = rows [i bs + 1, (i+1) bs + 1); pass 3: the closing hkz of
- * every block, bkz.cpp:643-660, mask ignored) and stops; info[4 L] of a primal pass = 1 when every block
- * of the mask came out unchanged.  The tour itself — dealing the blocks over devices / ranks, gathering
- * each block's rows from the device that reduced it (the merged rows are a basis of the same lattice: a
- * block-triangular unimodular transformation of the pass's input), the bounded LLL and the repeat-until-clean
- * of the primal passes, the slide potential (gso_interface.cpp:244-258) — is host code:
- * fplll_amd.distributed.slide_reduction_blocks.  Every block is reduced from the PASS-START basis, whoever
- * reduces it, so the result does not depend on the number of devices; it is not the sequential reference's
- * (there block i sees block i - 1's new rows), and is accepted by the reference's predicates. */
-int fphip_gso_slide_pass(fphip_gso *g, int block_size, double delta, double eta, int flags, double gh_factor,
-                         const fphip_strategies *S, fphip_rand_fn rnd, void *rnd_user, int pass,
-                         unsigned long long block_mask, int *status, int *info);
 int fphip_gso_bkz_inloop_pruning(fphip_gso *g, double preproc_cost, double target, int min_block_size,
                                  int pruner_flags, int on_device);
 /* prune() calls of the service so far, and the volume jobs they evaluated by kernels / inline on the host */
@@ -283,6 +266,23 @@ typedef unsigned long (*fphip_rand_fn)(void *user, int lattice, unsigned long n)
 int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double delta, double eta, int flags,
                              int max_loops, double gh_factor, const fphip_strategies *strategies,
                              fphip_rand_fn rnd, void *rnd_user, int *status, int *info);
+/* Slide reduction, BLOCK-PARALLEL (SURVEY 8(e) row 2).  The p primal blocks of a pass of slide_tour
+ * (bkz.cpp:475-480) are disjoint, and so are its p - 1 dual blocks (:495-499); with BKZ_BOUNDED_LLL (flag
+ * 0x10, required: otherwise every svp_reduction starts with an LLL from row 0) a block's svp_reduction
+ * rewrites only its own rows — it reads the rows above them for the size reduction.  fphip_gso_slide_pass
+ * runs ONE pass restricted to the blocks whose bit is set in block_mask (pass 1: primal block i = rows
+ * [i bs, min(d, (i+1) bs)); pass 2: dual block i = rows [i bs + 1, (i+1) bs + 1); pass 3: the closing hkz of
+ * every block, bkz.cpp:643-660, mask ignored) and stops; info[4 L] of a primal pass = 1 when every block
+ * of the mask came out unchanged.  The tour itself — dealing the blocks over devices / ranks, gathering
+ * each block's rows from the device that reduced it (the merged rows are a basis of the same lattice: a
+ * block-triangular unimodular transformation of the pass's input), the bounded LLL and the repeat-until-clean
+ * of the primal passes, the slide potential (gso_interface.cpp:244-258) — is host code:
+ * fplll_amd.distributed.slide_reduction_blocks.  Every block is reduced from the PASS-START basis, whoever
+ * reduces it, so the result does not depend on the number of devices; it is not the sequential reference's
+ * (there block i sees block i - 1's new rows), and is accepted by the reference's predicates. */
+int fphip_gso_slide_pass(fphip_gso *g, int block_size, double delta, double eta, int flags, double gh_factor,
+                         const fphip_strategies *S, fphip_rand_fn rnd, void *rnd_user, int pass,
+                         unsigned long long block_mask, int *status, int *info);
 /* LLLReduction::lll in a selectable floating-point type (lll_x.hip): precision 106 = double-double
  * arithmetic on the device (the stand-in for FP_NR<dd_real>: what Wrapper::lll's fast_lll<dd_real>
  * runs, wrapper.cpp:322-330; libqd's algorithms restated, csrc/ftx.h), 53 = plain double.  Same

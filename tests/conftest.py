@@ -21,6 +21,24 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
 
 
+_exit_status = [0]
+
+
+def pytest_sessionfinish(session, exitstatus):
+    _exit_status[0] = int(exitstatus)
+
+
+def pytest_unconfigure(config):
+    """A FAILED session must not sit behind the two long background kernels (round 3: 632 s of waiting after
+    the first failure under -x): their host threads are still inside a launch, so leave without joining
+    them.  A green session has joined them in tests/test_zzz_long_runs_gpu.py."""
+    alive = [k for k, v in LONG_RUNS.items() if k.startswith("thread_") and hasattr(v, "is_alive") and v.is_alive()]
+    if alive and _exit_status[0] != 0:
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(_exit_status[0])
+
+
 def note(make):
     """Timing / progress line of a GPU test.  `make` is a callable returning the print arguments: it
     is evaluated HERE, inside a try, so that a formatting problem in a perf line can never fail a
