@@ -385,6 +385,102 @@ template <int NQ, int CQ, int QA, int EB> struct GramCons  // QA: chunks 0..QA-1
   }
 };
 
+// sum over the 64 lanes (an inclusive scan with DPP row shifts and the two row broadcasts; lane 63 ends
+// with the total)
+__device__ __forceinline__ int wave_sum_i32(int v)
+{
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+  return __builtin_amdgcn_readlane(v, 63);
+}
+
+// The integer AXPY FUSED into the Gram pass that follows it (round 4).  babai's row operation
+// b_kappa += sum_j X_j b_j and the Gram row of the new b_kappa read the SAME numbers — the entries of the
+// rows above kappa — once row-major (b16) and once column-major (bT16).  Column c of the column-major mirror
+// holds b(j, c) for every j in lane j: the new entry b'(kappa, c) = b(kappa, c) + sum_j X_j b(j, c) is one
+// wave-wide INTEGER sum (exact in any order), after which the column's Gram products
+// bf'(kappa, c) bf(j, c) can be formed at once — c still ascending, as numvect.h:386-396 wants it.  The row
+// exponent of the new row is only known when all of it is: the pass accumulates with the UNSCALED
+// (double) b'(kappa, c), and the caller multiplies the sums by 2^-row_expo afterwards (twice for
+// g(kappa, kappa)) — a power of two commutes with every rounding on the way, so these are the doubles the
+// separate passes produce.  Saves the whole AXPY stream: 6 of 55 MB per 180-dimensional lattice.
+// Multipliers must fit 32 bits (every |X_j b(j,c)| < 2^46; the lane sums are reduced as two 24 / 25-bit halves).
+template <int NQ, int CQ, int QA> struct GramAxpyCons
+{
+  double (&acc)[NQ];
+  long long (&bv)[NQ];      // row kappa, lane c = column c: updated in place
+  const int (&lx)[NQ];      // multiplier of row j in lane j (0 for j >= kappa)
+  const double (&sc)[NQ];
+  const bool (&isk)[NQ];    // this (lane, chunk) is row kappa
+  unsigned lane;
+  int cc;
+  bool second;
+  int x0[NQ], x1[NQ];
+  __device__ __forceinline__ void load(unsigned w, unsigned lane4)
+  {
+    const short *h   = (const short *)s2_smem;
+    const unsigned a = 2 * w + (lane4 >> 2);
+#pragma unroll
+    for (int q = 0; q < QA; ++q)
+    {
+      x0[q] = (int)h[a + 64 * q];
+      x1[q] = (int)h[a + 64 * q + Cfg<NQ>::ESZ / 2];
+    }
+  }
+  __device__ __forceinline__ void column(const int (&x)[NQ], int c)
+  {
+    long long t = 0;
+#pragma unroll
+    for (int q = 0; q < QA; ++q)
+      t += (long long)lx[q] * (long long)x[q];
+    const int lo       = wave_sum_i32((int)(t & 0x7fffff));
+    const int hi       = wave_sum_i32((int)(t >> 23));
+    const long long nb = g_rl_i64(bv[CQ], c) + (((long long)hi << 23) + (long long)lo);
+    bv[CQ]             = ((int)lane == c) ? nb : bv[CQ];
+    const double f     = (double)nb;
+#pragma unroll
+    for (int q = 0; q < QA; ++q)
+    {
+      const double v = isk[q] ? f : (double)x[q] * sc[q];
+      const double p = f * v;
+      acc[q]         = acc[q] + p;
+    }
+  }
+  __device__ __forceinline__ void compute()
+  {
+    column(x0, cc);
+    if (second)
+      column(x1, cc + 1);
+    cc += 2;
+  }
+};
+
+template <int NQ, int QA, int CQ = 0>
+__device__ __forceinline__ void gram_axpy_phase(Stream<NQ> &S, double (&acc)[NQ], long long (&bv)[NQ],
+                                                const int (&lx)[NQ], const double (&sc)[NQ],
+                                                const bool (&isk)[NQ], unsigned lane, int n)
+{
+  if constexpr (CQ < NQ)
+  {
+    const int rows = min(n - 64 * CQ, 64);
+    if (rows > 0)
+    {
+      GramAxpyCons<NQ, CQ, QA> g{acc, bv, lx, sc, isk, lane, 0, true};
+      S.template run<(1u << K_GRAM) | (1u << K_REC)>(g, rows >> 1);
+      if (rows & 1)
+      {
+        g.second = false;
+        S.template run<(1u << K_GRAM) | (1u << K_REC)>(g, 1);
+      }
+      gram_axpy_phase<NQ, QA, CQ + 1>(S, acc, bv, lx, sc, isk, lane, n);
+    }
+  }
+}
+
 template <int NQ, int KQ, int QA> struct RecCons
 {
   double (&acc)[NQ];
@@ -947,7 +1043,8 @@ __device__ __forceinline__ bool update_full(Lattice<NQ> &T, Planes &PL, Stream<N
 // LLLReduction::babai(kappa, kappa, 0) followed by update_gso_row(kappa, kappa) (lll.h:107-122).
 // 1 ok, 0 GSO failure, -1 babai failure, -2 multiplier beyond 63 bits.
 template <int NQ>
-__device__ __forceinline__ int babai2(Lattice<NQ> &T, Planes &PL, Stream<NQ> &S, int kappa, double eta)
+__device__ __forceinline__ int babai2(Lattice<NQ> &T, Planes &PL, Stream<NQ> &S, int kappa, double eta,
+                                      bool P_fuse)
 {
   const int n = T.n, lane = T.lane, ldd = T.ldd, ldn = T.ldn;
   const int sr_start = 0;
@@ -974,10 +1071,15 @@ __device__ __forceinline__ int babai2(Lattice<NQ> &T, Planes &PL, Stream<NQ> &S,
   settle(rexpk);
   double gkk         = 0.0;
   double sc[NQ];
+  bool have_pass     = false;  // the fused AXPY + Gram pass of the previous iteration has left acc / gkk
   for (int iter = 0;; ++iter)
   {
-    scale_vector<NQ>(T, kappa, rexpj, rexpk, sc);
-    gso_pass<NQ>(T, PL, S, kappa, bk, sc, acc, gkk);
+    if (!have_pass)
+    {
+      scale_vector<NQ>(T, kappa, rexpj, rexpk, sc);
+      gso_pass<NQ>(T, PL, S, kappa, bk, sc, acc, gkk);
+    }
+    have_pass = false;
     if (!mu_from_r<NQ>(T, kappa, acc, rd, mu))
       return 0;
     int e[NQ];
@@ -1051,6 +1153,58 @@ __device__ __forceinline__ int babai2(Lattice<NQ> &T, Planes &PL, Stream<NQ> &S,
     for (int q = 0; q < NQ; ++q)
       settle(bv[q]);
     const int anarrow = (PL.np16 >= kappa) ? 2 : (T.np >= kappa) ? 1 : 0;  // rows below kappa are read
+    if (anarrow == 2 && small && P_fuse)
+    {
+      // ---- AXPY fused into the Gram pass of the new row (GramAxpyCons), then the recurrence
+      int lx32[NQ];
+      bool isk[NQ];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+      {
+        lx32[q] = (int)lxv[q];
+        isk[q]  = (lane + 64 * q == kappa);
+      }
+      scale_vector<NQ>(T, kappa, rexpj, rexpk, sc);
+      const int nrec = kappa - 1;
+      S.rp      = (const char *)PL.muA;
+      S.rstride = (long)ldd * 8;
+      S.rk      = 0;
+      S.rlast   = kappa - 1;
+      S.gp      = (const char *)PL.bT16;
+      S.gstride = (long)ldd * 2;
+      S.gmask   = ~0ull >> (63 - (kappa >> 3));
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+        acc[q] = -0.0;
+      S.begin(K_GRAM, (n + 1) >> 1, K_REC, nrec);
+      const int qact = (kappa >> 6) + 1;
+      if (NQ == 1 || qact == 1)
+        gram_axpy_phase<NQ, 1>(S, acc, bv, lx32, sc, isk, (unsigned)lane, n);
+      else if (NQ == 2 || qact == 2)
+        gram_axpy_phase<NQ, (NQ >= 2 ? 2 : 1)>(S, acc, bv, lx32, sc, isk, (unsigned)lane, n);
+      else if (NQ == 3 || qact == 3)
+        gram_axpy_phase<NQ, (NQ >= 3 ? 3 : 1)>(S, acc, bv, lx32, sc, isk, (unsigned)lane, n);
+      else
+        gram_axpy_phase<NQ, (NQ >= 4 ? 4 : 1)>(S, acc, bv, lx32, sc, isk, (unsigned)lane, n);
+      // row_op_end: update_bf(kappa), gso.cpp:24-48 — and with the row's exponent the scale of the sums
+      store_row_and_refloat<NQ, true>(T, kappa, bv, bk, rexpk);
+      store_mirror16<NQ>(T, PL, kappa, bv);
+      const int ek = T.row_expo_on ? (int)rexpk : 0;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+        acc[q] = ldexp(acc[q], isk[q] ? -2 * ek : -ek);
+      gkk = g_rl_f64(acc[NQ == 1 ? 0 : (kappa >> 6)], kappa & 63);
+      if (NQ == 1 || qact == 1)
+        rec_phase<NQ, 1>(S, acc, nrec, (unsigned)lane);
+      else if (NQ == 2 || qact == 2)
+        rec_phase<NQ, (NQ >= 2 ? 2 : 1)>(S, acc, nrec, (unsigned)lane);
+      else if (NQ == 3 || qact == 3)
+        rec_phase<NQ, (NQ >= 3 ? 3 : 1)>(S, acc, nrec, (unsigned)lane);
+      else
+        rec_phase<NQ, (NQ >= 4 ? 4 : 1)>(S, acc, nrec, (unsigned)lane);
+      have_pass = true;
+      continue;
+    }
     if (anarrow != 0)
     {
       int pairs = 0;
@@ -1174,7 +1328,7 @@ __global__ void __launch_bounds__(256, Cfg<NQ>::WAVES_PER_SIMD)
         __threadfence_block();
         if (mode == 1 && kappa > 0)
         {
-          const int rc = babai2<NQ>(T, PL, S, kappa, eta);
+          const int rc = babai2<NQ>(T, PL, S, kappa, eta, P.use_narrow > 2);
           if (rc != 1)
           {
             status = rc;
