@@ -91,12 +91,16 @@ class HipError(RuntimeError):
 class Context:
     """One context per GPU (one process per GPU; device = LOCAL_RANK)."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, priority=0):
+        """priority: stream priority class of the context, -1 low / 0 normal / +1 high (fphip_create_ex): a
+        context that runs minutes-long single launches beside others should be low."""
         import weakref
         self.lib = load()
         self._children = weakref.WeakSet()  # batch objects living on this context
         self.handle = ctypes.c_void_p()
-        rc = self.lib.fphip_create(int(device), ctypes.byref(self.handle))
+        self.lib.fphip_create_ex.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+        self.lib.fphip_create_ex.restype = ctypes.c_int
+        rc = self.lib.fphip_create_ex(int(device), int(priority), ctypes.byref(self.handle))
         if rc != FPHIP_OK:
             msg = self.lib.fphip_last_error(self.handle).decode() if self.handle else "?"
             if self.handle:

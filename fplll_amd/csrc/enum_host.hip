@@ -179,7 +179,17 @@ static int env_int(const char *name, int dflt)
   return (s && *s) ? atoi(s) : dflt;
 }
 
-extern "C" int fphip_create(int device, fphip_ctx **out)
+// Streams and hardware queues.  The runtime maps streams onto a small pool of hardware queues PER PRIORITY
+// (four by default) and lets streams share a queue once the pool is used up.  Some kernels of this library
+// are PERSISTENT — the strategy-BKZ schedule kernel sits on its stream until every mailbox request of the
+// run has been answered — and whatever shares their queue waits behind them: a helper kernel that has to
+// finish BEFORE the mailbox is answered (the pruner's volume kernel, a handed-off enumeration) must never
+// do that (round 4: eight volume engines next to one schedule kernel deadlocked; two did not, by the luck
+// of the round-robin).  Hence the priority classes: helper streams are HIGH (their own queue pool), a
+// context that is known to run minutes-long launches beside others can be created LOW.
+extern "C" int fphip_create(int device, fphip_ctx **out) { return fphip_create_ex(device, 0, out); }
+
+extern "C" int fphip_create_ex(int device, int priority, fphip_ctx **out)
 {
   if (!out)
     return FPHIP_ERROR;
@@ -199,7 +209,14 @@ extern "C" int fphip_create(int device, fphip_ctx **out)
   hipDeviceProp_t prop;
   HIPCHK(ctx, hipGetDeviceProperties(&prop, device));
   ctx->num_cus = prop.multiProcessorCount;
-  HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  if (priority == 0)
+    HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  else
+  {
+    int least = 0, greatest = 0;  // (numerically: greatest priority = the smaller number)
+    HIPCHK(ctx, hipDeviceGetStreamPriorityRange(&least, &greatest));
+    HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, priority > 0 ? greatest : least));
+  }
   HIPCHK(ctx, hipEventCreate(&ctx->ev[0]));
   HIPCHK(ctx, hipEventCreate(&ctx->ev[1]));
   HIPCHK(ctx, fphip_dev_alloc((void **)&ctx->g, sizeof(DevShared), ctx->stream));

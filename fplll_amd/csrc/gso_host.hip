@@ -1552,7 +1552,7 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
     H.il_min_block = g->il_min_block;
     H.il_flags     = g->il_flags;
     const char *we = getenv("FPHIP_BKZ_PRUNE_WORKERS");
-    n_workers      = we ? atoi(we) : 8;
+    n_workers      = we ? atoi(we) : 4;
     n_workers      = std::max(1, std::min(n_workers, (int)std::min<size_t>(B, 64)));
     for (int w = 0; w < n_workers && g->il_device; ++w)
     {
@@ -1574,7 +1574,7 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
   {
     // hand-off mode: a second context on this device for the enumerations, the blocks' mu rows in
     // pinned host memory (the wave writes them, the worker thread reads them without a HIP call)
-    if (!g->ectx && fphip_create(fphip_ctx_device(g->ctx), &g->ectx) != FPHIP_OK)
+    if (!g->ectx && fphip_create_ex(fphip_ctx_device(g->ctx), 1 /* never behind the schedule kernel */, &g->ectx) != FPHIP_OK)
     {
       snprintf(fphip_ctx_errbuf(g->ctx), 512, "bkz_strategies: no enumeration context for the hand-off: %s",
                g->ectx ? fphip_last_error(g->ectx) : "?");

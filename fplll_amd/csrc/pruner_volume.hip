@@ -267,7 +267,14 @@ VolumeEngine *create_device_volume_engine(int device, char *err, size_t errlen)
   e->device       = device;
   hipError_t rc   = hipSetDevice(device);
   if (rc == hipSuccess)
-    rc = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+  {
+    // HIGH priority: a queue pool of its own — an engine's kernels must never queue behind the persistent
+    // schedule kernel whose mailbox they are answering (enum_host.hip: "Streams and hardware queues")
+    int least = 0, greatest = 0;
+    rc = hipDeviceGetStreamPriorityRange(&least, &greatest);
+    if (rc == hipSuccess)
+      rc = hipStreamCreateWithPriority(&e->stream, hipStreamNonBlocking, greatest);
+  }
   if (rc != hipSuccess)
   {
     if (err)

@@ -54,6 +54,13 @@ typedef struct fphip_ctx fphip_ctx;
 
 /* Context bound to one HIP device (one process per GPU; device = LOCAL_RANK under torchrun). */
 int fphip_create(int device, fphip_ctx **out);
+/* The same with a stream priority class: -1 low, 0 normal (fphip_create), +1 high.  Streams of different
+ * classes never share a hardware queue; inside a class they may, once the pool (four queues) is used up —
+ * and a kernel queued behind a minutes-long launch of another context waits for it.  Create the context
+ * of a long single launch (a whole BKZ run in one kernel) LOW when other contexts of the process must stay
+ * responsive.  The library's own helper streams (pruner volume engines, the hand-off enumeration context
+ * of a strategy-BKZ run) are HIGH: they must finish while the schedule kernel waits on its mailboxes. */
+int fphip_create_ex(int device, int priority, fphip_ctx **out);
 void fphip_destroy(fphip_ctx *ctx);
 const char *fphip_last_error(const fphip_ctx *ctx);
 int fphip_device_count(void);

@@ -52,7 +52,7 @@ def _run_config3_tour(out):
     from fplll_amd.gso import MatGSOBatch
     try:
         f = C.load_bkz_fixture(os.path.join(C.GOLDEN, "c3_bkz60_tour_strategies.json.gz"))
-        ctx3 = fplll_amd.Context(int(os.environ.get("LOCAL_RANK", "0")))
+        ctx3 = fplll_amd.Context(int(os.environ.get("LOCAL_RANK", "0")), priority=-1)
         B = 2
         g = MatGSOBatch(ctx3, B, f["d"], f["n"])
         g.set_basis(np.stack([f["b_in"]] * B))
@@ -97,7 +97,7 @@ def _run_config3_tour_handoff(out):
     from fplll_amd.gso import MatGSOBatch
     try:
         f = C.load_bkz_fixture(os.path.join(C.GOLDEN, "c3_bkz60_tour_strategies.json.gz"))
-        ctx4 = fplll_amd.Context(int(os.environ.get("LOCAL_RANK", "0")))
+        ctx4 = fplll_amd.Context(int(os.environ.get("LOCAL_RANK", "0")), priority=-1)
         g = MatGSOBatch(ctx4, 1, f["d"], f["n"])
         g.set_basis(np.stack([f["b_in"]]))
         rnd, draws = C.gmp_streams_native(1, f["rng_seed"])
@@ -121,7 +121,7 @@ def _run_config5_hlll(out):
     try:
         f = _c5()
         assert (f["d"], f["n"]) == (256, 256)
-        ctx2 = fplll_amd.Context(int(os.environ.get("LOCAL_RANK", "0")))
+        ctx2 = fplll_amd.Context(int(os.environ.get("LOCAL_RANK", "0")), priority=-1)
         B = 2
         h = MatHouseholderBatch(ctx2, B, 256, 256, row_expo=True)
         h.set_basis(np.stack([f["b_in"]] * B))
