@@ -300,7 +300,10 @@ static int launch(fphip_gso *g, int kmin, int kend, double eta, int mode, const 
     const int ring   = nq == 1 ? s2::Cfg<1>::RING : nq == 2 ? s2::Cfg<2>::RING : nq == 3 ? s2::Cfg<3>::RING : s2::Cfg<4>::RING;
     const int wps    = nq == 4 ? s2::Cfg<4>::WAVES_PER_SIMD : s2::Cfg<1>::WAVES_PER_SIMD;
     const size_t lds2 = (size_t)wpb * ring;
-    int bpc2          = g->blocks_per_cu > 0 ? g->blocks_per_cu : (int)((160 * 1024) / lds2);
+    // NQ = 3: three blocks of four waves per CU, not the four that fit — measured 100.8-101.9 ms against
+    // 104.5-105.1 ms at batch 8192 (three alternating repetitions on one box, profiles/r04_gso_roof_ab.log):
+    // the kernel is bound by the memory system, a quarter fewer lattices in flight thrash it less
+    int bpc2          = g->blocks_per_cu > 0 ? g->blocks_per_cu : std::min((int)((160 * 1024) / lds2), nq == 3 ? 3 : 4);
     if (bpc2 * wpb > 4 * wps)
       bpc2 = 4 * wps / wpb;
     if (bpc2 < 1)
@@ -1552,7 +1555,7 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
     H.il_min_block = g->il_min_block;
     H.il_flags     = g->il_flags;
     const char *we = getenv("FPHIP_BKZ_PRUNE_WORKERS");
-    n_workers      = we ? atoi(we) : 4;
+    n_workers      = we ? atoi(we) : 8;
     n_workers      = std::max(1, std::min(n_workers, (int)std::min<size_t>(B, 64)));
     for (int w = 0; w < n_workers && g->il_device; ++w)
     {
