@@ -298,7 +298,7 @@ static int launch(fphip_gso *g, int kmin, int kend, double eta, int mode, const 
   if (!la && g->sweep_version == 2)
   {  // gso_sweep2_kernel: its own ring geometry (gso_sweep2.h)
     const int ring   = nq == 1 ? s2::Cfg<1>::RING : nq == 2 ? s2::Cfg<2>::RING : nq == 3 ? s2::Cfg<3>::RING : s2::Cfg<4>::RING;
-    const int wps    = nq == 4 ? s2::Cfg<4>::WAVES_PER_SIMD : s2::Cfg<1>::WAVES_PER_SIMD;
+    const int wps    = nq == 4 ? s2::Cfg<4>::WAVES_PER_SIMD : nq == 3 ? s2::Cfg<3>::WAVES_PER_SIMD : s2::Cfg<1>::WAVES_PER_SIMD;
     const size_t lds2 = (size_t)wpb * ring;
     // NQ = 3: three blocks of four waves per CU, not the four that fit — measured 100.8-101.9 ms against
     // 104.5-105.1 ms at batch 8192 (three alternating repetitions on one box, profiles/r04_gso_roof_ab.log):
