@@ -137,14 +137,16 @@ int MatHouseholderHip::hlll_device(double delta, double eta, double theta, doubl
   const int rc = fphip_hh_hlll(h_, delta, eta, theta, c, &st, inf);
   if (rc != FPHIP_OK)
     st = -100;
-  else if (st != -2)
+  else if (st == 1 || st == -4 || st == -5)  // a finished run or a precision alarm: the device's basis is the result
     mirror_from_device(true);
+  // (-2 multiplier beyond 63 bits, -6 iteration cap, a device error: the host objects stay as they were —
+  //  the interposed hlll() hands the UNCHANGED input to the reference's own loop)
   if (info)
   {
     info[0] = inf[0];
     info[1] = inf[1];
   }
-  n_swaps = inf[0];
+  n_swaps = (st == 1 || st == -4 || st == -5) ? inf[0] : 0;
   device_seconds += now_s() - t0;
   ++n_device_calls;
   return st;
