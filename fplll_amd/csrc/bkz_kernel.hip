@@ -97,12 +97,13 @@ __global__ void __launch_bounds__(256)
     T.r           = P.r + (size_t)L * d * ldd;
     T.rdg         = P.rdg + (size_t)L * d;
     T.rexp        = P.rexp + (size_t)L * d;
-    // no narrow mirrors here (the host re-floats every row afterwards): np = 0 keeps every pass
-    // on the 8-byte rows; the pointers only have to be valid
-    T.bfT32       = (float *)T.bfT;
+    // the positional narrow prefix of the sweep kernels does not apply here (rows live in slots): np = 0
+    // keeps the shared code on the 8-byte rows.  The FLOAT mirror of bf is used, lattice-wide: f32ok
+    T.bfT32       = P.bfT32 + (size_t)L * n * ldd;
     T.b32         = (int *)T.b;
     T.narrow_flag = (int *)T.rexp;
     T.np          = 0;
+    T.f32ok       = all_rows_narrow<NQ>(P, (size_t)L, lane);
     LllCtx C{P.gf + (size_t)L * d * ldd, P.vc + (size_t)L * d};
     double *mu_blk = P.enum_mu + (size_t)L * (64 * 63 / 2);  // scaled mu rows of the current block
     SlotMap<NQ> M;

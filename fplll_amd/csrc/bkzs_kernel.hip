@@ -193,10 +193,11 @@ bkzs_body(GsoBatch P, BkzStrat S, BkzMail *mailbox, int *abort_flag, int block_s
     T.r           = P.r + (size_t)L * d * ldd;
     T.rdg         = P.rdg + (size_t)L * d;
     T.rexp        = P.rexp + (size_t)L * d;
-    T.bfT32       = (float *)T.bfT;  // no narrow mirrors here (see bkz_kernel.hip)
+    T.bfT32       = P.bfT32 + (size_t)L * P.n * P.ldd;  // the float mirror of bf (see bkz_kernel.hip)
     T.b32         = (int *)T.b;
     T.narrow_flag = (int *)T.rexp;
     T.np          = 0;
+    T.f32ok       = all_rows_narrow<NQ>(P, (size_t)L, lane);
     LllCtx C{P.gf + (size_t)L * d * ldd, P.vc + (size_t)L * d};
     // scaled mu rows of the block being enumerated: in LDS behind this wave's column stack when the
     // host asked for it (top_flags bit 30: few lattices per CU, where the L1 latency of every row

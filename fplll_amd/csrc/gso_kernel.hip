@@ -69,6 +69,7 @@ __global__ void __launch_bounds__(256)
     T.b32         = P.b32 + (size_t)L * P.d * P.ldn;
     T.narrow_flag = P.narrow + (size_t)L * P.d;
     T.np          = 0;
+    T.f32ok       = 0;
     if (mode != 2)
     {  // narrow prefix from the per-row flags (FPHIP_GSO_NARROW=0: P.use_narrow == 0)
       int p = 0;

@@ -1284,6 +1284,7 @@ __global__ void __launch_bounds__(256, Cfg<NQ>::WAVES_PER_SIMD)
     T.b32         = P.b32 + (size_t)L * P.d * P.ldn;
     T.narrow_flag = P.narrow + (size_t)L * P.d;
     T.np          = 0;
+    T.f32ok       = 0;
     Planes PL;
     PL.muA = muA + (size_t)L * P.d * P.ldd;
     // m16: [batch][n*ldd + d*ldn] shorts — bT16 then b16 of each lattice

@@ -52,6 +52,10 @@ template <int NQ> struct Lattice
   int *b32;          // [d][ldn]
   int *narrow_flag;  // [d] per row: every entry of the row is below 2^24 in magnitude
   int np;            // narrow prefix: rows 0..np-1 are all narrow (wave-uniform)
+  // slot-mode kernels (LLL / BKZ: rows never move, a slot table maps positions): 1 while EVERY row of the
+  // lattice is below 2^24 — the Gram passes then stream the float mirror (half the bytes of bfT, exact);
+  // kept by store_row_and_refloat, cleared for good by the first wide row.  0 in the other kernels.
+  int f32ok;
   int lane;
   double murow[NQ];  // mu(kappa, j) of the row last updated (lane j)
   double rrow[NQ];   // r(kappa, j)  of the row last updated (lane j)
@@ -316,6 +320,35 @@ template <int NQ, int IPS, int RR = FPHIP_GSO_RING> struct Ring
                    : "memory");
   }
 
+  // gather variant of read32()
+  template <int W> __device__ __forceinline__ void readg32(unsigned (&w)[NQ], const unsigned (&a)[NQ])
+  {
+    if constexpr (NQ == 1)
+      asm volatile("s_waitcnt vmcnt(%2)\n\tds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)"
+                   : "=&v"(w[0])
+                   : "v"(a[0]), "n"(W)
+                   : "memory");
+    else if constexpr (NQ == 2)
+      asm volatile("s_waitcnt vmcnt(%4)\n\tds_read_b32 %0, %2\n\tds_read_b32 %1, %3\n\t"
+                   "s_waitcnt lgkmcnt(0)"
+                   : "=&v"(w[0]), "=&v"(w[1])
+                   : "v"(a[0]), "v"(a[1]), "n"(W)
+                   : "memory");
+    else if constexpr (NQ == 3)
+      asm volatile("s_waitcnt vmcnt(%6)\n\tds_read_b32 %0, %3\n\tds_read_b32 %1, %4\n\t"
+                   "ds_read_b32 %2, %5\n\ts_waitcnt lgkmcnt(0)"
+                   : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2])
+                   : "v"(a[0]), "v"(a[1]), "v"(a[2]), "n"(W)
+                   : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(%8)\n\tds_read_b32 %0, %4\n\tds_read_b32 %1, %5\n\t"
+                   "ds_read_b32 %2, %6\n\tds_read_b32 %3, %7\n\t"
+                   "s_waitcnt lgkmcnt(0)"
+                   : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3])
+                   : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "n"(W)
+                   : "memory");
+  }
+
   // One phase of `cnt` steps.  Rows [0, ahead) of it may already be in flight (prefetched by the
   // previous phase).  While consuming, keep the pipe full: first with this phase's remaining rows,
   // then with the first rows of the NEXT phase (ncnt rows, nrow(s)) — phases are chained without
@@ -344,6 +377,11 @@ template <int NQ, int IPS, int RR = FPHIP_GSO_RING> struct Ring
   {
     static constexpr int IPR = IPS32;
   };
+  struct GatherF32Fetch  // rows of float read back by slot (byte offsets slot * 4), widened to double
+  {
+    static constexpr int IPR = IPS32;
+    const unsigned (&off)[NQ];
+  };
   struct I32Fetch  // rows of int32, delivered as the bit pattern of the sign-extended int64
   {
     static constexpr int IPR = IPS32;
@@ -355,6 +393,20 @@ template <int NQ, int IPS, int RR = FPHIP_GSO_RING> struct Ring
     --ahead;
     unsigned w[NQ];
     read32<P * IPS32>(w, addr);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+      v[q] = (double)__uint_as_float(w[q]);
+  }
+  template <int P> __device__ __forceinline__ void consume(double (&v)[NQ], const GatherF32Fetch &g)
+  {
+    const unsigned sb = base + tail * SLOT;
+    tail              = (tail + 1 == R) ? 0 : tail + 1;
+    --ahead;
+    unsigned w[NQ], a[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+      a[q] = sb + g.off[q];
+    readg32<P * IPS32>(w, a);
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
       v[q] = (double)__uint_as_float(w[q]);
@@ -658,7 +710,17 @@ __device__ __forceinline__ void store_row_and_refloat_impl(Lattice<NQ> &T, int p
         T.b32[(size_t)pk * ldn + c]   = (int)bv[q];
         wide |= (bv[q] >= (1ll << 24) || bv[q] <= -(1ll << 24));
       }
+      else if (T.f32ok)
+      {  // slot-mode kernels: the float mirror of bf only (their Gram passes stream it)
+        T.bfT32[(size_t)c * ldd + pk] = (float)f;
+        wide |= (bv[q] >= (1ll << 24) || bv[q] <= -(1ll << 24));
+      }
     }
+  }
+  if constexpr (!MIRRORS)
+  {
+    if (T.f32ok && __any(wide))
+      T.f32ok = 0;  // a row left the exact range of the float mirror: the 8-byte rows from now on
   }
   if constexpr (MIRRORS)
   {  // keep the row's flag and the narrow prefix (identity layout: slot pk = position pk)

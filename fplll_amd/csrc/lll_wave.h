@@ -14,6 +14,23 @@ struct LllCtx
   int *vc;     // [d] valid columns of the row in each slot
 };
 
+// every row of lattice L carries the 2^24 flag the host's re-float pass (mode 2 of the sweep kernel) has just
+// written, and the narrow paths are not switched off (FPHIP_GSO_NARROW=0): the slot-mode kernels may then
+// stream the float mirror of bf in their Gram passes (Lattice::f32ok)
+template <int NQ> __device__ __forceinline__ int all_rows_narrow(const GsoBatch &P, size_t L, int lane)
+{
+  const int *fl = P.narrow + L * (size_t)P.d;
+  bool ok       = P.use_narrow != 0;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+  {
+    const int i = lane + 64 * q;
+    if (i < P.d)
+      ok &= (fl[i] != 0);
+  }
+  return __all(ok) ? 1 : 0;
+}
+
 __device__ __forceinline__ double make_nan() { return __longlong_as_double(0x7ff8000000000000LL); }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
@@ -112,21 +129,31 @@ __device__ __forceinline__ bool update_row_cached(Lattice<NQ> &T, LllCtx &C, con
       settle(rd[q]);
       settle(mold[q]);
     }
-    auto gram_row = [&](int c) { return RowDesc{T.bfT + (size_t)c * ldd, 0, row_bytes}; };
-    ring.reset();
-    ring.run_with(
-        n, gram_row,
-        [&](int c, const double(&v)[NQ])
-        {
-          const double bkc = lane_get<NQ>(bk, c);
+    auto gram_body = [&](int c, const double(&v)[NQ])
+    {
+      const double bkc = lane_get<NQ>(bk, c);
 #pragma unroll
-          for (int q = 0; q < NQ; ++q)
-          {
-            const double p = bkc * v[q];
-            g[q]           = (c == 0) ? p : g[q] + p;
-          }
-        },
-        0, gram_row, typename Ring<NQ, IPS, RR>::GatherFetch{off});
+      for (int q = 0; q < NQ; ++q)
+      {
+        const double p = bkc * v[q];
+        g[q]           = (c == 0) ? p : g[q] + p;
+      }
+    };
+    ring.reset();
+    if (T.f32ok)
+    {  // every row is below 2^24: the float mirror holds the same numbers in half the bytes
+      unsigned off4[NQ];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+        off4[q] = off[q] >> 1;
+      auto gram_row4 = [&](int c) { return RowDesc{T.bfT32 + (size_t)c * ldd, 0, row_bytes >> 1}; };
+      ring.run_with(n, gram_row4, gram_body, 0, gram_row4, typename Ring<NQ, IPS, RR>::GatherF32Fetch{off4});
+    }
+    else
+    {
+      auto gram_row = [&](int c) { return RowDesc{T.bfT + (size_t)c * ldd, 0, row_bytes}; };
+      ring.run_with(n, gram_row, gram_body, 0, gram_row, typename Ring<NQ, IPS, RR>::GatherFetch{off});
+    }
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
     {
