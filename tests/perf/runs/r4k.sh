@@ -8,3 +8,4 @@ echo "suite rc=$?" >> $O/suite.log
 tail -5 $O/suite.log
 ( time timeout 300 python -c "import __graft_entry__ as g; g.smoke()" ) > $O/smoke.log 2>&1
 echo "smoke rc=$?" >> $O/smoke.log; tail -2 $O/smoke.log
+( timeout 300 python -m pytest tests/test_zzz_long_runs_gpu.py -q -s -m gpu -k handoff 2>&1 | grep -E "hand-off:|passed|failed" | cut -c1-400 ) | tee $O/handoff.log
