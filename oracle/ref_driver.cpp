@@ -1177,7 +1177,7 @@ static int cmd_bkztour(int argc, char **argv)
  *   [first, first + d) of the basis, radius = gh_factor x Gaussian heuristic of the block (the way the
  *   survey built its strategies); plus svp_probability<FP_NR<double>> and Pruner::single_enum_cost /
  *   measure_metric of the result AND of LinearPruningParams(d, d/2) through the public API.  Doubles in
- *   hex: the pruner of the product (fplll_amd/csrc/pruner_host.hip) is compared bit for bit. */
+ *   hex: the pruner of the product (fplll_amd/csrc/pruner_search.hip) is compared bit for bit. */
 static void put_hex(const char *name, const vector<double> &v, bool last = false)
 {
   printf("\"%s\":[", name);
