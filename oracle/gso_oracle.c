@@ -649,7 +649,24 @@ typedef struct
   uint64_t nodes;
   uint64_t enum_calls, rerandomizations;
   double sld_potential; /* BKZReduction::sld_potential */
+  const void *top_par;  /* the BKZParam of the top-level tour (in-loop pruning applies to its blocks only) */
 } bkz_ctx;
+
+/* In-loop pruning (the product's FPHIP_BKZ_PRUNE_IN_LOOP; oracle/ref_driver.cpp: InloopBKZ drives the real
+ * reference the same way): where svp_reduction picks a pruning set of the strategies (bkz.cpp:325) a
+ * top-level primal block of at least min_block rows asks this hook for coefficients computed on its own
+ * r-profile and radius.  Test infrastructure: the hook is installed by tests/conftest.py (which hands the
+ * request to the PRODUCT's pruner: the CPU suite then pins "this schedule + that pruner = the driven
+ * reference" without a GPU). */
+static oracle_inloop_fn g_inloop_fn = NULL;
+static void *g_inloop_user          = NULL;
+static int g_inloop_min_block       = 0;
+void oracle_gso_bkz_set_inloop(oracle_inloop_fn fn, void *user, int min_block)
+{
+  g_inloop_fn        = fn;
+  g_inloop_user      = user;
+  g_inloop_min_block = min_block;
+}
 
 /* MatGSOInterface::get_root_det / get_log_det, gso_interface.cpp:220-242 */
 static double get_root_det(oracle_gso *g, int start_row, int end_row)
@@ -813,11 +830,24 @@ static int svp_reduction(oracle_gso *g, bkz_ctx *cx, const bkz_par *par, int kap
     const int pr           = get_pruning(g, cx, kappa, bs);
     const double *pruning  = NULL;
     double expectation     = 1.0; /* PruningParams(): no pruning, expectation 1 (pruner.h:47) */
+    double inloop_co[256], inloop_r[256];
     if (pr >= 0)
     {
       expectation = cx->strat->prune_exp[pr];
       if (cx->strat->coeff_off[pr + 1] > cx->strat->coeff_off[pr])
         pruning = cx->strat->coeff + cx->strat->coeff_off[pr];
+    }
+    if (g_inloop_fn && (const void *)par == cx->top_par && !dual && bs >= g_inloop_min_block && bs >= 4 && bs <= 256)
+    { /* prune THIS block: r_ii with the row exponents applied (get_r), radius as the driver passes it */
+      for (int i = 0; i < bs; ++i)
+        inloop_r[i] = ldexp(R(g, kappa + i, kappa + i), (int)(2 * g->row_expo[kappa + i]));
+      const double radius = max_dist * pow(2, (double)max_dist_expo);
+      double ex           = 1.0;
+      if (isfinite(radius) && radius > 0 && g_inloop_fn(g_inloop_user, bs, inloop_r, radius, inloop_co, &ex) == 1)
+      {
+        pruning     = inloop_co;
+        expectation = ex;
+      }
     }
     /* EnumerationDyn::enumerate, enumerate.cpp:88-141 */
     long normexp = -1;
@@ -1095,6 +1125,7 @@ int oracle_gso_bkz_param(oracle_gso *g, int block_size, double delta, double eta
   cx.rnd       = rnd;
   cx.rnd_user  = rnd_user;
   bkz_par par  = {block_size, flags, gh_factor, 0.5, 3};
+  cx.top_par   = &par;
   int status = 1, tours = 0;
   const int sd = (flags & 0x100) != 0, sld = (flags & 0x200) != 0; /* BKZ_SD_VARIANT, BKZ_SLD_RED */
   if (sd && sld)

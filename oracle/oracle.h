@@ -110,6 +110,12 @@ typedef unsigned long (*oracle_rand_fn)(void *user, unsigned long n);
 int oracle_gso_bkz_param(oracle_gso *g, int block_size, double delta, double eta, int flags,
                          int max_loops, double gh_factor, const oracle_strategies *strat,
                          oracle_rand_fn rnd, void *rnd_user, int *info);
+/* in-loop pruning hook of oracle_gso_bkz_param (NULL: off): fn(user, bs, gso_r[bs], radius, coefficients[bs] out,
+ * expectation out) -> 1 when it pruned the block (else the strategies' set stays); top-level primal blocks
+ * of at least min_block rows */
+typedef int (*oracle_inloop_fn)(void *user, int bs, const double *gso_r, double radius, double *coefficients,
+                                double *expectation);
+void oracle_gso_bkz_set_inloop(oracle_inloop_fn fn, void *user, int min_block);
 /* one svp_reduction(kappa, block_size, empty strategies, dual), bkz.cpp:274-358 */
 int oracle_gso_svp_reduction(oracle_gso *g, int kappa, int block_size, int dual, double delta,
                              double eta, int *clean, uint64_t *nodes);

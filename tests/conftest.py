@@ -352,6 +352,38 @@ class OracleGSO:
                                           sp, fn, None, info.ctypes.data_as(ctypes.c_void_p))
         return status, info
 
+    def bkz_param_inloop(self, block_size, delta, eta, flags, max_loops, gh_factor, strategies, rng_seed, inloop):
+        """oracle_gso_bkz_param with the in-loop pruning hook installed: every top-level primal block of at
+        least inloop["min_block"] rows is pruned by the PRODUCT's pruner (fplll_amd.pruner.prune on the host
+        volume engine) on its own r-profile — the CPU-side twin of FPHIP_BKZ_PRUNE_IN_LOOP.  Returns
+        (status, info[5], number of prune() calls)."""
+        from fplll_amd import pruner as P
+        HOOK = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_double),
+                                ctypes.c_double, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double))
+        calls = [0]
+
+        def hook(_user, bs, gso_r, radius, coeffs, expectation):
+            calls[0] += 1
+            r = np.array([gso_r[i] for i in range(bs)], dtype=np.float64)
+            try:
+                pp = P.prune(radius, inloop["preproc_cost"], r, inloop["target"],
+                             P.PRUNER_METRIC_PROBABILITY_OF_SHORTEST, inloop["pruner_flags"])
+            except Exception:
+                return 0
+            for i in range(bs):
+                coeffs[i] = float(pp.coefficients[i])
+            expectation[0] = float(pp.expectation)
+            return 1
+        cb = HOOK(hook)
+        self.lib.oracle_gso_bkz_set_inloop.restype = None
+        self.lib.oracle_gso_bkz_set_inloop.argtypes = [HOOK, ctypes.c_void_p, ctypes.c_int]
+        self.lib.oracle_gso_bkz_set_inloop(cb, None, int(inloop["min_block"]))
+        try:
+            st, info = self.bkz_param(block_size, delta, eta, flags, max_loops, gh_factor, strategies, rng_seed)
+        finally:
+            self.lib.oracle_gso_bkz_set_inloop(ctypes.cast(None, HOOK), None, 0)
+        return st, info, calls[0]
+
     def _arr(self, fn, shape, dtype):
         p = getattr(self.lib, fn)(self.h)
         return np.ctypeslib.as_array(p, shape=shape).astype(dtype).copy()
