@@ -20,6 +20,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -75,7 +76,14 @@ public:
     host_jobs += (unsigned long long)njobs;
     return true;
   }
-  int lookahead() const override { return 1; }
+  // 1: the host pays for every wasted candidate.  FPHIP_PRUNER_HOST_LOOKAHEAD (tests): a larger value makes
+  // the searches take their batched / look-ahead paths on host arithmetic — the paths the device engine
+  // takes — so that the CPU suite covers them
+  int lookahead() const override
+  {
+    static const int la = getenv("FPHIP_PRUNER_HOST_LOOKAHEAD") ? atoi(getenv("FPHIP_PRUNER_HOST_LOOKAHEAD")) : 1;
+    return la > 1 ? la : 1;
+  }
 };
 }  // namespace
 
