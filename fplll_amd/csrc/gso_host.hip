@@ -1584,12 +1584,16 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
       if (g->ectx)
         fphip_destroy(g->ectx);
       g->ectx = nullptr;
+      for (auto *x : il_engines)
+        fphip_pruner::destroy_volume_engine(x);
       cleanup();
       return FPHIP_ERROR;
     }
     g->P.enum_mu_h = (double *)pinned_get(B * (64 * 63 / 2) * sizeof(double));
     if (!g->P.enum_mu_h)
     {
+      for (auto *x : il_engines)
+        fphip_pruner::destroy_volume_engine(x);
       cleanup();
       snprintf(fphip_ctx_errbuf(g->ctx), 512, "bkz_strategies: no pinned memory for the hand-off");
       return FPHIP_ERROR;
