@@ -50,12 +50,20 @@ def blocks(tmp_path_factory):
     return out
 
 
+def sweep2_infl(nq):
+    """Cfg<NQ>::INFL of gso_sweep2.h (LDS-DMA entries a wave keeps in flight), from the header's constants."""
+    src = open(os.path.join(C.ROOT, "fplll_amd", "csrc", "gso_sweep2.h")).read()
+    lds3 = int(re.search(r"#define FPHIP_S2_NQ3_LDS (\d+)", src).group(1))
+    wave_lds = 13312 if nq == 4 else lds3 if nq == 3 else 9984
+    npair = min(16, wave_lds // (2 * nq * 256))
+    return 2 * (npair - 1)
+
+
 def _ring(blocks):
     return [b for b in blocks if any("global_load_lds" in i for i in b) and any(i.startswith("s_waitcnt vmcnt") for i in b)]
 
 
 def test_ring_loops_wait_with_the_compile_time_count_only(blocks):
-    from fplll_amd.csrc_consts import sweep2_infl  # noqa: F401  (see below: parsed from gso_sweep2.h)
     ring = _ring(blocks)
     assert len(ring) >= 200, len(ring)
     want = "s_waitcnt vmcnt(%d)" % (sweep2_infl(3) - 2)
