@@ -978,6 +978,7 @@ extern "C" int fphip_gso_bkz(fphip_gso *g, int block_size, double delta, double 
 // roundings) and the rerandomisation plan (drawn from the caller's generator, rnd(user, lattice,
 // n) = gmp_urandomm_ui(state of that lattice, n)).
 #include <atomic>
+#include <functional>
 #include <condition_variable>
 #include <deque>
 #include <mutex>
@@ -1308,6 +1309,207 @@ extern "C" int fphip_gso_slide_pass(fphip_gso *g, int block_size, double delta, 
   g->P.sld_pass = 0;
   g->P.sld_mask = 0;
   return rc;
+}
+
+// The block-parallel slide TOUR over several batch-of-one objects (one per context / device), host threads in
+// this process: what fplll_amd.distributed.slide_reduction_blocks does with LocalGather, behind the C ABI so
+// that a C++ caller (an fplll process that holds several devices) needs no Python.  Same calls in the same
+// order per participant, hence the same result: block i of a pass is reduced by gs[i % count] from the
+// pass-start basis, the merged basis replaces every copy, the bounded LLL / the potential test / the closing
+// hkz run on every copy alike.
+extern "C" int fphip_gso_slide_reduction_blocks(fphip_gso **gs, int count, int block_size, double delta, double eta,
+                                                int flags, int max_loops, double gh_factor,
+                                                const fphip_strategies *S, fphip_rand_fn rnd, void *rnd_user,
+                                                int *status, unsigned long long *nodes_out, int *tours_out)
+{
+  if (!gs || count < 1 || block_size < 2)
+    return FPHIP_ERROR;
+  for (int r = 0; r < count; ++r)
+    if (!gs[r] || gs[r]->P.batch != 1 || gs[r]->P.d != gs[0]->P.d || gs[r]->P.n != gs[0]->P.n)
+      return FPHIP_ERROR;
+  if (!(flags & 0x10))
+    return FPHIP_UNSUPPORTED;  // the blocks of a pass are independent only with BKZ_BOUNDED_LLL
+  const int d = gs[0]->P.d, n = gs[0]->P.n;
+  const int p = (d + block_size - 1) / block_size;
+  struct Blk
+  {
+    int lo, hi;
+  };
+  std::vector<Blk> primal, dual;
+  for (int i = 0; i < p; ++i)
+    primal.push_back(Blk{i * block_size, std::min(d, (i + 1) * block_size)});
+  for (int i = 0; i + 1 < p; ++i)
+    dual.push_back(Blk{i * block_size + 1, (i + 1) * block_size + 1});
+  const size_t rowsz = (size_t)n;
+  std::vector<int64_t> start((size_t)d * n), merged((size_t)d * n);
+  std::atomic<int> failed{0};
+  unsigned long long total_nodes = 0;
+  // every participant on a thread of its own: f(r) for r = 0 .. count-1
+  int caller_dev = 0;
+  (void)hipGetDevice(&caller_dev);
+  auto on_all = [&](const std::function<void(int)> &f)
+  {
+    // (the GSO entry points launch on their context's stream with the calling thread's current device:
+    //  every thread selects its object's device first)
+    auto on_dev = [&](int r)
+    {
+      (void)hipSetDevice(fphip_ctx_device(gs[r]->ctx));
+      f(r);
+    };
+    std::vector<std::thread> ts;
+    for (int r = 1; r < count; ++r)
+      ts.emplace_back(on_dev, r);
+    on_dev(0);
+    for (auto &t : ts)
+      t.join();
+    (void)hipSetDevice(caller_dev);
+  };
+  auto set_all = [&](const std::vector<int64_t> &b)
+  {
+    on_all([&](int r)
+           {
+             if (fphip_gso_set_basis(gs[r], 0, 1, b.data()) != FPHIP_OK || fphip_gso_refresh(gs[r]) != FPHIP_OK)
+               failed = 1;
+           });
+  };
+  auto run_pass = [&](int pass, const std::vector<Blk> &layout, bool &clean) -> unsigned long long
+  {
+    if (fphip_gso_get_basis(gs[0], 0, 1, start.data()) != FPHIP_OK)
+      failed = 1;
+    merged = start;
+    std::atomic<int> all_clean{1};
+    std::atomic<unsigned long long> nd{0};
+    on_all([&](int r)
+           {
+             std::vector<int64_t> mine((size_t)d * n);
+             for (int i = r; i < (int)layout.size(); i += count)
+             {
+               int st = 0, info[4] = {0, 0, 0, 0};
+               if (fphip_gso_set_basis(gs[r], 0, 1, start.data()) != FPHIP_OK || fphip_gso_refresh(gs[r]) != FPHIP_OK ||
+                   fphip_gso_slide_pass(gs[r], block_size, delta, eta, flags & (0x10 | 0x80 | 0x2000), gh_factor, S, rnd,
+                                        rnd_user, pass, 1ull << i, &st, info) != FPHIP_OK ||
+                   st <= 0 || fphip_gso_get_basis(gs[r], 0, 1, mine.data()) != FPHIP_OK)
+               {
+                 failed = 1;
+                 return;
+               }
+               // (the blocks of a pass are disjoint row ranges: no two threads write the same rows)
+               memcpy(&merged[(size_t)layout[i].lo * rowsz], &mine[(size_t)layout[i].lo * rowsz],
+                      sizeof(int64_t) * rowsz * (size_t)(layout[i].hi - layout[i].lo));
+               if (pass == 1 && !info[0])
+                 all_clean = 0;
+               nd += ((unsigned long long)(unsigned)info[2] << 32) | (unsigned)info[1];
+             }
+           });
+    set_all(merged);
+    clean = all_clean.load() != 0;
+    return nd.load();
+  };
+  auto potential = [&]() -> double
+  {
+    int st = 0;
+    std::vector<double> rm((size_t)d * d), diag(d);
+    std::vector<int64_t> re(d);
+    if (fphip_gso_update(gs[0], &st) != FPHIP_OK || st != 1 || fphip_gso_get_r(gs[0], 0, rm.data()) != FPHIP_OK ||
+        fphip_gso_get_row_expo(gs[0], 0, re.data()) != FPHIP_OK)
+    {
+      failed = 1;
+      return 0.0;
+    }
+    for (int i = 0; i < d; ++i)
+      diag[i] = rm[(size_t)i * d + i];
+    return fphip_gso_util_slide_potential(diag.data(), re.data(), d, 0, d, block_size);
+  };
+  int st_out = 1, tours = 0;
+  double old = potential();
+  while (!failed)
+  {
+    if (max_loops > 0 && tours >= max_loops)
+    {
+      st_out = 8;  // RED_BKZ_LOOPS_LIMIT
+      break;
+    }
+    for (;;)
+    {  // primal passes until one leaves every block, and the bounded LLL, unchanged (bkz.cpp:472-494)
+      bool clean = true;
+      total_nodes += run_pass(1, primal, clean);
+      if (failed)
+        break;
+      std::atomic<int> lll_bad{0}, swaps{0};
+      on_all([&](int r)
+             {
+               int st = 0, info[4] = {0, 0, 0, 0};
+               if (fphip_gso_lll(gs[r], 0, 0, d, delta, eta, &st, info) != FPHIP_OK)
+                 failed = 1;
+               else if (st != 1)
+                 lll_bad = st == 0 ? -100 : st;
+               if (r == 0)
+                 swaps = info[1];
+             });
+      if (failed)
+        break;
+      if (lll_bad.load())
+      {
+        st_out = lll_bad.load() == -100 ? 0 : lll_bad.load();
+        failed = 2;  // (a reduction status, not a device error)
+        break;
+      }
+      if (swaps.load() > 0)
+        clean = false;
+      if (clean)
+        break;
+    }
+    if (failed)
+      break;
+    if (!dual.empty())
+    {
+      bool unused = true;
+      total_nodes += run_pass(2, dual, unused);
+      if (failed)
+        break;
+    }
+    ++tours;
+    const double now = potential();
+    if (failed || now >= old || block_size >= d)
+      break;
+    old = now;
+  }
+  if (failed == 1)
+  {
+    snprintf(fphip_ctx_errbuf(gs[0]->ctx), 512, "fphip_gso_slide_reduction_blocks: a pass failed: %s",
+             fphip_last_error(gs[0]->ctx));
+    return FPHIP_ERROR;
+  }
+  if (failed == 0)
+  {  // the closing hkz of every block (bkz.cpp:643-660) on every copy alike; counted once
+    std::atomic<int> bad{0};
+    std::atomic<unsigned long long> nd{0};
+    on_all([&](int r)
+           {
+             int st = 0, info[4] = {0, 0, 0, 0};
+             if (fphip_gso_slide_pass(gs[r], block_size, delta, eta, flags & (0x10 | 0x80 | 0x2000), gh_factor, S, rnd,
+                                      rnd_user, 3, 0, &st, info) != FPHIP_OK)
+               bad = 1;
+             else if (r == 0)
+             {
+               nd = ((unsigned long long)(unsigned)info[2] << 32) | (unsigned)info[1];
+               if (st <= 0)
+                 bad = 2 + (st == 0 ? 100 : -st);
+             }
+           });
+    if (bad.load() == 1)
+      return FPHIP_ERROR;
+    total_nodes += nd.load();
+    if (bad.load() >= 2)
+      st_out = bad.load() - 2 == 100 ? 0 : -(bad.load() - 2);
+  }
+  if (status)
+    *status = st_out;
+  if (nodes_out)
+    *nodes_out = total_nodes;
+  if (tours_out)
+    *tours_out = tours;
+  return FPHIP_OK;
 }
 
 extern "C" int fphip_gso_bkz_inloop_pruning(fphip_gso *g, double preproc_cost, double target, int min_block_size,

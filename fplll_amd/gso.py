@@ -290,6 +290,29 @@ class MatGSOBatch:
         self._chk(rc, "slide_pass")
         return st, info
 
+    @staticmethod
+    def slide_reduction_blocks(objects, block_size, strategies=None, rnd=None, delta=LLL_DEF_DELTA, eta=LLL_DEF_ETA,
+                               max_loops=0, gh_bnd=False, gh_factor=1.1):
+        """fphip_gso_slide_reduction_blocks: the block-parallel slide tour (BKZ_SLD_RED | BKZ_BOUNDED_LLL) over
+        `objects` — batch-of-one MatGSOBatch objects, one per context / device, all holding the same LLL-reduced
+        basis — driven by the C library's own host threads.  Returns (status, nodes, tours); every object then
+        holds the result."""
+        assert strategies is None and rnd is None, "strategies: use fplll_amd.distributed.slide_reduction_blocks"
+        lib = objects[0].lib
+        arr = (ctypes.c_void_p * len(objects))(*[o.h for o in objects])
+        fn = lib.fphip_gso_slide_reduction_blocks
+        fn.restype = ctypes.c_int
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_int,
+                       ctypes.c_int, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                       ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_ulonglong), ctypes.POINTER(ctypes.c_int)]
+        st, nodes, tours = ctypes.c_int(0), ctypes.c_ulonglong(0), ctypes.c_int(0)
+        rc = fn(arr, len(objects), block_size, delta, eta, 0x10 | (0x80 if gh_bnd else 0), max_loops, gh_factor,
+                None, None, None, ctypes.byref(st), ctypes.byref(nodes), ctypes.byref(tours))
+        if rc == _lib.FPHIP_UNSUPPORTED:
+            raise NotImplementedError("block-parallel slide reduction needs BKZ_BOUNDED_LLL and blocks up to 64 rows")
+        objects[0]._chk(rc, "slide_reduction_blocks")
+        return st.value, nodes.value, tours.value
+
     def inloop_stats(self):
         """(prune() calls of the in-loop service, volume jobs on the device, inline on the host, launches)"""
         v = [ctypes.c_ulonglong(0) for _ in range(4)]

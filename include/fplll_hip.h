@@ -290,6 +290,15 @@ int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double delta, double 
 int fphip_gso_slide_pass(fphip_gso *g, int block_size, double delta, double eta, int flags, double gh_factor,
                          const fphip_strategies *S, fphip_rand_fn rnd, void *rnd_user, int pass,
                          unsigned long long block_mask, int *status, int *info);
+/* The whole block-parallel tour over `count` batch-of-one objects — one per context / device, all holding the
+ * same LLL-reduced basis — on host threads of this process (what fplll_amd.distributed.slide_reduction_blocks
+ * does with LocalGather, for callers without Python): BKZ_SLD_RED | BKZ_BOUNDED_LLL (flags must hold 0x10; 0x80
+ * BKZ_GH_BND and FPHIP_BKZ_PRUNE_IN_LOOP allowed), max_loops 0 = until the potential stops falling.  On return
+ * every object holds the result; *status 1 RED_SUCCESS / 8 RED_BKZ_LOOPS_LIMIT / a failure status, *nodes the
+ * enumeration nodes of all blocks, *tours the number of slide tours. */
+int fphip_gso_slide_reduction_blocks(fphip_gso **gs, int count, int block_size, double delta, double eta, int flags,
+                                     int max_loops, double gh_factor, const fphip_strategies *S, fphip_rand_fn rnd,
+                                     void *rnd_user, int *status, unsigned long long *nodes, int *tours);
 /* LLLReduction::lll in a selectable floating-point type (lll_x.hip): precision 106 = double-double
  * arithmetic on the device (the stand-in for FP_NR<dd_real>: what Wrapper::lll's fast_lll<dd_real>
  * runs, wrapper.cpp:322-330; libqd's algorithms restated, csrc/ftx.h), 53 = plain double.  Same

@@ -166,3 +166,32 @@ def test_block_parallel_slide_reduction_over_ranks(ctx):
     for r in range(2):
         assert out[r][1] == res[0][0] and out[r][3] == res[0][2] and out[r][4] == res[0][3]
         assert np.array_equal(np.array(out[r][2]), res[0][1])
+
+
+def test_block_parallel_slide_tour_behind_the_c_abi():
+    """fphip_gso_slide_reduction_blocks — the same tour driven by the C library's own host threads over 1 and 3
+    contexts (what a C++ caller without Python uses): the basis, node count and number of tours of the Python
+    orchestration (`slide_reduction_blocks` with LocalGather)."""
+    import fplll_amd
+    from fplll_amd.distributed import LocalGather
+    from fplll_amd.gso import MatGSOBatch
+    f = C.load_bkz_fixture(os.path.join(C.GOLDEN, "bkzd_q64_b16_slide_bounded_lll.json"))
+    res = [None]
+    _slide_blocks_run(1, f, res, LocalGather(1), 0)
+    assert not isinstance(res[0], BaseException), repr(res[0])
+    st0, out0, nodes0, tours0 = res[0]
+    for count in (1, 3):
+        ctxs = [fplll_amd.Context(0) for _ in range(count)]
+        gs = [MatGSOBatch(c, 1, f["d"], f["n"]) for c in ctxs]
+        for g in gs:
+            g.set_basis(f["b_in"][None])
+        st, nodes, tours = MatGSOBatch.slide_reduction_blocks(gs, f["block_size"], delta=f["delta"], eta=f["eta"],
+                                                              max_loops=f["max_loops"])
+        outs = [g.get_basis(0, 1)[0] for g in gs]
+        for g in gs:
+            g.close()
+        for c in ctxs:
+            c.close()
+        assert (st, nodes, tours) == (st0, nodes0, tours0), (count, st, nodes, tours, st0, nodes0, tours0)
+        for o in outs:
+            assert np.array_equal(o, out0), "the C ABI tour differs from the Python orchestration (count %d)" % count
