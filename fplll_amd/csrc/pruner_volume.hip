@@ -62,6 +62,144 @@ static inline double finish(double raw, int k)
   return (k & 1) ? -res : res;
 }
 
+// ---------------------------------------------------------------------------------------------
+// host form, EIGHT jobs side by side.  One job is a chain: every step's multiply-then-add waits for the
+// step before it (8 cycles on a core that could start two of each per cycle), and a candidate of the
+// searches is m jobs of depths 1 .. m over the same bounds.  The jobs of a batch are therefore taken in
+// groups of eight, deepest first, as the lanes of two 4-wide vectors: the same round structure as the
+// device kernel above (round s has s + 1 steps whatever k is; a lane whose job is finished keeps going
+// through the motions with x = 0 and does not touch its result), the same operations in the same order
+// on every lane — IEEE division, product and sum, no contraction — so each lane's double is
+// simplex_volume()'s.  The vectors are the compiler's generic ones: 256-bit registers where the CPU has
+// AVX2 (checked at run time), pairs of SSE2 registers elsewhere.
+// ---------------------------------------------------------------------------------------------
+typedef double v4d __attribute__((vector_size(32)));
+typedef long long v4l __attribute__((vector_size(32)));
+
+struct Lanes8
+{
+  std::vector<v4d> c;  // [2 * (kmax + 1)] the polynomials: c[2 j + h] = coefficient j of lanes 4 h .. 4 h + 3
+  std::vector<v4d> x;  // [2 * kmax] the evaluation points of round s
+};
+
+__attribute__((always_inline)) static inline void volumes8_body(const double *const y[8], const int k[8], v4d *c,
+                                                                 v4d *x, double raw[8])
+{
+  const int kmax = k[0];  // (the caller sorts: lane 0 is the deepest)
+  v4l kv[2];
+  for (int h = 0; h < 2; ++h)
+    for (int l = 0; l < 4; ++l)
+    {
+      const int kl = k[4 * h + l];
+      kv[h][l]     = kl;
+      const double *yl = y[4 * h + l];
+      const double top = yl[kl - 1];
+      for (int s = 0; s < kmax; ++s)
+        x[2 * s + h][l] = s < kl ? yl[kl - 1 - s] / top : 0.0;
+    }
+  const v4d one = {1.0, 1.0, 1.0, 1.0}, zero = {0.0, 0.0, 0.0, 0.0}, mone = {-1.0, -1.0, -1.0, -1.0};
+  c[0] = one;
+  c[1] = one;
+  for (int s = 0; s < kmax; ++s)
+  {
+    const v4d x0 = x[2 * s], x1 = x[2 * s + 1];
+    v4d a0 = zero, a1 = zero;
+    for (int j = s; j >= 0; --j)
+    {
+      const double dj = j + 1.0;
+      const v4d dv    = {dj, dj, dj, dj};
+      const v4d t0 = c[2 * j] / dv, t1 = c[2 * j + 1] / dv;
+      c[2 * j + 2] = t0;
+      c[2 * j + 3] = t1;
+      a0 = a0 * x0;
+      a1 = a1 * x1;
+      a0 = a0 + t0;
+      a1 = a1 + t1;
+    }
+    a0 = a0 * x0;
+    a1 = a1 * x1;
+    a0 = a0 + zero;
+    a1 = a1 + zero;
+    a0 = mone * a0;
+    a1 = mone * a1;
+    const v4l sv = {s, s, s, s};
+    const v4l on0 = sv < kv[0], on1 = sv < kv[1];
+    c[0] = (v4d)(((v4l)a0 & on0) | ((v4l)c[0] & ~on0));
+    c[1] = (v4d)(((v4l)a1 & on1) | ((v4l)c[1] & ~on1));
+  }
+  for (int l = 0; l < 4; ++l)
+  {
+    raw[l]     = c[0][l];
+    raw[4 + l] = c[1][l];
+  }
+}
+__attribute__((target("avx2"))) static void volumes8_avx2(const double *const y[8], const int k[8], v4d *c, v4d *x,
+                                                          double raw[8])
+{
+  volumes8_body(y, k, c, x, raw);
+}
+static void volumes8_generic(const double *const y[8], const int k[8], v4d *c, v4d *x, double raw[8])
+{
+  volumes8_body(y, k, c, x, raw);
+}
+
+// out[j] = the finished volume of jobs[j], for every job of the batch
+static void host_volumes(const double *bounds, int m, const VolumeJob *jobs, int njobs, double *out, Lanes8 &L,
+                         std::vector<unsigned> &order, std::vector<double> &scratch)
+{
+  static const bool avx2 = __builtin_cpu_supports("avx2");
+  static const bool wide = !(getenv("FPHIP_PRUNER_HOST_SCALAR") && atoi(getenv("FPHIP_PRUNER_HOST_SCALAR")) != 0);
+  if ((int)scratch.size() < m + 2)
+    scratch.resize(m + 2);
+  if (njobs < 3 || !wide)
+  {  // (one or two chains: nothing to put side by side)
+    for (int j = 0; j < njobs; ++j)
+      out[j] = finish(simplex_volume(bounds + (size_t)jobs[j].vec * m, jobs[j].k, scratch.data()), jobs[j].k);
+    return;
+  }
+  // counting sort of the job indices by k, deepest first: the lanes of a group then finish together
+  order.resize(njobs);
+  {
+    std::vector<int> head(m + 2, 0);
+    for (int j = 0; j < njobs; ++j)
+      ++head[m - jobs[j].k + 1];
+    for (int k = 1; k <= m + 1; ++k)
+      head[k] += head[k - 1];
+    for (int j = 0; j < njobs; ++j)
+      order[head[m - jobs[j].k]++] = (unsigned)j;
+  }
+  if (L.c.size() < (size_t)2 * (m + 2))
+  {
+    L.c.resize((size_t)2 * (m + 2));
+    L.x.resize((size_t)2 * (m + 2));
+  }
+  for (int g = 0; g < njobs; g += 8)
+  {
+    const int cnt = std::min(8, njobs - g);
+    if (cnt < 3)
+    {
+      for (int l = 0; l < cnt; ++l)
+      {
+        const VolumeJob &J = jobs[order[g + l]];
+        out[order[g + l]]  = finish(simplex_volume(bounds + (size_t)J.vec * m, J.k, scratch.data()), J.k);
+      }
+      continue;
+    }
+    const double *y[8];
+    int k[8];
+    double raw[8];
+    for (int l = 0; l < 8; ++l)
+    {  // (a short last group repeats its first job on the idle lanes)
+      const VolumeJob &J = jobs[order[g + (l < cnt ? l : 0)]];
+      y[l]               = bounds + (size_t)J.vec * m;
+      k[l]               = J.k;
+    }
+    (avx2 ? volumes8_avx2 : volumes8_generic)(y, k, L.c.data(), L.x.data(), raw);
+    for (int l = 0; l < cnt; ++l)
+      out[order[g + l]] = finish(raw[l], k[l]);
+  }
+}
+
 namespace
 {
 class HostEngine : public VolumeEngine
@@ -70,9 +208,11 @@ public:
   bool run(const double *bounds, int nvec, int m, const VolumeJob *jobs, int njobs, double *out) override
   {
     (void)nvec;
-    std::vector<double> scratch((size_t)m + 2);
-    for (int j = 0; j < njobs; ++j)
-      out[j] = finish(simplex_volume(bounds + (size_t)jobs[j].vec * m, jobs[j].k, scratch.data()), jobs[j].k);
+    // (the one host engine serves every caller: per-thread work areas)
+    static thread_local Lanes8 L;
+    static thread_local std::vector<unsigned> order;
+    static thread_local std::vector<double> scratch;
+    host_volumes(bounds, m, jobs, njobs, out, L, order, scratch);
     host_jobs += (unsigned long long)njobs;
     return true;
   }
@@ -155,6 +295,7 @@ public:
   char err[256]      = {0};
   std::vector<double> scratch;
   std::vector<unsigned> order;
+  Lanes8 lanes;
 
   ~DeviceEngine() override
   {
@@ -187,10 +328,7 @@ public:
       steps += (long long)jobs[j].k * (jobs[j].k + 1) / 2;
     if (steps < min_steps || nvec >= (1 << 20) || m > 255)
     {
-      if ((int)scratch.size() < m + 2)
-        scratch.resize(m + 2);
-      for (int j = 0; j < njobs; ++j)
-        out[j] = finish(simplex_volume(bounds + (size_t)jobs[j].vec * m, jobs[j].k, scratch.data()), jobs[j].k);
+      host_volumes(bounds, m, jobs, njobs, out, lanes, order, scratch);
       host_jobs += (unsigned long long)njobs;
       return true;
     }

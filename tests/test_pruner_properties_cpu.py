@@ -85,3 +85,43 @@ def test_prune_returns_feasible_coefficients_and_its_own_metric(n, target):
     cost, metric, levels = P.enum_cost(radius, r, c)
     assert metric == pp.expectation and abs(levels.sum() - cost) < 1e-9 * cost
     assert cost < P.enum_cost(radius, r, np.ones(n))[0]
+
+
+_SCALAR_CHILD = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+from fplll_amd import pruner as P
+z = np.load(sys.argv[2])
+np.save(sys.argv[3], P.volumes(z["bounds"], z["vec"], z["k"]))
+"""
+
+
+@pytest.mark.parametrize("m,nvec", [(5, 3), (18, 7), (30, 40), (64, 9)])
+def test_eight_jobs_side_by_side_are_the_one_chain_doubles(m, nvec, tmp_path):
+    """The host engine takes the jobs of a batch eight at a time as vector lanes (pruner_volume.hip:
+    host_volumes); FPHIP_PRUNER_HOST_SCALAR=1 keeps the one-job-after-the-other loop.  Same doubles, bit for bit,
+    for ragged batches: every depth 1..m of several bound vectors, in shuffled order, batch sizes that leave short
+    last groups, and a batch of two (below the width at which lanes are used at all)."""
+    import os
+    import subprocess
+    import sys
+    from fplll_amd import pruner as P
+    rng = np.random.default_rng(1000 * m + nvec)
+    steps = rng.uniform(0.0, 1.0, size=(nvec, m))
+    bounds = np.sort(steps, axis=1)          # non-decreasing bounds in (0, 1], the last one 1
+    bounds /= bounds[:, -1:]
+    bounds[bounds < 1e-3] = 1e-3
+    vec, k = np.meshgrid(np.arange(nvec), np.arange(1, m + 1), indexing="ij")
+    vec, k = vec.ravel(), k.ravel()
+    perm = rng.permutation(vec.size)[: vec.size - 3]          # (not a multiple of eight)
+    vec, k = vec[perm].astype(np.int32), k[perm].astype(np.int32)
+    wide = P.volumes(bounds, vec, k)
+    pair = P.volumes(bounds, vec[:2], k[:2])
+    src, dst = str(tmp_path / "in.npz"), str(tmp_path / "out.npy")
+    np.savez(src, bounds=bounds, vec=vec, k=k)
+    subprocess.run([sys.executable, "-c", _SCALAR_CHILD, C.ROOT, src, dst], check=True, timeout=300,
+                   env=dict(os.environ, FPHIP_PRUNER_HOST_SCALAR="1"))
+    scalar = np.load(dst)
+    assert np.array_equal(wide.view(np.uint64), scalar.view(np.uint64))
+    assert np.array_equal(pair.view(np.uint64), scalar[:2].view(np.uint64))
+    assert np.all(np.isfinite(wide))
