@@ -63,95 +63,176 @@ static inline double finish(double raw, int k)
 }
 
 // ---------------------------------------------------------------------------------------------
-// host form, EIGHT jobs side by side.  One job is a chain: every step's multiply-then-add waits for the
+// host form, SEVERAL jobs side by side.  One job is a chain: every step's multiply-then-add waits for the
 // step before it (8 cycles on a core that could start two of each per cycle), and a candidate of the
 // searches is m jobs of depths 1 .. m over the same bounds.  The jobs of a batch are therefore taken in
 // groups of eight, deepest first, as the lanes of two 4-wide vectors: the same round structure as the
-// device kernel above (round s has s + 1 steps whatever k is; a lane whose job is finished keeps going
+// device kernel below (round s has s + 1 steps whatever k is; a lane whose job is finished keeps going
 // through the motions with x = 0 and does not touch its result), the same operations in the same order
-// on every lane — IEEE division, product and sum, no contraction — so each lane's double is
-// simplex_volume()'s.  The vectors are the compiler's generic ones: 256-bit registers where the CPU has
-// AVX2 (checked at run time), pairs of SSE2 registers elsewhere.
+// on every lane, so each lane's double is simplex_volume()'s.  The vectors are the compiler's generic
+// ones: 256-bit registers where the CPU has AVX2 (checked at run time), pairs of SSE2 registers elsewhere.
+//
+// The division.  c_j / (j + 1) is what the divider of the core limits (one 4-wide division per 8 cycles).
+// Where the CPU has FMA the quotient by the small integer d = j + 1 is computed WITHOUT the divider and
+// still correctly rounded:   q0 = RN(c r),  r = RN(1 / d);   e = c - q0 d  (one FMA, exact);
+//                            q  = RN(q0 + e r)               (one FMA)   ==  RN(c / d).
+// Why this is the divider's result, for 1 <= d <= 256 and 2^-900 <= |c| <= 2^900 (u = the spacing of the
+// doubles at c / d):  |q0 - c/d| <= 2^-52 |c/d| < 2u (1 + 2^-53), so e = d (c/d - q0) is a multiple of u / 2
+// below 2^11 of them — exactly representable, the FMA does not round; c / d = q0 + e / d as real numbers and
+// |e r - e / d| <= 2^-52 u.  c is a multiple of u (d >= 1), so c / d = (K + 1/2 + t) u with 2 d t an integer:
+// c / d is either a double, or at least u / (2 d) >= u / 512 away from every midpoint between two doubles
+// (t = 0 would need a 54-bit c) — moving it by 2^-52 u cannot change the way it rounds.  Zeros, infinities,
+// NaNs and the subnormal neighbourhood are outside the range: every coefficient of a job descends from a
+// constant term c_0 (or the initial 1) by at most k divisions by integers <= k, so with k <= 100 it is
+// enough that every c_0 written lies in [2^-300, 2^300] (100! < 2^525); a group in which one does not is
+// computed again with the divider.  (tests/test_pruner_properties_cpu.py compares with the one-chain loop
+// bit for bit; every pruner fixture of the reference goes through this path in the CPU suite.)
 // ---------------------------------------------------------------------------------------------
 typedef double v4d __attribute__((vector_size(32)));
 typedef long long v4l __attribute__((vector_size(32)));
 
-struct Lanes8
+struct LaneWork
 {
-  std::vector<v4d> c;  // [2 * (kmax + 1)] the polynomials: c[2 j + h] = coefficient j of lanes 4 h .. 4 h + 3
-  std::vector<v4d> x;  // [2 * kmax] the evaluation points of round s
+  std::vector<v4d> c;  // [NV * (kmax + 1)] the polynomials: c[NV j + h] = coefficient j of lanes 4 h .. 4 h + 3
+  std::vector<v4d> x;  // [NV * kmax] the evaluation points of round s
 };
 
-__attribute__((always_inline)) static inline void volumes8_body(const double *const y[8], const int k[8], v4d *c,
-                                                                 v4d *x, double raw[8])
+static const double *reciprocal_table()  // RN(1 / d), d = 0 .. 256 (entry 0 unused)
 {
-  const int kmax = k[0];  // (the caller sorts: lane 0 is the deepest)
-  v4l kv[2];
-  for (int h = 0; h < 2; ++h)
+  static double t[257];
+  static const bool init = []
+  {
+    for (int d = 1; d <= 256; ++d)
+      t[d] = 1.0 / (double)d;
+    return true;
+  }();
+  (void)init;
+  return t;
+}
+
+// NV vectors of four lanes; FMA: the quotient by the FMA correction above.  Returns false when a constant
+// term left the range in which that quotient is proven (the caller repeats the group with FMA = false).
+template <int NV, bool FMA>
+__attribute__((always_inline)) static inline bool volumes_body(const double *const *y, const int *k, v4d *c, v4d *x,
+                                                               double *raw)
+{
+  const int kmax    = k[0];  // (the caller sorts: lane 0 is the deepest)
+  const double *rcp = reciprocal_table();
+  v4l kv[NV];
+  for (int h = 0; h < NV; ++h)
     for (int l = 0; l < 4; ++l)
     {
-      const int kl = k[4 * h + l];
-      kv[h][l]     = kl;
+      const int kl     = k[4 * h + l];
+      kv[h][l]         = kl;
       const double *yl = y[4 * h + l];
       const double top = yl[kl - 1];
       for (int s = 0; s < kmax; ++s)
-        x[2 * s + h][l] = s < kl ? yl[kl - 1 - s] / top : 0.0;
+        x[NV * s + h][l] = s < kl ? yl[kl - 1 - s] / top : 0.0;
     }
   const v4d one = {1.0, 1.0, 1.0, 1.0}, zero = {0.0, 0.0, 0.0, 0.0}, mone = {-1.0, -1.0, -1.0, -1.0};
-  c[0] = one;
-  c[1] = one;
+  const v4d lo = {0x1p-300, 0x1p-300, 0x1p-300, 0x1p-300}, hi = {0x1p300, 0x1p300, 0x1p300, 0x1p300};
+  const v4l absmask = {0x7fffffffffffffffLL, 0x7fffffffffffffffLL, 0x7fffffffffffffffLL, 0x7fffffffffffffffLL};
+  v4l good          = {-1, -1, -1, -1};
+  for (int h = 0; h < NV; ++h)
+    c[h] = one;
   for (int s = 0; s < kmax; ++s)
   {
-    const v4d x0 = x[2 * s], x1 = x[2 * s + 1];
-    v4d a0 = zero, a1 = zero;
+    v4d xs[NV], a[NV];
+    for (int h = 0; h < NV; ++h)
+    {
+      xs[h] = x[NV * s + h];
+      a[h]  = zero;
+    }
     for (int j = s; j >= 0; --j)
     {
       const double dj = j + 1.0;
       const v4d dv    = {dj, dj, dj, dj};
-      const v4d t0 = c[2 * j] / dv, t1 = c[2 * j + 1] / dv;
-      c[2 * j + 2] = t0;
-      c[2 * j + 3] = t1;
-      a0 = a0 * x0;
-      a1 = a1 * x1;
-      a0 = a0 + t0;
-      a1 = a1 + t1;
+      v4d t[NV];
+      if (FMA)
+      {
+        const double rj = rcp[j + 1];
+        const v4d rv    = {rj, rj, rj, rj};
+        for (int h = 0; h < NV; ++h)
+        {
+          const v4d cj = c[NV * j + h];
+          const v4d q0 = cj * rv;
+          const v4d e  = __builtin_elementwise_fma(-q0, dv, cj);
+          t[h]         = __builtin_elementwise_fma(e, rv, q0);
+        }
+      }
+      else
+      {
+        for (int h = 0; h < NV; ++h)
+          t[h] = c[NV * j + h] / dv;
+      }
+      for (int h = 0; h < NV; ++h)
+      {
+        c[NV * (j + 1) + h] = t[h];
+        a[h]                = a[h] * xs[h];
+      }
+      for (int h = 0; h < NV; ++h)
+        a[h] = a[h] + t[h];
     }
-    a0 = a0 * x0;
-    a1 = a1 * x1;
-    a0 = a0 + zero;
-    a1 = a1 + zero;
-    a0 = mone * a0;
-    a1 = mone * a1;
     const v4l sv = {s, s, s, s};
-    const v4l on0 = sv < kv[0], on1 = sv < kv[1];
-    c[0] = (v4d)(((v4l)a0 & on0) | ((v4l)c[0] & ~on0));
-    c[1] = (v4d)(((v4l)a1 & on1) | ((v4l)c[1] & ~on1));
+    for (int h = 0; h < NV; ++h)
+    {
+      a[h] = a[h] * xs[h];
+      a[h] = a[h] + zero;
+      a[h] = mone * a[h];
+      const v4l on = sv < kv[h];
+      if (FMA)
+      {  // (a finished lane's a[h] is not written and does not count)
+        const v4d mag = (v4d)((v4l)a[h] & absmask);
+        good &= ((mag >= lo) & (mag <= hi)) | ~on;
+      }
+      c[h] = (v4d)(((v4l)a[h] & on) | ((v4l)c[h] & ~on));
+    }
   }
-  for (int l = 0; l < 4; ++l)
+  for (int h = 0; h < NV; ++h)
+    for (int l = 0; l < 4; ++l)
+      raw[4 * h + l] = c[h][l];
+  return !FMA || (good[0] & good[1] & good[2] & good[3]) != 0;
+}
+__attribute__((target("avx2,fma"))) static bool volumes8_fma(const double *const *y, const int *k, v4d *c, v4d *x,
+                                                            double *raw)
+{
+  return volumes_body<2, true>(y, k, c, x, raw);
+}
+__attribute__((target("avx2"))) static bool volumes8_avx2(const double *const *y, const int *k, v4d *c, v4d *x,
+                                                          double *raw)
+{
+  return volumes_body<2, false>(y, k, c, x, raw);
+}
+static bool volumes8_generic(const double *const *y, const int *k, v4d *c, v4d *x, double *raw)
+{
+  return volumes_body<2, false>(y, k, c, x, raw);
+}
+
+// FPHIP_PRUNER_HOST_MODE: 0 one job after the other; 1 eight lanes, the divider; 2 (default) eight lanes and
+// the FMA quotient where the CPU has it (sixteen lanes were tried: no faster — with the divider out of the way
+// a step of eight lanes is about as long as the chain)
+static int host_mode()
+{
+  static const int mode = []
   {
-    raw[l]     = c[0][l];
-    raw[4 + l] = c[1][l];
-  }
-}
-__attribute__((target("avx2"))) static void volumes8_avx2(const double *const y[8], const int k[8], v4d *c, v4d *x,
-                                                          double raw[8])
-{
-  volumes8_body(y, k, c, x, raw);
-}
-static void volumes8_generic(const double *const y[8], const int k[8], v4d *c, v4d *x, double raw[8])
-{
-  volumes8_body(y, k, c, x, raw);
+    int v = getenv("FPHIP_PRUNER_HOST_MODE") ? atoi(getenv("FPHIP_PRUNER_HOST_MODE")) : 2;
+    if (getenv("FPHIP_PRUNER_HOST_SCALAR") && atoi(getenv("FPHIP_PRUNER_HOST_SCALAR")) != 0)
+      v = 0;
+    return v;
+  }();
+  return mode;
 }
 
 // out[j] = the finished volume of jobs[j], for every job of the batch
-static void host_volumes(const double *bounds, int m, const VolumeJob *jobs, int njobs, double *out, Lanes8 &L,
+static void host_volumes(const double *bounds, int m, const VolumeJob *jobs, int njobs, double *out, LaneWork &L,
                          std::vector<unsigned> &order, std::vector<double> &scratch)
 {
   static const bool avx2 = __builtin_cpu_supports("avx2");
-  static const bool wide = !(getenv("FPHIP_PRUNER_HOST_SCALAR") && atoi(getenv("FPHIP_PRUNER_HOST_SCALAR")) != 0);
+  static const bool fma  = avx2 && __builtin_cpu_supports("fma");
+  const int mode         = host_mode();
   if ((int)scratch.size() < m + 2)
     scratch.resize(m + 2);
-  if (njobs < 3 || !wide)
+  if (njobs < 3 || mode == 0)
   {  // (one or two chains: nothing to put side by side)
     for (int j = 0; j < njobs; ++j)
       out[j] = finish(simplex_volume(bounds + (size_t)jobs[j].vec * m, jobs[j].k, scratch.data()), jobs[j].k);
@@ -173,18 +254,20 @@ static void host_volumes(const double *bounds, int m, const VolumeJob *jobs, int
     L.c.resize((size_t)2 * (m + 2));
     L.x.resize((size_t)2 * (m + 2));
   }
-  for (int g = 0; g < njobs; g += 8)
+  for (int g = 0; g < njobs;)
   {
-    const int cnt = std::min(8, njobs - g);
-    if (cnt < 3)
+    const int left = njobs - g;
+    if (left < 3)
     {
-      for (int l = 0; l < cnt; ++l)
+      for (int l = 0; l < left; ++l)
       {
         const VolumeJob &J = jobs[order[g + l]];
         out[order[g + l]]  = finish(simplex_volume(bounds + (size_t)J.vec * m, J.k, scratch.data()), J.k);
       }
-      continue;
+      break;
     }
+    const bool quick = fma && mode >= 2 && jobs[order[g]].k <= 100;
+    const int cnt = std::min(8, left);
     const double *y[8];
     int k[8];
     double raw[8];
@@ -194,9 +277,11 @@ static void host_volumes(const double *bounds, int m, const VolumeJob *jobs, int
       y[l]               = bounds + (size_t)J.vec * m;
       k[l]               = J.k;
     }
-    (avx2 ? volumes8_avx2 : volumes8_generic)(y, k, L.c.data(), L.x.data(), raw);
+    if (!(quick && volumes8_fma(y, k, L.c.data(), L.x.data(), raw)))
+      (avx2 ? volumes8_avx2 : volumes8_generic)(y, k, L.c.data(), L.x.data(), raw);
     for (int l = 0; l < cnt; ++l)
       out[order[g + l]] = finish(raw[l], k[l]);
+    g += cnt;
   }
 }
 
@@ -209,7 +294,7 @@ public:
   {
     (void)nvec;
     // (the one host engine serves every caller: per-thread work areas)
-    static thread_local Lanes8 L;
+    static thread_local LaneWork L;
     static thread_local std::vector<unsigned> order;
     static thread_local std::vector<double> scratch;
     host_volumes(bounds, m, jobs, njobs, out, L, order, scratch);
@@ -295,7 +380,7 @@ public:
   char err[256]      = {0};
   std::vector<double> scratch;
   std::vector<unsigned> order;
-  Lanes8 lanes;
+  LaneWork lanes;
 
   ~DeviceEngine() override
   {

@@ -96,12 +96,14 @@ np.save(sys.argv[3], P.volumes(z["bounds"], z["vec"], z["k"]))
 """
 
 
-@pytest.mark.parametrize("m,nvec", [(5, 3), (18, 7), (30, 40), (64, 9)])
-def test_eight_jobs_side_by_side_are_the_one_chain_doubles(m, nvec, tmp_path):
-    """The host engine takes the jobs of a batch eight at a time as vector lanes (pruner_volume.hip:
-    host_volumes); FPHIP_PRUNER_HOST_SCALAR=1 keeps the one-job-after-the-other loop.  Same doubles, bit for bit,
-    for ragged batches: every depth 1..m of several bound vectors, in shuffled order, batch sizes that leave short
-    last groups, and a batch of two (below the width at which lanes are used at all)."""
+@pytest.mark.parametrize("m,nvec,tiny", [(5, 3, 0), (18, 7, 0), (30, 40, 0), (64, 9, 0), (30, 11, 12), (120, 5, 0)])
+def test_jobs_side_by_side_are_the_one_chain_doubles(m, nvec, tiny, tmp_path):
+    """The host engine takes the jobs of a batch 8 or 16 at a time as vector lanes and divides by the FMA
+    correction where the CPU has FMA (pruner_volume.hip: host_volumes); FPHIP_PRUNER_HOST_SCALAR=1 keeps the
+    one-job-after-the-other loop with the divider.  Same doubles, bit for bit, for ragged batches: every depth 1..m
+    of several bound vectors, in shuffled order, batch sizes that leave short last groups, a batch of two (below the
+    width at which lanes are used at all); bounds whose first `tiny` entries are 1e-200 (constant terms far below
+    2^-300: the group is repeated with the divider); m = 120 (deeper than the FMA quotient is used for)."""
     import os
     import subprocess
     import sys
@@ -111,6 +113,8 @@ def test_eight_jobs_side_by_side_are_the_one_chain_doubles(m, nvec, tmp_path):
     bounds = np.sort(steps, axis=1)          # non-decreasing bounds in (0, 1], the last one 1
     bounds /= bounds[:, -1:]
     bounds[bounds < 1e-3] = 1e-3
+    if tiny:
+        bounds[:, :tiny] = 1e-200
     vec, k = np.meshgrid(np.arange(nvec), np.arange(1, m + 1), indexing="ij")
     vec, k = vec.ravel(), k.ravel()
     perm = rng.permutation(vec.size)[: vec.size - 3]          # (not a multiple of eight)
