@@ -295,6 +295,38 @@ private:
   std::vector<dvec> one = std::vector<dvec>(1);
   std::vector<Score> one_out;
 
+  // sqrt(pow(x, i + 1)) of the cost model.  The candidates of a batch differ from one another in a coordinate or
+  // two (a gradient perturbs one), so level i sees the same x again and again: the last two (x, value) pairs of
+  // every level are kept — libm's own doubles, returned instead of computed a second time
+  struct PowMemo
+  {
+    unsigned long long key[2] = {~0ull, ~0ull};  // (the bit pattern of a NaN no bound has)
+    double val[2]             = {0.0, 0.0};
+    int last                  = 0;
+  };
+  mutable std::vector<PowMemo> pow_memo;
+  double root_of_power(double x, int i) const
+  {
+    if ((int)pow_memo.size() < 2 * half)
+      pow_memo.resize((size_t)2 * half);
+    PowMemo &M = pow_memo[i];
+    unsigned long long kx;
+    std::memcpy(&kx, &x, sizeof kx);
+    if (M.key[M.last] == kx)
+      return M.val[M.last];
+    const int other = M.last ^ 1;
+    if (M.key[other] == kx)
+    {
+      M.last = other;
+      return M.val[other];
+    }
+    const double v = std::sqrt(std::pow(x, (double)(1 + i)));
+    M.key[other]   = kx;
+    M.val[other]   = v;
+    M.last         = other;
+    return v;
+  }
+
   // nodes per level and in all for one bound vector h, from V_1 .. V_m (pruner_cost.cpp:11-72): the
   // odd-dimensional volumes are the geometric means of their neighbours
   bool half_cost(const double *h, const double *v, dvec *levels, double &total) const
@@ -311,7 +343,7 @@ private:
         rv = v[i / 2];
       else
         rv = i == 0 ? 1.0 : std::sqrt(v[i / 2 - 1] * v[i / 2]);
-      double t = rpow * rv * fphip_pruner_ball_vol[i + 1] * std::sqrt(std::pow(h[i / 2], (double)(1 + i))) * ipv[i];
+      double t = rpow * rv * fphip_pruner_ball_vol[i + 1] * root_of_power(h[i / 2], i) * ipv[i];
       t *= sym;
       if (levels)
         (*levels)[2 * m - (i + 1)] = t;

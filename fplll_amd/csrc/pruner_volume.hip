@@ -90,54 +90,79 @@ static inline double finish(double raw, int k)
 // ---------------------------------------------------------------------------------------------
 typedef double v4d __attribute__((vector_size(32)));
 typedef long long v4l __attribute__((vector_size(32)));
+typedef double v8d __attribute__((vector_size(64)));
 
 struct LaneWork
 {
-  std::vector<v4d> c;  // [NV * (kmax + 1)] the polynomials: c[NV j + h] = coefficient j of lanes 4 h .. 4 h + 3
-  std::vector<v4d> x;  // [NV * kmax] the evaluation points of round s
+  std::vector<v8d> c;  // the polynomials, [kmax + 2] rows of eight lanes (read as two v4d; 64-byte aligned)
+  std::vector<v8d> x;  // the evaluation points of round s, [kmax] rows
 };
 
-static const double *reciprocal_table()  // RN(1 / d), d = 0 .. 256 (entry 0 unused)
+struct DivisorTables
 {
-  static double t[257];
-  static const bool init = []
+  double d[257], r[257];  // d and RN(1 / d), d = 0 .. 256 (entry 0 unused)
+  DivisorTables()
   {
-    for (int d = 1; d <= 256; ++d)
-      t[d] = 1.0 / (double)d;
-    return true;
-  }();
-  (void)init;
+    d[0] = r[0] = 0.0;
+    for (int i = 1; i <= 256; ++i)
+    {
+      d[i] = (double)i;
+      r[i] = 1.0 / (double)i;
+    }
+  }
+};
+static const DivisorTables &divisor_tables()
+{
+  static const DivisorTables t;
   return t;
 }
-
-// NV vectors of four lanes; FMA: the quotient by the FMA correction above.  Returns false when a constant
-// term left the range in which that quotient is proven (the caller repeats the group with FMA = false).
-template <int NV, bool FMA>
-__attribute__((always_inline)) static inline bool volumes_body(const double *const *y, const int *k, v4d *c, v4d *x,
-                                                               double *raw)
+template <class VD, int LW> __attribute__((always_inline)) static inline VD splat(double v)
 {
+  VD r;
+  for (int l = 0; l < LW; ++l)
+    r[l] = v;
+  return r;
+}
+
+// Eight lanes as NV vectors of LW lanes (VD / VL: the vector of doubles / of 64-bit integers); FMA: the
+// quotient by the FMA correction above.  Returns false when a constant term left the range in which that
+// quotient is proven (the caller repeats the group with FMA = false).
+template <class VD, class VL, int LW, int NV, bool FMA>
+__attribute__((always_inline)) static inline bool volumes_body(const double *const *y, const int *k, void *cbuf,
+                                                               void *xbuf, double *raw)
+{
+  VD *c = (VD *)cbuf, *x = (VD *)xbuf;
   const int kmax    = k[0];  // (the caller sorts: lane 0 is the deepest)
-  const double *rcp = reciprocal_table();
-  v4l kv[NV];
+  const DivisorTables &dt = divisor_tables();
+  const VD zero     = {};
+  const VL izero    = {};
+  VL kv[NV];
+  VD top[NV];
   for (int h = 0; h < NV; ++h)
-    for (int l = 0; l < 4; ++l)
+    for (int l = 0; l < LW; ++l)
     {
-      const int kl     = k[4 * h + l];
-      kv[h][l]         = kl;
-      const double *yl = y[4 * h + l];
-      const double top = yl[kl - 1];
-      for (int s = 0; s < kmax; ++s)
-        x[NV * s + h][l] = s < kl ? yl[kl - 1 - s] / top : 0.0;
+      kv[h][l]  = k[LW * h + l];
+      top[h][l] = y[LW * h + l][k[LW * h + l] - 1];
     }
-  const v4d one = {1.0, 1.0, 1.0, 1.0}, zero = {0.0, 0.0, 0.0, 0.0}, mone = {-1.0, -1.0, -1.0, -1.0};
-  const v4d lo = {0x1p-300, 0x1p-300, 0x1p-300, 0x1p-300}, hi = {0x1p300, 0x1p300, 0x1p300, 0x1p300};
-  const v4l absmask = {0x7fffffffffffffffLL, 0x7fffffffffffffffLL, 0x7fffffffffffffffLL, 0x7fffffffffffffffLL};
-  v4l good          = {-1, -1, -1, -1};
+  for (int s = 0; s < kmax; ++s)
+    for (int h = 0; h < NV; ++h)
+    {  // y / top of the live lanes (the one-chain loop's division), 0 / top on the finished ones
+      VD num = zero;
+      for (int l = 0; l < LW; ++l)
+      {
+        const int kl = k[LW * h + l];
+        num[l]       = s < kl ? y[LW * h + l][kl - 1 - s] : 0.0;
+      }
+      x[NV * s + h] = num / top[h];
+    }
+  const VD one = zero + 1.0, mone = zero - 1.0, lo = zero + 0x1p-300, hi = zero + 0x1p300;
+  const VL absmask = izero + 0x7fffffffffffffffLL;
+  VL good          = izero - 1;
   for (int h = 0; h < NV; ++h)
     c[h] = one;
   for (int s = 0; s < kmax; ++s)
   {
-    v4d xs[NV], a[NV];
+    VD xs[NV], a[NV];
     for (int h = 0; h < NV; ++h)
     {
       xs[h] = x[NV * s + h];
@@ -145,19 +170,17 @@ __attribute__((always_inline)) static inline bool volumes_body(const double *con
     }
     for (int j = s; j >= 0; --j)
     {
-      const double dj = j + 1.0;
-      const v4d dv    = {dj, dj, dj, dj};
-      v4d t[NV];
+      const VD dv = splat<VD, LW>(dt.d[j + 1]);
+      VD t[NV];
       if (FMA)
       {
-        const double rj = rcp[j + 1];
-        const v4d rv    = {rj, rj, rj, rj};
+        const VD rv = splat<VD, LW>(dt.r[j + 1]);
         for (int h = 0; h < NV; ++h)
         {
-          const v4d cj = c[NV * j + h];
-          const v4d q0 = cj * rv;
-          const v4d e  = __builtin_elementwise_fma(-q0, dv, cj);
-          t[h]         = __builtin_elementwise_fma(e, rv, q0);
+          const VD cj = c[NV * j + h];
+          const VD q0 = cj * rv;
+          const VD e  = __builtin_elementwise_fma(-q0, dv, cj);
+          t[h]        = __builtin_elementwise_fma(e, rv, q0);
         }
       }
       else
@@ -173,39 +196,43 @@ __attribute__((always_inline)) static inline bool volumes_body(const double *con
       for (int h = 0; h < NV; ++h)
         a[h] = a[h] + t[h];
     }
-    const v4l sv = {s, s, s, s};
+    const VL sv = izero + (long long)s;
     for (int h = 0; h < NV; ++h)
     {
       a[h] = a[h] * xs[h];
       a[h] = a[h] + zero;
       a[h] = mone * a[h];
-      const v4l on = sv < kv[h];
+      const VL on = sv < kv[h];
       if (FMA)
       {  // (a finished lane's a[h] is not written and does not count)
-        const v4d mag = (v4d)((v4l)a[h] & absmask);
+        const VD mag = (VD)((VL)a[h] & absmask);
         good &= ((mag >= lo) & (mag <= hi)) | ~on;
       }
-      c[h] = (v4d)(((v4l)a[h] & on) | ((v4l)c[h] & ~on));
+      c[h] = (VD)(((VL)a[h] & on) | ((VL)c[h] & ~on));
     }
   }
+  long long all = -1;
   for (int h = 0; h < NV; ++h)
-    for (int l = 0; l < 4; ++l)
-      raw[4 * h + l] = c[h][l];
-  return !FMA || (good[0] & good[1] & good[2] & good[3]) != 0;
+    for (int l = 0; l < LW; ++l)
+      raw[LW * h + l] = c[h][l];
+  for (int l = 0; l < LW; ++l)
+    all &= good[l];
+  return !FMA || all != 0;
 }
-__attribute__((target("avx2,fma"))) static bool volumes8_fma(const double *const *y, const int *k, v4d *c, v4d *x,
+typedef bool (*volumes8_fn)(const double *const *, const int *, void *, void *, double *);
+__attribute__((target("avx2,fma"))) static bool volumes8_fma(const double *const *y, const int *k, void *c, void *x,
                                                             double *raw)
 {
-  return volumes_body<2, true>(y, k, c, x, raw);
+  return volumes_body<v4d, v4l, 4, 2, true>(y, k, c, x, raw);
 }
-__attribute__((target("avx2"))) static bool volumes8_avx2(const double *const *y, const int *k, v4d *c, v4d *x,
+__attribute__((target("avx2"))) static bool volumes8_avx2(const double *const *y, const int *k, void *c, void *x,
                                                           double *raw)
 {
-  return volumes_body<2, false>(y, k, c, x, raw);
+  return volumes_body<v4d, v4l, 4, 2, false>(y, k, c, x, raw);
 }
-static bool volumes8_generic(const double *const *y, const int *k, v4d *c, v4d *x, double *raw)
+static bool volumes8_generic(const double *const *y, const int *k, void *c, void *x, double *raw)
 {
-  return volumes_body<2, false>(y, k, c, x, raw);
+  return volumes_body<v4d, v4l, 4, 2, false>(y, k, c, x, raw);
 }
 
 // FPHIP_PRUNER_HOST_MODE: 0 one job after the other; 1 eight lanes, the divider; 2 (default) eight lanes and
@@ -229,6 +256,8 @@ static void host_volumes(const double *bounds, int m, const VolumeJob *jobs, int
 {
   static const bool avx2 = __builtin_cpu_supports("avx2");
   static const bool fma  = avx2 && __builtin_cpu_supports("fma");
+  static const volumes8_fn quick_fn = volumes8_fma;
+  static const volumes8_fn exact_fn = avx2 ? volumes8_avx2 : volumes8_generic;
   const int mode         = host_mode();
   if ((int)scratch.size() < m + 2)
     scratch.resize(m + 2);
@@ -249,10 +278,10 @@ static void host_volumes(const double *bounds, int m, const VolumeJob *jobs, int
     for (int j = 0; j < njobs; ++j)
       order[head[m - jobs[j].k]++] = (unsigned)j;
   }
-  if (L.c.size() < (size_t)2 * (m + 2))
+  if (L.c.size() < (size_t)(m + 2))
   {
-    L.c.resize((size_t)2 * (m + 2));
-    L.x.resize((size_t)2 * (m + 2));
+    L.c.resize((size_t)(m + 2));
+    L.x.resize((size_t)(m + 2));
   }
   for (int g = 0; g < njobs;)
   {
@@ -267,7 +296,7 @@ static void host_volumes(const double *bounds, int m, const VolumeJob *jobs, int
       break;
     }
     const bool quick = fma && mode >= 2 && jobs[order[g]].k <= 100;
-    const int cnt = std::min(8, left);
+    const int cnt    = std::min(8, left);
     const double *y[8];
     int k[8];
     double raw[8];
@@ -277,8 +306,8 @@ static void host_volumes(const double *bounds, int m, const VolumeJob *jobs, int
       y[l]               = bounds + (size_t)J.vec * m;
       k[l]               = J.k;
     }
-    if (!(quick && volumes8_fma(y, k, L.c.data(), L.x.data(), raw)))
-      (avx2 ? volumes8_avx2 : volumes8_generic)(y, k, L.c.data(), L.x.data(), raw);
+    if (!(quick && quick_fn(y, k, L.c.data(), L.x.data(), raw)))
+      exact_fn(y, k, L.c.data(), L.x.data(), raw);
     for (int l = 0; l < cnt; ++l)
       out[order[g + l]] = finish(raw[l], k[l]);
     g += cnt;
