@@ -125,7 +125,7 @@ struct fphip_ctx
   DevShared *g      = nullptr;  // device
   DevShared *stage  = nullptr;  // pinned host staging copy
   HostCtl *h        = nullptr;  // pinned, coherent; same pointer is valid on the device
-  TaskBuf buf[3];  // [0], [1]: task lists of the launches; [2]: second frontier of the breadth-first stage
+  TaskBuf buf[3] = {};  // [0], [1]: task lists of the launches; [2]: second frontier of the breadth-first stage
   unsigned cap                 = 0;
   unsigned long long ring_next = 0;
   unsigned long long *keys     = nullptr;  // device: content key per task (multi-GPU partition)
@@ -187,6 +187,40 @@ static int env_int(const char *name, int dflt)
 // do that (round 4: eight volume engines next to one schedule kernel deadlocked; two did not, by the luck
 // of the round-robin).  Hence the priority classes: helper streams are HIGH (their own queue pool), a
 // context that is known to run minutes-long launches beside others can be created LOW.
+
+// The task buffers of the enumeration (three generations of cap tasks with their 64 partial sums and 64
+// coefficients, keys, slots: ~3.6 GB at the default cap) are allocated by the first fphip_enum_run of a context —
+// a context that only carries GSO objects (MatGSOHip, MatHouseholderHip, the batched reductions) never needs
+// them.  Called with the context's device current.
+static int ensure_task_buffers(fphip_ctx *ctx)
+{
+  if (ctx->qm)
+    return FPHIP_OK;
+#define ONCE(ptr, bytes) \
+  if (!(ptr))             \
+  HIPCHK(ctx, fphip_dev_alloc((void **)&(ptr), (bytes), ctx->stream))
+  ONCE(ctx->slots, (size_t)ctx->cap * sizeof(unsigned));
+  ONCE(ctx->pdc, (size_t)ctx->cap * sizeof(double));
+  for (int b = 0; b < 3; ++b)
+  {
+    ONCE(ctx->buf[b].col, (size_t)ctx->cap * 64 * sizeof(double));
+    ONCE(ctx->buf[b].x, (size_t)ctx->cap * 64 * sizeof(double));
+    ONCE(ctx->buf[b].pd, (size_t)ctx->cap * sizeof(double));
+    ONCE(ctx->buf[b].level, (size_t)ctx->cap * sizeof(int));
+    ONCE(ctx->buf[b].root, (size_t)ctx->cap * sizeof(int));
+    ONCE(ctx->buf[b].count, 64);
+    ctx->buf[b].cap = ctx->cap;
+  }
+  ONCE(ctx->keys, (size_t)ctx->cap * sizeof(unsigned long long));
+  ONCE(ctx->idxlist, (size_t)ctx->cap * sizeof(unsigned));
+  ONCE(ctx->xhi_root, (size_t)ctx->cap * 64 * sizeof(double));
+  HIPCHK(ctx, hipMemsetAsync(ctx->xhi_root, 0, 64 * sizeof(double), ctx->stream));
+  // (qm last: it is the "buffers are there" flag, so a failed allocation above is retried by the next call)
+  ONCE(ctx->qm, sizeof(QueueMem));
+#undef ONCE
+  return FPHIP_OK;
+}
+
 extern "C" int fphip_create(int device, fphip_ctx **out) { return fphip_create_ex(device, 0, out); }
 
 extern "C" int fphip_create_ex(int device, int priority, fphip_ctx **out)
@@ -227,23 +261,6 @@ extern "C" int fphip_create_ex(int device, int priority, fphip_ctx **out)
   memset(ctx->h, 0, sizeof(HostCtl));
   ctx->cap = (unsigned)env_int("FPHIP_TASK_CAP", 1 << 20);
   ctx->cap = (ctx->cap + FPHIP_NQ - 1) / FPHIP_NQ * FPHIP_NQ;  // regions of cap / FPHIP_NQ slots
-  HIPCHK(ctx, fphip_dev_alloc((void **)&ctx->qm, sizeof(QueueMem), ctx->stream));
-  HIPCHK(ctx, fphip_dev_alloc((void **)&ctx->slots, (size_t)ctx->cap * sizeof(unsigned), ctx->stream));
-  HIPCHK(ctx, fphip_dev_alloc((void **)&ctx->pdc, (size_t)ctx->cap * sizeof(double), ctx->stream));
-  for (int b = 0; b < 3; ++b)
-  {
-    HIPCHK(ctx, fphip_dev_alloc((void **)&ctx->buf[b].col, (size_t)ctx->cap * 64 * sizeof(double), ctx->stream));
-    HIPCHK(ctx, fphip_dev_alloc((void **)&ctx->buf[b].x, (size_t)ctx->cap * 64 * sizeof(double), ctx->stream));
-    HIPCHK(ctx, fphip_dev_alloc((void **)&ctx->buf[b].pd, (size_t)ctx->cap * sizeof(double), ctx->stream));
-    HIPCHK(ctx, fphip_dev_alloc((void **)&ctx->buf[b].level, (size_t)ctx->cap * sizeof(int), ctx->stream));
-    HIPCHK(ctx, fphip_dev_alloc((void **)&ctx->buf[b].root, (size_t)ctx->cap * sizeof(int), ctx->stream));
-    HIPCHK(ctx, fphip_dev_alloc((void **)&ctx->buf[b].count, 64, ctx->stream));
-    ctx->buf[b].cap = ctx->cap;
-  }
-  HIPCHK(ctx, fphip_dev_alloc((void **)&ctx->keys, (size_t)ctx->cap * sizeof(unsigned long long), ctx->stream));
-  HIPCHK(ctx, fphip_dev_alloc((void **)&ctx->idxlist, (size_t)ctx->cap * sizeof(unsigned), ctx->stream));
-  HIPCHK(ctx, fphip_dev_alloc((void **)&ctx->xhi_root, (size_t)ctx->cap * 64 * sizeof(double), ctx->stream));
-  HIPCHK(ctx, hipMemsetAsync(ctx->xhi_root, 0, 64 * sizeof(double), ctx->stream));
   HIPCHK(ctx, hipFuncSetAttribute((const void *)enum_phase_kernel<true, false, false>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(ctx, hipFuncSetAttribute((const void *)enum_phase_kernel<false, false, false>,
@@ -545,6 +562,8 @@ extern "C" int fphip_enum_run(fphip_ctx *ctx, int dim, double maxdist, const dou
   }
 
   HIPCHK(ctx, hipSetDevice(ctx->device));
+  if (int rc_ = ensure_task_buffers(ctx))
+    return rc_;
   // Breadth-first stage instead of the depth-first split launches (see enum_bfs_kernel): the default;
   // sub-solution calls keep the split launches (the expansion does not report sub-solutions), and a
   // call whose expansion overflowed a buffer starts over with them.
