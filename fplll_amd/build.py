@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 
 HIP_SOURCES = ["enum_kernel.hip", "enum_host.hip", "gso_kernel.hip", "gso_sweep2.hip", "lll_kernel.hip", "hlll_kernel.hip", "hh_blocked.hip", "hlll_x.hip", "lll_x.hip", "bkz_kernel.hip", "bkzs_kernel.hip", "gso_host.hip", "pruner_volume.hip", "pruner_search.hip", "gso_util_host.hip"]
-HIP_HEADERS = ["dev_mem.h", "trace.h", "pruner_tables.h", "pruner_engine.h", "enum_device.h", "gso_device.h", "gso_wave.h", "gso_sweep2.h", "ftx.h", "lll_wave.h", os.path.join(ROOT, "include", "fplll_hip.h")]
+HIP_HEADERS = ["dev_mem.h", "trace.h", "pruner_tables.h", "pruner_engine.h", "enum_device.h", "gso_device.h", "gso_wave.h", "gso_sweep2.h", "ftx.h", "lll_wave.h", "lll_stream.h", os.path.join(ROOT, "include", "fplll_hip.h")]
 HIPCC_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17",
     "-ffp-contract=off",  # fplll's arithmetic is separate mul/add (nr/nr_FP_d.inl:178); no FMA
@@ -78,13 +78,18 @@ def build_hip(force=False):
     os.makedirs(objdir, exist_ok=True)
     objs = []
     relink = force or not os.path.exists(out)
+    jobs = []
     for src in srcs:
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
         objs.append(obj)
         if force or _newer(obj, [src, os.path.abspath(__file__)] + hdrs):  # (the flags live in this file)
-            _run([hipcc()] + HIPCC_FLAGS + extra + PER_FILE_FLAGS.get(os.path.basename(src), []) +
-                 ["-c", "-o", obj, src])
+            jobs.append([hipcc()] + HIPCC_FLAGS + extra + PER_FILE_FLAGS.get(os.path.basename(src), []) +
+                        ["-c", "-o", obj, src])
             relink = True
+    if jobs:  # the translation units are independent: compile them side by side
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=max(1, min(len(jobs), os.cpu_count() or 1))) as ex:
+            list(ex.map(_run, jobs))
     if relink:
         _run([hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared", "-pthread", "-o", out] + objs)
     return out

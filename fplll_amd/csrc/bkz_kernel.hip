@@ -72,13 +72,10 @@ __global__ void __launch_bounds__(256)
   const int lane = threadIdx.x & 63;
   const int wpb  = blockDim.x >> 6;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  Ring<NQ, IPS, FPHIP_RING_REDUCE> ring;
-  ring.base = (unsigned)(wave * Ring<NQ, IPS, FPHIP_RING_REDUCE>::R * Ring<NQ, IPS, FPHIP_RING_REDUCE>::SLOT);
-  ring.lane = lane;
-  ring.head = ring.tail = 0;
-  ring.ahead            = 0;
+  ReduceRing<NQ> ring;
+  ring.init(wave, lane);
   // enumeration stack (triangular column stack of the walk) behind the rings
-  double *stk = (double *)(bkz_smem + (size_t)wpb * Ring<NQ, IPS, FPHIP_RING_REDUCE>::R * Ring<NQ, IPS, FPHIP_RING_REDUCE>::SLOT) +
+  double *stk = (double *)(bkz_smem + (size_t)wpb * ReduceRing<NQ>::BYTES) +
                 (size_t)wave * stack_doubles;
   const int d = P.d, n = P.n, ldd = P.ldd, ldn = P.ldn;
   for (int L = blockIdx.x * wpb + wave; L < P.batch; L += gridDim.x * wpb)

@@ -160,18 +160,15 @@ bkzs_body(GsoBatch P, BkzStrat S, BkzMail *mailbox, int *abort_flag, int block_s
           double delta, double eta, double logdelta, int max_loops, int stack_doubles, int run_mode)
 {
   constexpr int IPS = (NQ + 1) / 2;
-  using RingT       = Ring<NQ, IPS, FPHIP_RING_REDUCE>;
+  using RingT       = ReduceRing<NQ>;
   extern __shared__ __attribute__((aligned(16))) char bkzs_smem[];
   const int lane = threadIdx.x & 63;
   const int wpb  = blockDim.x >> 6;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   RingT ring;
-  ring.base = (unsigned)(wave * RingT::R * RingT::SLOT);
-  ring.lane = lane;
-  ring.head = ring.tail = 0;
-  ring.ahead            = 0;
+  ring.init(wave, lane);
   // behind the rings: per wave the enumeration stack, then the frame stack
-  char *after_rings = bkzs_smem + (size_t)wpb * RingT::R * RingT::SLOT;
+  char *after_rings = bkzs_smem + (size_t)wpb * RingT::BYTES;
   double *stk       = (double *)after_rings + (size_t)wave * stack_doubles;
   BkzsFrame *frames = (BkzsFrame *)((double *)after_rings + (size_t)wpb * stack_doubles) +
                       (size_t)wave * FPHIP_BKZS_MAX_DEPTH;

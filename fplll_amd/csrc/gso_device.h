@@ -14,6 +14,7 @@
 #ifndef FPHIP_GSO_DEVICE_H
 #define FPHIP_GSO_DEVICE_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 // LDS-DMA ring depths (slots per wave): sweep kernels / reduction drivers (see gso_wave.h)
@@ -23,6 +24,20 @@
 #ifndef FPHIP_RING_REDUCE
 #define FPHIP_RING_REDUCE 8
 #endif
+
+// bytes of LDS per wave of the slot-mode reduction kernels (LLL / BKZ): the block ring of lll_stream.h
+// (LStream<NQ>::BYTES), or with -DFPHIP_LLL_STREAM=0 the first generation's ring of single rows
+#ifndef FPHIP_LLL_STREAM
+#define FPHIP_LLL_STREAM 1
+#endif
+static inline size_t fphip_reduce_ring_bytes(int nq)
+{
+#if FPHIP_LLL_STREAM
+  return nq == 3 ? 15360 : 16384;
+#else
+  return (size_t)FPHIP_RING_REDUCE * (size_t)((nq + 1) / 2) * 1024;
+#endif
+}
 
 namespace fphip
 {

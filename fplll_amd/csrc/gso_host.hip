@@ -334,7 +334,8 @@ static int launch(fphip_gso *g, int kmin, int kend, double eta, int mode, const 
     return FPHIP_OK;
   }
   // per-wave LDS-DMA ring: FPHIP_GSO_RING slots of IPS KiB (IPS = ceil(NQ/2))
-  const size_t lds = (size_t)wpb * (la ? FPHIP_RING_REDUCE : FPHIP_GSO_RING) * (size_t)((nq + 1) / 2) * 1024;
+  const size_t lds = la ? (size_t)wpb * fphip_reduce_ring_bytes(nq)
+                        : (size_t)wpb * FPHIP_GSO_RING * (size_t)((nq + 1) / 2) * 1024;
   int bpc          = g->blocks_per_cu > 0 ? g->blocks_per_cu : (int)((160 * 1024) / lds);
   if (bpc * wpb > 32)
     bpc = 32 / wpb;
@@ -733,7 +734,7 @@ static int bkz_launch(fphip_gso *g, int block_size, double delta, double eta, in
   const int wpb  = g->waves_per_block;
   const int bs   = block_size < 2 ? 2 : (block_size < g->P.d ? block_size : g->P.d);
   const int stack_doubles = (bs * (bs + 1)) / 2 + 2;
-  const size_t ring_bytes = (size_t)wpb * FPHIP_RING_REDUCE * (size_t)((nq + 1) / 2) * 1024;
+  const size_t ring_bytes = (size_t)wpb * fphip_reduce_ring_bytes(nq);
   const size_t lds        = ring_bytes + (size_t)wpb * stack_doubles * sizeof(double);
   if (ring_bytes > 64 * 1024 || lds > 160 * 1024)
   {
@@ -1690,7 +1691,7 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
   const int nq   = (need + 63) / 64;
   const int wpb  = g->waves_per_block;
   const int bs   = block_size < 2 ? 2 : bsz;
-  const size_t ring_bytes = (size_t)wpb * FPHIP_RING_REDUCE * (size_t)((nq + 1) / 2) * 1024;
+  const size_t ring_bytes = (size_t)wpb * fphip_reduce_ring_bytes(nq);
   // The scaled mu rows of the block under enumeration go to LDS (behind the column stack) when few
   // lattices share a CU — every row's L1 latency is exposed to a lone wave — and when they fit;
   // large batches keep them in global memory and spend the LDS on resident waves.

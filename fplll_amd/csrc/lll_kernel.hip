@@ -40,16 +40,12 @@ template <int NQ>
 __global__ void __launch_bounds__(256)
     lll_kernel(GsoBatch P, int kmin, int kstart, int kend, double delta, double eta, double logdelta)
 {
-  constexpr int IPS = (NQ + 1) / 2;
   extern __shared__ __attribute__((aligned(16))) char lll_smem[];
   const int lane = threadIdx.x & 63;
   const int wpb  = blockDim.x >> 6;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  Ring<NQ, IPS, FPHIP_RING_REDUCE> ring;
-  ring.base = (unsigned)(wave * Ring<NQ, IPS, FPHIP_RING_REDUCE>::R * Ring<NQ, IPS, FPHIP_RING_REDUCE>::SLOT);
-  ring.lane = lane;
-  ring.head = ring.tail = 0;
-  ring.ahead            = 0;
+  ReduceRing<NQ> ring;
+  ring.init(wave, lane);
   const int d = P.d, n = P.n, ldd = P.ldd, ldn = P.ldn;
   for (int L = blockIdx.x * wpb + wave; L < P.batch; L += gridDim.x * wpb)
   {

@@ -4,9 +4,37 @@
 #define FPHIP_LLL_WAVE_H
 
 #include "gso_wave.h"
+#include "lll_stream.h"
 
 namespace fphip
 {
+
+// The streaming machinery of the slot-mode kernels: the block streams of lll_stream.h, or (build with
+// -DFPHIP_LLL_STREAM=0: the A/B and fallback build) the first generation's ring of single rows.
+#ifndef FPHIP_LLL_STREAM
+#define FPHIP_LLL_STREAM 1
+#endif
+#if FPHIP_LLL_STREAM
+template <int NQ> struct ReduceRing : LStream<NQ>
+{
+};
+#else
+template <int NQ> struct ReduceRing : Ring<NQ, (NQ + 1) / 2, FPHIP_RING_REDUCE>
+{
+  using Base = Ring<NQ, (NQ + 1) / 2, FPHIP_RING_REDUCE>;
+  static constexpr int BYTES = Base::R * Base::SLOT;
+  __device__ __forceinline__ void init(int wave, int lane_)
+  {
+    this->base  = (unsigned)(wave * BYTES);
+    this->lane  = lane_;
+    this->head  = 0;
+    this->tail  = 0;
+    this->ahead = 0;
+  }
+};
+#endif
+static_assert(ReduceRing<1>::BYTES == 16384 && ReduceRing<2>::BYTES == 16384 || !FPHIP_LLL_STREAM, "fphip_reduce_ring_bytes");
+static_assert(ReduceRing<3>::BYTES == 15360 && ReduceRing<4>::BYTES == 16384 || !FPHIP_LLL_STREAM, "fphip_reduce_ring_bytes");
 
 struct LllCtx
 {
@@ -273,6 +301,308 @@ __device__ __forceinline__ bool update_row_cached(Lattice<NQ> &T, LllCtx &C, con
   return __all(ok);
 }
 
+// ---- the same on the block streams of lll_stream.h (round 5) ------------------------------------------
+template <int NQ>
+__device__ __forceinline__ bool update_row_cached(Lattice<NQ> &T, LllCtx &C, const SlotMap<NQ> &M,
+                                                  LStream<NQ> &S, int kappa, int last)
+{
+  const int n = T.n, lane = T.lane, ldd = T.ldd;
+  const int sk    = M.phys(kappa);
+  const int start = uni(C.vc[sk]);
+  double *rrowp   = T.r + (size_t)sk * ldd;
+  double *murowp  = T.mu + (size_t)sk * ldd;
+  double *gfrow   = C.gf + (size_t)sk * ldd;
+  if (start > last)
+  {  // nothing to compute: bring the row into registers
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+    {
+      const int j = lane + 64 * q;
+      T.rrow[q]   = (j < start && j <= kappa) ? rrowp[j] : 0.0;
+      T.murow[q]  = (j < start && j < kappa) ? murowp[j] : 0.0;
+    }
+    return true;
+  }
+  double acc[NQ], rd[NQ], mold[NQ];
+  bool miss = false;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+  {
+    const int j = lane + 64 * q;
+    acc[q]      = 0.0;
+    rd[q]       = 1.0;
+    mold[q]     = 0.0;
+    if (j < start)
+    {
+      acc[q]  = rrowp[j];  // final r(kappa,j)
+      mold[q] = (j < kappa) ? murowp[j] : 0.0;
+    }
+    else if (j <= last)
+    {
+      acc[q] = gfrow[M.sl[q]];  // cached g(kappa,j)
+      miss |= (acc[q] != acc[q]);
+    }
+    if (j < kappa && j <= last)
+      rd[q] = T.rdg[M.sl[q]];
+  }
+  // rows are gathered by slot: only slots up to the largest one among positions <= last are needed
+  int hi_slot = 0;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+    if (lane + 64 * q <= last)
+      hi_slot = max(hi_slot, M.sl[q]);
+  const int row_bytes = min((wave_max_i32(hi_slot) + 1) * 8, ldd * 8);
+  const int qact      = (last >> 6) + 1;
+  if (__any(miss))
+  {
+    // ---- Gram row: g(kappa,j) = bf_kappa . bf_j, columns ascending (numvect.h:386-396)
+    double bk[NQ], g[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+    {
+      const int c = lane + 64 * q;
+      bk[q]       = (c < n) ? T.bfT[(size_t)c * ldd + sk] : 0.0;
+      g[q]        = -0.0;  // -0.0 + p == p for every p: the first product starts the sum
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+    {
+      settle(bk[q]);
+      settle(acc[q]);
+      settle(rd[q]);
+      settle(mold[q]);
+    }
+    if (T.f32ok)
+    {  // every row is below 2^24: the float mirror holds the same numbers in half the bytes
+      GramPh<NQ, true> ph{(const char *)T.bfT32, (long)ldd * 4, ls_make_win(row_bytes >> 1), n, 0, S.lane16, {}, g, bk, qact};
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+        ph.off[q] = (unsigned)M.sl[q] * 4u;
+      ls_run<NQ>(S, ph, n);
+    }
+    else
+    {
+      GramPh<NQ, false> ph{(const char *)T.bfT, (long)ldd * 8, ls_make_win(row_bytes), n, 0, S.lane16, {}, g, bk, qact};
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+        ph.off[q] = (unsigned)M.sl[q] * 8u;
+      ls_run<NQ>(S, ph, n);
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+    {
+      const int j = lane + 64 * q;
+      if (j >= start && j <= last && acc[q] != acc[q])
+      {
+        acc[q]                           = g[q];
+        gfrow[M.sl[q]]                   = g[q];
+        C.gf[(size_t)M.sl[q] * ldd + sk] = g[q];
+      }
+    }
+  }
+  if (start == 0 || last - start >= 3)
+  {
+    // ---- column-oriented recurrence over k = 0..last-1 (gso_interface.cpp:143-158)
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+    {
+      settle(acc[q]);
+      settle(rd[q]);
+      settle(mold[q]);
+    }
+    RecPh<NQ> ph{(const char *)T.muT, (long)ldd * 8, ls_make_win(row_bytes), last, 0, S.lane16, lane, {}, acc, rd, {}, last == kappa, kappa};
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+    {
+      const int j = lane + 64 * q;
+      ph.off[q]   = (unsigned)M.sl[q] * 8u;
+      ph.bmask[q] = __ballot(j <= last && j >= start);
+    }
+    ls_run<NQ>(S, ph, last);
+  }
+  else
+  {
+    // ---- a few new columns: row-oriented, the reference's own loop order
+    for (int j = start; j <= last; ++j)
+    {
+      const double *mj = T.mu + (size_t)M.phys(j) * ldd;
+      double p[NQ];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+      {
+        const int k = lane + 64 * q;
+        double mm   = 0.0;
+        if (k < j)
+          mm = (j == kappa) ? acc[q] / rd[q] : mj[k];
+        p[q] = mm * acc[q];
+      }
+      double s = lane_get<NQ>(acc, j);
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+      {
+        const int hi = min(j - 64 * q, 64);
+        for (int kk = 0; kk < hi; ++kk)
+          s = s - g_rl_f64(p[q], kk);
+      }
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+        acc[q] = (lane + 64 * q == j) ? s : acc[q];
+    }
+  }
+  // ---- store the new columns
+  bool ok = true;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+  {
+    const int j = lane + 64 * q;
+    T.murow[q]  = 0.0;
+    T.rrow[q]   = (j <= last) ? acc[q] : 0.0;
+    if (j <= last)
+    {
+      if (j < start)
+      {
+        T.murow[q] = mold[q];
+      }
+      else if (j < kappa)
+      {
+        const double m = acc[q] / rd[q];  // mu(kappa,j) = r(kappa,j) / r(j,j)
+        if (!isfinite(m))
+          ok = false;
+        T.murow[q]                  = m;
+        rrowp[j]                    = acc[q];
+        murowp[j]                   = m;
+        T.muT[(size_t)j * ldd + sk] = m;
+      }
+      else
+      {  // j == kappa
+        rrowp[j]  = acc[q];
+        T.rdg[sk] = acc[q];
+      }
+    }
+  }
+  if (lane == 0)
+    C.vc[sk] = last + 1;
+  return __all(ok);
+}
+
+// LLLReduction::babai(kappa, kappa, size_reduction_start), lll.cpp:166-224, on the block streams.
+// 1 ok, 0 GSO failure, -1 babai failure, -2 multiplier beyond 63 bits.
+template <int NQ, class Upd, class After>
+__device__ __forceinline__ int babai_impl(Lattice<NQ> &T, LStream<NQ> &S, int kappa, double eta,
+                                          const SlotMap<NQ> &map, Upd upd, After after, int sr_start = 0)
+{
+  const int pk = map.phys(kappa);  // physical slot of row kappa
+  const int n = T.n, lane = T.lane, ldd = T.ldd, ldn = T.ldn;
+  long long max_expo = LLONG_MAX;
+  for (int iter = 0;; ++iter)
+  {
+    if (!upd(kappa, kappa - 1))
+      return 0;
+    const long long rexpk = T.rexp[pk];
+    int e[NQ];
+    bool need = false;
+    int mexp  = INT_MIN;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+    {
+      const int j = lane + 64 * q;
+      e[q]        = 0;
+      if (j < kappa)
+      {
+        e[q]           = (int)(rexpk - T.rexp[map.sl[q]]);
+        const double f = fabs(ldexp(T.murow[q], e[q]));  // get_mu, gso_interface.h:694-702
+        need |= (j >= sr_start) && (f > eta);
+        const long long ex = (long long)e[q] + fexponent(T.murow[q]);
+        mexp               = max(mexp, (int)max(ex, (long long)INT_MIN + 2));
+      }
+    }
+    if (!__any(need))
+      break;
+    if (iter >= 2)
+    {  // lll.cpp:187-195
+      const long long new_max = (long long)wave_max_i32(mexp);
+      if (new_max > max_expo - 5)
+        return -1;
+      max_expo = new_max;
+    }
+    double bm[NQ], xs[NQ];
+    unsigned long long nz[NQ];
+    long long bv[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+    {
+      const int c = lane + 64 * q;
+      bm[q]       = T.murow[q];
+      xs[q]       = 0.0;
+      nz[q]       = 0;
+      bv[q]       = (c < n) ? T.b[(size_t)pk * ldn + c] : 0;
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+    {
+      settle(e[q]);
+      settle(bv[q]);
+      settle(bm[q]);
+    }
+    // ---- lll.cpp:202-214: lane k owns babai_mu[k]; rows j = kappa-1 .. sr_start, descending
+    {
+      constexpr int U = LStream<NQ>::U;
+      const int jtop  = (kappa - 1) | (U - 1);
+      SweepPh<NQ> ph{(const char *)T.mu, (long)ldd * 8, jtop, kappa, sr_start, 0, S.lane16, lane, map, bm, xs, e, nz, {}};
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+        ph.srmask[q] = __ballot(lane + 64 * q >= sr_start);
+      ls_run<NQ>(S, ph, jtop - sr_start + 1);
+    }
+    // ---- the multipliers: row_addmul_we(kappa, j, -X, e_j) -> get_si_exp_we, nr_FP_d.inl:46-53
+    long long lxv[NQ];
+    bool too_big = false, big32 = false;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+    {
+      lxv[q] = 0;
+      if (xs[q] != 0.0)
+      {
+        if (fexponent(-xs[q]) + e[q] - 63 > 0)
+          too_big = true;
+        lxv[q] = (long long)ldexp(-xs[q], e[q]);
+        big32 |= (lxv[q] != (long long)(int)lxv[q]);
+      }
+    }
+    if (__any(too_big))
+      return -2;  // nothing has been stored yet: the basis is unchanged
+    // ---- integer row operation on row kappa (row_add / row_sub / row_addmul_si, gso.cpp:84-158)
+    {
+      int rows = 0;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+        rows += __builtin_popcountll(nz[q]);
+      if (T.f32ok && !__any(big32))
+      {
+        AxpyPh<NQ, true> ph{(const char *)T.b, (long)ldn * 8, ls_make_win(n * 8), S.lane16, lane, map, bv, lxv, {}, {}};
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+          ph.ic.m[q] = ph.cc.m[q] = nz[q];
+        ls_run<NQ>(S, ph, rows);
+      }
+      else
+      {
+        AxpyPh<NQ, false> ph{(const char *)T.b, (long)ldn * 8, ls_make_win(n * 8), S.lane16, lane, map, bv, lxv, {}, {}};
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+          ph.ic.m[q] = ph.cc.m[q] = nz[q];
+        ls_run<NQ>(S, ph, rows);
+      }
+    }
+    // ---- row_op_end: update_bf(kappa), gso.cpp:24-48
+    store_row_and_refloat<NQ, false>(T, pk, bv);
+    after(kappa);
+    // later reads of b / bfT / rexp in this wave must see these stores
+    __threadfence_block();
+  }
+  return 1;
+}
+
 // row_op_end(kappa, kappa+1) after b_kappa changed (gso_interface.cpp:32-53): the vector's Gram row
 // and column, its own GSO row, and columns >= kappa of every later row become invalid
 template <int NQ>
@@ -399,8 +729,8 @@ __device__ __forceinline__ void lll_init_state(Lattice<NQ> &T, LllCtx &C, SlotMa
 // LLLReduction::lll(kmin, kstart, kend, 0), lll.cpp:44-164, on the cached state (T, C, M).
 // status: 1 RED_SUCCESS, 0 RED_GSO_FAILURE, -1 RED_BABAI_FAILURE, -2 multiplier beyond 63 bits,
 //         -3 RED_LLL_FAILURE (iteration limit, lll.cpp:159-160)
-template <int NQ, int IPS, int RR>
-__device__ __forceinline__ int lll_run(Lattice<NQ> &T, LllCtx &C, SlotMap<NQ> &M, Ring<NQ, IPS, RR> &ring,
+template <int NQ, class RingT>
+__device__ __forceinline__ int lll_run(Lattice<NQ> &T, LllCtx &C, SlotMap<NQ> &M, RingT &ring,
                                        int kmin, int kstart, int kend, double delta, double eta,
                                        double logdelta, int &final_kappa, int &nswaps, int &zeros,
                                        long long &iter, int &vp)
