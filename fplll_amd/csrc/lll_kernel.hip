@@ -35,6 +35,12 @@
 namespace fphip
 {
 
+#if FPHIP_LLL_PROF
+// profiling build only: per phase kind {phases, rows, start-up ticks, total ticks}, then [4 * LS_KINDS] = kernel
+// ticks summed over the waves, [+1] = LLL iterations, [+2] = waves
+__device__ unsigned long long fphip_lll_prof_dev[4 * LS_KINDS + 4];
+#endif
+
 // info[4] per lattice: final_kappa, n_swaps, zeros, loop iterations (low 31 bits)
 template <int NQ>
 __global__ void __launch_bounds__(256)
@@ -47,6 +53,11 @@ __global__ void __launch_bounds__(256)
   ReduceRing<NQ> ring;
   ring.init(wave, lane);
   const int d = P.d, n = P.n, ldd = P.ldd, ldn = P.ldn;
+#if FPHIP_LLL_PROF
+  const unsigned long long pk0 = LStream<NQ>::now();
+  unsigned long long piter     = 0;
+  bool pany                    = false;
+#endif
   for (int L = blockIdx.x * wpb + wave; L < P.batch; L += gridDim.x * wpb)
   {
     Lattice<NQ> T;
@@ -87,7 +98,21 @@ __global__ void __launch_bounds__(256)
       P.lll_info[4 * L + 3] = (int)(iter & 0x7fffffff);
     }
     __threadfence_block();
+#if FPHIP_LLL_PROF
+    piter += (unsigned long long)iter;
+    pany = true;
+#endif
   }
+#if FPHIP_LLL_PROF
+  if (pany && lane == 0)
+  {
+    for (int i = 0; i < 4 * LS_KINDS; ++i)
+      atomicAdd(&fphip_lll_prof_dev[i], ring.pf[i]);
+    atomicAdd(&fphip_lll_prof_dev[4 * LS_KINDS + 0], LStream<NQ>::now() - pk0);
+    atomicAdd(&fphip_lll_prof_dev[4 * LS_KINDS + 1], piter);
+    atomicAdd(&fphip_lll_prof_dev[4 * LS_KINDS + 2], 1ull);
+  }
+#endif
 }
 
 template __global__ void lll_kernel<1>(GsoBatch, int, int, int, double, double, double);
@@ -96,3 +121,17 @@ template __global__ void lll_kernel<3>(GsoBatch, int, int, int, double, double, 
 template __global__ void lll_kernel<4>(GsoBatch, int, int, int, double, double, double);
 
 }  // namespace fphip
+
+#if FPHIP_LLL_PROF
+// profiling build only (not part of any header): read and clear the counters above
+extern "C" int fphip_debug_lll_prof(unsigned long long *out, int count)
+{
+  unsigned long long h[4 * fphip::LS_KINDS + 4] = {0};
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(fphip::fphip_lll_prof_dev), sizeof(h)) != hipSuccess)
+    return -1;
+  for (int i = 0; i < count && i < 4 * fphip::LS_KINDS + 4; ++i)
+    out[i] = h[i];
+  unsigned long long z[4 * fphip::LS_KINDS + 4] = {0};
+  return hipMemcpyToSymbol(HIP_SYMBOL(fphip::fphip_lll_prof_dev), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
+#endif

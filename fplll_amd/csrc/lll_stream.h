@@ -64,6 +64,21 @@ __device__ __forceinline__ double ls_wl_f64(double val, int lane, double old)
   return __hiloint2double(hi, lo);
 }
 
+// -DFPHIP_LLL_PROF=1 (tests/perf/build_lll_variants.sh, libPROF.so): every phase adds its count, rows, start-up
+// time (first block landed) and total time, in ticks of the 100 MHz real-time counter, to pf[4 * KIND ..]
+#ifndef FPHIP_LLL_PROF
+#define FPHIP_LLL_PROF 0
+#endif
+enum
+{
+  LS_GRAM   = 0,
+  LS_REC    = 1,
+  LS_SWEEP  = 2,
+  LS_AXPY   = 3,
+  LS_SINGLE = 4,  // Gram entries completed one by one (update_row_cached)
+  LS_KINDS  = 5
+};
+
 template <int NQ> struct LStream
 {
   static constexpr int U    = (NQ <= 2) ? 4 : 2;                       // rows per block
@@ -74,11 +89,36 @@ template <int NQ> struct LStream
   unsigned base;    // LDS byte address of this wave's ring
   int lane;
   unsigned lane16;
+#if FPHIP_LLL_PROF
+  unsigned long long pf[4 * LS_KINDS];
+#endif
   __device__ __forceinline__ void init(int wave, int lane_)
   {
     base   = (unsigned)(wave * BYTES);
     lane   = lane_;
     lane16 = (unsigned)lane_ * 16u;
+#if FPHIP_LLL_PROF
+    for (int i = 0; i < 4 * LS_KINDS; ++i)
+      pf[i] = 0;
+#endif
+  }
+  __device__ __forceinline__ void prof_add(int kind, unsigned long long rows, unsigned long long t_first,
+                                           unsigned long long t_all)
+  {
+#if FPHIP_LLL_PROF
+    pf[4 * kind + 0] += 1;
+    pf[4 * kind + 1] += rows;
+    pf[4 * kind + 2] += t_first;
+    pf[4 * kind + 3] += t_all;
+#endif
+  }
+  static __device__ __forceinline__ unsigned long long now()
+  {
+#if FPHIP_LLL_PROF
+    return __builtin_amdgcn_s_memrealtime();
+#else
+    return 0;
+#endif
   }
 };
 
@@ -194,7 +234,7 @@ template <int IPB, int MAXB> __device__ __forceinline__ void ls_wait_dyn(int blo
 //                                     FULL: the row is known to exist
 //   struct Regs; load(Regs &, addr)   this lane's words of the U rows of the block at LDS address addr
 //   compute(const Regs &, s0)         the arithmetic of rows s0 .. s0+U-1 (those below nrows)
-template <int NQ, class Ph> __device__ __forceinline__ void ls_run(const LStream<NQ> &S, Ph &ph, int nrows)
+template <int NQ, class Ph> __device__ __forceinline__ void ls_run(LStream<NQ> &S, Ph &ph, int nrows)
 {
   using L           = LStream<NQ>;
   constexpr int U   = L::U;
@@ -206,6 +246,7 @@ template <int NQ, class Ph> __device__ __forceinline__ void ls_run(const LStream
   const int nblk = (nrows + U - 1) / U;
   // everything older (stores of the previous phase, ordinary loads) is retired first: the counted waits
   // below then only ever see this phase's DMA instructions
+  const unsigned long long pt0 = L::now();
   ls_wait<0>();
   unsigned hoff = 0;  // ring offset of the block slot to fill next
   int rreq      = 0;  // rows requested so far
@@ -231,6 +272,7 @@ template <int NQ, class Ph> __device__ __forceinline__ void ls_run(const LStream
   for (int i = 0; i < npro; ++i)
     issue_block();
   ls_wait_dyn<IPB, NB - 1>(npro - 1);  // block 0 has landed
+  const unsigned long long pt1 = L::now();
   typename Ph::Regs A, B;
   unsigned toff = 0;
   ph.load(A, S.base + toff);
@@ -258,6 +300,7 @@ template <int NQ, class Ph> __device__ __forceinline__ void ls_run(const LStream
     }
     A = B;
   }
+  S.prof_add(Ph::KIND, (unsigned long long)nrows, pt1 - pt0, L::now() - pt0);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -267,6 +310,7 @@ template <int NQ, class Ph> __device__ __forceinline__ void ls_run(const LStream
 template <int NQ, bool F32> struct GramPh
 {
   using L = LStream<NQ>;
+  static constexpr int KIND = LS_GRAM;
   static constexpr int IPR = F32 ? 1 : (NQ + 1) / 2;
   const char *p;
   long stride;
@@ -348,6 +392,7 @@ template <int NQ, bool F32> struct GramPh
 template <int NQ> struct RecPh
 {
   using L = LStream<NQ>;
+  static constexpr int KIND = LS_REC;
   static constexpr int IPR = (NQ + 1) / 2;
   const char *p;
   long stride;
@@ -434,6 +479,7 @@ __device__ __forceinline__ double ls_rnd_we(double b, int e)
 template <int NQ> struct SweepPh
 {
   using L = LStream<NQ>;
+  static constexpr int KIND = LS_SWEEP;
   static constexpr int IPR = (NQ + 1) / 2;
   const char *mu;  // T.mu
   long stride;     // ldd * 8
@@ -535,6 +581,7 @@ template <int NQ> struct RowCursor
 template <int NQ, bool SMALL> struct AxpyPh
 {
   using L = LStream<NQ>;
+  static constexpr int KIND = LS_AXPY;
   static constexpr int IPR = (NQ + 1) / 2;
   const char *b;  // T.b
   long stride;    // ldn * 8

@@ -14,6 +14,10 @@ namespace fphip
 #ifndef FPHIP_LLL_STREAM
 #define FPHIP_LLL_STREAM 1
 #endif
+// a Gram row with at most this many unknown entries is completed entry by entry (update_row_cached)
+#ifndef FPHIP_LLL_GRAM_SINGLES
+#define FPHIP_LLL_GRAM_SINGLES 4
+#endif
 #if FPHIP_LLL_STREAM
 template <int NQ> struct ReduceRing : LStream<NQ>
 {
@@ -306,7 +310,7 @@ template <int NQ>
 __device__ __forceinline__ bool update_row_cached(Lattice<NQ> &T, LllCtx &C, const SlotMap<NQ> &M,
                                                   LStream<NQ> &S, int kappa, int last)
 {
-  const int n = T.n, lane = T.lane, ldd = T.ldd;
+  const int n = T.n, lane = T.lane, ldd = T.ldd, ldn = T.ldn;
   const int sk    = M.phys(kappa);
   const int start = uni(C.vc[sk]);
   double *rrowp   = T.r + (size_t)sk * ldd;
@@ -351,19 +355,80 @@ __device__ __forceinline__ bool update_row_cached(Lattice<NQ> &T, LllCtx &C, con
   for (int q = 0; q < NQ; ++q)
     if (lane + 64 * q <= last)
       hi_slot = max(hi_slot, M.sl[q]);
-  const int row_bytes = min((wave_max_i32(hi_slot) + 1) * 8, ldd * 8);
-  const int qact      = (last >> 6) + 1;
-  if (__any(miss))
+  hi_slot             = wave_max_i32(hi_slot);
+  const int row_bytes = min((hi_slot + 1) * 8, ldd * 8);
+  int nmiss           = 0;
+  unsigned long long missb[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
   {
-    // ---- Gram row: g(kappa,j) = bf_kappa . bf_j, columns ascending (numvect.h:386-396)
-    double bk[NQ], g[NQ];
+    missb[q] = __ballot(lane + 64 * q >= start && lane + 64 * q <= last && acc[q] != acc[q]);
+    nmiss += __builtin_popcountll(missb[q]);
+  }
+  if (nmiss > 0)
+  {
+    // bf(kappa, c) for lane c from the contiguous integer row: bf = b 2^-row_expo exactly (update_bf,
+    // gso.cpp:24-48: mantissa and exponent of every entry, renormalised to the row's largest exponent) —
+    // the doubles store_row_and_refloat wrote into column sk of bfT, from 8 cache lines instead of n
+    double bk[NQ];
+    {
+      const int ek = T.row_expo_on ? (int)T.rexp[sk] : 0;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+      {
+        const int c = lane + 64 * q;
+        bk[q]       = (c < n) ? ldexp((double)T.b[(size_t)sk * ldn + c], -ek) : 0.0;
+      }
+    }
+    if (nmiss <= FPHIP_LLL_GRAM_SINGLES)
+    {
+      // ---- a few entries only (the vectors that changed since this row was last here): each one its own
+      //      ordered dot product, columns ascending (numvect.h:386-396), from the two integer rows
+      RowCursor<NQ> cur;
+      const unsigned long long pt0 = LStream<NQ>::now();
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+        cur.m[q] = missb[q];
+      for (int t = 0; t < nmiss; ++t)
+      {
+        const int j  = cur.next();
+        const int sj = M.phys(j);
+        const int ej = T.row_expo_on ? (int)T.rexp[sj] : 0;
+        double pr[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+        {
+          const int c    = lane + 64 * q;
+          const double w = (c < n) ? ldexp((double)T.b[(size_t)sj * ldn + c], -ej) : 0.0;
+          pr[q]          = bk[q] * w;
+        }
+        const double gj = seq_sum<NQ>(pr, 0, n);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+          if (lane + 64 * q == j)
+          {
+            acc[q]                     = gj;
+            gfrow[sj]                  = gj;
+            C.gf[(size_t)sj * ldd + sk] = gj;
+          }
+      }
+      S.prof_add(LS_SINGLE, (unsigned long long)nmiss, 0, LStream<NQ>::now() - pt0);
+    }
+    else
+    {
+    // ---- Gram row: g(kappa,j) = bf_kappa . bf_j, columns ascending (numvect.h:386-396).  The pass also
+    //      yields g(kappa,kappa) in the lane of kappa (the Lovasz test asks for it next, lll.cpp:110): the
+    //      window and the chunks are extended to position kappa when that entry is unknown
+    const double gkk_old = gfrow[sk];
+    const bool want_diag = uni((gkk_old != gkk_old) ? 1 : 0) != 0 && last == kappa - 1;
+    const int glast      = want_diag ? kappa : last;
+    const int ghi        = want_diag ? max(hi_slot, sk) : hi_slot;
+    const int grow_bytes = min((ghi + 1) * 8, ldd * 8);
+    const int gqact      = (glast >> 6) + 1;
+    double g[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
-    {
-      const int c = lane + 64 * q;
-      bk[q]       = (c < n) ? T.bfT[(size_t)c * ldd + sk] : 0.0;
-      g[q]        = -0.0;  // -0.0 + p == p for every p: the first product starts the sum
-    }
+      g[q] = -0.0;  // -0.0 + p == p for every p: the first product starts the sum
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
     {
@@ -374,7 +439,7 @@ __device__ __forceinline__ bool update_row_cached(Lattice<NQ> &T, LllCtx &C, con
     }
     if (T.f32ok)
     {  // every row is below 2^24: the float mirror holds the same numbers in half the bytes
-      GramPh<NQ, true> ph{(const char *)T.bfT32, (long)ldd * 4, ls_make_win(row_bytes >> 1), n, 0, S.lane16, {}, g, bk, qact};
+      GramPh<NQ, true> ph{(const char *)T.bfT32, (long)ldd * 4, ls_make_win(grow_bytes >> 1), n, 0, S.lane16, {}, g, bk, gqact};
 #pragma unroll
       for (int q = 0; q < NQ; ++q)
         ph.off[q] = (unsigned)M.sl[q] * 4u;
@@ -382,7 +447,7 @@ __device__ __forceinline__ bool update_row_cached(Lattice<NQ> &T, LllCtx &C, con
     }
     else
     {
-      GramPh<NQ, false> ph{(const char *)T.bfT, (long)ldd * 8, ls_make_win(row_bytes), n, 0, S.lane16, {}, g, bk, qact};
+      GramPh<NQ, false> ph{(const char *)T.bfT, (long)ldd * 8, ls_make_win(grow_bytes), n, 0, S.lane16, {}, g, bk, gqact};
 #pragma unroll
       for (int q = 0; q < NQ; ++q)
         ph.off[q] = (unsigned)M.sl[q] * 8u;
@@ -398,8 +463,13 @@ __device__ __forceinline__ bool update_row_cached(Lattice<NQ> &T, LllCtx &C, con
         gfrow[M.sl[q]]                   = g[q];
         C.gf[(size_t)M.sl[q] * ldd + sk] = g[q];
       }
+      if (want_diag && j == kappa)
+        gfrow[sk] = g[q];
+    }
     }
   }
+  const int qact = (last >> 6) + 1;
+  (void)qact;
   if (start == 0 || last - start >= 3)
   {
     // ---- column-oriented recurrence over k = 0..last-1 (gso_interface.cpp:143-158)
