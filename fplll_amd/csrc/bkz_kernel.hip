@@ -184,21 +184,8 @@ __global__ void __launch_bounds__(256)
           }
           // rows below the verified prefix are size-reduced with r(k,k) in place: babai and
           // update_gso_row are no-ops on them
-          for (int k = max(kmin, min(vp, kend)); k < kend && status == 1; ++k)
-          {
-            if (k > 0)
-            {
-              const int rc = babai_impl(T, ring, k, eta, M, upd, after, sr0);
-              if (rc != 1)
-              {
-                status = rc;
-                break;
-              }
-            }
-            if (!upd(k, k))
-              status = 0;
-            __threadfence_block();
-          }
+          if (status == 1)
+            status = size_reduce_call(T, C, M, ring, max(kmin, min(vp, kend)), kend, eta, sr0, vp);
           if (tail || status != 1)
             break;
           const int sk0 = M.phys(kappa);
@@ -215,7 +202,7 @@ __global__ void __launch_bounds__(256)
           {
             int fk, ns, zs;
             long long it;
-            const int rc = lll_run(T, C, M, ring, 0, 0, kappa + bs, delta, eta, logdelta,
+            const int rc = lll_run_call(T, C, M, ring, 0, 0, kappa + bs, delta, eta, logdelta,
                                             fk, ns, zs, it, vp);
             if (rc != 1)
             {

@@ -363,7 +363,7 @@ bkzs_body(GsoBatch P, BkzStrat S, BkzMail *mailbox, int *abort_flag, int block_s
       {  // SD-BKZ starts with lll(0, 0, num_rows), bkz.cpp:576-577
         int fk, ns, zs;
         long long it;
-        const int rc = lll_run(T, C, M, ring, 0, 0, num_rows, delta, eta, logdelta, fk, ns, zs, it, vp);
+        const int rc = lll_run_call(T, C, M, ring, 0, 0, num_rows, delta, eta, logdelta, fk, ns, zs, it, vp);
         if (rc != 1)
           status = rc;
       }
@@ -509,7 +509,7 @@ bkzs_body(GsoBatch P, BkzStrat S, BkzMail *mailbox, int *abort_flag, int block_s
             {
               int fk, ns, zs;
               long long it;
-              const int rc = lll_run(T, C, M, ring, F.min_row, F.min_row, F.max_row, delta, eta, logdelta, fk, ns,
+              const int rc = lll_run_call(T, C, M, ring, F.min_row, F.min_row, F.max_row, delta, eta, logdelta, fk, ns,
                                      zs, it, vp);
               if (rc != 1)
               {
@@ -589,21 +589,8 @@ bkzs_body(GsoBatch P, BkzStrat S, BkzMail *mailbox, int *abort_flag, int block_s
       {
         // lll_obj.size_reduction(kmin, kend, sr_start), lll.h:107-122, on the cached state: rows
         // below the verified prefix are size-reduced with r(k,k) in place (no-ops in the reference)
-        for (int k = max(sr_kmin, min(vp, sr_kend)); k < sr_kend && status == 1; ++k)
-        {
-          if (k > 0)
-          {
-            const int rc = babai_impl(T, ring, k, eta, M, upd, after, sr_start);
-            if (rc != 1)
-            {
-              status = rc;
-              break;
-            }
-          }
-          if (!upd(k, k))
-            status = 0;
-          __threadfence_block();
-        }
+        if (status == 1)
+          status = size_reduce_call(T, C, M, ring, max(sr_kmin, min(vp, sr_kend)), sr_kend, eta, sr_start, vp);
         F.phase = sr_next;
         continue;
       }
@@ -682,7 +669,7 @@ bkzs_body(GsoBatch P, BkzStrat S, BkzMail *mailbox, int *abort_flag, int block_s
           const int ls = (F.flags & 0x10) ? F.kappa : 0;  // BKZ_BOUNDED_LLL
           int fk, ns, zs;
           long long it;
-          const int rc = lll_run(T, C, M, ring, ls, ls, F.kappa + F.bs, delta, eta, logdelta, fk, ns, zs, it, vp);
+          const int rc = lll_run_call(T, C, M, ring, ls, ls, F.kappa + F.bs, delta, eta, logdelta, fk, ns, zs, it, vp);
           if (rc != 1)
           {
             status = rc;
@@ -737,15 +724,8 @@ bkzs_body(GsoBatch P, BkzStrat S, BkzMail *mailbox, int *abort_flag, int block_s
         // every row of the block is valid here in the reference (the preprocessing LLL / tours end
         // with all rows below kappa + bs updated); make sure the cache agrees — a recomputation
         // gives the same values, they are functions of the basis
-        for (int k = kappa; k < kappa + bs && status == 1; ++k)
-        {
-          if (uni(C.vc[M.phys(k)]) <= k)
-          {
-            if (!upd(k, k))
-              status = 0;
-            __threadfence_block();
-          }
-        }
+        if (status == 1 && !update_rows_call(T, C, M, ring, kappa, kappa + bs))
+          status = 0;
         if (status != 1)
           break;
         // ---- radius (bkz.cpp:309-323) and pruning set (:325) -----------------------------------

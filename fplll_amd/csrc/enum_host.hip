@@ -355,6 +355,14 @@ void **fphip_ctx_gso_slot(fphip_ctx *ctx) { return &ctx->gso; }
 char *fphip_ctx_errbuf(fphip_ctx *ctx) { return ctx->err; }
 int fphip_ctx_num_cus(fphip_ctx *ctx) { return ctx->num_cus; }
 int fphip_ctx_device(fphip_ctx *ctx) { return ctx->device; }
+// the task buffers NOW (gso_host.hip's hand-off set-up: before the persistent schedule kernel is launched, never from
+// the worker thread that answers its mailbox — a multi-gigabyte allocation there would stall the kernel at best)
+int fphip_ctx_ensure_task_buffers(fphip_ctx *ctx)
+{
+  if (hipSetDevice(ctx->device) != hipSuccess)
+    return FPHIP_ERROR;
+  return ensure_task_buffers(ctx);
+}
 
 // ---------------------------------------------------------------------------------------------
 // ring consumer

@@ -91,6 +91,7 @@ hipStream_t fphip_ctx_stream(fphip_ctx *ctx);
 char *fphip_ctx_errbuf(fphip_ctx *ctx);
 int fphip_ctx_num_cus(fphip_ctx *ctx);
 int fphip_ctx_device(fphip_ctx *ctx);
+int fphip_ctx_ensure_task_buffers(fphip_ctx *ctx);  // enum_host.hip
 
 struct fphip_gso
 {
@@ -336,7 +337,7 @@ static int launch(fphip_gso *g, int kmin, int kend, double eta, int mode, const 
   // per-wave LDS-DMA ring: FPHIP_GSO_RING slots of IPS KiB (IPS = ceil(NQ/2))
   const size_t lds = la ? (size_t)wpb * fphip_reduce_ring_bytes(nq)
                         : (size_t)wpb * FPHIP_GSO_RING * (size_t)((nq + 1) / 2) * 1024;
-  int bpc          = g->blocks_per_cu > 0 ? g->blocks_per_cu : (int)((160 * 1024) / lds);
+  int bpc          = g->blocks_per_cu > 0 ? g->blocks_per_cu : (lds ? (int)((160 * 1024) / lds) : 32);  // (no LDS: the register streams)
   if (bpc * wpb > 32)
     bpc = 32 / wpb;
   const int cap = fphip_ctx_num_cus(g->ctx) * (bpc > 0 ? bpc : 1);
@@ -741,7 +742,7 @@ static int bkz_launch(fphip_gso *g, int block_size, double delta, double eta, in
     snprintf(fphip_ctx_errbuf(g->ctx), 512, "bkz: %zu bytes of LDS per workgroup do not fit", lds);
     return FPHIP_ERROR;
   }
-  int bpc = (int)((160 * 1024) / lds);
+  int bpc = lds ? (int)((160 * 1024) / lds) : 32;
   if (bpc * wpb > 32)
     bpc = 32 / wpb;
   int grid      = (g->P.batch + wpb - 1) / wpb;
@@ -1018,6 +1019,7 @@ struct BkzsHost
   int inloop           = 0;
   double il_preproc    = 0, il_target = 0;
   int il_min_block     = 0, il_flags = 0;
+  std::atomic<int> *il_errors = nullptr;  // prune() calls that failed for another reason than the profile
 };
 // the blocks in-loop pruning applies to: primal blocks of the top-level tour (not of a preprocessing
 // tour: 0x10000, not dual: 0x20000)
@@ -1101,8 +1103,15 @@ void serve_radius(const BkzsHost &H, BkzMail *m, fphip_pruner::VolumeEngine *eng
     for (int i = 0; i < bs; ++i)
       rr[i] = std::ldexp(m->r[i], m->e2[i]);
     const double radius = max_dist * pow(2, expo);
-    if (std::isfinite(radius) && radius > 0 &&
-        fphip_pruner::prune_block(engine, bs, rr, radius, H.il_preproc, H.il_target, H.il_flags, co, &ex) == FPHIP_OK)
+    int prc = FPHIP_UNSUPPORTED;
+    if (std::isfinite(radius) && radius > 0)
+    {
+      prc = fphip_pruner::prune_block(engine, bs, rr, radius, H.il_preproc, H.il_target, H.il_flags, co, &ex);
+      // a device engine that failed (its message is in error()) is not a degenerate profile: the call reports it
+      if (prc != FPHIP_OK && engine && engine->error()[0] && H.il_errors)
+        H.il_errors->fetch_add(1);
+    }
+    if (prc == FPHIP_OK)
     {
       for (int i = 0; i < bs; ++i)
         m->prn[i] = co[i];
@@ -1297,11 +1306,14 @@ extern "C" int fphip_gso_slide_pass(fphip_gso *g, int block_size, double delta, 
                                     double gh_factor, const fphip_strategies *S, fphip_rand_fn rnd, void *rnd_user,
                                     int pass, unsigned long long block_mask, int *status, int *info)
 {
-  if (!g || pass < 1 || pass > 3)
+  if (!g || pass < 1 || pass > 3 || block_size < 2)
     return FPHIP_ERROR;
   // without BKZ_BOUNDED_LLL every svp_reduction starts with an LLL from row 0: the blocks of a pass are
   // not independent then (bkz.cpp:107-108)
   if (!(flags & 0x10))
+    return FPHIP_UNSUPPORTED;
+  // the block mask has 64 bits (advisor, round 4: a wider pass would silently reduce nothing)
+  if ((g->P.d + block_size - 1) / block_size > 64)
     return FPHIP_UNSUPPORTED;
   g->P.sld_pass = pass;
   g->P.sld_mask = block_mask;
@@ -1330,8 +1342,25 @@ extern "C" int fphip_gso_slide_reduction_blocks(fphip_gso **gs, int count, int b
       return FPHIP_ERROR;
   if (!(flags & 0x10))
     return FPHIP_UNSUPPORTED;  // the blocks of a pass are independent only with BKZ_BOUNDED_LLL
+  // A caller generator cannot be shared by the participants: the host threads would race on its state, and
+  // every copy / rank would consume a different number of draws, so that the closing hkz's rerandomisations
+  // (and with them the result) would depend on the number of devices (advisor, round 4).  The block-parallel
+  // tour is defined for the deterministic case — no rerandomisation: rnd == NULL.
+  if (rnd)
+    return FPHIP_UNSUPPORTED;
   const int d = gs[0]->P.d, n = gs[0]->P.n;
   const int p = (d + block_size - 1) / block_size;
+  if (p > 64)
+    return FPHIP_UNSUPPORTED;  // 64-bit block masks
+  // the GSO entry points launch on the calling thread's current device: gs[0]'s while this thread uses it
+  int caller_dev0 = 0;
+  (void)hipGetDevice(&caller_dev0);
+  (void)hipSetDevice(fphip_ctx_device(gs[0]->ctx));
+  struct RestoreDev
+  {
+    int dev;
+    ~RestoreDev() { (void)hipSetDevice(dev); }
+  } restore_dev{caller_dev0};
   struct Blk
   {
     int lo, hi;
@@ -1630,8 +1659,12 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
   int *d_pre_off = nullptr, *d_pre = nullptr, *d_coeff_off = nullptr, *d_abort = nullptr;
   double *d_coeff = nullptr;
   BkzMail *mail   = nullptr;
+  std::vector<fphip_pruner::VolumeEngine *> il_engines;  // in-loop pruning: one volume engine per service worker
   auto cleanup = [&]()
   {
+    for (auto *x : il_engines)  // (every error return goes through here: streams and pinned staging go with it)
+      fphip_pruner::destroy_volume_engine(x);
+    il_engines.clear();
     fphip_dev_free(d_pre_off, fphip_ctx_stream(g->ctx));
     fphip_dev_free(d_pre, fphip_ctx_stream(g->ctx));
     fphip_dev_free(d_coeff_off, fphip_ctx_stream(g->ctx));
@@ -1716,7 +1749,7 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
     snprintf(fphip_ctx_errbuf(g->ctx), 512, "bkz: %zu bytes of LDS per workgroup do not fit", lds);
     return FPHIP_ERROR;
   }
-  int bpc = (int)((160 * 1024) / lds);
+  int bpc = lds ? (int)((160 * 1024) / lds) : 32;
   if (bpc * wpb > 32)
     bpc = 32 / wpb;
   int grid      = (g->P.batch + wpb - 1) / wpb;
@@ -1748,7 +1781,6 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
   BkzsHost H{S, gh_factor, rnd, rnd_user, 0.0};
   // in-loop pruning: a pool of worker threads (one prune() is tens of milliseconds; the lattices of a batch
   // ask at about the same time), each with a volume engine of its own (stream, staging, device buffers)
-  std::vector<fphip_pruner::VolumeEngine *> il_engines;
   int n_workers = 1;
   if (inloop)
   {
@@ -1766,8 +1798,6 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
       fphip_pruner::VolumeEngine *e = fphip_pruner::create_device_volume_engine(fphip_ctx_device(g->ctx), why, sizeof why);
       if (!e)
       {
-        for (auto *x : il_engines)
-          fphip_pruner::destroy_volume_engine(x);
         cleanup();
         snprintf(fphip_ctx_errbuf(g->ctx), 512, "bkz_strategies: %s", why);
         return FPHIP_ERROR;
@@ -1776,6 +1806,9 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
     }
   }
   std::atomic<unsigned long long> il_calls{0};
+  std::atomic<int> il_errors{0};
+  H.il_errors = &il_errors;
+  const unsigned long long il_host_jobs0 = inloop ? (unsigned long long)fphip_pruner::host_volume_engine()->host_jobs : 0ull;
   if (handoff)
   {
     // hand-off mode: a second context on this device for the enumerations, the blocks' mu rows in
@@ -1787,16 +1820,27 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
       if (g->ectx)
         fphip_destroy(g->ectx);
       g->ectx = nullptr;
-      for (auto *x : il_engines)
-        fphip_pruner::destroy_volume_engine(x);
       cleanup();
       return FPHIP_ERROR;
+    }
+    // the enumeration's task buffers exist before the schedule kernel runs (advisor, round 4: the first
+    // fphip_enum_run of a context allocates them — here that would be the worker thread, mid-launch)
+    {
+      int cur_dev = 0;
+      (void)hipGetDevice(&cur_dev);
+      const int erc = fphip_ctx_ensure_task_buffers(g->ectx);
+      (void)hipSetDevice(cur_dev);
+      if (erc != FPHIP_OK)
+      {
+        snprintf(fphip_ctx_errbuf(g->ctx), 512, "bkz_strategies: task buffers of the hand-off context: %s",
+                 fphip_last_error(g->ectx));
+        cleanup();
+        return FPHIP_ERROR;
+      }
     }
     g->P.enum_mu_h = (double *)pinned_get(B * (64 * 63 / 2) * sizeof(double));
     if (!g->P.enum_mu_h)
     {
-      for (auto *x : il_engines)
-        fphip_pruner::destroy_volume_engine(x);
       cleanup();
       snprintf(fphip_ctx_errbuf(g->ctx), 512, "bkz_strategies: no pinned memory for the hand-off");
       return FPHIP_ERROR;
@@ -2035,7 +2079,6 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
     }
   }
 #undef BCHK
-  cleanup();  // (run_once's GCHKs return to this function, never past it: nothing leaks on a HIP error)
   if (inloop)
   {
     g->il_calls += il_calls.load();
@@ -2044,9 +2087,13 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
       g->il_device_jobs += e->device_jobs;
       g->il_host_jobs += e->host_jobs;
       g->il_launches += e->launches;
-      fphip_pruner::destroy_volume_engine(e);
     }
+    // without device engines the workers share the host engine: its jobs of this call
+    if (il_engines.empty())
+      g->il_host_jobs += fphip_pruner::host_volume_engine()->host_jobs - il_host_jobs0;
   }
+  cleanup();  // (run_once's GCHKs return to this function, never past it: nothing leaks on a HIP error; the
+              //  volume engines go here too)
   if (handoff && getenv("FPHIP_DEBUG"))
     fprintf(stderr, "[fphip] bkz_strategies: %llu block enumerations handed to the multi-wave enumerator\n",
             handoff_calls);
@@ -2054,6 +2101,12 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
   {
     snprintf(fphip_ctx_errbuf(g->ctx), 512, "bkz_strategies: a handed-off enumeration failed: %s",
              g->ectx ? fphip_last_error(g->ectx) : "?");
+    rc = FPHIP_ERROR;
+  }
+  if (il_errors.load() > 0 && rc == FPHIP_OK)
+  {
+    snprintf(fphip_ctx_errbuf(g->ctx), 512, "bkz_strategies: %d in-loop prune() calls lost their volume engine "
+             "(the strategies' sets were used for those blocks)", il_errors.load());
     rc = FPHIP_ERROR;
   }
   if (rnd_failed && rc == FPHIP_OK)

@@ -9,7 +9,7 @@
 namespace fphip
 {
 
-// The streaming machinery of the slot-mode kernels: the block streams of lll_stream.h, or (build with
+// The streaming machinery of the slot-mode kernels: the register streams of lll_stream.h (no LDS), or (build with
 // -DFPHIP_LLL_STREAM=0: the A/B and fallback build) the first generation's ring of single rows.
 #ifndef FPHIP_LLL_STREAM
 #define FPHIP_LLL_STREAM 1
@@ -37,8 +37,7 @@ template <int NQ> struct ReduceRing : Ring<NQ, (NQ + 1) / 2, FPHIP_RING_REDUCE>
   }
 };
 #endif
-static_assert(ReduceRing<1>::BYTES == 16384 && ReduceRing<2>::BYTES == 16384 || !FPHIP_LLL_STREAM, "fphip_reduce_ring_bytes");
-static_assert(ReduceRing<3>::BYTES == 15360 && ReduceRing<4>::BYTES == 16384 || !FPHIP_LLL_STREAM, "fphip_reduce_ring_bytes");
+static_assert((ReduceRing<1>::BYTES == 0 && ReduceRing<4>::BYTES == 0) || !FPHIP_LLL_STREAM, "fphip_reduce_ring_bytes");
 
 struct LllCtx
 {
@@ -305,7 +304,7 @@ __device__ __forceinline__ bool update_row_cached(Lattice<NQ> &T, LllCtx &C, con
   return __all(ok);
 }
 
-// ---- the same on the block streams of lll_stream.h (round 5) ------------------------------------------
+// ---- the same on the register streams of lll_stream.h (round 5) ------------------------------------------
 template <int NQ>
 __device__ __forceinline__ bool update_row_cached(Lattice<NQ> &T, LllCtx &C, const SlotMap<NQ> &M,
                                                   LStream<NQ> &S, int kappa, int last)
@@ -349,15 +348,13 @@ __device__ __forceinline__ bool update_row_cached(Lattice<NQ> &T, LllCtx &C, con
     if (j < kappa && j <= last)
       rd[q] = T.rdg[M.sl[q]];
   }
-  // rows are gathered by slot: only slots up to the largest one among positions <= last are needed
-  int hi_slot = 0;
+  // rows of the transposed arrays are gathered by slot: this lane's element of a row (lanes beyond the last
+  // position read slot 0: never used)
+  unsigned gslot[NQ];
 #pragma unroll
   for (int q = 0; q < NQ; ++q)
-    if (lane + 64 * q <= last)
-      hi_slot = max(hi_slot, M.sl[q]);
-  hi_slot             = wave_max_i32(hi_slot);
-  const int row_bytes = min((hi_slot + 1) * 8, ldd * 8);
-  int nmiss           = 0;
+    gslot[q] = (lane + 64 * q < T.d) ? (unsigned)M.sl[q] : 0u;
+  int nmiss = 0;
   unsigned long long missb[NQ];
 #pragma unroll
   for (int q = 0; q < NQ; ++q)
@@ -422,8 +419,6 @@ __device__ __forceinline__ bool update_row_cached(Lattice<NQ> &T, LllCtx &C, con
     const double gkk_old = gfrow[sk];
     const bool want_diag = uni((gkk_old != gkk_old) ? 1 : 0) != 0 && last == kappa - 1;
     const int glast      = want_diag ? kappa : last;
-    const int ghi        = want_diag ? max(hi_slot, sk) : hi_slot;
-    const int grow_bytes = min((ghi + 1) * 8, ldd * 8);
     const int gqact      = (glast >> 6) + 1;
     double g[NQ];
 #pragma unroll
@@ -439,18 +434,18 @@ __device__ __forceinline__ bool update_row_cached(Lattice<NQ> &T, LllCtx &C, con
     }
     if (T.f32ok)
     {  // every row is below 2^24: the float mirror holds the same numbers in half the bytes
-      GramPh<NQ, true> ph{(const char *)T.bfT32, (long)ldd * 4, ls_make_win(grow_bytes >> 1), n, 0, S.lane16, {}, g, bk, gqact};
+      GramPh<NQ, true> ph{ls_rsrc(T.bfT32, (unsigned)(n * ldd * 4)), (unsigned)ldd * 4u, n, {}, g, bk, gqact};
 #pragma unroll
       for (int q = 0; q < NQ; ++q)
-        ph.off[q] = (unsigned)M.sl[q] * 4u;
+        ph.off[q] = gslot[q] * 4u;
       ls_run<NQ>(S, ph, n);
     }
     else
     {
-      GramPh<NQ, false> ph{(const char *)T.bfT, (long)ldd * 8, ls_make_win(grow_bytes), n, 0, S.lane16, {}, g, bk, gqact};
+      GramPh<NQ, false> ph{ls_rsrc(T.bfT, (unsigned)(n * ldd * 8)), (unsigned)ldd * 8u, n, {}, g, bk, gqact};
 #pragma unroll
       for (int q = 0; q < NQ; ++q)
-        ph.off[q] = (unsigned)M.sl[q] * 8u;
+        ph.off[q] = gslot[q] * 8u;
       ls_run<NQ>(S, ph, n);
     }
 #pragma unroll
@@ -480,12 +475,12 @@ __device__ __forceinline__ bool update_row_cached(Lattice<NQ> &T, LllCtx &C, con
       settle(rd[q]);
       settle(mold[q]);
     }
-    RecPh<NQ> ph{(const char *)T.muT, (long)ldd * 8, ls_make_win(row_bytes), last, 0, S.lane16, lane, {}, acc, rd, {}, last == kappa, kappa};
+    RecPh<NQ> ph{ls_rsrc(T.muT, (unsigned)(T.d * ldd * 8)), (unsigned)ldd * 8u, last, lane, {}, acc, rd, {}, last == kappa, kappa};
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
     {
       const int j = lane + 64 * q;
-      ph.off[q]   = (unsigned)M.sl[q] * 8u;
+      ph.off[q]   = gslot[q] * 8u;
       ph.bmask[q] = __ballot(j <= last && j >= start);
     }
     ls_run<NQ>(S, ph, last);
@@ -616,13 +611,11 @@ __device__ __forceinline__ int babai_impl(Lattice<NQ> &T, LStream<NQ> &S, int ka
     }
     // ---- lll.cpp:202-214: lane k owns babai_mu[k]; rows j = kappa-1 .. sr_start, descending
     {
-      constexpr int U = LStream<NQ>::U;
-      const int jtop  = (kappa - 1) | (U - 1);
-      SweepPh<NQ> ph{(const char *)T.mu, (long)ldd * 8, jtop, kappa, sr_start, 0, S.lane16, lane, map, bm, xs, e, nz, {}};
+      SweepPh<NQ> ph{ls_rsrc(T.mu, (unsigned)(T.d * ldd * 8)), (unsigned)ldd * 8u, kappa, sr_start, lane, map, bm, xs, e, nz, {}};
 #pragma unroll
       for (int q = 0; q < NQ; ++q)
         ph.srmask[q] = __ballot(lane + 64 * q >= sr_start);
-      ls_run<NQ>(S, ph, jtop - sr_start + 1);
+      ls_run<NQ>(S, ph, kappa - sr_start);
     }
     // ---- the multipliers: row_addmul_we(kappa, j, -X, e_j) -> get_si_exp_we, nr_FP_d.inl:46-53
     long long lxv[NQ];
@@ -649,7 +642,7 @@ __device__ __forceinline__ int babai_impl(Lattice<NQ> &T, LStream<NQ> &S, int ka
         rows += __builtin_popcountll(nz[q]);
       if (T.f32ok && !__any(big32))
       {
-        AxpyPh<NQ, true> ph{(const char *)T.b, (long)ldn * 8, ls_make_win(n * 8), S.lane16, lane, map, bv, lxv, {}, {}};
+        AxpyPh<NQ, true> ph{ls_rsrc(T.b, (unsigned)(T.d * ldn * 8)), (unsigned)ldn * 8u, lane, map, bv, lxv, {}, {}};
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
           ph.ic.m[q] = ph.cc.m[q] = nz[q];
@@ -657,7 +650,7 @@ __device__ __forceinline__ int babai_impl(Lattice<NQ> &T, LStream<NQ> &S, int ka
       }
       else
       {
-        AxpyPh<NQ, false> ph{(const char *)T.b, (long)ldn * 8, ls_make_win(n * 8), S.lane16, lane, map, bv, lxv, {}, {}};
+        AxpyPh<NQ, false> ph{ls_rsrc(T.b, (unsigned)(T.d * ldn * 8)), (unsigned)ldn * 8u, lane, map, bv, lxv, {}, {}};
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
           ph.ic.m[q] = ph.cc.m[q] = nz[q];
@@ -1047,6 +1040,180 @@ __device__ __forceinline__ int lll_run(Lattice<NQ> &T, LllCtx &C, SlotMap<NQ> &M
   if (ok)
     status = (kappa < kend - zeros) ? -3 : 1;
   return status;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Out-of-line entry points for kernels that reach the LLL machinery from several places (bkz_kernel.hip,
+// bkzs_kernel.hip).  Everything above is force-inlined, and with the register streams an inlined copy of
+// update_row_cached / babai_impl is a few thousand instructions of unrolled loops: three lll() sites, a size
+// reduction and two GSO updates per kernel, times eight kernels, took the compile of bkzs_kernel.hip beyond
+// a quarter of an hour.  Here the state goes through ONE block of private memory per call (copied in, copied
+// back: some fifty words per lane, against the thousands of iterations of an lll() or the d rows of a size
+// reduction), and each entry point exists once per chunk count.  (The first generation's ring must not see
+// scratch traffic between its counted waits: that build keeps everything inline.)
+// ---------------------------------------------------------------------------------------------------
+template <int NQ, class RingT> struct LllFrame
+{
+  Lattice<NQ> T;
+  LllCtx C;
+  SlotMap<NQ> M;
+  RingT ring;
+  int vp, final_kappa, nswaps, zeros;
+  long long iter;
+};
+
+#if FPHIP_LLL_STREAM
+#define FPHIP_LLL_OOL __noinline__
+#else
+#define FPHIP_LLL_OOL __forceinline__
+#endif
+
+// What comes out of private memory (and every argument of an out-of-line function) is a vector value for the
+// compiler; the wave-uniform members go back to scalar registers here, so that the loops branch on the scalar unit
+// and the lane masks are scalar pairs, as in the inlined form.
+template <class P> __device__ __forceinline__ P *uni_ptr(P *p)
+{
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned lo          = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+  const unsigned hi          = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+  return (P *)(((unsigned long long)hi << 32) | lo);
+}
+template <int NQ, class RingT> __device__ __forceinline__ void uniformize(LllFrame<NQ, RingT> &f)
+{
+#if FPHIP_LLL_STREAM
+  f.T.d           = uni(f.T.d);
+  f.T.n           = uni(f.T.n);
+  f.T.ldd         = uni(f.T.ldd);
+  f.T.ldn         = uni(f.T.ldn);
+  f.T.row_expo_on = uni(f.T.row_expo_on);
+  f.T.b           = uni_ptr(f.T.b);
+  f.T.bfT         = uni_ptr(f.T.bfT);
+  f.T.mu          = uni_ptr(f.T.mu);
+  f.T.muT         = uni_ptr(f.T.muT);
+  f.T.r           = uni_ptr(f.T.r);
+  f.T.rdg         = uni_ptr(f.T.rdg);
+  f.T.rexp        = uni_ptr(f.T.rexp);
+  f.T.bfT32       = uni_ptr(f.T.bfT32);
+  f.T.b32         = uni_ptr(f.T.b32);
+  f.T.narrow_flag = uni_ptr(f.T.narrow_flag);
+  f.T.np          = uni(f.T.np);
+  f.T.f32ok       = uni(f.T.f32ok);
+  f.C.gf          = uni_ptr(f.C.gf);
+  f.C.vc          = uni_ptr(f.C.vc);
+  f.vp            = uni(f.vp);
+#endif
+}
+__device__ __forceinline__ double uni_f64(double v)
+{
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)),
+                          __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+
+template <int NQ, class RingT>
+__device__ FPHIP_LLL_OOL int lll_run_ool(LllFrame<NQ, RingT> *fp, int kmin, int kstart, int kend, double delta,
+                                         double eta, double logdelta)
+{
+  LllFrame<NQ, RingT> f = *fp;
+  uniformize(f);
+  const int rc = lll_run(f.T, f.C, f.M, f.ring, uni(kmin), uni(kstart), uni(kend), uni_f64(delta), uni_f64(eta),
+                         uni_f64(logdelta), f.final_kappa, f.nswaps, f.zeros, f.iter, f.vp);
+  *fp = f;
+  return rc;
+}
+template <int NQ, class RingT>
+__device__ __forceinline__ int lll_run_call(Lattice<NQ> &T, LllCtx &C, SlotMap<NQ> &M, RingT &ring, int kmin,
+                                            int kstart, int kend, double delta, double eta, double logdelta,
+                                            int &final_kappa, int &nswaps, int &zeros, long long &iter, int &vp)
+{
+  LllFrame<NQ, RingT> f{T, C, M, ring, vp, 0, 0, 0, 0};
+  const int rc = lll_run_ool<NQ, RingT>(&f, kmin, kstart, kend, delta, eta, logdelta);
+  T           = f.T;
+  M           = f.M;
+  ring        = f.ring;
+  vp          = f.vp;
+  final_kappa = f.final_kappa;
+  nswaps      = f.nswaps;
+  zeros       = f.zeros;
+  iter        = f.iter;
+  return rc;
+}
+
+// lll_obj.size_reduction(kfrom, kend, sr_start), lll.h:107-122, on the cached state: babai(k) then
+// update_gso_row(k, k) for every row.  1, or the failing status (0 GSO, -1 babai, -2 multiplier).
+template <int NQ, class RingT>
+__device__ __forceinline__ int size_reduce_rows(Lattice<NQ> &T, LllCtx &C, SlotMap<NQ> &M, RingT &ring, int kfrom,
+                                                int kend, double eta, int sr_start, int &vp)
+{
+  auto upd   = [&](int k, int last) { return update_row_cached(T, C, M, ring, k, last); };
+  auto after = [&](int k)
+  {
+    after_rowop<NQ>(T, C, M, k);
+    vp = min(vp, k);
+  };
+  for (int k = kfrom; k < kend; ++k)
+  {
+    if (k > 0)
+    {
+      const int rc = babai_impl(T, ring, k, eta, M, upd, after, sr_start);
+      if (rc != 1)
+        return rc;
+    }
+    if (!upd(k, k))
+      return 0;
+    __threadfence_block();
+  }
+  return 1;
+}
+template <int NQ, class RingT>
+__device__ FPHIP_LLL_OOL int size_reduce_ool(LllFrame<NQ, RingT> *fp, int kfrom, int kend, double eta, int sr_start)
+{
+  LllFrame<NQ, RingT> f = *fp;
+  uniformize(f);
+  const int rc = size_reduce_rows(f.T, f.C, f.M, f.ring, uni(kfrom), uni(kend), uni_f64(eta), uni(sr_start), f.vp);
+  *fp                   = f;
+  return rc;
+}
+template <int NQ, class RingT>
+__device__ __forceinline__ int size_reduce_call(Lattice<NQ> &T, LllCtx &C, SlotMap<NQ> &M, RingT &ring, int kfrom,
+                                                int kend, double eta, int sr_start, int &vp)
+{
+  if (kfrom >= kend)
+    return 1;
+  LllFrame<NQ, RingT> f{T, C, M, ring, vp, 0, 0, 0, 0};
+  const int rc = size_reduce_ool<NQ, RingT>(&f, kfrom, kend, eta, sr_start);
+  T            = f.T;
+  ring         = f.ring;
+  vp           = f.vp;
+  return rc;
+}
+
+// update_gso_row(k, k) for the rows of [k0, k1) whose cached row is shorter than that.  false: GSO failure.
+template <int NQ, class RingT>
+__device__ FPHIP_LLL_OOL int update_rows_ool(LllFrame<NQ, RingT> *fp, int k0, int k1)
+{
+  LllFrame<NQ, RingT> f = *fp;
+  uniformize(f);
+  k0     = uni(k0);
+  k1     = uni(k1);
+  int ok = 1;
+  for (int k = k0; k < k1 && ok; ++k)
+    if (uni(f.C.vc[f.M.phys(k)]) <= k)
+    {
+      if (!update_row_cached(f.T, f.C, f.M, f.ring, k, k))
+        ok = 0;
+      __threadfence_block();
+    }
+  *fp = f;
+  return ok;
+}
+template <int NQ, class RingT>
+__device__ __forceinline__ bool update_rows_call(Lattice<NQ> &T, LllCtx &C, SlotMap<NQ> &M, RingT &ring, int k0, int k1)
+{
+  LllFrame<NQ, RingT> f{T, C, M, ring, 0, 0, 0, 0, 0};
+  const int ok = update_rows_ool<NQ, RingT>(&f, k0, k1);
+  T            = f.T;
+  ring         = f.ring;
+  return ok != 0;
 }
 
 // the rows in position order (b2), after which the host rebuilds the identity-layout GSO

@@ -11,6 +11,8 @@
 // Both produce the SAME doubles (one fixed operation sequence of +, *, / per value, no contraction).
 #ifndef FPHIP_PRUNER_ENGINE_H
 #define FPHIP_PRUNER_ENGINE_H
+
+#include <atomic>
 #include <cstddef>
 
 namespace fphip_pruner
@@ -33,7 +35,8 @@ public:
   virtual int lookahead() const = 0;
   virtual const char *error() const { return ""; }
   // accounting (tests, bench): jobs evaluated by a kernel / inline on the host, kernel launches
-  unsigned long long device_jobs = 0, host_jobs = 0, launches = 0;
+  // (atomic: the host engine is one object shared by the service workers of an in-loop BKZ)
+  std::atomic<unsigned long long> device_jobs{0}, host_jobs{0}, launches{0};
 };
 
 // V_k(y) on the host; poly = k + 1 doubles of scratch

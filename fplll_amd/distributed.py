@@ -243,6 +243,13 @@ def slide_reduction_blocks(g, rank, world, gather, block_size, max_loops=0, stra
     from .gso import slide_potential
     assert g.batch == 1
     d = g.d
+    # the C entry points' rules (fphip_gso_slide_reduction_blocks): a caller generator would be consumed
+    # differently by every participant — the rerandomisations of the closing hkz, and with them the result,
+    # would depend on `world` — and a pass has at most 64 blocks (64-bit block masks)
+    if rnd is not None:
+        raise ValueError("slide_reduction_blocks: the block-parallel tour is defined without rerandomisation (rnd=None)")
+    if (d + block_size - 1) // block_size > 64:
+        raise ValueError("slide_reduction_blocks: more than 64 blocks per pass (d=%d, block_size=%d)" % (d, block_size))
     primal, dual = slide_blocks(d, block_size)
     is_dist = isinstance(gather, DistGather)
 

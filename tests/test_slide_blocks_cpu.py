@@ -135,3 +135,23 @@ def test_ranks_over_gloo_agree_with_the_single_participant():
     for r in range(2):
         assert out[r][1] == one[0] and out[r][3] == one[2] and out[r][4] == one[3]
         assert np.array_equal(np.array(out[r][2]), one[1])
+
+
+def test_block_parallel_tour_rejects_what_would_depend_on_the_participants():
+    """A caller generator would be drawn from differently by every participant (the closing hkz's
+    rerandomisations would depend on `world`), and a pass with more than 64 blocks does not fit the 64-bit
+    block mask — `1 << i` would be truncated to 0 and the pass would reduce nothing while reporting the block
+    clean.  Both are refused up front, here and in the C entry points (fphip_gso_slide_pass,
+    fphip_gso_slide_reduction_blocks)."""
+    from fplll_amd.distributed import LocalGather, slide_reduction_blocks
+    with pytest.raises(ValueError, match="rnd"):
+        slide_reduction_blocks(ToyBatch(_basis(1)), 0, 1, LocalGather(1), 5, rnd=lambda *a: 0)
+    with pytest.raises(ValueError, match="64 blocks"):
+        slide_reduction_blocks(ToyBatch(_basis(2, d=180, n=4)), 0, 1, LocalGather(1), 2)
+    import ctypes
+    from fplll_amd import _lib
+    src = open(os.path.join(os.path.dirname(_lib.LIB_PATH), "..", "csrc", "gso_host.hip")).read()
+    body = src[src.index('extern "C" int fphip_gso_slide_reduction_blocks'):]
+    body = body[:body.index("\n}\n")]
+    assert "if (rnd)\n    return FPHIP_UNSUPPORTED;" in body and "if (p > 64)\n    return FPHIP_UNSUPPORTED;" in body
+    assert ctypes  # (the library itself is exercised on the GPU: tests/test_zz_slide_gpu.py)
