@@ -25,16 +25,15 @@
 #define FPHIP_RING_REDUCE 8
 #endif
 
-// bytes of LDS per wave of the slot-mode reduction kernels (LLL / BKZ): none with the register streams of
-// lll_stream.h (LStream<NQ>::BYTES), with -DFPHIP_LLL_STREAM=0 the first generation's ring of single rows
+// bytes of LDS per wave of the slot-mode reduction kernels (LLL / BKZ): the block ring of lll_stream.h
+// (LStream<NQ>::BYTES), or with -DFPHIP_LLL_STREAM=0 the first generation's ring of single rows
 #ifndef FPHIP_LLL_STREAM
 #define FPHIP_LLL_STREAM 1
 #endif
 static inline size_t fphip_reduce_ring_bytes(int nq)
 {
 #if FPHIP_LLL_STREAM
-  (void)nq;
-  return 0;
+  return nq == 3 ? 15360 : 16384;
 #else
   return (size_t)FPHIP_RING_REDUCE * (size_t)((nq + 1) / 2) * 1024;
 #endif

@@ -55,6 +55,7 @@ __global__ void __launch_bounds__(256)
   const int d = P.d, n = P.n, ldd = P.ldd, ldn = P.ldn;
 #if FPHIP_LLL_PROF
   const unsigned long long pk0 = LStream<NQ>::now();
+  const unsigned long long pc0 = __builtin_readcyclecounter();  // s_memtime: shader clock
   unsigned long long piter     = 0;
   bool pany                    = false;
 #endif
@@ -111,6 +112,7 @@ __global__ void __launch_bounds__(256)
     atomicAdd(&fphip_lll_prof_dev[4 * LS_KINDS + 0], LStream<NQ>::now() - pk0);
     atomicAdd(&fphip_lll_prof_dev[4 * LS_KINDS + 1], piter);
     atomicAdd(&fphip_lll_prof_dev[4 * LS_KINDS + 2], 1ull);
+    atomicAdd(&fphip_lll_prof_dev[4 * LS_KINDS + 3], (unsigned long long)__builtin_readcyclecounter() - pc0);
   }
 #endif
 }

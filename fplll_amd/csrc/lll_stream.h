@@ -5,31 +5,32 @@
 // gso.h:314-331), the column recurrence of update_gso_row (gso_interface.cpp:143-158), the mu sweep of
 // babai (lll.cpp:202-214) and its integer row operation (gso.cpp:84-158) — all have the shape
 //     for step s:  v = ROW_s;  state = f(state, v, scalar_s)
-// with ROW_s a contiguous row in HBM whose address does not depend on the state.
-//
-// The first generation (Ring in gso_wave.h) streamed the rows through an LDS ring filled by global_load_lds
-// and spent 57 issued instructions and 500 cycles per row on a lone wave (profiles/r04_lll_kernel_pmc_summary.txt:
-// 13 600 instructions per LLL iteration).  Rebuilding that ring in blocks of four rows with double-buffered LDS
-// reads, scalar lane masks and precomputed windows (this file's first form this round, commit 98065d4) passed every
-// parity test and took the batched LLL from 171 to 245 lattices/s, but its per-phase timers
-// (profiles/r05_lll_phase_timers_lds_dma_*.log) still showed 88-205 ns per streamed row: one global_load_lds
-// instruction stalls the issuing wave for ~60 cycles (MI355X_MICROARCH.md, "LDS-DMA piece issue cost"), and the
-// 16 KiB of ring a wave can have hold 8-12 rows for the 400-900 cycles a row is under way.
-//
-// The rows therefore go through REGISTERS now:
-//   * one raw buffer load per row and 64-lane chunk — descriptor base, scalar row offset, per-lane element
-//     offset (the slot gather is the lane's own offset), no address arithmetic on the vector unit;
-//   * D rows in flight (16 up to 128 columns, 8 above) in a rotating window of registers: the loop body is D
-//     rows unrolled, every row = use the window entry, then refill it with the row D steps ahead; the waits are
-//     the compiler's own vmcnt bookkeeping (the loads are ordinary tracked instructions);
-//   * loops are chunk-major: the register that holds the step's scalar is a compile-time constant of the
-//     unrolled group (Gram, recurrence) or chosen by one branch per row (sweep, row operation);
-//   * lane predicates of the recurrence and the sweep are 64-bit scalar masks applied with v_cndmask_b32_e64;
+// with ROW_s a contiguous row in HBM.  The first generation (Ring in gso_wave.h) spent 57 issued
+// instructions per streamed row, most of them scalar bookkeeping (ring indices modulo R, a window test
+// and an m0 save / restore per DMA instruction, a branch on the chunk that owns the step's scalar, a
+// pipeline-state switch), and exposed the LDS latency of every row: a lone wave needed 500 cycles per row
+// (profiles/r04_lll_kernel_pmc_summary.txt: 13 600 instructions per LLL iteration).  Here
+//   * rows move in BLOCKS of U (4 for up to 128 columns, 2 above): one counted s_waitcnt, one chunk
+//     dispatch, one ring-index update and U x NQ ds_read with compile-time offsets per block;
+//   * the LDS reads of block b+1 are issued BEFORE the arithmetic of block b (two register sets), so a
+//     lone wave no longer waits for LDS once per row;
+//   * a DMA instruction is s_mov m0 / s_mov exec / global_load_lds / s_mov exec — the window of a row is a
+//     lane mask, m0 is declared clobbered instead of saved;
+//   * lane predicates of the recurrence and the sweep are 64-bit scalar masks applied with
+//     v_cndmask_b32_e64; the per-step part of a mask is one s_lshl_b64 + s_and_b64;
 //   * the integer row operation streams only the rows whose multiplier is not zero, and on lattices below
-//     2^24 with 32-bit multipliers it is one v_mad_i64_i32 per chunk on the low words;
+//     2^24 with 32-bit multipliers it is one v_mad_i64_i32 per chunk;
 //   * the sums start from -0.0 (x + -0.0 == x for every x) instead of selecting the first product.
-// No LDS at all.  The arithmetic — every product, sum, quotient and rounding, and their order per output
-// element — is the first generation's, which is the reference's.
+// The arithmetic — every product, sum, quotient and rounding, and their order per output element — is the
+// first generation's, which is the reference's.
+//
+// Tried and measured against this (commit 7c6a3d6, profiles/r05_lll_phase_timers_register_streams_*.log): the same
+// phases through REGISTERS — one raw buffer load per row and chunk (the slot gather as the lane's own offset),
+// 16 rows in flight in a rotating register window, no LDS.  Parity green, but 129 ns per Gram row instead of 88,
+// 137 LLL/s at batch 2048 instead of 245, 6.45 s for a lone lattice instead of 5.55: a gathered dword load per
+// 64 lanes costs the memory pipeline more than a sixteenth of a 1-KiB LDS-DMA row, and 256 registers per wave leave
+// the same two waves per SIMD.  The contiguous phases (sweep, row operation) were 20 % faster per row that way and
+// 2.5 us slower to start; not kept.
 #ifndef FPHIP_LLL_STREAM_H
 #define FPHIP_LLL_STREAM_H
 
@@ -40,6 +41,15 @@
 namespace fphip
 {
 
+// every kernel that includes this header runs with dynamic LDS only: the rings start at LDS address 0
+extern __shared__ __attribute__((aligned(16))) char fphip_lds[];
+
+__device__ __forceinline__ unsigned long long ls_uni64(unsigned long long v)
+{
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+  return ((unsigned long long)hi << 32) | lo;
+}
 // m ? a : b per lane, the mask in a scalar register pair
 __device__ __forceinline__ int ls_sel_i32(unsigned long long m, int a, int b)
 {
@@ -62,28 +72,8 @@ __device__ __forceinline__ double ls_wl_f64(double val, int lane, double old)
   return __hiloint2double(hi, lo);
 }
 
-// an array of `bytes` bytes as a buffer resource (untyped 32-bit data, range-checked: reads behind the end give 0)
-typedef unsigned ls_v2u __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t ls_rsrc(const void *base, unsigned bytes)
-{
-  return __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, (int)bytes, 0x00020000);
-}
-__device__ __forceinline__ unsigned ls_ld32(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
-{
-  return (unsigned)__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0);
-}
-__device__ __forceinline__ ls_v2u ls_ld64(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
-{
-  return __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0);
-}
-__device__ __forceinline__ double ls_f64(ls_v2u v) { return __hiloint2double((int)v.y, (int)v.x); }
-__device__ __forceinline__ long long ls_i64(ls_v2u v)
-{
-  return (long long)(((unsigned long long)v.y << 32) | (unsigned long long)v.x);
-}
-
 // -DFPHIP_LLL_PROF=1 (tests/perf/build_lll_variants.sh, libPROF.so): every phase adds its count, rows, start-up
-// time (first group computed) and total time, in ticks of the 100 MHz real-time counter, to pf[4 * KIND ..]
+// time (first block landed) and total time, in ticks of the 100 MHz real-time counter, to pf[4 * KIND ..]
 #ifndef FPHIP_LLL_PROF
 #define FPHIP_LLL_PROF 0
 #endif
@@ -99,15 +89,22 @@ enum
 
 template <int NQ> struct LStream
 {
-  static constexpr int D     = (NQ <= 2) ? 16 : 8;  // rows in flight
-  static constexpr int BYTES = 0;                   // no LDS
+  static constexpr int U    = (NQ <= 2) ? 4 : 2;                       // rows per block
+  static constexpr int ROWB = 512 * NQ;                                // bytes of a ring row (64 NQ doubles)
+  static constexpr int NB   = (NQ == 1) ? 8 : (NQ == 3 ? 5 : 4);       // blocks in the ring
+  static constexpr int BLKB = U * ROWB;
+  static constexpr int BYTES = NB * BLKB;                              // per wave: 16 / 16 / 15 / 16 KiB
+  unsigned base;    // LDS byte address of this wave's ring
   int lane;
+  unsigned lane16;
 #if FPHIP_LLL_PROF
   unsigned long long pf[4 * LS_KINDS];
 #endif
-  __device__ __forceinline__ void init(int, int lane_)
+  __device__ __forceinline__ void init(int wave, int lane_)
   {
-    lane = lane_;
+    base   = (unsigned)(wave * BYTES);
+    lane   = lane_;
+    lane16 = (unsigned)lane_ * 16u;
 #if FPHIP_LLL_PROF
     for (int i = 0; i < 4 * LS_KINDS; ++i)
       pf[i] = 0;
@@ -133,31 +130,185 @@ template <int NQ> struct LStream
   }
 };
 
-// One phase: nrows rows through the register window.  Ph provides
-//   struct Row                      this lane's words of one row
-//   fetch(Row &, s)                 issue the loads of row s (any s >= 0: behind the end a valid row is read again)
-//   group(Row (&)[D], s0)           rows s0 .. s0+D-1: for each, the arithmetic (rows < nrows), then fetch(s + D)
+// bytes [0, len) of the row at p (wave-uniform, 16-byte aligned) to LDS address dst (wave-uniform) in IPR
+// instructions of 1 KiB; len <= 0 (and every instruction whose span lies behind len): lane 0 alone fetches
+// the row's first 16 bytes again — the count of instructions in flight per row is always IPR.
+template <int IPR>
+__device__ __forceinline__ void ls_dma_row(const char *p_, int len, unsigned dst_, unsigned lane16)
+{
+  const char *p      = (const char *)ls_uni64((unsigned long long)p_);
+  const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)dst_);
+  const int nl       = __builtin_amdgcn_readfirstlane((len + 15) >> 4);  // 16-byte lanes
+  const unsigned long long mA = nl >= 64 ? ~0ull : (nl > 0 ? ((1ull << nl) - 1) : 1ull);
+  if constexpr (IPR == 1)
+  {
+    asm volatile("s_mov_b32 m0, %1\n\t"
+                 "s_mov_b64 exec, %2\n\t"
+                 "global_load_lds_dwordx4 %3, %0\n\t"
+                 "s_mov_b64 exec, -1"
+                 :
+                 : "s"(p), "s"(dst), "s"(mA), "v"(lane16)
+                 : "memory", "m0");
+  }
+  else
+  {
+    const bool two               = nl > 64;
+    const unsigned long long mB  = two ? (nl >= 128 ? ~0ull : ((1ull << (nl - 64)) - 1)) : 1ull;
+    const char *pB               = two ? p + 1024 : p;
+    const unsigned dstB          = two ? dst + 1024 : dst;
+    asm volatile("s_mov_b32 m0, %2\n\t"
+                 "s_mov_b64 exec, %4\n\t"
+                 "global_load_lds_dwordx4 %6, %0\n\t"
+                 "s_mov_b32 m0, %3\n\t"
+                 "s_mov_b64 exec, %5\n\t"
+                 "global_load_lds_dwordx4 %6, %1\n\t"
+                 "s_mov_b64 exec, -1"
+                 :
+                 : "s"(p), "s"(pB), "s"(dst), "s"(dstB), "s"(mA), "s"(mB), "v"(lane16)
+                 : "memory", "m0");
+  }
+}
+
+// the same with the lane masks of a window that many rows share, computed once
+struct LsWin
+{
+  unsigned long long mA, mB;
+  unsigned offB;  // 1024 when the second instruction carries data, else 0 (lane 0 repeats the first 16 bytes)
+};
+__device__ __forceinline__ LsWin ls_make_win(int len)
+{
+  const int nl = __builtin_amdgcn_readfirstlane((len + 15) >> 4);
+  LsWin w;
+  w.mA           = nl >= 64 ? ~0ull : (nl > 0 ? ((1ull << nl) - 1) : 1ull);
+  const bool two = nl > 64;
+  w.mB           = two ? (nl >= 128 ? ~0ull : ((1ull << (nl - 64)) - 1)) : 1ull;
+  w.offB         = two ? 1024u : 0u;
+  return w;
+}
+template <int IPR>
+__device__ __forceinline__ void ls_dma_win(const char *p_, const LsWin &w, unsigned dst_, unsigned lane16)
+{
+  const char *p      = (const char *)ls_uni64((unsigned long long)p_);
+  const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)dst_);
+  if constexpr (IPR == 1)
+  {
+    asm volatile("s_mov_b32 m0, %1\n\t"
+                 "s_mov_b64 exec, %2\n\t"
+                 "global_load_lds_dwordx4 %3, %0\n\t"
+                 "s_mov_b64 exec, -1"
+                 :
+                 : "s"(p), "s"(dst), "s"(w.mA), "v"(lane16)
+                 : "memory", "m0");
+  }
+  else
+  {
+    const char *pB      = p + w.offB;
+    const unsigned dstB = dst + w.offB;
+    asm volatile("s_mov_b32 m0, %2\n\t"
+                 "s_mov_b64 exec, %4\n\t"
+                 "global_load_lds_dwordx4 %6, %0\n\t"
+                 "s_mov_b32 m0, %3\n\t"
+                 "s_mov_b64 exec, %5\n\t"
+                 "global_load_lds_dwordx4 %6, %1\n\t"
+                 "s_mov_b64 exec, -1"
+                 :
+                 : "s"(p), "s"(pB), "s"(dst), "s"(dstB), "s"(w.mA), "s"(w.mB), "v"(lane16)
+                 : "memory", "m0");
+  }
+}
+
+template <int K> __device__ __forceinline__ void ls_wait()
+{
+  static_assert(K >= 0 && K <= 63, "vmcnt is a 6-bit field");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K) : "memory");
+}
+// at most `blocks` blocks of IPB instructions may still be in flight
+template <int IPB, int MAXB> __device__ __forceinline__ void ls_wait_dyn(int blocks)
+{
+  if constexpr (MAXB <= 0)
+    ls_wait<0>();
+  else
+  {
+    if (blocks >= MAXB)
+      ls_wait<(MAXB * IPB <= 63 ? MAXB * IPB : 63)>();
+    else
+      ls_wait_dyn<IPB, MAXB - 1>(blocks);
+  }
+}
+
+// One phase: nrows rows through the ring.  Ph provides
+//   IPR                               DMA instructions per row
+//   issue<FULL>(dst)                  request the next row (or a dummy behind the last) into LDS address dst;
+//                                     FULL: the row is known to exist
+//   struct Regs; load(Regs &, addr)   this lane's words of the U rows of the block at LDS address addr
+//   compute(const Regs &, s0)         the arithmetic of rows s0 .. s0+U-1 (those below nrows)
 template <int NQ, class Ph> __device__ __forceinline__ void ls_run(LStream<NQ> &S, Ph &ph, int nrows)
 {
-  constexpr int D = LStream<NQ>::D;
+  using L           = LStream<NQ>;
+  constexpr int U   = L::U;
+  constexpr int NB  = L::NB;
+  constexpr int IPB = U * Ph::IPR;
+  static_assert((NB - 1) * IPB <= 63, "the ring holds more instructions than vmcnt can count");
   if (nrows <= 0)
     return;
-  const unsigned long long pt0 = LStream<NQ>::now();
-  unsigned long long pt1       = pt0;
-  typename Ph::Row win[D];
-#pragma unroll
-  for (int u = 0; u < D; ++u)
-    ph.fetch(win[u], u);
-#pragma unroll 1
-  for (int s0 = 0; s0 < nrows; s0 += D)
+  const int nblk = (nrows + U - 1) / U;
+  // everything older (stores of the previous phase, ordinary loads) is retired first: the counted waits
+  // below then only ever see this phase's DMA instructions
+  const unsigned long long pt0 = L::now();
+  ls_wait<0>();
+  unsigned hoff = 0;  // ring offset of the block slot to fill next
+  int rreq      = 0;  // rows requested so far
+  auto issue_block = [&]()
   {
-    ph.group(win, s0);
-#if FPHIP_LLL_PROF
-    if (s0 == 0)
-      pt1 = LStream<NQ>::now();
-#endif
+    if (rreq + U <= nrows)
+    {  // every row of the block exists
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        ph.template issue<true>(S.base + hoff + (unsigned)(u * L::ROWB));
+    }
+    else
+    {
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        ph.template issue<false>(S.base + hoff + (unsigned)(u * L::ROWB));
+    }
+    rreq += U;
+    hoff = (hoff + L::BLKB == (unsigned)L::BYTES) ? 0u : hoff + L::BLKB;
+  };
+  const int npro = nblk < NB ? nblk : NB;
+#pragma unroll 1
+  for (int i = 0; i < npro; ++i)
+    issue_block();
+  ls_wait_dyn<IPB, NB - 1>(npro - 1);  // block 0 has landed
+  const unsigned long long pt1 = L::now();
+  typename Ph::Regs A, B;
+  unsigned toff = 0;
+  ph.load(A, S.base + toff);
+  toff = (toff + L::BLKB == (unsigned)L::BYTES) ? 0u : toff + L::BLKB;
+#pragma unroll 1
+  for (int b = 0; b < nblk; ++b)
+  {
+    const int rest = nblk - b - 2;  // blocks behind block b+1 that exist
+    if (rest >= 0)
+    {
+      // blocks 0 .. min(b + NB, nblk) - 1 have been requested: all but min(NB - 2, rest) of them must be here
+      if (rest >= NB - 2)
+        ls_wait<(NB - 2) * IPB>();
+      else
+        ls_wait_dyn<IPB, NB - 2>(rest);
+      ph.load(B, S.base + toff);
+      toff = (toff + L::BLKB == (unsigned)L::BYTES) ? 0u : toff + L::BLKB;
+    }
+    ph.compute(A, b * U);
+    if (b + NB < nblk)
+    {
+      // the slot of block b is free once its reads have returned (they were issued before those of B)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      issue_block();
+    }
+    A = B;
   }
-  S.prof_add(Ph::KIND, (unsigned long long)nrows, pt1 - pt0, LStream<NQ>::now() - pt0);
+  S.prof_add(Ph::KIND, (unsigned long long)nrows, pt1 - pt0, L::now() - pt0);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -168,59 +319,75 @@ template <int NQ, bool F32> struct GramPh
 {
   using L = LStream<NQ>;
   static constexpr int KIND = LS_GRAM;
-  __amdgpu_buffer_rsrc_t rs;  // bfT32 or bfT of the lattice
-  unsigned stride;            // bytes per row
-  int nrows;
+  static constexpr int IPR = F32 ? 1 : (NQ + 1) / 2;
+  const char *p;
+  long stride;
+  LsWin win;  // bytes [0, len) of every row
+  int nrows, srq;
+  unsigned lane16;
   unsigned off[NQ];  // byte offset of this lane's element in a row (slot * 4 or slot * 8)
   double (&g)[NQ];
   const double (&bk)[NQ];
-  int qact;  // chunks 0 .. qact-1 hold a position that is wanted
-  struct Row
+  int qact;  // chunks 0 .. qact-1 hold a position <= last
+  struct Regs
   {
-    typename std::conditional<F32, unsigned, ls_v2u>::type x[NQ];
+    typename std::conditional<F32, float, double>::type x[L::U][NQ];
   };
-  __device__ __forceinline__ void fetch(Row &R, int s) const
+  template <bool FULL> __device__ __forceinline__ void issue(unsigned dst)
   {
-    const unsigned so = (unsigned)(s < nrows ? s : nrows - 1) * stride;  // behind the end: the last row again
+    if (FULL || srq < nrows)
+    {
+      ls_dma_win<IPR>(p, win, dst, lane16);
+      p += stride;
+    }
+    else
+      ls_dma_row<IPR>(p - stride, 0, dst, lane16);  // (a dummy: the last row's first bytes)
+    ++srq;
+  }
+  __device__ __forceinline__ void load(Regs &R, unsigned a) const
+  {
+    using E = typename std::conditional<F32, float, double>::type;
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
-      if (q < qact)
-      {
-        if constexpr (F32)
-          R.x[q] = ls_ld32(rs, off[q], so);
-        else
-          R.x[q] = ls_ld64(rs, off[q], so);
-      }
+#pragma unroll
+      for (int u = 0; u < L::U; ++u)
+        R.x[u][q] = *(const E *)(fphip_lds + (a + off[q] + (unsigned)(u * L::ROWB)));
   }
-  __device__ __forceinline__ double val(const Row &R, int q) const
+  __device__ __forceinline__ void compute(const Regs &R, int s0)
   {
-    if constexpr (F32)
-      return (double)__uint_as_float(R.x[q]);
-    else
-      return ls_f64(R.x[q]);
-  }
-  __device__ __forceinline__ void group(Row (&W)[L::D], int s0)
-  {
+    const int nv = nrows - s0;  // >= 1
     dispatch_chunk<NQ>(s0,
                        [&](auto cq_, int cc0)
                        {
                          constexpr int cq = decltype(cq_)::value;
+                         double bkc[L::U];
 #pragma unroll
-                         for (int u = 0; u < L::D; ++u)
-                         {
-                           if (s0 + u < nrows)
+                         for (int u = 0; u < L::U; ++u)
+                           bkc[u] = g_rl_f64(bk[cq], cc0 + u);
+#pragma unroll
+                         for (int q = 0; q < NQ; ++q)
+                           if (q < qact)
                            {
-                             const double bkc = g_rl_f64(bk[cq], cc0 + u);
+                             if (nv >= L::U)
+                             {
 #pragma unroll
-                             for (int q = 0; q < NQ; ++q)
-                               if (q < qact)
+                               for (int u = 0; u < L::U; ++u)
                                {
-                                 const double pr = bkc * val(W[u], q);
+                                 const double pr = bkc[u] * (double)R.x[u][q];
                                  g[q]            = g[q] + pr;
                                }
+                             }
+                             else
+                             {
+#pragma unroll
+                               for (int u = 0; u < L::U; ++u)
+                                 if (u < nv)
+                                 {
+                                   const double pr = bkc[u] * (double)R.x[u][q];
+                                   g[q]            = g[q] + pr;
+                                 }
+                             }
                            }
-                           fetch(W[u], s0 + u + L::D);
-                         }
                        });
   }
 };
@@ -234,9 +401,12 @@ template <int NQ> struct RecPh
 {
   using L = LStream<NQ>;
   static constexpr int KIND = LS_REC;
-  __amdgpu_buffer_rsrc_t rs;  // muT of the lattice
-  unsigned stride;
-  int nrows;
+  static constexpr int IPR = (NQ + 1) / 2;
+  const char *p;
+  long stride;
+  LsWin win;  // bytes [0, len) of every row
+  int nrows, srq;
+  unsigned lane16;
   int lane;
   unsigned off[NQ];
   double (&acc)[NQ];
@@ -244,27 +414,37 @@ template <int NQ> struct RecPh
   unsigned long long bmask[NQ];  // lanes whose position lies in [start, last]
   bool diag;
   int kappa;
-  struct Row
+  struct Regs
   {
-    ls_v2u m[NQ];
+    double m[L::U][NQ];
   };
-  __device__ __forceinline__ void fetch(Row &R, int s) const
+  template <bool FULL> __device__ __forceinline__ void issue(unsigned dst)
   {
-    const unsigned so = (unsigned)(s < nrows ? s : nrows - 1) * stride;
+    if (FULL || srq < nrows)
+    {
+      ls_dma_win<IPR>(p, win, dst, lane16);
+      p += stride;
+    }
+    else
+      ls_dma_row<IPR>(p - stride, 0, dst, lane16);
+    ++srq;
+  }
+  __device__ __forceinline__ void load(Regs &R, unsigned a) const
+  {
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
-      if (bmask[q] != 0)
-        R.m[q] = ls_ld64(rs, off[q], so);
+#pragma unroll
+      for (int u = 0; u < L::U; ++u)
+        R.m[u][q] = *(const double *)(fphip_lds + (a + off[q] + (unsigned)(u * L::ROWB)));
   }
-  __device__ __forceinline__ void group(Row (&W)[L::D], int s0)
+  __device__ __forceinline__ void compute(const Regs &R, int s0)
   {
     dispatch_chunk<NQ>(s0,
                        [&](auto kq_, int kk0)
                        {
                          constexpr int kq = decltype(kq_)::value;
 #pragma unroll
-                         for (int u = 0; u < L::D; ++u)
-                         {
+                         for (int u = 0; u < L::U; ++u)
                            if (s0 + u < nrows)
                            {
                              const int kk    = kk0 + u;
@@ -278,7 +458,7 @@ template <int NQ> struct RecPh
                                {
                                  const unsigned long long mk =
                                      (q == kq) ? (bmask[q] & ((~1ull) << kk)) : bmask[q];  // positions > k
-                                 double m = ls_f64(W[u].m[q]);
+                                 double m = R.m[u][q];
                                  if (diag)
                                    m = (lane + 64 * q == kappa) ? muk : m;
                                  const double t  = m * rk;
@@ -286,8 +466,6 @@ template <int NQ> struct RecPh
                                  acc[q]          = ls_sel_f64(mk, uu, acc[q]);
                                }
                            }
-                           fetch(W[u], s0 + u + L::D);
-                         }
                        });
   }
 };
@@ -302,49 +480,65 @@ __device__ __forceinline__ double ls_rnd_we(double b, int e)
 }
 
 // ---------------------------------------------------------------------------------------------------
-// babai's sweep, lll.cpp:202-214: rows j = kappa-1 .. sr_start of mu, descending (row s is j = kappa-1-s);
-// lane k owns babai_mu[k].
+// babai's sweep, lll.cpp:202-214: rows j = kappa-1 .. sr_start of mu, descending; lane k owns
+// babai_mu[k].  The stream is aligned to blocks of U rows: row s is j = jtop - s with
+// jtop = (kappa - 1) | (U - 1), so that a block never straddles a chunk of 64.
 // ---------------------------------------------------------------------------------------------------
 template <int NQ> struct SweepPh
 {
   using L = LStream<NQ>;
   static constexpr int KIND = LS_SWEEP;
-  __amdgpu_buffer_rsrc_t rs;  // mu of the lattice
-  unsigned stride;            // ldd * 8
-  int kappa, sr_start;
+  static constexpr int IPR = (NQ + 1) / 2;
+  const char *mu;  // T.mu
+  long stride;     // ldd * 8
+  int jtop, kappa, sr_start, srq;
+  unsigned lane16;
   int lane;
   const SlotMap<NQ> &M;
   double (&bm)[NQ];
-  double (&xs)[NQ];              // the multipliers X_j (lane j), 0 where none
+  double (&xs)[NQ];             // the multipliers X_j (lane j), 0 where none
   const int (&e)[NQ];
   unsigned long long (&nz)[NQ];  // rows of each chunk with X_j != 0
   unsigned long long srmask[NQ];  // lanes k >= sr_start
-  struct Row
+  struct Regs
   {
-    ls_v2u m[NQ];
+    double m[L::U][NQ];
   };
-  __device__ __forceinline__ void fetch(Row &R, int s) const
+  template <bool FULL> __device__ __forceinline__ void issue(unsigned dst)
   {
-    int j = kappa - 1 - s;
-    j     = j < 0 ? 0 : j;  // behind the last row: row 0 again, never used
-    const unsigned so = (unsigned)M.phys(j) * stride;
-    const int qj      = j >> 6;  // mu(j, k) is wanted for k < j only
+    const int j = jtop - srq;
+    ++srq;
+    if (j < kappa && j > sr_start)
+    {  // mu(j, 0 .. j-1); row sr_start itself has nothing to its left that is reduced
+      const int slot = M.phys(j);
+      ls_dma_row<IPR>(mu + (long)slot * stride, j * 8, dst, lane16);
+    }
+    else
+      ls_dma_row<IPR>(mu, 0, dst, lane16);
+  }
+  __device__ __forceinline__ void load(Regs &R, unsigned a) const
+  {
+    const unsigned la = a + (unsigned)lane * 8u;
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
-      if (q <= qj)
-        R.m[q] = ls_ld64(rs, (unsigned)(lane + 64 * q) * 8u, so);
-  }
-  __device__ __forceinline__ void group(Row (&W)[L::D], int s0)
-  {
 #pragma unroll
-    for (int u = 0; u < L::D; ++u)
-    {
-      const int j = kappa - 1 - (s0 + u);
-      if (j >= sr_start)
-        dispatch_chunk<NQ>(j,
-                           [&](auto jq_, int jj)
+      for (int u = 0; u < L::U; ++u)
+        R.m[u][q] = *(const double *)(fphip_lds + (la + (unsigned)(q * 512 + u * L::ROWB)));
+  }
+  __device__ __forceinline__ void compute(const Regs &R, int s0)
+  {
+    const int jhi = jtop - s0;
+    dispatch_chunk<NQ>(jhi,
+                       [&](auto jq_, int jjhi)
+                       {
+                         constexpr int jq = decltype(jq_)::value;
+#pragma unroll
+                         for (int u = 0; u < L::U; ++u)
+                         {
+                           const int j = jhi - u;
+                           if (j < kappa && j >= sr_start)
                            {
-                             constexpr int jq = decltype(jq_)::value;
+                             const int jj     = jjhi - u;
                              const double bmj = g_rl_f64(bm[jq], jj);
                              const int ej     = __builtin_amdgcn_readlane(e[jq], jj);
                              const double X   = ls_rnd_we(bmj, ej);
@@ -358,14 +552,14 @@ template <int NQ> struct SweepPh
                                  // chunks below jq hold only k < j; the chunk of j itself needs the test
                                  const unsigned long long mk =
                                      (q == jq) ? (srmask[q] & ((1ull << jj) - 1)) : srmask[q];
-                                 const double t  = X * ls_f64(W[u].m[q]);
+                                 const double t  = X * R.m[u][q];
                                  const double uu = bm[q] - t;
                                  bm[q]           = ls_sel_f64(mk, uu, bm[q]);
                                }
                              }
-                           });
-      fetch(W[u], s0 + u + L::D);
-    }
+                           }
+                         }
+                       });
   }
 };
 
@@ -396,35 +590,45 @@ template <int NQ, bool SMALL> struct AxpyPh
 {
   using L = LStream<NQ>;
   static constexpr int KIND = LS_AXPY;
-  __amdgpu_buffer_rsrc_t rs;  // b of the lattice
-  unsigned stride;            // ldn * 8
+  static constexpr int IPR = (NQ + 1) / 2;
+  const char *b;  // T.b
+  long stride;    // ldn * 8
+  LsWin win;      // bytes [0, n * 8) of every row
+  unsigned lane16;
   int lane;
   const SlotMap<NQ> &M;
   long long (&bv)[NQ];
   const long long (&lxv)[NQ];  // multiplier of row j in lane j
   RowCursor<NQ> ic, cc;        // rows still to request / to apply
-  struct Row
+  struct Regs
   {
-    typename std::conditional<SMALL, unsigned, ls_v2u>::type w[NQ];
+    typename std::conditional<SMALL, int, long long>::type w[L::U][NQ];
   };
-  __device__ __forceinline__ void fetch(Row &R, int)
+  template <bool FULL> __device__ __forceinline__ void issue(unsigned dst)
   {
-    int j = ic.next();
-    j     = j < 0 ? 0 : j;  // behind the last row: row 0 again, never used
-    const unsigned so = (unsigned)M.phys(j) * stride;
+    const int j = ic.next();
+    if (FULL || j >= 0)
+    {
+      const int slot = M.phys(j);
+      ls_dma_win<IPR>(b + (long)slot * stride, win, dst, lane16);
+    }
+    else
+      ls_dma_row<IPR>(b, 0, dst, lane16);
+  }
+  __device__ __forceinline__ void load(Regs &R, unsigned a) const
+  {
+    using E           = typename std::conditional<SMALL, int, long long>::type;
+    const unsigned la = a + (unsigned)lane * 8u;
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
-    {
-      if constexpr (SMALL)
-        R.w[q] = ls_ld32(rs, (unsigned)(lane + 64 * q) * 8u, so);  // (the low words)
-      else
-        R.w[q] = ls_ld64(rs, (unsigned)(lane + 64 * q) * 8u, so);
-    }
+#pragma unroll
+      for (int u = 0; u < L::U; ++u)
+        R.w[u][q] = *(const E *)(fphip_lds + (la + (unsigned)(q * 512 + u * L::ROWB)));
   }
-  __device__ __forceinline__ void group(Row (&W)[L::D], int s0)
+  __device__ __forceinline__ void compute(const Regs &R, int)
   {
 #pragma unroll
-    for (int u = 0; u < L::D; ++u)
+    for (int u = 0; u < L::U; ++u)
     {
       const int j = cc.next();
       if (j >= 0)
@@ -433,20 +637,18 @@ template <int NQ, bool SMALL> struct AxpyPh
         dispatch_chunk<NQ>(j, [&](auto jq_, int jj) { lx = g_rl_i64(lxv[decltype(jq_)::value], jj); });
         if constexpr (SMALL)
         {
-          const int sx = (int)lx;
+          const int s = (int)lx;
 #pragma unroll
           for (int q = 0; q < NQ; ++q)
-            bv[q] = bv[q] + (long long)(int)W[u].w[q] * (long long)sx;
+            bv[q] = bv[q] + (long long)R.w[u][q] * (long long)s;
         }
         else
         {
 #pragma unroll
           for (int q = 0; q < NQ; ++q)
-            bv[q] = (long long)((unsigned long long)bv[q] +
-                                (unsigned long long)ls_i64(W[u].w[q]) * (unsigned long long)lx);
+            bv[q] = (long long)((unsigned long long)bv[q] + (unsigned long long)R.w[u][q] * (unsigned long long)lx);
         }
       }
-      fetch(W[u], s0 + u + L::D);
     }
   }
 };

@@ -9,7 +9,7 @@
 namespace fphip
 {
 
-// The streaming machinery of the slot-mode kernels: the register streams of lll_stream.h (no LDS), or (build with
+// The streaming machinery of the slot-mode kernels: the block streams of lll_stream.h, or (build with
 // -DFPHIP_LLL_STREAM=0: the A/B and fallback build) the first generation's ring of single rows.
 #ifndef FPHIP_LLL_STREAM
 #define FPHIP_LLL_STREAM 1
@@ -37,7 +37,8 @@ template <int NQ> struct ReduceRing : Ring<NQ, (NQ + 1) / 2, FPHIP_RING_REDUCE>
   }
 };
 #endif
-static_assert((ReduceRing<1>::BYTES == 0 && ReduceRing<4>::BYTES == 0) || !FPHIP_LLL_STREAM, "fphip_reduce_ring_bytes");
+static_assert(ReduceRing<1>::BYTES == 16384 && ReduceRing<2>::BYTES == 16384 || !FPHIP_LLL_STREAM, "fphip_reduce_ring_bytes");
+static_assert(ReduceRing<3>::BYTES == 15360 && ReduceRing<4>::BYTES == 16384 || !FPHIP_LLL_STREAM, "fphip_reduce_ring_bytes");
 
 struct LllCtx
 {
@@ -304,7 +305,7 @@ __device__ __forceinline__ bool update_row_cached(Lattice<NQ> &T, LllCtx &C, con
   return __all(ok);
 }
 
-// ---- the same on the register streams of lll_stream.h (round 5) ------------------------------------------
+// ---- the same on the block streams of lll_stream.h (round 5) ------------------------------------------
 template <int NQ>
 __device__ __forceinline__ bool update_row_cached(Lattice<NQ> &T, LllCtx &C, const SlotMap<NQ> &M,
                                                   LStream<NQ> &S, int kappa, int last)
@@ -348,13 +349,15 @@ __device__ __forceinline__ bool update_row_cached(Lattice<NQ> &T, LllCtx &C, con
     if (j < kappa && j <= last)
       rd[q] = T.rdg[M.sl[q]];
   }
-  // rows of the transposed arrays are gathered by slot: this lane's element of a row (lanes beyond the last
-  // position read slot 0: never used)
-  unsigned gslot[NQ];
+  // rows are gathered by slot: only slots up to the largest one among positions <= last are needed
+  int hi_slot = 0;
 #pragma unroll
   for (int q = 0; q < NQ; ++q)
-    gslot[q] = (lane + 64 * q < T.d) ? (unsigned)M.sl[q] : 0u;
-  int nmiss = 0;
+    if (lane + 64 * q <= last)
+      hi_slot = max(hi_slot, M.sl[q]);
+  hi_slot             = wave_max_i32(hi_slot);
+  const int row_bytes = min((hi_slot + 1) * 8, ldd * 8);
+  int nmiss           = 0;
   unsigned long long missb[NQ];
 #pragma unroll
   for (int q = 0; q < NQ; ++q)
@@ -419,6 +422,8 @@ __device__ __forceinline__ bool update_row_cached(Lattice<NQ> &T, LllCtx &C, con
     const double gkk_old = gfrow[sk];
     const bool want_diag = uni((gkk_old != gkk_old) ? 1 : 0) != 0 && last == kappa - 1;
     const int glast      = want_diag ? kappa : last;
+    const int ghi        = want_diag ? max(hi_slot, sk) : hi_slot;
+    const int grow_bytes = min((ghi + 1) * 8, ldd * 8);
     const int gqact      = (glast >> 6) + 1;
     double g[NQ];
 #pragma unroll
@@ -434,18 +439,18 @@ __device__ __forceinline__ bool update_row_cached(Lattice<NQ> &T, LllCtx &C, con
     }
     if (T.f32ok)
     {  // every row is below 2^24: the float mirror holds the same numbers in half the bytes
-      GramPh<NQ, true> ph{ls_rsrc(T.bfT32, (unsigned)(n * ldd * 4)), (unsigned)ldd * 4u, n, {}, g, bk, gqact};
+      GramPh<NQ, true> ph{(const char *)T.bfT32, (long)ldd * 4, ls_make_win(grow_bytes >> 1), n, 0, S.lane16, {}, g, bk, gqact};
 #pragma unroll
       for (int q = 0; q < NQ; ++q)
-        ph.off[q] = gslot[q] * 4u;
+        ph.off[q] = (unsigned)M.sl[q] * 4u;
       ls_run<NQ>(S, ph, n);
     }
     else
     {
-      GramPh<NQ, false> ph{ls_rsrc(T.bfT, (unsigned)(n * ldd * 8)), (unsigned)ldd * 8u, n, {}, g, bk, gqact};
+      GramPh<NQ, false> ph{(const char *)T.bfT, (long)ldd * 8, ls_make_win(grow_bytes), n, 0, S.lane16, {}, g, bk, gqact};
 #pragma unroll
       for (int q = 0; q < NQ; ++q)
-        ph.off[q] = gslot[q] * 8u;
+        ph.off[q] = (unsigned)M.sl[q] * 8u;
       ls_run<NQ>(S, ph, n);
     }
 #pragma unroll
@@ -475,12 +480,12 @@ __device__ __forceinline__ bool update_row_cached(Lattice<NQ> &T, LllCtx &C, con
       settle(rd[q]);
       settle(mold[q]);
     }
-    RecPh<NQ> ph{ls_rsrc(T.muT, (unsigned)(T.d * ldd * 8)), (unsigned)ldd * 8u, last, lane, {}, acc, rd, {}, last == kappa, kappa};
+    RecPh<NQ> ph{(const char *)T.muT, (long)ldd * 8, ls_make_win(row_bytes), last, 0, S.lane16, lane, {}, acc, rd, {}, last == kappa, kappa};
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
     {
       const int j = lane + 64 * q;
-      ph.off[q]   = gslot[q] * 8u;
+      ph.off[q]   = (unsigned)M.sl[q] * 8u;
       ph.bmask[q] = __ballot(j <= last && j >= start);
     }
     ls_run<NQ>(S, ph, last);
@@ -611,11 +616,13 @@ __device__ __forceinline__ int babai_impl(Lattice<NQ> &T, LStream<NQ> &S, int ka
     }
     // ---- lll.cpp:202-214: lane k owns babai_mu[k]; rows j = kappa-1 .. sr_start, descending
     {
-      SweepPh<NQ> ph{ls_rsrc(T.mu, (unsigned)(T.d * ldd * 8)), (unsigned)ldd * 8u, kappa, sr_start, lane, map, bm, xs, e, nz, {}};
+      constexpr int U = LStream<NQ>::U;
+      const int jtop  = (kappa - 1) | (U - 1);
+      SweepPh<NQ> ph{(const char *)T.mu, (long)ldd * 8, jtop, kappa, sr_start, 0, S.lane16, lane, map, bm, xs, e, nz, {}};
 #pragma unroll
       for (int q = 0; q < NQ; ++q)
         ph.srmask[q] = __ballot(lane + 64 * q >= sr_start);
-      ls_run<NQ>(S, ph, kappa - sr_start);
+      ls_run<NQ>(S, ph, jtop - sr_start + 1);
     }
     // ---- the multipliers: row_addmul_we(kappa, j, -X, e_j) -> get_si_exp_we, nr_FP_d.inl:46-53
     long long lxv[NQ];
@@ -642,7 +649,7 @@ __device__ __forceinline__ int babai_impl(Lattice<NQ> &T, LStream<NQ> &S, int ka
         rows += __builtin_popcountll(nz[q]);
       if (T.f32ok && !__any(big32))
       {
-        AxpyPh<NQ, true> ph{ls_rsrc(T.b, (unsigned)(T.d * ldn * 8)), (unsigned)ldn * 8u, lane, map, bv, lxv, {}, {}};
+        AxpyPh<NQ, true> ph{(const char *)T.b, (long)ldn * 8, ls_make_win(n * 8), S.lane16, lane, map, bv, lxv, {}, {}};
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
           ph.ic.m[q] = ph.cc.m[q] = nz[q];
@@ -650,7 +657,7 @@ __device__ __forceinline__ int babai_impl(Lattice<NQ> &T, LStream<NQ> &S, int ka
       }
       else
       {
-        AxpyPh<NQ, false> ph{ls_rsrc(T.b, (unsigned)(T.d * ldn * 8)), (unsigned)ldn * 8u, lane, map, bv, lxv, {}, {}};
+        AxpyPh<NQ, false> ph{(const char *)T.b, (long)ldn * 8, ls_make_win(n * 8), S.lane16, lane, map, bv, lxv, {}, {}};
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
           ph.ic.m[q] = ph.cc.m[q] = nz[q];
@@ -1044,7 +1051,7 @@ __device__ __forceinline__ int lll_run(Lattice<NQ> &T, LllCtx &C, SlotMap<NQ> &M
 
 // ---------------------------------------------------------------------------------------------------
 // Out-of-line entry points for kernels that reach the LLL machinery from several places (bkz_kernel.hip,
-// bkzs_kernel.hip).  Everything above is force-inlined, and with the register streams an inlined copy of
+// bkzs_kernel.hip).  Everything above is force-inlined, and with the block streams an inlined copy of
 // update_row_cached / babai_impl is a few thousand instructions of unrolled loops: three lll() sites, a size
 // reduction and two GSO updates per kernel, times eight kernels, took the compile of bkzs_kernel.hip beyond
 // a quarter of an hour.  Here the state goes through ONE block of private memory per call (copied in, copied

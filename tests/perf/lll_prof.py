@@ -30,6 +30,7 @@ assert np.all(st == 1)
 lib.fphip_debug_lll_prof(out, 24)
 v = list(out)
 waves, iters, ktick = v[22], v[21], v[20]
+print("shader clock (s_memtime ticks per 10 ns tick of the real-time counter): %.1f MHz" % (v[23] / ktick * 100.0))
 print("d=%d B=%d: kernel %.1f ms; %d waves, %.0f iterations per wave, %.2f us per iteration"
       % (d, B, g.last_kernel_ms, waves, iters / waves, ktick * 0.01 / iters))
 for k, name in enumerate(["gram", "rec", "sweep", "axpy", "single"]):
