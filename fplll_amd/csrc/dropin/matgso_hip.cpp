@@ -41,6 +41,9 @@ MatGSOHip::MatGSOHip(Matrix<ZT> &arg_b, Matrix<ZT> &arg_u, Matrix<ZT> &arg_uinv_
   hmu_.resize(d * d);
   hr_.resize(d * d);
   hexp_.resize(d);
+  hvc_.resize(d);
+  hb2_.resize(d * n);
+  resident_ = !(getenv("FPLLL_HIP_RESIDENT") && atoi(getenv("FPLLL_HIP_RESIDENT")) == 0);
 }
 
 MatGSOHip::~MatGSOHip()
@@ -60,6 +63,7 @@ void MatGSOHip::upload_basis()
     for (int j = 0; j < n; ++j)
       hb_[(size_t)i * n + j] = b(i, j).get_si();
   fphip_gso_set_basis(g_, 0, 1, hb_.data());
+  session_ = false;  // (fphip_gso_set_basis ends a device session)
 }
 
 // Device state -> host members.  The integer rows that changed go through row_op_begin /
@@ -155,10 +159,97 @@ int MatGSOHip::size_reduction_device(int kappa_min, int kappa_end, double eta)
   return st;
 }
 
+// Session state -> host members: the rows the device changed go through row_op_begin / row_op_end as before;
+// mu / r are the device's for the columns it holds valid, gso_valid_cols its counts (what is not valid there is
+// recomputed lazily by the reference's own update_gso_row on the host members, from the same basis).
+void MatGSOHip::mirror_from_session()
+{
+  const int d = b.get_rows(), n = b.get_cols();
+  discover_all_rows();
+  fphip_gso_session_read(g_, 0, hb2_.data(), hmu_.data(), hr_.data(), hvc_.data(), hexp_.data());
+  for (int i = 0; i < d; ++i)
+  {
+    bool diff = false;
+    for (int j = 0; j < n && !diff; ++j)
+      diff = (b(i, j).get_si() != hb2_[(size_t)i * n + j]);
+    if (!diff)
+      continue;
+    row_op_begin(i, i + 1);
+    for (int j = 0; j < n; ++j)
+      b(i, j) = (long)hb2_[(size_t)i * n + j];
+    row_op_end(i, i + 1);
+  }
+  hb_ = hb2_;
+  for (int i = 0; i < d; ++i)
+  {
+    const int valid = hvc_[i] < 0 ? 0 : (hvc_[i] > i + 1 ? i + 1 : hvc_[i]);
+    const int upto  = valid < i ? valid : i;
+    for (int j = 0; j < upto; ++j)
+    {
+      mu(i, j) = hmu_[(size_t)i * d + j];
+      r(i, j)  = hr_[(size_t)i * d + j];
+    }
+    if (valid == i + 1)
+      r(i, i) = hr_[(size_t)i * d + i];
+    gso_valid_cols[i] = valid;
+  }
+}
+
+int MatGSOHip::lll_device_resident(int kappa_min, int kappa_start, int kappa_end, double delta, double eta, int info[4])
+{
+  const double t0 = now_s();
+  const int d = b.get_rows(), n = b.get_cols();
+  int st = 0, rc;
+  if (!session_)
+  {
+    upload_basis();
+    ++n_session_starts;
+    rc = fphip_gso_session_lll(g_, 0, kappa_min, kappa_start, kappa_end, delta, eta, 0, nullptr, nullptr, &st, info);
+  }
+  else
+  {
+    dpos_.clear();
+    drows_.clear();
+    for (int i = 0; i < d; ++i)
+    {
+      bool diff = false;
+      for (int j = 0; j < n && !diff; ++j)
+        diff = (b(i, j).get_si() != hb_[(size_t)i * n + j]);
+      if (!diff)
+        continue;
+      dpos_.push_back(i);
+      for (int j = 0; j < n; ++j)
+        drows_.push_back(b(i, j).get_si());
+    }
+    n_dirty_rows += (long)dpos_.size();
+    rc = fphip_gso_session_lll(g_, 1, kappa_min, kappa_start, kappa_end, delta, eta, (int)dpos_.size(), dpos_.data(),
+                               drows_.data(), &st, info);
+  }
+  if (rc == FPHIP_OK)
+    kernel_seconds += fphip_gso_last_kernel_ms(g_) * 1e-3;
+  if (rc != FPHIP_OK)
+  {
+    session_ = false;
+    st       = -100;
+  }
+  else if (st == -2)
+    session_ = false;  // the device went ahead of the host members, which take over unchanged: start over next time
+  else
+  {
+    mirror_from_session();
+    session_ = (st == 1);
+  }
+  device_seconds += now_s() - t0;
+  ++n_device_calls;
+  return st;
+}
+
 int MatGSOHip::lll_device(int kappa_min, int kappa_start, int kappa_end, double delta, double eta, int info[4])
 {
   if (!g_)
     return -100;
+  if (resident_)
+    return lll_device_resident(kappa_min, kappa_start, kappa_end, delta, eta, info);
   const double t0 = now_s();
   upload_basis();
   int st = 0;

@@ -60,9 +60,25 @@ public:
   long n_device_calls = 0;
   double device_seconds = 0.0;
 
+  // FPLLL_HIP_RESIDENT=0 makes every lll_device() call stateless again (upload, fresh GSO, download: the A/B)
+  bool resident() const { return resident_; }
+  long n_session_starts = 0, n_dirty_rows = 0;
+  double kernel_seconds = 0.0;  // of the session calls: the LLL kernel alone
+
 private:
   void upload_basis();
   void mirror_from_device(bool basis_changed);
+  int lll_device_resident(int kappa_min, int kappa_start, int kappa_end, double delta, double eta, int info[4]);
+  void mirror_from_session();
+
+  // Resident session (fphip_gso_session_lll): the device keeps this object's state between lll() calls, like the
+  // reference's MatGSO does on the host (gso_interface.h:675-732, gso_interface.cpp:26-53).  hb_ is then the
+  // basis as of the last synchronisation: rows that differ from it at the next call are the host's row
+  // operations since (insertions, rerandomisation, row moves of svp_postprocessing) and go up as such.
+  bool resident_ = true;
+  bool session_  = false;
+  std::vector<int> hvc_, dpos_;
+  std::vector<int64_t> drows_, hb2_;
 
   fphip_ctx *ctx_ = nullptr;
   fphip_gso *g_   = nullptr;

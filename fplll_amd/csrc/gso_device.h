@@ -78,7 +78,25 @@ struct GsoBatch
   // bit is set in sld_mask (bit i = i-th block of the pass); 0 = the whole tour as usual
   int sld_pass;
   unsigned long long sld_mask;
+  // Resident LLL session (lll_kernel.hip, fphip_gso_session_lll: what MatGSOHip keeps between the reference's
+  // lll() calls).  sess_mode 0: every launch starts from a fresh MatGSO of the basis (the stateless calls).
+  // 1: the same, and the kernel's state is left behind — the rows stay in their SLOTS; slot table, verified prefix
+  // and the narrow flag go to sess_slots / sess_state; Gram cache, mu / r / rdg / rexp by slot and the valid-column
+  // counts are the arrays above.  2: resume from that state.  Before lll() the launch replaces sess_ndirty rows
+  // (batch of one): sess_in = the positions as int64, then the integer rows [ndirty][ldn] — a row operation each
+  // (row_op_end, gso_interface.cpp:32-53).  After it the launch writes the state in POSITION order into sess_out:
+  // b [d][ldn] int64, mu [d][ldd], r [d][ldd] doubles, row_expo [d] int64, valid columns [d] int32.
+  int sess_mode;
+  int sess_ndirty;
+  int *sess_slots;           // [batch][256]
+  int *sess_state;           // [batch][4]: verified prefix, f32ok
+  const long long *sess_in;
+  char *sess_out;            // [batch][fphip_session_out_bytes(d, ldd, ldn)]
 };
+static constexpr size_t fphip_session_out_bytes(size_t d, size_t ldd, size_t ldn)
+{
+  return d * ldn * 8 + 2 * d * ldd * 8 + d * 8 + ((d * 4 + 15) / 16) * 16;
+}
 // ---- BKZ with strategies (bkzs_kernel.hip) ------------------------------------------------------
 #define FPHIP_BKZS_MAX_DEPTH 4  /* nested tour() activations: the BKZ tour + 3 levels of preprocessing */
 #define FPHIP_BKZS_PLAN_MAX 448 /* 4*63 row moves + 3*61 row additions of one rerandomize_block */

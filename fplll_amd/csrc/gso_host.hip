@@ -113,6 +113,11 @@ struct fphip_gso
   double il_preproc = 1e6, il_target = 0.5;
   int il_min_block = 24, il_flags = 0x4 /* PRUNER_GRADIENT */, il_device = 1;
   unsigned long long il_calls = 0, il_device_jobs = 0, il_host_jobs = 0, il_launches = 0;
+  // resident LLL session (fphip_gso_session_lll): the rows live in the kernel's slots while it is active
+  bool session_active  = false;
+  long long *sess_in_d = nullptr;  // device: positions then rows of the caller's row operations
+  long long *sess_in_h = nullptr;  // pinned staging of the same
+  char *sess_out_h     = nullptr;  // pinned: the state in position order after the last session call
 };
 
 static int gfail(fphip_ctx *ctx, const char *what, hipError_t e)
@@ -254,6 +259,14 @@ extern "C" void fphip_gso_destroy(fphip_gso *g)
   fphip_dev_free(g->muA, fphip_ctx_stream(g->ctx));
   fphip_dev_free(g->m16, fphip_ctx_stream(g->ctx));
   fphip_dev_free(g->flag16, fphip_ctx_stream(g->ctx));
+  fphip_dev_free(g->P.sess_slots, fphip_ctx_stream(g->ctx));
+  fphip_dev_free(g->P.sess_state, fphip_ctx_stream(g->ctx));
+  fphip_dev_free(g->P.sess_out, fphip_ctx_stream(g->ctx));
+  fphip_dev_free(g->sess_in_d, fphip_ctx_stream(g->ctx));
+  if (g->sess_in_h)
+    fphip_pinned_put(g->sess_in_h);
+  if (g->sess_out_h)
+    fphip_pinned_put(g->sess_out_h);
   if (g->P.gf)
     fphip_dev_free(g->P.gf, fphip_ctx_stream(g->ctx));
   if (g->P.vc)
@@ -281,8 +294,20 @@ struct LllArgs
   double delta, logdelta;
 };
 
+static int session_guard(fphip_gso *g, const char *what)
+{
+  if (!g->session_active)
+    return FPHIP_OK;
+  snprintf(fphip_ctx_errbuf(g->ctx), 512, "%s: a resident LLL session is active (the rows live in the kernel's slots); "
+           "fphip_gso_set_basis ends it", what);
+  return FPHIP_ERROR;
+}
+
 static int launch(fphip_gso *g, int kmin, int kend, double eta, int mode, const LllArgs *la = nullptr)
 {
+  if (g->P.sess_mode != 2)
+    if (int rcg = session_guard(g, "gso"))
+      return rcg;
   if (mode == 2)
     g->dirty = false;
   else if (g->dirty)
@@ -385,6 +410,8 @@ static int launch(fphip_gso *g, int kmin, int kend, double eta, int mode, const 
   }
   GCHK(hipGetLastError());
   GCHK(hipEventRecord(g->ev[1], s));
+  if (g->P.sess_mode != 0)
+    return FPHIP_OK;  // (a session call: its copies are queued behind the kernel, one wait for all of it)
   GCHK(hipStreamSynchronize(s));
   GCHK(hipEventElapsedTime(&g->last_ms, g->ev[0], g->ev[1]));
   return FPHIP_OK;
@@ -404,7 +431,8 @@ extern "C" int fphip_gso_set_basis(fphip_gso *g, int first, int count, const int
   const size_t rows = (size_t)g->P.d * count;
   GCHK(hipMemcpy2D(g->P.b + (size_t)first * g->P.d * g->P.ldn, (size_t)g->P.ldn * 8, b,
                    (size_t)g->P.n * 8, (size_t)g->P.n * 8, rows, hipMemcpyHostToDevice));
-  g->dirty = true;
+  g->dirty          = true;
+  g->session_active = false;  // (the rows are in position order again)
   return FPHIP_OK;
 }
 
@@ -448,6 +476,8 @@ extern "C" int fphip_gso_get_basis(fphip_gso *g, int first, int count, int64_t *
 {
   if (!g || !b || first < 0 || count <= 0 || first + count > g->P.batch)
     return FPHIP_ERROR;
+  if (int rcg = session_guard(g, "fphip_gso_get_basis"))  // (fphip_gso_session_read has the basis in position order)
+    return rcg;
   const size_t rows = (size_t)g->P.d * count;
   GCHK(hipMemcpy2D(b, (size_t)g->P.n * 8, g->P.b + (size_t)first * g->P.d * g->P.ldn,
                    (size_t)g->P.ldn * 8, (size_t)g->P.n * 8, rows, hipMemcpyDeviceToHost));
@@ -538,6 +568,148 @@ extern "C" int fphip_gso_lll(fphip_gso *g, int kappa_min, int kappa_start, int k
   if (status)
     memcpy(status, st.data(), sizeof(int) * B);
   return rc;
+}
+
+// ---- resident LLL session --------------------------------------------------------------------------------
+// What MatGSOHip (csrc/dropin/) keeps between the reference's lll() calls: the reference's MatGSO is an OBJECT —
+// its rows, Gram cache, mu / r and gso_valid_cols persist from one lll() to the next (gso_interface.h:675-732 the
+// accessors, gso_interface.cpp:26-53 the validity tracking), and BKZ's 16 000 lll() calls of a config-2 run each
+// touch a few rows.  The stateless fphip_gso_lll rebuilds all of it per call (upload, re-float, every Gram row,
+// update_gso, download: 6.2 ms); here the kernel's own state stays on the device: the rows in their slots, slot
+// table, symmetric Gram cache, mu / r by slot, valid-column counts, verified prefix.
+static int ensure_session_buffers(fphip_gso *g)
+{
+  const size_t B = (size_t)g->P.batch, d = g->P.d, ldd = g->P.ldd, ldn = g->P.ldn;
+  hipStream_t s = fphip_ctx_stream(g->ctx);
+  const size_t outb = fphip_session_out_bytes(d, ldd, ldn);
+  if (!g->P.sess_slots)
+    GCHK(fphip_dev_alloc((void **)&g->P.sess_slots, B * 256 * sizeof(int), s));
+  if (!g->P.sess_state)
+    GCHK(fphip_dev_alloc((void **)&g->P.sess_state, B * 4 * sizeof(int), s));
+  if (!g->P.sess_out)
+    GCHK(fphip_dev_alloc((void **)&g->P.sess_out, B * outb + 4096, s));
+  if (!g->sess_in_d)
+    GCHK(fphip_dev_alloc((void **)&g->sess_in_d, (d + d * ldn) * sizeof(long long) + 4096, s));
+  if (!g->sess_in_h)
+    g->sess_in_h = (long long *)fphip_pinned_get((d + d * ldn) * sizeof(long long));
+  if (!g->sess_out_h)
+    g->sess_out_h = (char *)fphip_pinned_get(B * outb);
+  if (!g->sess_in_h || !g->sess_out_h)
+  {
+    snprintf(fphip_ctx_errbuf(g->ctx), 512, "fphip_gso_session_lll: no pinned staging memory");
+    return FPHIP_ERROR;
+  }
+  return FPHIP_OK;
+}
+
+extern "C" int fphip_gso_session_lll(fphip_gso *g, int resume, int kappa_min, int kappa_start, int kappa_end,
+                                     double delta, double eta, int n_dirty, const int *dirty_pos,
+                                     const int64_t *dirty_rows, int *status, int *info)
+{
+  FPHIP_RANGE("fphip_gso_session_lll");
+  if (!g)
+    return FPHIP_ERROR;
+  if (kappa_end < 0)
+    kappa_end = g->P.d;
+  if (kappa_min < 0 || kappa_min > kappa_start || kappa_start >= kappa_end || kappa_end > g->P.d)
+  {
+    snprintf(fphip_ctx_errbuf(g->ctx), 512, "fphip_gso_session_lll: need 0 <= kappa_min <= kappa_start < kappa_end <= d");
+    return FPHIP_ERROR;
+  }
+  const size_t B = (size_t)g->P.batch, d = g->P.d, ldn = g->P.ldn, n = g->P.n;
+  if (resume && !g->session_active)
+  {
+    snprintf(fphip_ctx_errbuf(g->ctx), 512, "fphip_gso_session_lll: no session to resume (start one with resume = 0)");
+    return FPHIP_ERROR;
+  }
+  if (n_dirty < 0 || n_dirty > (int)d || (n_dirty > 0 && (!resume || B != 1 || !dirty_pos || !dirty_rows)))
+  {
+    snprintf(fphip_ctx_errbuf(g->ctx), 512, "fphip_gso_session_lll: row operations need a running session of a batch of one");
+    return FPHIP_ERROR;
+  }
+  int rc = ensure_lll_buffers(g);
+  if (rc == FPHIP_OK)
+    rc = ensure_session_buffers(g);
+  if (rc != FPHIP_OK)
+    return rc;
+  hipStream_t s = fphip_ctx_stream(g->ctx);
+  if (!resume)
+  {
+    g->session_active = false;
+    rc = launch(g, 0, g->P.d, 0.0, 2);  // bf / row_expo / narrow flags of every row from b
+    if (rc != FPHIP_OK)
+      return rc;
+  }
+  else if (n_dirty > 0)
+  {
+    for (int t = 0; t < n_dirty; ++t)
+    {
+      if (dirty_pos[t] < 0 || dirty_pos[t] >= (int)d)
+        return FPHIP_ERROR;
+      g->sess_in_h[t] = dirty_pos[t];
+      long long *row = g->sess_in_h + n_dirty + (size_t)t * ldn;
+      memcpy(row, dirty_rows + (size_t)t * n, n * sizeof(long long));
+      for (size_t c = n; c < ldn; ++c)
+        row[c] = 0;
+    }
+    GCHK(hipMemcpyAsync(g->sess_in_d, g->sess_in_h, ((size_t)n_dirty + (size_t)n_dirty * ldn) * sizeof(long long),
+                        hipMemcpyHostToDevice, s));
+  }
+  g->P.sess_mode   = resume ? 2 : 1;
+  g->P.sess_ndirty = n_dirty;
+  g->P.sess_in     = g->sess_in_d;
+  LllArgs la{kappa_start, delta, std::log(delta)};
+  rc = launch(g, kappa_min, kappa_end, eta, 3, &la);
+  g->P.sess_mode   = 0;
+  g->P.sess_ndirty = 0;
+  g->session_active = false;
+  if (rc != FPHIP_OK)
+    return rc;
+  std::vector<int> st(B);
+  const size_t outb = fphip_session_out_bytes(d, g->P.ldd, ldn);
+  GCHK(hipMemcpyAsync(g->sess_out_h, g->P.sess_out, B * outb, hipMemcpyDeviceToHost, s));
+  GCHK(hipMemcpyAsync(st.data(), g->P.status, sizeof(int) * B, hipMemcpyDeviceToHost, s));
+  if (info)
+    GCHK(hipMemcpyAsync(info, g->P.lll_info, sizeof(int) * 4 * B, hipMemcpyDeviceToHost, s));
+  GCHK(hipStreamSynchronize(s));
+  GCHK(hipEventElapsedTime(&g->last_ms, g->ev[0], g->ev[1]));
+  // a failed reduction leaves a state the reference would not continue from either; -2 (a multiplier beyond
+  // 63 bits) has changed rows the caller's host copy does not have: either way the next call starts over
+  bool all_ok = true;
+  for (size_t L = 0; L < B; ++L)
+    all_ok &= (st[L] == 1);
+  g->session_active = all_ok;
+  if (status)
+    memcpy(status, st.data(), sizeof(int) * B);
+  return FPHIP_OK;
+}
+
+extern "C" int fphip_gso_session_read(fphip_gso *g, int lattice, int64_t *b, double *mu, double *r,
+                                      int *valid_cols, int64_t *row_expo)
+{
+  if (!g || lattice < 0 || lattice >= g->P.batch || !g->sess_out_h)
+    return FPHIP_ERROR;
+  const size_t d = g->P.d, ldd = g->P.ldd, ldn = g->P.ldn, n = g->P.n;
+  const char *out      = g->sess_out_h + (size_t)lattice * fphip_session_out_bytes(d, ldd, ldn);
+  const long long *ob  = (const long long *)out;
+  const double *omu    = (const double *)(out + d * ldn * 8);
+  const double *orr    = omu + d * ldd;
+  const long long *oex = (const long long *)(orr + d * ldd);
+  const int *ovc       = (const int *)(oex + d);
+  for (size_t i = 0; i < d; ++i)
+  {
+    if (b)
+      memcpy(b + i * n, ob + i * ldn, n * sizeof(long long));
+    if (mu)
+      memcpy(mu + i * d, omu + i * ldd, d * sizeof(double));
+    if (r)
+      memcpy(r + i * d, orr + i * ldd, d * sizeof(double));
+    if (row_expo)
+      row_expo[i] = oex[i];
+    if (valid_cols)
+      valid_cols[i] = ovc[i];
+  }
+  return FPHIP_OK;
 }
 
 // LLLReduction::lll in a selectable floating-point type (lll_x.hip): precision 106 = double-double on
@@ -730,6 +902,8 @@ static int ensure_lll_buffers(fphip_gso *g)
 static int bkz_launch(fphip_gso *g, int block_size, double delta, double eta, int use_loops,
                       int max_loops, float *ms, int *st_out, int *info_out)
 {
+  if (int rcg = session_guard(g, "bkz"))
+    return rcg;
   const int need = (g->P.d > g->P.n ? g->P.d : g->P.n);
   const int nq   = (need + 63) / 64;
   const int wpb  = g->waves_per_block;
@@ -1576,6 +1750,9 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
                                         const fphip_strategies *S, fphip_rand_fn rnd, void *rnd_user,
                                         int *status, int *info)
 {
+  if (g)
+    if (int rcg = session_guard(g, "bkz_strategies"))
+      return rcg;
   FPHIP_RANGE("fphip_gso_bkz_strategies");
   if (!g)
     return FPHIP_ERROR;
@@ -2128,6 +2305,8 @@ extern "C" int fphip_gso_get_mu(fphip_gso *g, int lattice, double *mu)
 {
   if (!g || !mu || lattice < 0 || lattice >= g->P.batch)
     return FPHIP_ERROR;
+  if (int rcg = session_guard(g, "fphip_gso_get_mu"))
+    return rcg;
   GCHK(hipMemcpy2D(mu, (size_t)g->P.d * 8, g->P.mu + (size_t)lattice * g->P.d * g->P.ldd,
                    (size_t)g->P.ldd * 8, (size_t)g->P.d * 8, g->P.d, hipMemcpyDeviceToHost));
   return FPHIP_OK;
@@ -2137,6 +2316,8 @@ extern "C" int fphip_gso_get_r(fphip_gso *g, int lattice, double *r)
 {
   if (!g || !r || lattice < 0 || lattice >= g->P.batch)
     return FPHIP_ERROR;
+  if (int rcg = session_guard(g, "fphip_gso_get_r"))
+    return rcg;
   GCHK(hipMemcpy2D(r, (size_t)g->P.d * 8, g->P.r + (size_t)lattice * g->P.d * g->P.ldd,
                    (size_t)g->P.ldd * 8, (size_t)g->P.d * 8, g->P.d, hipMemcpyDeviceToHost));
   return FPHIP_OK;
@@ -2146,6 +2327,8 @@ extern "C" int fphip_gso_get_row_expo(fphip_gso *g, int lattice, int64_t *row_ex
 {
   if (!g || !row_expo || lattice < 0 || lattice >= g->P.batch)
     return FPHIP_ERROR;
+  if (int rcg = session_guard(g, "fphip_gso_get_row_expo"))
+    return rcg;
   GCHK(hipMemcpy(row_expo, g->P.rexp + (size_t)lattice * g->P.d, sizeof(long long) * g->P.d,
                  hipMemcpyDeviceToHost));
   return FPHIP_OK;

@@ -84,12 +84,116 @@ __global__ void __launch_bounds__(256)
     T.f32ok       = all_rows_narrow<NQ>(P, (size_t)L, lane);
     LllCtx C{P.gf + (size_t)L * d * ldd, P.vc + (size_t)L * d};
     SlotMap<NQ> M;
-    lll_init_state<NQ>(T, C, M);
     int final_kappa, nswaps, zeros, vp = 0;
     long long iter;
+    if (P.sess_mode == 2)
+    {  // resume the session: slot table, verified prefix, narrow flag; everything else is in place
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+        M.sl[q] = P.sess_slots[(size_t)L * 256 + lane + 64 * q];
+      vp      = uni(P.sess_state[4 * L + 0]);
+      T.f32ok = uni(P.sess_state[4 * L + 1]);
+    }
+    else
+      lll_init_state<NQ>(T, C, M);
+    if (P.sess_mode != 0 && P.sess_ndirty > 0)
+    {
+      // the caller's row operations since the last launch: row p <- the given integers, then row_op_end(p, p + 1)
+      // (update_bf, the vector's Gram row and column, the GSO rows from p on: gso_interface.cpp:32-53)
+      const long long *pos = P.sess_in;
+      const long long *rows = P.sess_in + P.sess_ndirty;
+      for (int t = 0; t < P.sess_ndirty; ++t)
+      {
+        const int p = uni((int)pos[t]);
+        const int s = M.phys(p);
+        long long bv[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+        {
+          const int c = lane + 64 * q;
+          bv[q]       = (c < n) ? rows[(size_t)t * ldn + c] : 0;
+        }
+        store_row_and_refloat<NQ, false>(T, s, bv);
+        after_rowop<NQ>(T, C, M, p);
+        vp = min(vp, p);
+        __threadfence_block();
+      }
+    }
     const int status = lll_run(T, C, M, ring, kmin, kstart, kend, delta, eta, logdelta,
                                         final_kappa, nswaps, zeros, iter, vp);
-    lll_write_ordered<NQ>(T, M, P.b2 + (size_t)L * d * ldn);
+    if (P.sess_mode != 0)
+    {
+      // leave the state behind, and the caller's view of it: everything in position order
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+        P.sess_slots[(size_t)L * 256 + lane + 64 * q] = M.sl[q];
+      if (lane == 0)
+      {
+        P.sess_state[4 * L + 0] = (status == 1) ? vp : 0;
+        P.sess_state[4 * L + 1] = T.f32ok;
+      }
+      char *out        = P.sess_out + (size_t)L * fphip_session_out_bytes(d, ldd, ldn);
+      long long *ob    = (long long *)out;
+      double *omu      = (double *)(out + (size_t)d * ldn * 8);
+      double *orr      = omu + (size_t)d * ldd;
+      long long *oexp  = (long long *)(orr + (size_t)d * ldd);
+      int *ovc         = (int *)(oexp + d);
+      // four rows per step, every load of the step before its stores (a row at a time would pay the latency
+      // of a load per row: the compiler cannot know that the output does not alias the state)
+      constexpr int G = 4;
+      for (int p0 = 0; p0 < d; p0 += G)
+      {
+        int sr[G];
+        long long bb[G][NQ];
+        double mm[G][NQ], rr[G][NQ];
+#pragma unroll
+        for (int u = 0; u < G; ++u)
+          sr[u] = M.phys(min(p0 + u, d - 1));
+#pragma unroll
+        for (int u = 0; u < G; ++u)
+#pragma unroll
+          for (int q = 0; q < NQ; ++q)
+          {
+            const int j = lane + 64 * q;
+            bb[u][q]    = (j < ldn) ? T.b[(size_t)sr[u] * ldn + j] : 0;
+            mm[u][q]    = (j < ldd) ? T.mu[(size_t)sr[u] * ldd + j] : 0.0;
+            rr[u][q]    = (j < ldd) ? T.r[(size_t)sr[u] * ldd + j] : 0.0;
+          }
+        long long ee = 0;
+        int vv       = 0;
+#pragma unroll
+        for (int u = 0; u < G; ++u)
+          if (lane == u)
+          {
+            ee = T.rexp[sr[u]];
+            vv = C.vc[sr[u]];
+          }
+#pragma unroll
+        for (int u = 0; u < G; ++u)
+          if (p0 + u < d)
+          {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+            {
+              const int j = lane + 64 * q;
+              if (j < ldn)
+                ob[(size_t)(p0 + u) * ldn + j] = bb[u][q];
+              if (j < ldd)
+              {
+                omu[(size_t)(p0 + u) * ldd + j] = mm[u][q];
+                orr[(size_t)(p0 + u) * ldd + j] = rr[u][q];
+              }
+            }
+          }
+        if (lane < G && p0 + lane < d)
+        {
+          oexp[p0 + lane] = ee;
+          ovc[p0 + lane]  = vv;
+        }
+      }
+    }
+    else
+      lll_write_ordered<NQ>(T, M, P.b2 + (size_t)L * d * ldn);
     if (lane == 0)
     {
       P.status[L]           = status;

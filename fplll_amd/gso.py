@@ -117,6 +117,42 @@ class MatGSOBatch:
                                          info.ctypes.data_as(ctypes.c_void_p)), "lll")
         return st, info
 
+    def session_lll(self, resume, kappa_min=0, kappa_start=0, kappa_end=-1, delta=LLL_DEF_DELTA, eta=LLL_DEF_ETA,
+                    dirty=None):
+        """The same lll() on a RESIDENT MatGSO (fphip_gso_session_lll): resume=False starts a session from the
+        basis on the device, resume=True continues it after the caller's row operations `dirty` =
+        {row position: new integer row} (batch of one).  Returns (status[batch], info[batch][4])."""
+        st = np.zeros(self.batch, dtype=np.int32)
+        info = np.zeros((self.batch, 4), dtype=np.int32)
+        fn = self.lib.fphip_gso_session_lll
+        fn.restype = ctypes.c_int
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double,
+                       ctypes.c_double, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                       ctypes.c_void_p]
+        dirty = dirty or {}
+        pos = np.ascontiguousarray(sorted(dirty), dtype=np.int32)
+        rows = np.ascontiguousarray([dirty[p] for p in sorted(dirty)], dtype=np.int64).reshape(len(pos), self.n)
+        self._chk(fn(self.h, 1 if resume else 0, kappa_min, kappa_start, kappa_end, delta, eta, len(pos),
+                     pos.ctypes.data_as(ctypes.c_void_p) if len(pos) else None,
+                     rows.ctypes.data_as(ctypes.c_void_p) if len(pos) else None,
+                     st.ctypes.data_as(ctypes.c_void_p), info.ctypes.data_as(ctypes.c_void_p)), "session_lll")
+        return st, info
+
+    def session_read(self, lattice=0):
+        """The state the last session_lll left, in position order: (b[d][n], mu[d][d], r[d][d], valid_cols[d],
+        row_expo[d]) — mu(i,j), r(i,j) are meaningful for j < valid_cols[i]."""
+        b = np.zeros((self.d, self.n), dtype=np.int64)
+        mu = np.zeros((self.d, self.d), dtype=np.float64)
+        r = np.zeros((self.d, self.d), dtype=np.float64)
+        vc = np.zeros(self.d, dtype=np.int32)
+        ex = np.zeros(self.d, dtype=np.int64)
+        fn = self.lib.fphip_gso_session_read
+        fn.restype = ctypes.c_int
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 5
+        self._chk(fn(self.h, lattice, *(a.ctypes.data_as(ctypes.c_void_p) for a in (b, mu, r, vc, ex))),
+                  "session_read")
+        return b, mu, r, vc, ex
+
     def lll_ex(self, precision=106, kappa_min=0, kappa_start=0, kappa_end=-1, delta=LLL_DEF_DELTA,
                eta=LLL_DEF_ETA):
         """LLLReduction::lll in double-double (precision 106) or plain double (53) — lll_x.hip; the

@@ -179,6 +179,24 @@ int fphip_gso_size_reduce(fphip_gso *g, int kappa_min, int kappa_end, double eta
  * zeros (rows moved to the end as linearly dependent), loop iterations. */
 int fphip_gso_lll(fphip_gso *g, int kappa_min, int kappa_start, int kappa_end, double delta,
                   double eta, int *status, int *info);
+/* The same lll() on a RESIDENT MatGSO: fplll's MatGSO is an object whose rows, Gram cache, mu / r and
+ * gso_valid_cols persist from one lll() to the next (accessors gso_interface.h:675-732, validity tracking
+ * gso_interface.cpp:26-53), and a BKZ run calls lll() thousands of times after touching a few rows.  resume = 0
+ * starts a session from the basis on the device (fphip_gso_set_basis) as a fresh MatGSO; resume = 1 continues it:
+ * first the caller's row operations since the last call — n_dirty rows (batch of one), dirty_pos[t] the row
+ * position, dirty_rows[t][n] its new integers, each a row_op_end(p, p + 1) — then lll() on the state the last call
+ * left (the verified prefix of rows that are a fixed point of the loop included, as fplll's own object would have
+ * them valid).  While a session is active the rows live in the kernel's slots: the other fphip_gso_* entry points
+ * refuse to run, fphip_gso_set_basis ends the session, a status other than 1 ends it too (the next call must be a
+ * resume = 0 after fphip_gso_set_basis).  status / info as fphip_gso_lll. */
+int fphip_gso_session_lll(fphip_gso *g, int resume, int kappa_min, int kappa_start, int kappa_end, double delta,
+                          double eta, int n_dirty, const int *dirty_pos, const int64_t *dirty_rows, int *status,
+                          int *info);
+/* The state the last fphip_gso_session_lll left, in position order (host copy, no device call): b [d][n],
+ * mu / r [d][d] row-major, valid_cols[d] = gso_valid_cols (entries mu(i,j), r(i,j) with j < valid_cols[i] are
+ * meaningful; r(i,i) when valid_cols[i] == i + 1), row_expo[d].  Every pointer is nullable. */
+int fphip_gso_session_read(fphip_gso *g, int lattice, int64_t *b, double *mu, double *r, int *valid_cols,
+                           int64_t *row_expo);
 /* BKZReduction<Z_NR<long>,FP_NR<double>>(m, lll_obj, BKZParam(block_size, {}, delta, flags,
  * max_loops)).bkz() (bkz.cpp:522-668: tour / trunc_tour / hkz :360-441, svp_reduction :274-358,
  * svp_preprocessing's lll :107-113, svp_postprocessing :126-272, the block enumeration with

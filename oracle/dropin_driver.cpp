@@ -171,9 +171,11 @@ int main(int argc, char **argv)
   const double secs =
       std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   printf("{\"what\":\"%s\",\"gso\":\"%s\",\"status\":%d,\"seconds\":%.3f,\"nodes\":%ld,\"n_swaps\":%d,"
-         "\"device_calls\":%ld,\"device_seconds\":%.3f,\"d\":%d,\"n\":%d,\"b_out\":[",
+         "\"device_calls\":%ld,\"device_seconds\":%.3f,\"kernel_seconds\":%.3f,\"session_starts\":%ld,"
+         "\"dirty_rows\":%ld,\"d\":%d,\"n\":%d,\"b_out\":[",
          cmd.c_str(), w.c_str(), status, secs, nodes, lll_obj.n_swaps, hip ? hip->n_device_calls : 0L,
-         hip ? hip->device_seconds : 0.0, bl.get_rows(), bl.get_cols());
+         hip ? hip->device_seconds : 0.0, hip ? hip->kernel_seconds : 0.0, hip ? hip->n_session_starts : 0L,
+         hip ? hip->n_dirty_rows : 0L, bl.get_rows(), bl.get_cols());
   for (int i = 0; i < bl.get_rows(); ++i)
     for (int j = 0; j < bl.get_cols(); ++j)
       printf("%s%ld", (i || j) ? "," : "", bl(i, j).get_si());

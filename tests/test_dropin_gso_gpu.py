@@ -62,11 +62,31 @@ def test_config2_reference_bkz_driver_on_device_gso():
         j = _run(["bkz", path, "20", "hip"])
     finally:
         os.unlink(path)
-    C.note(lambda: ("config 2 via the reference's BKZReduction on MatGSOHip: %.1f s, %d device calls (%.1f s in them); "
-          "reference on one core %.2f s" % (j["seconds"], j["device_calls"], j["device_seconds"], f["ref_seconds"]),))
+    C.note(lambda: ("config 2 via the reference's BKZReduction on MatGSOHip (resident session): %.1f s, %d device calls "
+          "(%.1f s in them, %.1f s of that the LLL kernel), %d session starts, %d rows sent up as the host's row "
+          "operations; reference on one core %.2f s"
+          % (j["seconds"], j["device_calls"], j["device_seconds"], j.get("kernel_seconds", 0.0),
+             j.get("session_starts", -1), j.get("dirty_rows", -1), f["ref_seconds"]),))
     assert j["status"] == 0 and j["device_calls"] > 1000
     assert j["nodes"] == f["nodes"] == 10252068
     assert np.array_equal(j["b_out"], f["b_out"])
+    # the session is what makes this a drop-in rather than a harness: one start, every later lll() resumes
+    assert j["session_starts"] == 1
+
+
+def test_config2_stateless_calls_give_the_same_run():
+    """FPLLL_HIP_RESIDENT=0: every interposed lll() uploads the basis and starts from a fresh MatGSO (the
+    round-3 behaviour, the A/B of the session): the same golden basis and node count, on a smaller instance of the
+    same family so that the suite does not pay 90 s for it."""
+    f = C.load_bkz_fixture(os.path.join(C.GOLDEN, "bkz_q60_b16.json"))
+    path = _write_basis(f["b_in"])
+    try:
+        a = _run_env(["bkz", path, "16", "hip"], {"FPLLL_HIP_RESIDENT": "0"})
+        b = _run_env(["bkz", path, "16", "hip"], {"FPLLL_HIP_RESIDENT": "1"})
+    finally:
+        os.unlink(path)
+    assert np.array_equal(a["b_out"], b["b_out"]) and a["nodes"] == b["nodes"] and a["status"] == b["status"] == 0
+    assert a["session_starts"] == 0 and b["session_starts"] >= 1 and a["device_calls"] == b["device_calls"] > 10
 
 
 def _run_env(args, env):

@@ -131,3 +131,76 @@ def test_lll_large_batch_stress(ctx):
             assert np.array_equal(out[L], o.b), (i, L)
         o.close()
     g.close()
+
+
+def test_resident_session_equals_stateless_calls(ctx):
+    """fphip_gso_session_lll: the kernel's state (rows in slots, slot table, Gram cache, mu / r, valid columns,
+    verified prefix) stays on the device between calls, the caller's row operations go up as dirty rows.  Every
+    call must leave what a stateless lll() of the same basis leaves: the basis, swaps / zeros, and — for the
+    columns the session holds valid — the mu / r of update_gso() on that basis (they are functions of the basis).
+    The row operations here are what BKZ does between lll() calls: a row replaced by a combination (insertion),
+    rows rotated (move_row), a row made linearly dependent."""
+    from fplll_amd.gso import MatGSOBatch
+    rng = np.random.default_rng(77)
+    for d in (24, 70, 130):
+        b0 = _qary(rng, d, d // 2, 1009)
+        g = MatGSOBatch(ctx, 1, d, d)
+        ref = MatGSOBatch(ctx, 1, d, d)
+        g.set_basis(b0[None])
+        st, info = g.session_lll(False)
+        cur = b0.copy()
+        for step in range(6):
+            # the stateless twin on the same input
+            ref.set_basis(cur[None])
+            if step == 0:
+                rst, rinfo = ref.lll()
+            else:
+                rst, rinfo = ref.lll(0, kstart, kend)
+            want = ref.get_basis(0, 1)[0]
+            b, mu, r, vc, ex = g.session_read(0)
+            assert int(st[0]) == int(rst[0]) == 1
+            assert list(info[0][:3]) == list(rinfo[0][:3]), (d, step)
+            assert np.array_equal(b, want), (d, step)
+            rmu, rr = ref.get_mu_matrix(0), ref.get_r_matrix(0)
+            for i in range(d):
+                v = int(vc[i])
+                assert 0 <= v <= i + 1
+                if step == 0 or i < kend:
+                    assert v == i + 1, (d, step, i, v)  # rows inside the reduced range are complete
+                up = min(v, i)
+                assert np.array_equal(mu[i, :up], rmu[i, :up]) and np.array_equal(r[i, :up], rr[i, :up]), (d, step, i)
+                if v == i + 1:
+                    assert r[i, i] == rr[i, i]
+            assert np.array_equal(ex, ref.row_expo(0))
+            # the caller's row operations before the next call
+            cur = b.copy()
+            dirty = {}
+            kend = int(rng.integers(max(3, d // 2), d + 1))
+            kstart = int(rng.integers(0, kend - 1))
+            kind = step % 3
+            if kind == 0:      # insertion: a row becomes a small combination of the rows of a block
+                i = int(rng.integers(kstart, kend))
+                co = rng.integers(-3, 4, size=kend - kstart)
+                co[i - kstart] = 1
+                cur[i] = (co[:, None] * cur[kstart:kend]).sum(axis=0)
+                dirty[i] = cur[i]
+            elif kind == 1:    # move_row: rotate a range
+                lo = int(rng.integers(kstart, kend - 1)); hi = int(rng.integers(lo + 1, kend))
+                cur[lo:hi + 1] = np.roll(cur[lo:hi + 1], 1, axis=0)
+                for i in range(lo, hi + 1):
+                    dirty[i] = cur[i]
+            else:              # two rows changed at once, one of them by a large multiple
+                i, j = (int(x) for x in rng.choice(np.arange(kstart, kend), size=2, replace=False))
+                cur[i] = cur[i] + 977 * cur[j]
+                dirty[i] = cur[i]
+                k2 = int(rng.integers(0, kend))
+                if k2 != i:
+                    cur[k2] = cur[k2] - cur[i]
+                    dirty[k2] = cur[k2]
+            st, info = g.session_lll(True, 0, kstart, kend, dirty=dirty)
+        # the other entry points refuse to run on slot-ordered rows; set_basis ends the session
+        with pytest.raises(Exception):
+            g.get_basis(0, 1)
+        g.set_basis(cur[None])
+        assert g.get_basis(0, 1)[0].shape == (d, d)
+        g.close(); ref.close()
