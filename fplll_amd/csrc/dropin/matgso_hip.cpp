@@ -195,7 +195,8 @@ void MatGSOHip::mirror_from_session()
   }
 }
 
-int MatGSOHip::lll_device_resident(int kappa_min, int kappa_start, int kappa_end, double delta, double eta, int info[4])
+int MatGSOHip::lll_device_resident(int kappa_min, int kappa_start, int kappa_end, double delta, double eta, int info[4],
+                                   int flags)
 {
   const double t0 = now_s();
   const int d = b.get_rows(), n = b.get_cols();
@@ -204,7 +205,7 @@ int MatGSOHip::lll_device_resident(int kappa_min, int kappa_start, int kappa_end
   {
     upload_basis();
     ++n_session_starts;
-    rc = fphip_gso_session_lll(g_, 0, kappa_min, kappa_start, kappa_end, delta, eta, 0, nullptr, nullptr, &st, info);
+    rc = fphip_gso_session_lll(g_, 0, kappa_min, kappa_start, kappa_end, delta, eta, flags, 0, nullptr, nullptr, &st, info);
   }
   else
   {
@@ -222,7 +223,7 @@ int MatGSOHip::lll_device_resident(int kappa_min, int kappa_start, int kappa_end
         drows_.push_back(b(i, j).get_si());
     }
     n_dirty_rows += (long)dpos_.size();
-    rc = fphip_gso_session_lll(g_, 1, kappa_min, kappa_start, kappa_end, delta, eta, (int)dpos_.size(), dpos_.data(),
+    rc = fphip_gso_session_lll(g_, 1, kappa_min, kappa_start, kappa_end, delta, eta, flags, (int)dpos_.size(), dpos_.data(),
                                drows_.data(), &st, info);
   }
   if (rc == FPHIP_OK)
@@ -244,16 +245,17 @@ int MatGSOHip::lll_device_resident(int kappa_min, int kappa_start, int kappa_end
   return st;
 }
 
-int MatGSOHip::lll_device(int kappa_min, int kappa_start, int kappa_end, double delta, double eta, int info[4])
+int MatGSOHip::lll_device(int kappa_min, int kappa_start, int kappa_end, double delta, double eta, int info[4],
+                          int flags)
 {
   if (!g_)
     return -100;
   if (resident_)
-    return lll_device_resident(kappa_min, kappa_start, kappa_end, delta, eta, info);
+    return lll_device_resident(kappa_min, kappa_start, kappa_end, delta, eta, info, flags);
   const double t0 = now_s();
   upload_basis();
   int st = 0;
-  const int rc = fphip_gso_lll(g_, kappa_min, kappa_start, kappa_end, delta, eta, &st, info);
+  const int rc = fphip_gso_lll_flags(g_, kappa_min, kappa_start, kappa_end, delta, eta, flags, &st, info);
   if (rc != FPHIP_OK)
     st = -100;
   else if (st != -2)
@@ -280,7 +282,7 @@ bool LLLReduction<Z_NR<long>, FP_NR<double>>::lll(int kappa_min, int kappa_start
                                                   int size_reduction_start)
 {
   fplll_hip::MatGSOHip *h = dynamic_cast<fplll_hip::MatGSOHip *>(&m);
-  const bool plain = !enable_early_red && !siegel && size_reduction_start == 0;
+  const bool plain = !enable_early_red && size_reduction_start == 0;  // (LLL_SIEGEL runs on the device)
   if (h && h->on_device() && plain)
   {
     if (kappa_end == -1)
@@ -289,7 +291,7 @@ bool LLLReduction<Z_NR<long>, FP_NR<double>>::lll(int kappa_min, int kappa_start
     if (m.d == 0)
       return set_status(RED_SUCCESS);
     int info[4]  = {0, 0, 0, 0};
-    const int st = h->lll_device(kappa_min, kappa_start, kappa_end, delta.get_d(), eta.get_d(), info);
+    const int st = h->lll_device(kappa_min, kappa_start, kappa_end, delta.get_d(), eta.get_d(), info, siegel ? 4 : 0);
     if (st != -2 && st != -100)
     {
       final_kappa    = info[0];

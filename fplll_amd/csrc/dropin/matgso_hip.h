@@ -52,9 +52,9 @@ public:
   // LLLReduction object.  Returns the device status: 1 ok, 0 GSO failure, -1 babai failure,
   // -2 multiplier beyond 63 bits (nothing was changed; fall back to the host path)
   int size_reduction_device(int kappa_min, int kappa_end, double eta);
-  // LLLReduction(m, delta, eta, LLL_DEFAULT).lll(kappa_min, kappa_start, kappa_end, 0) on the
+  // LLLReduction(m, delta, eta, flags: LLL_DEFAULT or LLL_SIEGEL).lll(kappa_min, kappa_start, kappa_end, 0) on the
   // device.  info[4]: final_kappa, n_swaps, zeros, loop iterations.
-  int lll_device(int kappa_min, int kappa_start, int kappa_end, double delta, double eta, int info[4]);
+  int lll_device(int kappa_min, int kappa_start, int kappa_end, double delta, double eta, int info[4], int flags = 0);
 
   // statistics: device calls made through this object and the seconds spent in them
   long n_device_calls = 0;
@@ -68,7 +68,7 @@ public:
 private:
   void upload_basis();
   void mirror_from_device(bool basis_changed);
-  int lll_device_resident(int kappa_min, int kappa_start, int kappa_end, double delta, double eta, int info[4]);
+  int lll_device_resident(int kappa_min, int kappa_start, int kappa_end, double delta, double eta, int info[4], int flags);
   void mirror_from_session();
 
   // Resident session (fphip_gso_session_lll): the device keeps this object's state between lll() calls, like the

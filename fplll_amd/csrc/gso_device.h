@@ -86,6 +86,7 @@ struct GsoBatch
   // (batch of one): sess_in = the positions as int64, then the integer rows [ndirty][ldn] — a row operation each
   // (row_op_end, gso_interface.cpp:32-53).  After it the launch writes the state in POSITION order into sess_out:
   // b [d][ldn] int64, mu [d][ldd], r [d][ldd] doubles, row_expo [d] int64, valid columns [d] int32.
+  int lll_siegel;            // lll_kernel: LLL_SIEGEL (the launch's delta is then the swap threshold delta - eta^2)
   int sess_mode;
   int sess_ndirty;
   int *sess_slots;           // [batch][256]

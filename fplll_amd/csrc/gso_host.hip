@@ -523,6 +523,8 @@ extern "C" int fphip_gso_size_reduce(fphip_gso *g, int kappa_min, int kappa_end,
 }
 
 static int ensure_lll_buffers(fphip_gso *g);
+extern "C" int fphip_gso_lll_flags(fphip_gso *g, int kappa_min, int kappa_start, int kappa_end,
+                                   double delta, double eta, int flags, int *status, int *info);
 
 // LLLReduction<Z_NR<long>, FP_NR<double>>(m, delta, eta, LLL_DEFAULT).lll(kappa_min, kappa_start,
 // kappa_end, 0) on a fresh MatGSO(b, GSO_ROW_EXPO) of every lattice (lll.cpp:44-164,
@@ -531,9 +533,33 @@ static int ensure_lll_buffers(fphip_gso *g);
 extern "C" int fphip_gso_lll(fphip_gso *g, int kappa_min, int kappa_start, int kappa_end,
                              double delta, double eta, int *status, int *info)
 {
+  return fphip_gso_lll_flags(g, kappa_min, kappa_start, kappa_end, delta, eta, 0, status, info);
+}
+
+// fplll's LLLFlags (defs.h:222-227): LLL_VERBOSE (1) is ignored, LLL_SIEGEL (4) runs on the device,
+// LLL_EARLY_RED (2) is not offered (FPHIP_UNSUPPORTED: the caller's host loop has it)
+static int lll_flags_check(fphip_gso *g, int flags, int *siegel)
+{
+  if (flags & ~7)
+  {
+    snprintf(fphip_ctx_errbuf(g->ctx), 512, "lll: unknown flags 0x%x", flags);
+    return FPHIP_ERROR;
+  }
+  if (flags & 2)
+    return FPHIP_UNSUPPORTED;
+  *siegel = (flags & 4) ? 1 : 0;
+  return FPHIP_OK;
+}
+
+extern "C" int fphip_gso_lll_flags(fphip_gso *g, int kappa_min, int kappa_start, int kappa_end,
+                                   double delta, double eta, int flags, int *status, int *info)
+{
   FPHIP_RANGE("fphip_gso_lll");
   if (!g)
     return FPHIP_ERROR;
+  int siegel = 0;
+  if (int rcf = lll_flags_check(g, flags, &siegel))
+    return rcf;
   if (kappa_end < 0)
     kappa_end = g->P.d;
   if (kappa_min < 0 || kappa_min > kappa_start || kappa_start >= kappa_end || kappa_end > g->P.d)
@@ -550,8 +576,11 @@ extern "C" int fphip_gso_lll(fphip_gso *g, int kappa_min, int kappa_start, int k
   int rc = launch(g, 0, g->P.d, 0.0, 2);  // bf / row_expo of every row from b
   if (rc != FPHIP_OK)
     return rc;
-  LllArgs la{kappa_start, delta, std::log(delta)};
-  rc = launch(g, kappa_min, kappa_end, eta, 3, &la);
+  // (swap_threshold = siegel ? delta - eta * eta : delta, lll.cpp:40; the iteration limit keeps log(delta))
+  LllArgs la{kappa_start, siegel ? delta - eta * eta : delta, std::log(delta)};
+  g->P.lll_siegel = siegel;
+  rc              = launch(g, kappa_min, kappa_end, eta, 3, &la);
+  g->P.lll_siegel = 0;
   if (rc != FPHIP_OK)
     return rc;
   const float lll_ms = g->last_ms;
@@ -603,12 +632,15 @@ static int ensure_session_buffers(fphip_gso *g)
 }
 
 extern "C" int fphip_gso_session_lll(fphip_gso *g, int resume, int kappa_min, int kappa_start, int kappa_end,
-                                     double delta, double eta, int n_dirty, const int *dirty_pos,
+                                     double delta, double eta, int flags, int n_dirty, const int *dirty_pos,
                                      const int64_t *dirty_rows, int *status, int *info)
 {
   FPHIP_RANGE("fphip_gso_session_lll");
   if (!g)
     return FPHIP_ERROR;
+  int siegel = 0;
+  if (int rcf = lll_flags_check(g, flags, &siegel))
+    return rcf;
   if (kappa_end < 0)
     kappa_end = g->P.d;
   if (kappa_min < 0 || kappa_min > kappa_start || kappa_start >= kappa_end || kappa_end > g->P.d)
@@ -658,8 +690,10 @@ extern "C" int fphip_gso_session_lll(fphip_gso *g, int resume, int kappa_min, in
   g->P.sess_mode   = resume ? 2 : 1;
   g->P.sess_ndirty = n_dirty;
   g->P.sess_in     = g->sess_in_d;
-  LllArgs la{kappa_start, delta, std::log(delta)};
-  rc = launch(g, kappa_min, kappa_end, eta, 3, &la);
+  LllArgs la{kappa_start, siegel ? delta - eta * eta : delta, std::log(delta)};
+  g->P.lll_siegel  = siegel;
+  rc               = launch(g, kappa_min, kappa_end, eta, 3, &la);
+  g->P.lll_siegel  = 0;
   g->P.sess_mode   = 0;
   g->P.sess_ndirty = 0;
   g->session_active = false;

@@ -93,6 +93,8 @@ __global__ void __launch_bounds__(256)
         M.sl[q] = P.sess_slots[(size_t)L * 256 + lane + 64 * q];
       vp      = uni(P.sess_state[4 * L + 0]);
       T.f32ok = uni(P.sess_state[4 * L + 1]);
+      if (uni(P.sess_state[4 * L + 2]) != P.lll_siegel)
+        vp = 0;  // the prefix was verified against the other swap test
     }
     else
       lll_init_state<NQ>(T, C, M);
@@ -120,7 +122,7 @@ __global__ void __launch_bounds__(256)
       }
     }
     const int status = lll_run(T, C, M, ring, kmin, kstart, kend, delta, eta, logdelta,
-                                        final_kappa, nswaps, zeros, iter, vp);
+                                        final_kappa, nswaps, zeros, iter, vp, P.lll_siegel != 0);
     if (P.sess_mode != 0)
     {
       // leave the state behind, and the caller's view of it: everything in position order
@@ -131,6 +133,7 @@ __global__ void __launch_bounds__(256)
       {
         P.sess_state[4 * L + 0] = (status == 1) ? vp : 0;
         P.sess_state[4 * L + 1] = T.f32ok;
+        P.sess_state[4 * L + 2] = P.lll_siegel;
       }
       char *out        = P.sess_out + (size_t)L * fphip_session_out_bytes(d, ldd, ldn);
       long long *ob    = (long long *)out;

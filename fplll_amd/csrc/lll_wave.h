@@ -803,8 +803,10 @@ template <int NQ, class RingT>
 __device__ __forceinline__ int lll_run(Lattice<NQ> &T, LllCtx &C, SlotMap<NQ> &M, RingT &ring,
                                        int kmin, int kstart, int kend, double delta, double eta,
                                        double logdelta, int &final_kappa, int &nswaps, int &zeros,
-                                       long long &iter, int &vp)
+                                       long long &iter, int &vp, bool siegel = false)
 {
+  // siegel (LLL_SIEGEL, lll.cpp:38-40,122,134): `delta` is then the caller's swap_threshold = delta - eta^2 and
+  // the two tests compare with lovasz_tests[kappa] instead of [kappa - 1]; logdelta stays log(delta)
   // vp ("verified prefix"): rows 0..vp-1 are known to be a fixed point of this loop — babai is a
   // no-op on each, Lovasz holds between neighbours, r(k,k) is set — and nothing they depend on has
   // changed since.  The reference would walk them again without effect (lll.cpp:82-155 with
@@ -986,10 +988,28 @@ __device__ __forceinline__ int lll_run(Lattice<NQ> &T, LllCtx &C, SlotMap<NQ> &M
       }
     }
     // g = lt[kappa]
+    double ltc[NQ];  // lane t: the value row t's threshold is compared with: lt[t], or lt[t + 1] with Siegel
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+      ltc[q] = ltv[q];
+    if (siegel)
+    {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+      {
+        double dn = __shfl_down(ltv[q], 1);
+        if (q + 1 < NQ)
+        {
+          const double carry = g_rl_f64(ltv[q + 1 < NQ ? q + 1 : q], 0);
+          dn                 = (lane == 63) ? carry : dn;
+        }
+        ltc[q] = (lane + 64 * q == kappa - 1) ? g : dn;
+      }
+    }
     bool swp = false;
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
-      swp |= (lane + 64 * q == kappa - 1) && (f[q] > ltv[q]);
+      swp |= (lane + 64 * q == kappa - 1) && (f[q] > ltc[q]);
     double ltk = g;
     if (__any(swp))
     {
@@ -1001,7 +1021,7 @@ __device__ __forceinline__ int lll_run(Lattice<NQ> &T, LllCtx &C, SlotMap<NQ> &M
       for (int q = 0; q < NQ; ++q)
       {
         const int t      = lane + 64 * q;
-        const bool cand  = t >= kmin && t <= old_k - 2 && f[q] < ltv[q];
+        const bool cand  = t >= kmin && t <= old_k - 2 && f[q] < ltc[q];
         const uint64_t m = __ballot(cand);
         if (m)
           knew = max(knew, 64 * q + (63 - __clzll((long long)m)) + 1);

@@ -107,18 +107,25 @@ class MatGSOBatch:
                                                  st.ctypes.data_as(ctypes.c_void_p)), "size_reduction")
         return st
 
-    def lll(self, kappa_min=0, kappa_start=0, kappa_end=-1, delta=LLL_DEF_DELTA, eta=LLL_DEF_ETA):
-        """LLLReduction::lll(kappa_min, kappa_start, kappa_end) on every lattice (lll.cpp:44-164).
+    def lll(self, kappa_min=0, kappa_start=0, kappa_end=-1, delta=LLL_DEF_DELTA, eta=LLL_DEF_ETA, flags=0):
+        """LLLReduction::lll(kappa_min, kappa_start, kappa_end) on every lattice (lll.cpp:44-164); flags are
+        fplll's LLLFlags: LLL_SIEGEL (4) on the device, LLL_EARLY_RED (2) raises (not offered).
         Returns (status[batch], info[batch][4] = final_kappa, n_swaps, zeros, iterations)."""
         st = np.zeros(self.batch, dtype=np.int32)
         info = np.zeros((self.batch, 4), dtype=np.int32)
-        self._chk(self.lib.fphip_gso_lll(self.h, kappa_min, kappa_start, kappa_end, delta, eta,
-                                         st.ctypes.data_as(ctypes.c_void_p),
-                                         info.ctypes.data_as(ctypes.c_void_p)), "lll")
+        fn = self.lib.fphip_gso_lll_flags
+        fn.restype = ctypes.c_int
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double,
+                       ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        rc = fn(self.h, kappa_min, kappa_start, kappa_end, delta, eta, flags,
+                st.ctypes.data_as(ctypes.c_void_p), info.ctypes.data_as(ctypes.c_void_p))
+        if rc == _lib.FPHIP_UNSUPPORTED:
+            raise NotImplementedError("LLL_EARLY_RED is not offered on the device (fphip_gso_lll_flags)")
+        self._chk(rc, "lll")
         return st, info
 
     def session_lll(self, resume, kappa_min=0, kappa_start=0, kappa_end=-1, delta=LLL_DEF_DELTA, eta=LLL_DEF_ETA,
-                    dirty=None):
+                    dirty=None, flags=0):
         """The same lll() on a RESIDENT MatGSO (fphip_gso_session_lll): resume=False starts a session from the
         basis on the device, resume=True continues it after the caller's row operations `dirty` =
         {row position: new integer row} (batch of one).  Returns (status[batch], info[batch][4])."""
@@ -127,12 +134,12 @@ class MatGSOBatch:
         fn = self.lib.fphip_gso_session_lll
         fn.restype = ctypes.c_int
         fn.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double,
-                       ctypes.c_double, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                       ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                        ctypes.c_void_p]
         dirty = dirty or {}
         pos = np.ascontiguousarray(sorted(dirty), dtype=np.int32)
         rows = np.ascontiguousarray([dirty[p] for p in sorted(dirty)], dtype=np.int64).reshape(len(pos), self.n)
-        self._chk(fn(self.h, 1 if resume else 0, kappa_min, kappa_start, kappa_end, delta, eta, len(pos),
+        self._chk(fn(self.h, 1 if resume else 0, kappa_min, kappa_start, kappa_end, delta, eta, flags, len(pos),
                      pos.ctypes.data_as(ctypes.c_void_p) if len(pos) else None,
                      rows.ctypes.data_as(ctypes.c_void_p) if len(pos) else None,
                      st.ctypes.data_as(ctypes.c_void_p), info.ctypes.data_as(ctypes.c_void_p)), "session_lll")

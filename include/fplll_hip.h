@@ -179,6 +179,11 @@ int fphip_gso_size_reduce(fphip_gso *g, int kappa_min, int kappa_end, double eta
  * zeros (rows moved to the end as linearly dependent), loop iterations. */
 int fphip_gso_lll(fphip_gso *g, int kappa_min, int kappa_start, int kappa_end, double delta,
                   double eta, int *status, int *info);
+/* The same with fplll's LLLFlags (defs.h:222-227; LLLReduction's constructor, lll.cpp:28-42): LLL_SIEGEL (4) —
+ * swap_threshold = delta - eta^2, the tests against lovasz_tests[kappa] (lll.cpp:122,134) — runs on the device;
+ * LLL_EARLY_RED (2) returns FPHIP_UNSUPPORTED (the caller's host loop has it); LLL_VERBOSE (1) is ignored. */
+int fphip_gso_lll_flags(fphip_gso *g, int kappa_min, int kappa_start, int kappa_end, double delta, double eta,
+                        int flags, int *status, int *info);
 /* The same lll() on a RESIDENT MatGSO: fplll's MatGSO is an object whose rows, Gram cache, mu / r and
  * gso_valid_cols persist from one lll() to the next (accessors gso_interface.h:675-732, validity tracking
  * gso_interface.cpp:26-53), and a BKZ run calls lll() thousands of times after touching a few rows.  resume = 0
@@ -188,10 +193,11 @@ int fphip_gso_lll(fphip_gso *g, int kappa_min, int kappa_start, int kappa_end, d
  * left (the verified prefix of rows that are a fixed point of the loop included, as fplll's own object would have
  * them valid).  While a session is active the rows live in the kernel's slots: the other fphip_gso_* entry points
  * refuse to run, fphip_gso_set_basis ends the session, a status other than 1 ends it too (the next call must be a
- * resume = 0 after fphip_gso_set_basis).  status / info as fphip_gso_lll. */
+ * resume = 0 after fphip_gso_set_basis).  flags as fphip_gso_lll_flags (a change of LLL_SIEGEL between calls
+ * forgets the verified prefix).  status / info as fphip_gso_lll. */
 int fphip_gso_session_lll(fphip_gso *g, int resume, int kappa_min, int kappa_start, int kappa_end, double delta,
-                          double eta, int n_dirty, const int *dirty_pos, const int64_t *dirty_rows, int *status,
-                          int *info);
+                          double eta, int flags, int n_dirty, const int *dirty_pos, const int64_t *dirty_rows,
+                          int *status, int *info);
 /* The state the last fphip_gso_session_lll left, in position order (host copy, no device call): b [d][n],
  * mu / r [d][d] row-major, valid_cols[d] = gso_valid_cols (entries mu(i,j), r(i,j) with j < valid_cols[i] are
  * meaningful; r(i,i) when valid_cols[i] == i + 1), row_expo[d].  Every pointer is nullable. */

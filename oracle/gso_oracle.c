@@ -380,10 +380,27 @@ static long zexponent(int64_t v)
 /* LLLReduction::lll(kappa_min, kappa_start, kappa_end, 0), lll.cpp:44-164 (no early reduction, no
  * Siegel).  Returns 1 RED_SUCCESS, 0 RED_GSO_FAILURE, -1 RED_BABAI_FAILURE, -2 multiplier beyond 63
  * bits, -3 RED_LLL_FAILURE.  info[0..3] = final_kappa, n_swaps, zeros, iterations. */
+static int oracle_gso_lll_impl(oracle_gso *g, int kappa_min, int kappa_start, int kappa_end, double delta_in,
+                               double eta, int siegel, int *info);
 int oracle_gso_lll(oracle_gso *g, int kappa_min, int kappa_start, int kappa_end, double delta,
                    double eta, int *info)
 {
+  return oracle_gso_lll_impl(g, kappa_min, kappa_start, kappa_end, delta, eta, 0, info);
+}
+/* ... with LLL_SIEGEL (flags & 4): swap_threshold = delta - eta^2 (lll.cpp:40) and the tests compare with
+ * lovasz_tests[kappa] instead of [kappa - 1] (lll.cpp:122,134).  LLL_EARLY_RED is not restated. */
+int oracle_gso_lll_flags(oracle_gso *g, int kappa_min, int kappa_start, int kappa_end, double delta,
+                         double eta, int flags, int *info)
+{
+  if (flags & 2)
+    return -100;
+  return oracle_gso_lll_impl(g, kappa_min, kappa_start, kappa_end, delta, eta, (flags & 4) != 0, info);
+}
+static int oracle_gso_lll_impl(oracle_gso *g, int kappa_min, int kappa_start, int kappa_end, double delta_in,
+                               double eta, int siegel, int *info)
+{
   const int n = g->n;
+  const double delta = siegel ? delta_in - eta * eta : delta_in; /* swap_threshold */
   if (kappa_end == -1)
     kappa_end = g->d;
   int kappa = kappa_start + 1;
@@ -425,7 +442,7 @@ int oracle_gso_lll(oracle_gso *g, int kappa_min, int kappa_start, int kappa_end,
         if (e > max_exp)
           max_exp = e;
       }
-    long long max_iter = (long long)(d - 2 * d * (d + 1) * ((max_exp + 3) / log(delta)));
+    long long max_iter = (long long)(d - 2 * d * (d + 1) * ((max_exp + 3) / log(delta_in)));
     for (iter = 0; iter < max_iter && kappa < kappa_end - zeros; iter++)
     {
       int rc = oracle_gso_babai(g, kappa, kappa, 0, eta);
@@ -444,7 +461,7 @@ int oracle_gso_lll(oracle_gso *g, int kappa_min, int kappa_start, int kappa_end,
       double f = R(g, kappa - 1, kappa - 1) * delta;
       if (g->row_expo_on)
         f = ldexp(f, (int)(2 * (g->row_expo[kappa - 1] - g->row_expo[kappa])));
-      if (f > lovasz[kappa - 1])
+      if (f > lovasz[siegel ? kappa : kappa - 1])
       {
         n_swaps++;
         int old_k = kappa;
@@ -453,7 +470,7 @@ int oracle_gso_lll(oracle_gso *g, int kappa_min, int kappa_start, int kappa_end,
           f = R(g, kappa - 1, kappa - 1) * delta;
           if (g->row_expo_on)
             f = ldexp(f, (int)(2 * (g->row_expo[kappa - 1] - g->row_expo[old_k])));
-          if (f < lovasz[kappa - 1])
+          if (f < lovasz[siegel ? kappa : kappa - 1])
             break;
         }
         if (lovasz[kappa] > 0)

@@ -78,6 +78,8 @@ int oracle_gso_size_reduction(oracle_gso *g, int kappa_min, int kappa_end, doubl
  * info[4] (nullable): final_kappa, n_swaps, zeros, iterations. */
 int oracle_gso_lll(oracle_gso *g, int kappa_min, int kappa_start, int kappa_end, double delta,
                    double eta, int *info);
+int oracle_gso_lll_flags(oracle_gso *g, int kappa_min, int kappa_start, int kappa_end, double delta,
+                         double eta, int flags, int *info);
 /* BKZReduction<Z_NR<long>,FP_NR<double>>::bkz() (bkz.cpp:522-668) with empty strategies (no pruning,
  * no preprocessing: BASELINE config 2), primal, flags BKZ_DEFAULT or BKZ_MAX_LOOPS.  1 RED_SUCCESS,
  * 8 RED_BKZ_LOOPS_LIMIT, <= 0 failure.  info[3] (nullable): tours, nodes lo, nodes hi. */

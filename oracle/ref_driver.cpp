@@ -607,7 +607,7 @@ static int cmd_lllfix(int argc, char **argv)
      << " seed=" << seed << " zero_rows=" << zero_rows << " dup_rows=" << dup_rows
      << "\",\n\"d\":" << d << ",\n\"n\":" << n << ",\n\"kmin\":" << kmin << ",\n\"kstart\":"
      << kstart << ",\n\"kend\":" << kend << ",\n\"delta\":" << hexd(LLL_DEF_DELTA) << ",\n\"eta\":"
-     << hexd(LLL_DEF_ETA) << ",\n\"b_in\":[";
+     << hexd(LLL_DEF_ETA) << ",\n\"flags\":" << (getenv("LLLFIX_FLAGS") ? atoi(getenv("LLLFIX_FLAGS")) : 0) << ",\n\"b_in\":[";
   for (int i = 0; i < d; ++i)
     for (int j = 0; j < n; ++j)
       os << ((i || j) ? "," : "") << b0(i, j).get_si();
@@ -620,7 +620,9 @@ static int cmd_lllfix(int argc, char **argv)
     b = b0;
     auto t0 = std::chrono::steady_clock::now();
     MatGSO<Z_NR<long>, FP_NR<double>> M(b, u, ut, GSO_ROW_EXPO);
-    LLLReduction<Z_NR<long>, FP_NR<double>> L(M, LLL_DEF_DELTA, LLL_DEF_ETA, LLL_DEFAULT);
+    // (LLLFIX_FLAGS: fplll's LLLFlags for this run — LLL_SIEGEL = 4; the fixture records them)
+    LLLReduction<Z_NR<long>, FP_NR<double>> L(M, LLL_DEF_DELTA, LLL_DEF_ETA,
+                                              getenv("LLLFIX_FLAGS") ? atoi(getenv("LLLFIX_FLAGS")) : LLL_DEFAULT);
     if (kstart > 0)
     {  // the caller's precondition: rows below kappa_start are known to the GSO
       for (int i = 0; i < kstart; ++i)

@@ -290,16 +290,17 @@ class OracleGSO:
         self.lib.oracle_gso_update_row.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
         return self.lib.oracle_gso_update_row(self.h, i, i if last is None else last)
 
-    def lll(self, kmin=0, kstart=0, kend=-1, delta=0.99, eta=0.51):
-        """LLLReduction::lll (oracle/gso_oracle.c).  Returns (status, info[4])."""
-        self.lib.oracle_gso_lll.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
-                                            ctypes.c_int, ctypes.c_double, ctypes.c_double,
-                                            ctypes.c_void_p]
+    def lll(self, kmin=0, kstart=0, kend=-1, delta=0.99, eta=0.51, flags=0):
+        """LLLReduction::lll (oracle/gso_oracle.c); flags = fplll's LLLFlags (LLL_SIEGEL = 4).
+        Returns (status, info[4])."""
+        self.lib.oracle_gso_lll_flags.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                                  ctypes.c_int, ctypes.c_double, ctypes.c_double,
+                                                  ctypes.c_int, ctypes.c_void_p]
         info = np.zeros(4, dtype=np.int32)
         for i in range(kstart):  # the caller's precondition in the reference
             self.update_row(i)
-        st = self.lib.oracle_gso_lll(self.h, kmin, kstart, kend, delta, eta,
-                                     info.ctypes.data_as(ctypes.c_void_p))
+        st = self.lib.oracle_gso_lll_flags(self.h, kmin, kstart, kend, delta, eta, flags,
+                                           info.ctypes.data_as(ctypes.c_void_p))
         return st, info
 
     def bkz(self, block_size, delta=0.99, eta=0.51, max_loops=0, auto_abort=False):
@@ -439,6 +440,7 @@ def load_lll_fixture(path):
     out["eta"] = float.fromhex(j["eta"])
     out["b_in"] = np.array(j["b_in"], dtype=np.int64).reshape(d, n)
     out["b_out"] = np.array(j["b_out"], dtype=np.int64).reshape(d, n)
+    out["flags"] = int(j.get("flags", 0))  # fplll's LLLFlags of the run (LLL_SIEGEL = 4)
     return out
 
 

@@ -48,6 +48,11 @@ $D lllfix q  72 36 16 2  0  0 -1 0 0 > $G/lll_q72.json
 $D lllfix q 130 65 12 3  0  0 -1 0 0 > $G/lll_q130.json
 $D lllfix r  30  0 40 4  0  0 -1 0 0 > $G/lll_r30.json
 $D lllfix u  24  0 30 5  0  0 -1 0 0 > $G/lll_u24.json
+# LLL_SIEGEL (LLLFIX_FLAGS = fplll's LLLFlags of the run; recorded in the fixture)
+LLLFIX_FLAGS=4 $D lllfix q  40 20 20 1  0  0 -1 0 0 > $G/lll_q40_siegel.json
+LLLFIX_FLAGS=4 $D lllfix q  72 36 16 2  0  0 -1 0 0 > $G/lll_q72_siegel.json
+LLLFIX_FLAGS=4 $D lllfix u  24  0 30 5  0  0 -1 0 0 > $G/lll_u24_siegel.json
+LLLFIX_FLAGS=4 $D lllfix q 130 65 12 3  0 40 100 0 0 > $G/lll_q130_siegel_sub.json
 $D lllfix q  40 20 20 6  0  0 -1 2 0 > $G/lll_q40_zero2.json
 $D lllfix q  40 20 20 7  0  0 -1 0 2 > $G/lll_q40_dup2.json
 $D lllfix q  40 20 20 8  0 10 30 0 0 > $G/lll_q40_range10_30.json

@@ -147,10 +147,11 @@ def test_reference_hlll_object_runs_on_the_device(name):
 
 
 @pytest.mark.parametrize("variant", ["siegel", "earlyred"])
-def test_unsupported_lll_variants_fall_back_to_the_reference_loop(variant):
-    """LLL_SIEGEL / LLL_EARLY_RED (lll.h:125-140, lll.cpp:40,116-122) are not offered by the device
-    kernels: on a MatGSOHip the interposed lll() must pass such a call to the reference's own loop —
-    no device call, the reference's result — instead of silently running plain LLL."""
+def test_lll_variants_through_the_interposed_lll(variant):
+    """LLL_SIEGEL (lll.cpp:38-40,122,134) runs on the device since round 5: one device call, the reference's
+    result.  LLL_EARLY_RED (lll.h:125-140) is not offered by the device kernels: on a MatGSOHip the interposed
+    lll() must pass such a call to the reference's own loop — no device call, the reference's result — instead
+    of silently running plain LLL."""
     f = C.load_lll_fixture(os.path.join(C.GOLDEN, "lll_q40.json"))
     path = _write_basis(f["b_in"])
     try:
@@ -159,5 +160,5 @@ def test_unsupported_lll_variants_fall_back_to_the_reference_loop(variant):
     finally:
         os.unlink(path)
     assert j["status"] == jc["status"] == 0
-    assert j["device_calls"] == 0
+    assert j["device_calls"] == (1 if variant == "siegel" else 0)
     assert np.array_equal(j["b_out"], jc["b_out"]) and j["n_swaps"] == jc["n_swaps"]

@@ -29,7 +29,7 @@ def test_reference_fixture_parity(ctx, path):
     f = C.load_lll_fixture(path)
     g = MatGSOBatch(ctx, 3, f["d"], f["n"])
     g.set_basis(np.stack([f["b_in"]] * 3))
-    st, info = g.lll(f["kmin"], f["kstart"], f["kend"], f["delta"], f["eta"])
+    st, info = g.lll(f["kmin"], f["kstart"], f["kend"], f["delta"], f["eta"], flags=f["flags"])
     assert list(st) == [f["status"]] * 3
     for L in range(3):
         assert info[L][1] == f["n_swaps"]
@@ -204,3 +204,28 @@ def test_resident_session_equals_stateless_calls(ctx):
         g.set_basis(cur[None])
         assert g.get_basis(0, 1)[0].shape == (d, d)
         g.close(); ref.close()
+
+
+def test_siegel_in_a_session_and_a_change_of_flags(ctx):
+    """LLL_SIEGEL inside a resident session equals the stateless Siegel call; switching the flag between two
+    calls of one session forgets the verified prefix (it was verified against the other swap test), so the
+    second call equals a stateless call with its own flags on the basis the first one left."""
+    from fplll_amd.gso import MatGSOBatch
+    f = C.load_lll_fixture(os.path.join(C.GOLDEN, "lll_q72_siegel.json"))
+    d = f["d"]
+    g = MatGSOBatch(ctx, 1, d, f["n"])
+    g.set_basis(f["b_in"][None])
+    st, info = g.session_lll(False, flags=4)
+    b, mu, r, vc, ex = g.session_read(0)
+    assert int(st[0]) == 1 and int(info[0][1]) == f["n_swaps"] and np.array_equal(b, f["b_out"])
+    # Siegel-reduced is weaker than delta-LLL-reduced: a plain call on the same session has swaps left to do
+    st2, info2 = g.session_lll(True, flags=0)
+    b2 = g.session_read(0)[0]
+    ref = MatGSOBatch(ctx, 1, d, f["n"])
+    ref.set_basis(b[None])
+    rst, rinfo = ref.lll()
+    assert int(st2[0]) == int(rst[0]) == 1 and int(info2[0][1]) == int(rinfo[0][1]) > 0
+    assert np.array_equal(b2, ref.get_basis(0, 1)[0])
+    with pytest.raises(NotImplementedError):
+        ref.lll(flags=2)
+    g.close(); ref.close()

@@ -16,7 +16,7 @@ import conftest as C
 def test_lll_oracle_matches_reference(path):
     f = C.load_lll_fixture(path)
     g = C.OracleGSO(f["b_in"])
-    st, info = g.lll(f["kmin"], f["kstart"], f["kend"], f["delta"], f["eta"])
+    st, info = g.lll(f["kmin"], f["kstart"], f["kend"], f["delta"], f["eta"], flags=f["flags"])
     assert st == f["status"]
     assert info[1] == f["n_swaps"]
     assert info[2] == f["zeros"]
