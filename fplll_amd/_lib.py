@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libfplll_hip.so")
 FPHIP_OK = 0
 FPHIP_UNSUPPORTED = 1
 FPHIP_ERROR = -1
-ENUM_MAX_DIM = 128
+ENUM_MAX_DIM = 256
 
 SOL_CB = ctypes.CFUNCTYPE(ctypes.c_double, ctypes.c_void_p, ctypes.c_double,
                           ctypes.POINTER(ctypes.c_double))

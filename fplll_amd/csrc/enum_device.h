@@ -8,7 +8,7 @@
 #define FPHIP_RING_CAP 1024u
 #define FPHIP_MAX_LAUNCHES 256
 #define FPHIP_TRI64 2016   /* 64*63/2 mu entries: rows below 64 (the wave-per-subtree walk) */
-#define FPHIP_TRI128 8128 /* 128*127/2: rows up to 127 (the top walk of blocks larger than 64) */
+#define FPHIP_TRI256 32640 /* 256*255/2: rows up to 255 (the top walk of blocks larger than 64) */
 
 /* Task queues.  One returning atomic on ONE address costs about 50 ns of that address's L2 channel
  * (measured on MI355X: a walk launch lasted 62-66 ns per task whatever the tasks held, 180 000 tickets
@@ -33,7 +33,7 @@ struct __attribute__((aligned(16))) SolRec
 {
   unsigned long long seq;  // == global index + 1 once the record is complete
   double dist;
-  double x[128];  // coefficients of levels 0..127
+  double x[256];  // coefficients of levels 0..255
   int kind;       // 0 = candidate solution (process_solution), 1 = sub-solution (process_subsolution)
   int offset;     // sub-solution: its level (the coefficients below it are zero)
 };
@@ -50,10 +50,10 @@ struct HostCtl
 // Device-resident per-enumeration state.
 struct DevShared
 {
-  double rdiag[128];
-  double pruning[128];
-  unsigned long long nodes[128];
-  unsigned long long sub_bits[128];  // findsubsols: best sub-solution distance per level (bit
+  double rdiag[256];
+  double pruning[256];
+  unsigned long long nodes[256];
+  unsigned long long sub_bits[256];  // findsubsols: best sub-solution distance per level (bit
                                      // pattern of a positive double; starts at rdiag, only lowered)
   unsigned long long sol_head;  // monotonically increasing across calls (ring sequence)
   unsigned long long iters;     // walk-loop iterations (diagnostics)
@@ -62,8 +62,7 @@ struct DevShared
   unsigned int pad;
   unsigned int task_head[FPHIP_MAX_LAUNCHES];
   unsigned int drain[FPHIP_MAX_LAUNCHES];  // set when a launch's task queue ran dry
-  double rp[128][2];  // (rdiag[k], pruning[k]) interleaved: one 16-byte scalar load per level
-  double mu_tri[FPHIP_TRI128];  // mu_tri[k(k-1)/2 + i] = mu(k,i), i<k
+  double rp[256][2];  // (rdiag[k], pruning[k]) interleaved: one 16-byte scalar load per level
   // breadth-first expansion of the top of the tree (enum_bfs_kernel): the table of the subtree-size
   // estimate (scheduling only: never affects which nodes are visited)
   float bfs_A[64][64];  // [L][k], k < L: log( V_{L-k}(1) / prod_{i=k}^{L-1} sqrt(r_ii) )
@@ -73,6 +72,8 @@ struct DevShared
   // clamp: the packed rows above cost three VALU instructions per load) and the pair as one scalar
   // load — both with the SAME byte offset, one scalar induction variable per loop.
   double mu_sq[64][FPHIP_MUROW];
+  // LAST (the host uploads the struct up to the rows the block has): mu_tri[k(k-1)/2 + i] = mu(k,i), i<k
+  double mu_tri[FPHIP_TRI256];
 };
 
 // Subtree tasks (structure of arrays; col/x rows are 64 doubles so that a wave loads them coalesced).
@@ -83,7 +84,7 @@ struct TaskBuf
   double *pd;           // [cap]      partial distance of the root node
   int *level;           // [cap]      root level L of the task (it walks levels < L)
   int *root;            // [cap]      index of the level-64 ancestor (blocks larger than 64): its
-                        //            coefficients of levels 64..127 are kept once, in xhi_root
+                        //            coefficients of levels >= 64 are kept once, in xhi_root
   unsigned int *count;  // number of tasks written (may exceed cap: overflow handled inline)
   unsigned int cap;
 };
@@ -99,8 +100,8 @@ struct QueueMem
 // Tasks of the top walk of a block larger than 64 (enum_top_kernel): subtree roots at a level > 64.
 struct TopBuf
 {
-  double *col;          // [cap][128] S_L: rows i<L of the centre partial sums at the root
-  double *xhi;          // [cap][64]  coefficients of levels 64..127 chosen so far (lane = level-64)
+  double *col;          // [cap][256] S_L: rows i<L of the centre partial sums at the root (row stride 128 up to d = 128)
+  double *xhi;          // [cap][192] coefficients of levels >= 64 chosen so far (row stride 64 up to d = 128)
   double *pd;           // [cap]
   int *level;           // [cap]
   unsigned int *count;  // tasks written (may exceed cap: the host declines the instance)

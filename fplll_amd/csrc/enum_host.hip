@@ -32,10 +32,10 @@ __global__ void enum_phase_kernel(DevShared *g, HostCtl *h, TaskBuf in, TaskBuf 
                                   unsigned budget, const double *xhi_root, double *gstk, int Tsplit,
                                   unsigned *qh, const unsigned *rcnt, unsigned rcap,
                                   unsigned long long bound_init);
-template <bool SUBS, bool DUAL>
+template <int NQT, bool SUBS, bool DUAL>
 __global__ void enum_top_kernel(DevShared *g, HostCtl *h, TopBuf in, unsigned n_in, TopBuf out_top,
                                 int stop, TaskBuf out, double *xhi_root, int d, double maxdist,
-                                int count_nodes, int launch_idx);
+                                int count_nodes, int launch_idx, double *gtop);
 __global__ void task_key_kernel(TaskBuf in, unsigned n, int d, unsigned long long *keys,
                                 const double *xhi_root, const unsigned *slots);
 template <bool DUAL>
@@ -130,13 +130,17 @@ struct fphip_ctx
   unsigned long long ring_next = 0;
   unsigned long long *keys     = nullptr;  // device: content key per task (multi-GPU partition)
   unsigned *idxlist            = nullptr;  // device: this rank's task indices, heaviest first
-  double *xhi_root             = nullptr;  // device: [cap][64] coefficients of levels 64..127 per
-                                           // level-64 ancestor (blocks larger than 64)
+  double *xhi_root             = nullptr;  // device: cap * 64 doubles: the coefficients of levels >= 64 per level-64
+                                           // ancestor (blocks larger than 64; 64 doubles per started chunk of levels)
   QueueMem *qm                 = nullptr;  // device: ticket / emission counters of the current call
   unsigned *slots              = nullptr;  // device: compact list of the occupied slots of a regioned buffer
   double *pdc                  = nullptr;  // device: their partial distances (multi-GPU partition)
   double *gstk                 = nullptr;  // device: per-wave scratch of the tall stack slots (split stack)
   size_t gstk_doubles          = 0;
+  int xhi_row                  = 64;       // doubles per level-64 ancestor xhi_root has room for (64, or 192 once a
+                                           // block above 128 rows has been seen)
+  double *gtop                 = nullptr;  // device: per-wave column stacks of the top walk of blocks above 128 rows
+  size_t gtop_doubles          = 0;
   TopBuf top[2] = {};                           // top tasks of blocks larger than 64 (allocated on demand)
   char err[512]                = {0};
   // GSO state lives in gso_host.hip, linked through this opaque slot
@@ -304,6 +308,8 @@ extern "C" void fphip_destroy(fphip_ctx *ctx)
     fphip_dev_free(ctx->xhi_root, ctx->stream);
   if (ctx->gstk)
     fphip_dev_free(ctx->gstk, ctx->stream);
+  if (ctx->gtop)
+    fphip_dev_free(ctx->gtop, ctx->stream);
   for (int b = 0; b < 2; ++b)
   {
     if (ctx->top[b].col)
@@ -415,9 +421,9 @@ static void drain(fphip_ctx *ctx, int dim, fphip_sol_cb cb, fphip_subsol_cb subc
     unsigned long long s = __atomic_load_n(&r->seq, __ATOMIC_ACQUIRE);
     if (s != ctx->ring_next + 1)
       return;
-    double x[128];
+    double x[FPHIP_ENUM_MAX_DIM];
     double dist = r->dist;
-    memcpy(x, (const void *)r->x, sizeof(double) * 128);
+    memcpy(x, (const void *)r->x, sizeof(double) * FPHIP_ENUM_MAX_DIM);
     if (r->kind == 1)
     {  // extenum_cb_process_subsol (enumerate_ext_api.h:70-71): no effect on the radius
       if (subcb)
@@ -579,7 +585,9 @@ extern "C" int fphip_enum_run(fphip_ctx *ctx, int dim, double maxdist, const dou
 restart:
   // ---- upload the block: rdiag, pruning, mu rows (triangular) ---------------------------------
   DevShared *st = ctx->stage;
-  memset(st, 0, sizeof(DevShared));
+  // (mu_tri is the struct's last member: a block of d rows uses — and uploads — its first d (d - 1) / 2 entries)
+  const size_t st_used = offsetof(DevShared, mu_tri) + (((size_t)d * (d - 1) / 2 * sizeof(double) + 63) & ~(size_t)63);
+  memset(st, 0, st_used);
   for (int i = 0; i < d; ++i)
   {
     st->rdiag[i]   = rdiag[i];
@@ -627,7 +635,7 @@ restart:
   st->bound_bits = dbits(maxdist);
   __atomic_store_n(&ctx->h->bound_bits, dbits(maxdist), __ATOMIC_RELEASE);
   __atomic_store_n(&ctx->h->consumed, ctx->ring_next, __ATOMIC_RELEASE);
-  HIPCHK(ctx, hipMemcpyAsync(ctx->g, st, sizeof(DevShared), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(ctx->g, st, st_used, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(ctx->qm, 0, sizeof(QueueMem), ctx->stream));
   // root task: level d, zero partial sums, zero prefix, zero partial distance (the breadth-first
   // stage reads its first frontier from buf[1] and leaves the final task list in buf[0])
@@ -650,21 +658,48 @@ restart:
     const unsigned cap2 = (unsigned)env_int("FPHIP_TOP_TASK_CAP", 32768);
     for (int b = 0; b < 2 && !ctx->top[1].col; ++b)
     {
-      HIPCHK(ctx, fphip_dev_alloc((void **)&ctx->top[b].col, (size_t)cap2 * 128 * sizeof(double), ctx->stream));
-      HIPCHK(ctx, fphip_dev_alloc((void **)&ctx->top[b].xhi, (size_t)cap2 * 64 * sizeof(double), ctx->stream));
+      // (sized for 256 rows: the kernels of blocks up to 128 rows use row strides 128 / 64 inside them)
+      HIPCHK(ctx, fphip_dev_alloc((void **)&ctx->top[b].col, (size_t)cap2 * 256 * sizeof(double), ctx->stream));
+      HIPCHK(ctx, fphip_dev_alloc((void **)&ctx->top[b].xhi, (size_t)cap2 * 192 * sizeof(double), ctx->stream));
       HIPCHK(ctx, fphip_dev_alloc((void **)&ctx->top[b].pd, (size_t)cap2 * sizeof(double), ctx->stream));
       HIPCHK(ctx, fphip_dev_alloc((void **)&ctx->top[b].level, (size_t)cap2 * sizeof(int), ctx->stream));
       HIPCHK(ctx, fphip_dev_alloc((void **)&ctx->top[b].count, 64, ctx->stream));
       ctx->top[b].cap = cap2;
     }
     // root top task: level d, zero column, no coefficient chosen, zero partial distance
-    HIPCHK(ctx, hipMemsetAsync(ctx->top[0].col, 0, 128 * sizeof(double), ctx->stream));
-    HIPCHK(ctx, hipMemsetAsync(ctx->top[0].xhi, 0, 64 * sizeof(double), ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(ctx->top[0].col, 0, 256 * sizeof(double), ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(ctx->top[0].xhi, 0, 192 * sizeof(double), ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(ctx->top[0].pd, 0, sizeof(double), ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(ctx->top[0].level, &d, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(ctx->top[1].count, 0, 4, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(ctx->buf[cur].count, 0, 4, ctx->stream));
-    const size_t tlds = (size_t)((d + 1) * d / 2 - 65 * 64 / 2) * sizeof(double);
+    // the column stack of the levels above 64: in LDS up to 128 rows (49 KB there), above that in a per-wave
+    // region of global memory (246 KB at 256 rows)
+    const bool wide     = d > 128;
+    const size_t tstack = (size_t)((d + 1) * d / 2 - 65 * 64 / 2);  // doubles per wave
+    const size_t tlds   = wide ? 0 : tstack * sizeof(double);
+    const unsigned top_waves_max = (unsigned)ctx->num_cus * 4u;
+    if (wide && ctx->gtop_doubles < tstack * top_waves_max)
+    {
+      if (ctx->gtop)
+        fphip_dev_free(ctx->gtop, ctx->stream);
+      ctx->gtop         = nullptr;
+      ctx->gtop_doubles = 0;
+      HIPCHK(ctx, fphip_dev_alloc((void **)&ctx->gtop, tstack * top_waves_max * sizeof(double), ctx->stream));
+      ctx->gtop_doubles = tstack * top_waves_max;
+    }
+    // xhi_root holds cap rows of 64 doubles; a block above 128 rows needs 128 or 192 per level-64 node: grown
+    // once, by the first such call of the context (1.6 GB at the default cap)
+    TaskBuf top_out = ctx->buf[cur];
+    if (wide && ctx->xhi_row < 192)
+    {
+      fphip_dev_free(ctx->xhi_root, ctx->stream);
+      ctx->xhi_root = nullptr;
+      ctx->xhi_row  = 64;
+      HIPCHK(ctx, fphip_dev_alloc((void **)&ctx->xhi_root, (size_t)ctx->cap * 192 * sizeof(double), ctx->stream));
+      HIPCHK(ctx, hipMemsetAsync(ctx->xhi_root, 0, 192 * sizeof(double), ctx->stream));
+      ctx->xhi_row = 192;
+    }
     // cut level of the first (single-wave) top launch: where the Gaussian heuristic expects a few
     // thousand nodes; the second launch walks those subtrees in parallel down to level 64
     int cut = 64;
@@ -680,18 +715,26 @@ restart:
     auto top_launch = [&](int in_idx, unsigned n_in, int stop, unsigned grid) -> int
     {
       HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-      if (dual)
-        hipLaunchKernelGGL((enum_top_kernel<false, true>), dim3(grid), dim3(64), tlds, ctx->stream, ctx->g,
-                           ctx->h, ctx->top[in_idx], n_in, ctx->top[in_idx ^ 1], stop, ctx->buf[cur],
-                           ctx->xhi_root, d, maxdist, top_count, launch_idx);
+#define FPHIP_TOP_LAUNCH(N, S_, D_)                                                                                \
+  hipLaunchKernelGGL((enum_top_kernel<N, S_, D_>), dim3(grid), dim3(64), tlds, ctx->stream, ctx->g, ctx->h,          \
+                     ctx->top[in_idx], n_in, ctx->top[in_idx ^ 1], stop, top_out, ctx->xhi_root, d, maxdist,        \
+                     top_count, launch_idx, ctx->gtop)
+      if (wide)
+      {
+        if (dual)
+          FPHIP_TOP_LAUNCH(4, false, true);
+        else if (subs)
+          FPHIP_TOP_LAUNCH(4, true, false);
+        else
+          FPHIP_TOP_LAUNCH(4, false, false);
+      }
+      else if (dual)
+        FPHIP_TOP_LAUNCH(2, false, true);
       else if (subs)
-        hipLaunchKernelGGL((enum_top_kernel<true, false>), dim3(grid), dim3(64), tlds, ctx->stream, ctx->g,
-                           ctx->h, ctx->top[in_idx], n_in, ctx->top[in_idx ^ 1], stop, ctx->buf[cur],
-                           ctx->xhi_root, d, maxdist, top_count, launch_idx);
+        FPHIP_TOP_LAUNCH(2, true, false);
       else
-        hipLaunchKernelGGL((enum_top_kernel<false, false>), dim3(grid), dim3(64), tlds, ctx->stream, ctx->g,
-                           ctx->h, ctx->top[in_idx], n_in, ctx->top[in_idx ^ 1], stop, ctx->buf[cur],
-                           ctx->xhi_root, d, maxdist, top_count, launch_idx);
+        FPHIP_TOP_LAUNCH(2, false, false);
+#undef FPHIP_TOP_LAUNCH
       HIPCHK(ctx, hipGetLastError());
       HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
       uint64_t nsub = 0;  // sub-solutions of the top levels arrive through the ring meanwhile
@@ -718,18 +761,18 @@ restart:
       }
       if (c1 > 0)
       {
-        const unsigned per_cu = (unsigned)std::max<size_t>(1, (160 * 1024) / std::max<size_t>(tlds, 1));
-        const unsigned grid   = std::min<unsigned>(c1, (unsigned)ctx->num_cus * std::min(per_cu, 8u));
+        const unsigned per_cu = wide ? 4u : (unsigned)std::max<size_t>(1, (160 * 1024) / std::max<size_t>(tlds, 1));
+        const unsigned grid   = std::min<unsigned>(c1, (unsigned)ctx->num_cus * std::min(per_cu, wide ? 4u : 8u));
         rct                   = top_launch(1, c1, 64, grid);
         if (rct != FPHIP_OK)
           return rct;
       }
     }
     HIPCHK(ctx, hipMemcpy(&top_tasks, ctx->buf[cur].count, 4, hipMemcpyDeviceToHost));
-    if (top_tasks > ctx->cap)
+    if (top_tasks > top_out.cap)
     {
       snprintf(ctx->err, sizeof ctx->err,
-               "more than %u surviving nodes at level 64: the block stays on the CPU enumerator", ctx->cap);
+               "more than %u surviving nodes at level 64: the block stays on the CPU enumerator", top_out.cap);
       return FPHIP_UNSUPPORTED;
     }
   }

@@ -436,8 +436,14 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK) __attribute__((amdgpu_waves_p
       SolRec *r  = &h->ring[idx % FPHIP_RING_CAP];
       double xf  = (lane < Lt) ? xs : xpre;
       r->x[lane] = (lane < d) ? xf : 0.0;
-      // levels 64..127: the coefficients chosen by the top walk, stored once per level-64 ancestor
-      r->x[64 + lane] = (64 + lane < d) ? xhi_root[(size_t)rid * 64 + lane] : 0.0;
+      // levels >= 64: the coefficients chosen by the top walk, stored once per level-64 ancestor (row stride
+      // of xhi_root: 64 per started chunk of levels above 64)
+      {
+        const int xstr = d > 64 ? 64 * ((d - 1) >> 6) : 64;
+#pragma unroll
+        for (int q = 1; q < 4; ++q)
+          r->x[64 * q + lane] = (64 * q + lane < d) ? xhi_root[(size_t)rid * xstr + 64 * (q - 1) + lane] : 0.0;
+      }
       if (lane == 0)
       {
         r->dist   = dist;
@@ -489,8 +495,13 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK) __attribute__((amdgpu_waves_p
       }
       SolRec *r       = &h->ring[idx % FPHIP_RING_CAP];
       const double xf = (lane < Lt) ? xs : xpre;
-      r->x[lane]      = (lane < d && lane >= lvl) ? xf : 0.0;
-      r->x[64 + lane] = (64 + lane < d) ? xhi_root[(size_t)rid * 64 + lane] : 0.0;
+      r->x[lane] = (lane < d && lane >= lvl) ? xf : 0.0;
+      {
+        const int xstr = d > 64 ? 64 * ((d - 1) >> 6) : 64;
+#pragma unroll
+        for (int q = 1; q < 4; ++q)
+          r->x[64 * q + lane] = (64 * q + lane < d) ? xhi_root[(size_t)rid * xstr + 64 * (q - 1) + lane] : 0.0;
+      }
       if (lane == 0)
       {
         r->dist   = dist;
@@ -1032,8 +1043,8 @@ template __global__ void enum_bfs_kernel<true>(DevShared *, double, QueueMem *, 
                                                int, float, int, int);
 
 // ---------------------------------------------------------------------------------------------
-// Blocks larger than 64 (up to 128): the levels 64..d-1.  The TOP of the tree is walked with two
-// registers per lane (rows / levels 0..127) — the same CHILD / STEP walk and the same arithmetic as
+// Blocks larger than 64 (up to 256): the levels 64..d-1.  The TOP of the tree is walked with two
+// (four above 128 rows) registers per lane (rows / levels 0..127 / 0..255) — the same CHILD / STEP walk and the same arithmetic as
 // enum_phase_kernel — in one or two launches of one-wave workgroups pulling "top tasks" (column of
 // all rows, coefficients of the levels >= 64 chosen so far, partial distance, root level): the
 // first launch walks the root down to a cut level and emits the survivors as top tasks, the second
@@ -1043,38 +1054,58 @@ template __global__ void enum_bfs_kernel<true>(DevShared *, double, QueueMem *, 
 // so the top runs under the initial radius (tasks that a later, smaller radius cuts die at their
 // first test in the next launch: the visited set is the reference's).
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ double rl2(const double (&v)[2], int idx)
+template <int NQT> __device__ __forceinline__ double rlq(const double (&v)[NQT], int idx)
 {
-  return idx < 64 ? rl_f64(v[0], idx) : rl_f64(v[1], idx - 64);
+  double r = 0.0;
+#pragma unroll
+  for (int q = 0; q < NQT; ++q)
+    if ((idx >> 6) == q)
+      r = rl_f64(v[q], idx & 63);
+  return r;
 }
-__device__ __forceinline__ int rl2i(const int (&v)[2], int idx)
+template <int NQT> __device__ __forceinline__ int rlqi(const int (&v)[NQT], int idx)
 {
-  return idx < 64 ? rl_i32(v[0], idx) : rl_i32(v[1], idx - 64);
+  int r = 0;
+#pragma unroll
+  for (int q = 0; q < NQT; ++q)
+    if ((idx >> 6) == q)
+      r = rl_i32(v[q], idx & 63);
+  return r;
 }
 
-template <bool SUBS, bool DUAL>
+// NQT = registers per lane: 2 for blocks up to 128 rows (the column stack of the levels above 64 in LDS,
+// 49 KB at d = 128), 4 up to 256 — FPLLL_MAX_ENUM_DIM, enumerate_base.h:59-101 — with the stack in a per-wave
+// region of global memory (246 KB at d = 256: more than a CU's LDS; the top of the tree is a vanishing share of
+// the nodes).  Row strides of the task buffers: 64 NQT for the columns, 64 (NQT - 1) for the coefficients of
+// the levels >= 64 (TopBuf::xhi, xhi_root).
+template <int NQT, bool SUBS, bool DUAL>
 __global__ void __launch_bounds__(64)
     enum_top_kernel(DevShared *__restrict__ g, HostCtl *__restrict__ h, TopBuf in, unsigned n_in,
                     TopBuf out_top, int stop, TaskBuf out, double *__restrict__ xhi_root, int d,
-                    double maxdist, int count_nodes, int launch_idx)
+                    double maxdist, int count_nodes, int launch_idx, double *__restrict__ gtop)
 {
-  extern __shared__ __attribute__((aligned(16))) double stk2[];  // slots 65..d (slot k: k doubles)
+  extern __shared__ __attribute__((aligned(16))) double stk_lds[];  // NQT == 2: slots 65..d (slot k: k doubles)
+  constexpr int COLS = 64 * NQT, XS = 64 * (NQT - 1);
   const int lane   = threadIdx.x & 63;
   const int off65  = tri_off(65);
   const double *mu = g->mu_tri;
-  double rd[2], bnd[2];
+  double *stk2     = (NQT == 2) ? stk_lds : gtop + (size_t)blockIdx.x * (size_t)(tri_off(d + 1) - off65);
+  double rd[NQT], bnd[NQT];
 #pragma unroll
-  for (int q = 0; q < 2; ++q)
+  for (int q = 0; q < NQT; ++q)
   {
     rd[q]  = g->rdiag[lane + 64 * q];
     bnd[q] = g->pruning[lane + 64 * q] * maxdist;
   }
-  unsigned long long cnt[2] = {0, 0};
-  double sb[2] = {0.0, 0.0};  // findsubsols: this wave's view of the best distance per level
-  if constexpr (SUBS)
+  unsigned long long cnt[NQT];
+  double sb[NQT];  // findsubsols: this wave's view of the best distance per level
+#pragma unroll
+  for (int q = 0; q < NQT; ++q)
   {
-    sb[0] = __longlong_as_double((long long)g->sub_bits[lane]);
-    sb[1] = __longlong_as_double((long long)g->sub_bits[64 + lane]);
+    cnt[q] = 0;
+    sb[q]  = 0.0;
+    if constexpr (SUBS)
+      sb[q] = __longlong_as_double((long long)g->sub_bits[64 * q + lane]);
   }
   for (;;)
   {
@@ -1085,11 +1116,19 @@ __global__ void __launch_bounds__(64)
     if (t >= n_in)
       break;
     const int Lt = __builtin_amdgcn_readfirstlane(in.level[t]);
-    double S[2]  = {in.col[(unsigned long long)t * 128 + lane], in.col[(unsigned long long)t * 128 + 64 + lane]};
-    // xs[1]: lane = level - 64; the levels >= Lt come from the task, the walk fills the others
-    double xs[2] = {0.0, in.xhi[(unsigned long long)t * 64 + lane]};
-    double cs[2] = {0.0, 0.0}, pds[2] = {0.0, 0.0};
-    int dxs[2] = {0, 0}, ddxs[2] = {0, 0};
+    double S[NQT], xs[NQT], cs[NQT], pds[NQT];
+    int dxs[NQT], ddxs[NQT];
+    // xs[q >= 1]: lane = level - 64 q; the levels >= Lt come from the task, the walk fills the others
+#pragma unroll
+    for (int q = 0; q < NQT; ++q)
+    {
+      S[q]    = in.col[(unsigned long long)t * COLS + 64 * q + lane];
+      xs[q]   = q == 0 ? 0.0 : in.xhi[(unsigned long long)t * XS + 64 * (q - 1) + lane];
+      cs[q]   = 0.0;
+      pds[q]  = 0.0;
+      dxs[q]  = 0;
+      ddxs[q] = 0;
+    }
     // process_subsolution for a node at level lvl >= 64
     auto sub_report = [&](int lvl, double dist)
     {
@@ -1099,7 +1138,7 @@ __global__ void __launch_bounds__(64)
       old               = rfl_u64(old);
       const double oldd = __longlong_as_double((long long)old);
 #pragma unroll
-      for (int q = 0; q < 2; ++q)
+      for (int q = 0; q < NQT; ++q)
         sb[q] = (lane + 64 * q == lvl) ? fmin(oldd, dist) : sb[q];
       if (!(dist < oldd))
         return;
@@ -1117,9 +1156,11 @@ __global__ void __launch_bounds__(64)
           break;
         }
       }
-      SolRec *r       = &h->ring[idx % FPHIP_RING_CAP];
-      r->x[lane]      = 0.0;
-      r->x[64 + lane] = (64 + lane < d && 64 + lane >= lvl) ? xs[1] : 0.0;
+      SolRec *r  = &h->ring[idx % FPHIP_RING_CAP];
+      r->x[lane] = 0.0;
+#pragma unroll
+      for (int q = 1; q < 4; ++q)
+        r->x[64 * q + lane] = (q < NQT && 64 * q + lane < d && 64 * q + lane >= lvl) ? xs[q < NQT ? q : 0] : 0.0;
       if (lane == 0)
       {
         r->dist   = dist;
@@ -1140,11 +1181,11 @@ __global__ void __launch_bounds__(64)
       {
         k               = __builtin_amdgcn_readfirstlane(k);
         const int kc    = k - 1;
-        const double c1 = rl2(S, kc);
+        const double c1 = rlq<NQT>(S, kc);
         const double x1 = round(c1);
         const double a1 = x1 - c1;
-        const double n1 = nd + a1 * a1 * rl2(rd, kc);
-        if (!(n1 <= rl2(bnd, kc)))
+        const double n1 = nd + a1 * a1 * rlq<NQT>(rd, kc);
+        if (!(n1 <= rlq<NQT>(bnd, kc)))
         {
           done = k >= Lt;
           break;
@@ -1159,9 +1200,11 @@ __global__ void __launch_bounds__(64)
             oi = (unsigned)__builtin_amdgcn_readfirstlane((int)oi);
             if (oi < out.cap)
             {
-              out.col[(unsigned long long)oi * 64 + lane]  = S[0];
-              out.x[(unsigned long long)oi * 64 + lane]    = 0.0;
-              xhi_root[(unsigned long long)oi * 64 + lane] = xs[1];
+              out.col[(unsigned long long)oi * 64 + lane] = S[0];
+              out.x[(unsigned long long)oi * 64 + lane]   = 0.0;
+#pragma unroll
+              for (int q = 1; q < NQT; ++q)
+                xhi_root[(unsigned long long)oi * XS + 64 * (q - 1) + lane] = xs[q];
               if (lane == 0)
               {
                 out.pd[oi]    = nd;
@@ -1177,9 +1220,13 @@ __global__ void __launch_bounds__(64)
             oi = (unsigned)__builtin_amdgcn_readfirstlane((int)oi);
             if (oi < out_top.cap)
             {
-              out_top.col[(unsigned long long)oi * 128 + lane]      = S[0];
-              out_top.col[(unsigned long long)oi * 128 + 64 + lane] = S[1];
-              out_top.xhi[(unsigned long long)oi * 64 + lane]       = xs[1];
+#pragma unroll
+              for (int q = 0; q < NQT; ++q)
+              {
+                out_top.col[(unsigned long long)oi * COLS + 64 * q + lane] = S[q];
+                if (q > 0)
+                  out_top.xhi[(unsigned long long)oi * XS + 64 * (q - 1) + lane] = xs[q];
+              }
               if (lane == 0)
               {
                 out_top.pd[oi]    = nd;
@@ -1190,13 +1237,13 @@ __global__ void __launch_bounds__(64)
           break;  // → next sibling at level k (an overfull buffer is detected by the host: count > cap)
         }
 #pragma unroll
-        for (int q = 0; q < 2; ++q)
+        for (int q = 0; q < NQT; ++q)
           if (lane + 64 * q < k)
             stk2[tri_off(k) - off65 + lane + 64 * q] = S[q];
         {
           const int s1 = (c1 >= x1) ? 1 : -1;
 #pragma unroll
-          for (int q = 0; q < 2; ++q)
+          for (int q = 0; q < NQT; ++q)
           {
             const bool me = lane + 64 * q == kc;
             cs[q]         = me ? c1 : cs[q];
@@ -1209,13 +1256,13 @@ __global__ void __launch_bounds__(64)
         }
         if constexpr (SUBS)
         {
-          if (n1 < rl2(sb, kc) && n1 != 0.0)
+          if (n1 < rlq<NQT>(sb, kc) && n1 != 0.0)
             sub_report(kc, n1);
         }
         k  = kc;
         nd = n1;  // k >= 64 here
 #pragma unroll
-        for (int q = 0; q < 2; ++q)
+        for (int q = 0; q < NQT; ++q)
         {
           const double mk = mu[tri_off(k) + min(lane + 64 * q, k - 1)];
           S[q]            = S[q] - (DUAL ? a1 : x1) * mk;
@@ -1227,17 +1274,17 @@ __global__ void __launch_bounds__(64)
       for (;;)
       {
         k = __builtin_amdgcn_readfirstlane(k);
-        double par[2], mk[2];
+        double par[NQT], mk[NQT];
 #pragma unroll
-        for (int q = 0; q < 2; ++q)
+        for (int q = 0; q < NQT; ++q)
         {
           par[q] = stk2[tri_off(k + 1) - off65 + min(lane + 64 * q, k)];
           mk[q]  = mu[tri_off(k) + min(lane + 64 * q, k - 1)];
         }
-        double xk        = rl2(xs, k);
-        const double ck  = rl2(cs, k);
-        const double pdk = rl2(pds, k);
-        int dxk = rl2i(dxs, k), ddxk = rl2i(ddxs, k);
+        double xk        = rlq<NQT>(xs, k);
+        const double ck  = rlq<NQT>(cs, k);
+        const double pdk = rlq<NQT>(pds, k);
+        int dxk = rlqi<NQT>(dxs, k), ddxk = rlqi<NQT>(ddxs, k);
         if (pdk != 0.0)
         {
           xk += (double)dxk;
@@ -1249,7 +1296,7 @@ __global__ void __launch_bounds__(64)
           xk += 1.0;
         }
 #pragma unroll
-        for (int q = 0; q < 2; ++q)
+        for (int q = 0; q < NQT; ++q)
         {
           const bool me = lane + 64 * q == k;
           xs[q]         = me ? xk : xs[q];
@@ -1257,8 +1304,8 @@ __global__ void __launch_bounds__(64)
           ddxs[q]       = me ? ddxk : ddxs[q];
         }
         const double a = xk - ck;
-        nd             = pdk + a * a * rl2(rd, k);
-        if (!(nd <= rl2(bnd, k)))
+        nd             = pdk + a * a * rlq<NQT>(rd, k);
+        if (!(nd <= rlq<NQT>(bnd, k)))
         {
           ++k;
           if (k >= Lt)
@@ -1269,15 +1316,15 @@ __global__ void __launch_bounds__(64)
           continue;
         }
 #pragma unroll
-        for (int q = 0; q < 2; ++q)
+        for (int q = 0; q < NQT; ++q)
           cnt[q] += (lane + 64 * q == k) ? 1ull : 0ull;
         if constexpr (SUBS)
         {
-          if (nd < rl2(sb, k) && nd != 0.0)
+          if (nd < rlq<NQT>(sb, k) && nd != 0.0)
             sub_report(k, nd);
         }
 #pragma unroll
-        for (int q = 0; q < 2; ++q)
+        for (int q = 0; q < NQT; ++q)
           S[q] = par[q] - (DUAL ? a : xk) * mk[q];
         break;
       }
@@ -1286,17 +1333,21 @@ __global__ void __launch_bounds__(64)
   if (count_nodes)
   {
 #pragma unroll
-    for (int q = 0; q < 2; ++q)
+    for (int q = 0; q < NQT; ++q)
       if (cnt[q] != 0)
         atomicAdd(&g->nodes[lane + 64 * q], cnt[q]);
   }
 }
-template __global__ void enum_top_kernel<false, false>(DevShared *, HostCtl *, TopBuf, unsigned, TopBuf,
-                                                       int, TaskBuf, double *, int, double, int, int);
-template __global__ void enum_top_kernel<true, false>(DevShared *, HostCtl *, TopBuf, unsigned, TopBuf,
-                                                      int, TaskBuf, double *, int, double, int, int);
-template __global__ void enum_top_kernel<false, true>(DevShared *, HostCtl *, TopBuf, unsigned, TopBuf,
-                                                      int, TaskBuf, double *, int, double, int, int);
+#define FPHIP_TOP_INST(N, S_, D_)                                                                                  \
+  template __global__ void enum_top_kernel<N, S_, D_>(DevShared *, HostCtl *, TopBuf, unsigned, TopBuf, int, TaskBuf, \
+                                                      double *, int, double, int, int, double *);
+FPHIP_TOP_INST(2, false, false)
+FPHIP_TOP_INST(2, true, false)
+FPHIP_TOP_INST(2, false, true)
+FPHIP_TOP_INST(4, false, false)
+FPHIP_TOP_INST(4, true, false)
+FPHIP_TOP_INST(4, false, true)
+#undef FPHIP_TOP_INST
 
 // 64-bit content key of every task (its coefficient prefix x[Lt..d)): the task ORDER in the buffer
 // is not deterministic across ranks, the content is.  One wave per task.
@@ -1315,12 +1366,15 @@ __global__ void __launch_bounds__(256)
     const bool on     = lane >= Lt && lane < d;
     unsigned h1 = on ? (unsigned)(int)xpre * (2654435761u * (unsigned)(lane + 1)) : 0u;
     unsigned h2 = on ? ((unsigned)(int)xpre ^ 0x9e3779b9u) * (40503u * (unsigned)(2 * lane + 3) + 2246822519u) : 0u;
-    if (64 + lane < d)
-    {  // blocks larger than 64: the coefficients of levels >= 64 (kept once per level-64 ancestor)
-      const double xh = xhi_root[(unsigned long long)in.root[ti] * 64 + lane];
-      h1 += (unsigned)(int)xh * (2654435761u * (unsigned)(lane + 65));
-      h2 += ((unsigned)(int)xh ^ 0x9e3779b9u) * (40503u * (unsigned)(2 * lane + 131) + 2246822519u);
-    }
+    const int xstr = d > 64 ? 64 * ((d - 1) >> 6) : 64;
+    for (int q = 1; q < 4; ++q)
+      if (64 * q + lane < d)
+      {  // blocks larger than 64: the coefficients of levels >= 64 (kept once per level-64 ancestor)
+        const int lv    = 64 * q + lane;
+        const double xh = xhi_root[(unsigned long long)in.root[ti] * xstr + 64 * (q - 1) + lane];
+        h1 += (unsigned)(int)xh * (2654435761u * (unsigned)(lv + 1));
+        h2 += ((unsigned)(int)xh ^ 0x9e3779b9u) * (40503u * (unsigned)(2 * lv + 3) + 2246822519u);
+      }
     for (int off = 32; off > 0; off >>= 1)
     {
       h1 += (unsigned)__shfl_xor((int)h1, off);

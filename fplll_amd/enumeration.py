@@ -163,7 +163,7 @@ def enumerate_block(ctx, mut, rdiag, pruning, maxdist, evaluator, shard_index=0,
     if state["exc"] is not None:
         raise state["exc"]
     if rc == _lib.FPHIP_UNSUPPORTED:
-        raise Unsupported("instance declined by the device layer (d=%d)" % d)
+        raise Unsupported("instance declined by the device layer (d=%d): %s" % (d, ctx.last_error()))
     if rc != _lib.FPHIP_OK:
         raise _lib.HipError("fphip_enum_run failed: %s" % ctx.last_error())
     return EnumResult(nodes, stats, state["maxdist"])

@@ -45,10 +45,11 @@ extern "C" {
 #define FPHIP_UNSUPPORTED 1
 #define FPHIP_ERROR (-1)
 
-/* largest enumeration dimension handled on the device (levels are lane-indexed: 64 per wavefront;
- * blocks of 65..128 levels are walked in two stages); larger blocks are declined
- * (FPHIP_UNSUPPORTED → fplll's own enumerator) */
-#define FPHIP_ENUM_MAX_DIM 128
+/* largest enumeration dimension handled on the device = fplll's FPLLL_MAX_ENUM_DIM (enum/enumerate_base.h:59-101).
+ * Levels are lane-indexed, 64 per wavefront: blocks of 65..256 levels are walked in two stages (the levels
+ * above 64 by the top walk with two — above 128 rows four — registers per lane, the rest by the wave-per-subtree
+ * kernel); larger blocks are declined (FPHIP_UNSUPPORTED → fplll's own enumerator) */
+#define FPHIP_ENUM_MAX_DIM 256
 
 typedef struct fphip_ctx fphip_ctx;
 

@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define ORACLE_MAX_DIM 256
+#define ORACLE_MAX_DIM 260
 
 /* Solution sink.  Mirrors extenum_cb_process_sol (fplll/enum/enumerate_ext_api.h:62-63):
  * receives the squared norm and the coefficient vector, returns the NEW enumeration bound. */

@@ -229,6 +229,20 @@ def synthetic_block(d, seed, slope=0.045, radius_factor=1.05):
     return mut, rdiag, maxdist
 
 
+def wide_block(d, seed, c, d0=70, rf=0.46):
+    """A block of d > 128 rows whose tree the C oracle can walk in seconds: the 70-row block
+    synthetic_block(70, seed, 0.03, rf) with d - 70 rows of r_kk = c * radius^2 (times a seeded factor in
+    [0.9, 1.1]) above it and seeded mu everywhere — the levels above 70 branch a little (a coefficient +-1 or two
+    survive the level bounds), every such node then descends into the 70-row tree with what is left of the radius.
+    Nodes at EVERY level: above 128 (four registers per lane, stack in global memory), 64..127, below 64."""
+    mut0, r0, maxdist = synthetic_block(d0, seed, 0.03, rf)
+    rng = np.random.default_rng(seed + 1000)
+    mu = np.tril(rng.uniform(-0.5, 0.5, size=(d, d)), -1)
+    mu[:d0, :d0] = mut0.T
+    rdiag = np.concatenate([r0, c * maxdist * rng.uniform(0.9, 1.1, size=d - d0)])
+    return np.ascontiguousarray(mu.T), rdiag, maxdist
+
+
 @pytest.fixture(scope="session")
 def ctx():
     import fplll_amd

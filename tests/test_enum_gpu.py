@@ -160,7 +160,7 @@ def test_edge_cases(ctx):
     res = enumerate_block(ctx, mut, np.array([1.0, 1.0]), None, 0.5, FastEvaluator(1, 0))
     assert [int(v) for v in res.nodes] == [1, 0, 0]
     # declined instances (fplll falls back to its own enumerator)
-    for d in (1, 129, 200):
+    for d in (1, 257, 300):  # (FPLLL_MAX_ENUM_DIM = 256 is the device's limit too since round 5)
         with pytest.raises(Unsupported):
             enumerate_block(ctx, np.zeros((d, d)), np.ones(d), None, 1.0, FastEvaluator(1, 0))
     with pytest.raises(Unsupported):  # dual + sub-solutions: the reference never asks for it
@@ -179,15 +179,18 @@ def test_edge_cases(ctx):
     assert len(ev.solutions) == len(ev_o.solutions)
 
 
-@pytest.mark.parametrize("d,seed,rf", [(65, 21, 0.5), (70, 22, 0.46), (100, 23, 0.22), (128, 24, 0.08)])
+@pytest.mark.parametrize("d,seed,rf", [(65, 21, 0.5), (70, 22, 0.46), (100, 23, 0.22), (128, 24, 0.08),
+                                       (129, 25, 0.15), (160, 26, 0.2), (200, 27, 0.3), (256, 28, 0.3)])
 def test_blocks_larger_than_64_vs_oracle(ctx, d, seed, rf):
-    """Two-stage walk (levels >= 64 by one wave, then the wave-per-subtree kernel): per-level counts
+    """Two-stage walk (levels >= 64 by the top walk, then the wave-per-subtree kernel): per-level counts
     and the reported candidates are the oracle's, on seeded blocks at the chunk boundary (65), in
-    between and at the maximum (128, where this tree dies above level 64: no task at all).  The
+    between, at 128 (the last block on two registers per lane with the column stack in LDS), right above it
+    (129: four registers per lane, the stack in global memory) and up to FPLLL_MAX_ENUM_DIM = 256.  The
     radii are far below the Gaussian heuristic so that the oracle finishes in seconds; candidates of
     large blocks are covered by the reference fixtures enum_d72/d80/d96."""
     from fplll_amd.enumeration import FastEvaluator, enumerate_block
-    mut, rdiag, maxdist = C.synthetic_block(d, seed, 0.03, rf)
+    # (above 128 rows: conftest.wide_block, `rf` is then its c — see there)
+    mut, rdiag, maxdist = C.synthetic_block(d, seed, 0.03, rf) if d <= 128 else C.wide_block(d, seed, rf)
     pruning = np.clip(np.linspace(1.0, 0.25, d)[::-1].copy(), 0.0, 1.0)[::-1].copy()
     ev = FastEvaluator(10**9, 0)
     res = enumerate_block(ctx, mut, rdiag, pruning, maxdist, ev)
@@ -195,9 +198,15 @@ def test_blocks_larger_than_64_vs_oracle(ctx, d, seed, rf):
     nodes_o, _ = C.oracle_enumerate(mut, rdiag, pruning, maxdist, ev_o)
     assert [int(v) for v in res.nodes] == [int(v) for v in nodes_o]
     assert sum(int(v) for v in nodes_o[64:]) > 0
+    if d > 128:
+        # the levels only the wide top walk reaches, the levels it hands down through, and the subtree kernel's
+        assert sum(int(v) for v in nodes_o[128:]) > 0 and sum(int(v) for v in nodes_o[64:128]) > 1000
+        assert sum(int(v) for v in nodes_o[:64]) > 10**7
     so = sorted((s[0], tuple(s[1])) for s in ev_o.solutions)
     sg = sorted((s[0], tuple(s[1])) for s in ev.solutions)
     assert sg == so
+    if d > 128:
+        return  # (no vector of these blocks is inside the radius: nothing shrinks)
     # shrinking radius: same final norm
     ev1, ev1o = FastEvaluator(1, 0), FastEvaluator(1, 0)
     enumerate_block(ctx, mut, rdiag, pruning, maxdist, ev1)
