@@ -23,6 +23,10 @@ EXCHANGE_CB = ctypes.CFUNCTYPE(ctypes.c_double, ctypes.c_void_p, ctypes.c_double
                                ctypes.POINTER(ctypes.c_int))
 
 
+GATHER_CB = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p,
+                             ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t))
+
+
 class EnumOpts(ctypes.Structure):
     _fields_ = [
         ("dual", ctypes.c_int),
@@ -36,6 +40,8 @@ class EnumOpts(ctypes.Structure):
         ("phase_growth", ctypes.c_int),
         ("waves_per_block", ctypes.c_int),
         ("min_nodes_decline", ctypes.c_int),
+        ("gather", GATHER_CB),
+        ("gather_user", ctypes.c_void_p),
     ]
 
 
@@ -50,6 +56,8 @@ class EnumStats(ctypes.Structure):
         ("final_tasks", ctypes.c_int),
         ("final_root_level", ctypes.c_int),
         ("overflowed", ctypes.c_int),
+        ("pad0", ctypes.c_int),
+        ("moved_tasks", ctypes.c_uint64),
     ]
 
 

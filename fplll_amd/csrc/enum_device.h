@@ -21,6 +21,8 @@
 #define FPHIP_NQ 128
 #define FPHIP_QS 16 /* unsigned words between two counters: 64 bytes */
 
+#define FPHIP_TASK_REC 130 /* doubles of a task on the wire (work movement between ranks): pd, level, col[64], x[64] */
+
 #define FPHIP_ERR_RING_TIMEOUT 1u
 #define FPHIP_FLAG_TASK_OVERFLOW 2u
 #define FPHIP_FLAG_BFS_OVERFLOW 4u /* a buffer of the breadth-first expansion was too small: the host starts over */

@@ -38,6 +38,8 @@ __global__ void enum_top_kernel(DevShared *g, HostCtl *h, TopBuf in, unsigned n_
                                 int count_nodes, int launch_idx, double *gtop);
 __global__ void task_key_kernel(TaskBuf in, unsigned n, int d, unsigned long long *keys,
                                 const double *xhi_root, const unsigned *slots);
+__global__ void task_pack_kernel(TaskBuf in, unsigned lo, unsigned n, double *rec);
+__global__ void task_unpack_kernel(TaskBuf out, unsigned lo, unsigned n, const double *rec);
 template <bool DUAL>
 __global__ void enum_bfs_kernel(DevShared *g, double maxdist, QueueMem *qm, TaskBuf f0, TaskBuf f1,
                                 TaskBuf fin, int L0, int nlev, int floor_level, float heavy, int count_nodes,
@@ -139,6 +141,8 @@ struct fphip_ctx
   size_t gstk_doubles          = 0;
   int xhi_row                  = 64;       // doubles per level-64 ancestor xhi_root has room for (64, or 192 once a
                                            // block above 128 rows has been seen)
+  double *wire                 = nullptr;  // device: task records on their way to / from other ranks (work movement)
+  size_t wire_doubles          = 0;
   double *gtop                 = nullptr;  // device: per-wave column stacks of the top walk of blocks above 128 rows
   size_t gtop_doubles          = 0;
   TopBuf top[2] = {};                           // top tasks of blocks larger than 64 (allocated on demand)
@@ -310,6 +314,8 @@ extern "C" void fphip_destroy(fphip_ctx *ctx)
     fphip_dev_free(ctx->gstk, ctx->stream);
   if (ctx->gtop)
     fphip_dev_free(ctx->gtop, ctx->stream);
+  if (ctx->wire)
+    fphip_dev_free(ctx->wire, ctx->stream);
   for (int b = 0; b < 2; ++b)
   {
     if (ctx->top[b].col)
@@ -500,6 +506,86 @@ static int choose_stop(const double *logN, int L, double C, double target_final,
   if (argmax >= 1 && best >= std::log(4.0 * C))
     return argmax;
   return -1;
+}
+
+// Work movement between the ranks at a round boundary of the final phase (fphip_enum_opts::gather): the ranks
+// learn each other's numbers of donated tasks; those above the average pack their surplus (the tail of their
+// list), the pool of all surpluses is gathered everywhere, and the ranks below the average take consecutive
+// slices of it in rank order.  Every rank computes the same plan from the same counts: no task is lost or walked
+// twice, whatever the order of the lists.  *cnt is this rank's number of tasks in `buf` before and after.
+// moved_out (nullable): tasks that left or reached this rank.
+static int rebalance_tasks(fphip_ctx *ctx, const fphip_enum_opts &o, TaskBuf buf, unsigned *cnt, unsigned *moved_out)
+{
+  const int W = o.shard_count, me = o.shard_index;
+  std::vector<unsigned long long> counts((size_t)W, 0);
+  std::vector<size_t> sizes((size_t)W, 0);
+  unsigned long long mine = *cnt;
+  if (o.gather(o.gather_user, &mine, sizeof mine, counts.data(), sizeof(unsigned long long) * (size_t)W, sizes.data()) != 0)
+    return fail(ctx, "work movement: the gather callback failed (counts)");
+  unsigned long long total = 0;
+  for (int r = 0; r < W; ++r)
+    total += counts[r];
+  std::vector<unsigned long long> surplus((size_t)W, 0), deficit((size_t)W, 0);
+  unsigned long long moved = 0;
+  for (int r = 0; r < W; ++r)
+  {
+    const unsigned long long target = total / W + ((unsigned long long)r < total % W ? 1 : 0);
+    if (counts[r] > target)
+      surplus[r] = counts[r] - target;
+    else
+      deficit[r] = target - counts[r];
+    moved += surplus[r];
+  }
+  if (moved_out)
+    *moved_out = 0;
+  // not worth a transfer: (nearly) balanced already, or a target beyond this context's buffers (the same
+  // decision on every rank: it only depends on the counts)
+  if (moved == 0 || moved * 16 < total || total / W + 1 > ctx->cap)
+    return FPHIP_OK;
+  const size_t recb = (size_t)FPHIP_TASK_REC * sizeof(double);
+  if (ctx->wire_doubles < (size_t)moved * FPHIP_TASK_REC)
+  {
+    if (ctx->wire)
+      fphip_dev_free(ctx->wire, ctx->stream);
+    ctx->wire         = nullptr;
+    ctx->wire_doubles = 0;
+    HIPCHK(ctx, fphip_dev_alloc((void **)&ctx->wire, (size_t)moved * recb, ctx->stream));
+    ctx->wire_doubles = (size_t)moved * FPHIP_TASK_REC;
+  }
+  std::vector<double> send((size_t)surplus[me] * FPHIP_TASK_REC), pool((size_t)moved * FPHIP_TASK_REC);
+  if (surplus[me] > 0)
+  {
+    const unsigned n  = (unsigned)surplus[me];
+    const unsigned lo = *cnt - n;  // the tail of the list leaves
+    hipLaunchKernelGGL(task_pack_kernel, dim3(std::min<unsigned>((n + 3) / 4, (unsigned)ctx->num_cus * 8u)), dim3(256), 0,
+                       ctx->stream, buf, lo, n, ctx->wire);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(send.data(), ctx->wire, (size_t)n * recb, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    *cnt = lo;
+  }
+  if (o.gather(o.gather_user, send.data(), (size_t)surplus[me] * recb, pool.data(), (size_t)moved * recb, sizes.data()) != 0)
+    return fail(ctx, "work movement: the gather callback failed (tasks)");
+  for (int r = 0; r < W; ++r)
+    if (sizes[r] != (size_t)surplus[r] * recb)
+      return fail(ctx, "work movement: rank %d sent %zu bytes, %zu expected", r, sizes[r], (size_t)surplus[r] * recb);
+  if (deficit[me] > 0)
+  {
+    unsigned long long off = 0;
+    for (int r = 0; r < me; ++r)
+      off += deficit[r];
+    const unsigned n = (unsigned)deficit[me];
+    HIPCHK(ctx, hipMemcpyAsync(ctx->wire, pool.data() + (size_t)off * FPHIP_TASK_REC, (size_t)n * recb,
+                               hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(task_unpack_kernel, dim3(std::min<unsigned>((n + 3) / 4, (unsigned)ctx->num_cus * 8u)), dim3(256), 0,
+                       ctx->stream, buf, *cnt, n, ctx->wire);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    *cnt += n;
+  }
+  if (moved_out)
+    *moved_out = (unsigned)(surplus[me] + deficit[me]);
+  return FPHIP_OK;
 }
 
 extern "C" int fphip_enum_run(fphip_ctx *ctx, int dim, double maxdist, const double *mut,
@@ -795,6 +881,7 @@ restart:
   const int max_rounds  = env_int("FPHIP_MAX_ROUNDS", 24);
   if (debug)
     fprintf(stderr, "[fphip] d=%d est_nodes=%.3e budget=%u\n", d, est_nodes, budget);
+  unsigned long long moved_tasks = 0;  // work movement between ranks: tasks that left or reached this rank
   bool in_final       = false;  // false: level-cut splitting phases; true: budgeted walk rounds
   int round           = 0;
   unsigned prevC      = 0;
@@ -1124,6 +1211,18 @@ restart:
       if (glob < local)
         publish_bound_min(ctx, glob);
       others_active = any != 0;
+      // work movement: while anybody still has tasks, the ranks level their lists (blocks up to 64 rows: a task
+      // of a larger block points into this rank's own table of level-64 ancestors)
+      if (o.gather && o.shard_count > 1 && d <= 64 && any != 0)
+      {
+        unsigned mv = 0;
+        const int rcm = rebalance_tasks(ctx, o, ctx->buf[nxt], &cnt, &mv);
+        if (rcm != FPHIP_OK)
+          return rcm;
+        moved_tasks += mv;
+        if (debug && mv)
+          fprintf(stderr, "[fphip s%d] round %d: %u tasks moved, %u here now\n", o.shard_index, round, mv, cnt);
+      }
     }
     if (in_final)
     {
@@ -1165,6 +1264,8 @@ restart:
     stats->final_tasks      = final_tasks;
     stats->final_root_level = final_L;
     stats->overflowed       = (st->error_flags & FPHIP_FLAG_TASK_OVERFLOW) ? 1 : 0;
+    stats->pad0             = 0;
+    stats->moved_tasks      = moved_tasks;
     stats->wall_ms =
         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin)
             .count();

@@ -1349,6 +1349,46 @@ FPHIP_TOP_INST(4, true, false)
 FPHIP_TOP_INST(4, false, true)
 #undef FPHIP_TOP_INST
 
+// Work movement between ranks (blocks up to 64 rows): tasks [lo, lo + n) of a buffer as contiguous records of
+// FPHIP_TASK_REC doubles — partial distance, root level, column, coefficient prefix — and back.  One wave per task.
+__global__ void __launch_bounds__(256) task_pack_kernel(TaskBuf in, unsigned lo, unsigned n, double *__restrict__ rec)
+{
+  const int lane   = threadIdx.x & 63;
+  const unsigned w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const unsigned nw = (gridDim.x * blockDim.x) >> 6;
+  for (unsigned t = w; t < n; t += nw)
+  {
+    const unsigned long long ti = lo + t;
+    double *r                   = rec + (unsigned long long)t * FPHIP_TASK_REC;
+    if (lane == 0)
+    {
+      r[0] = in.pd[ti];
+      r[1] = (double)in.level[ti];
+    }
+    r[2 + lane]  = in.col[ti * 64 + lane];
+    r[66 + lane] = in.x[ti * 64 + lane];
+  }
+}
+__global__ void __launch_bounds__(256) task_unpack_kernel(TaskBuf out, unsigned lo, unsigned n, const double *__restrict__ rec)
+{
+  const int lane   = threadIdx.x & 63;
+  const unsigned w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const unsigned nw = (gridDim.x * blockDim.x) >> 6;
+  for (unsigned t = w; t < n; t += nw)
+  {
+    const unsigned long long ti = lo + t;
+    const double *r             = rec + (unsigned long long)t * FPHIP_TASK_REC;
+    if (lane == 0)
+    {
+      out.pd[ti]    = r[0];
+      out.level[ti] = (int)r[1];
+      out.root[ti]  = 0;
+    }
+    out.col[ti * 64 + lane] = r[2 + lane];
+    out.x[ti * 64 + lane]   = r[66 + lane];
+  }
+}
+
 // 64-bit content key of every task (its coefficient prefix x[Lt..d)): the task ORDER in the buffer
 // is not deterministic across ranks, the content is.  One wave per task.
 __global__ void __launch_bounds__(256)

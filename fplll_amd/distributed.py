@@ -26,6 +26,50 @@ def make_exchange(dist, device="cpu"):
     return exchange
 
 
+def make_gather(dist, device="cpu"):
+    """Return ``gather(block: bytes) -> list of every rank's block`` (rank order): what fphip_gather_cb needs — the
+    all-gather the work movement between ranks rides on (counts of donated tasks, then the surplus tasks, at the
+    round boundaries of the walk).  Two collectives: the sizes, then the blocks padded to the largest.  Every
+    rank must call it the same number of times."""
+    import torch
+    world = dist.get_world_size()
+
+    def gather(block):
+        n = torch.tensor([len(block)], dtype=torch.int64, device=device)
+        ns = [torch.zeros_like(n) for _ in range(world)]
+        dist.all_gather(ns, n)
+        sizes = [int(t.item()) for t in ns]
+        m = max(sizes)
+        if m == 0:
+            return [b""] * world
+        buf = torch.zeros(m, dtype=torch.uint8, device=device)
+        if len(block):
+            buf[: len(block)] = torch.frombuffer(bytearray(block), dtype=torch.uint8).to(device)
+        out = [torch.empty_like(buf) for _ in range(world)]
+        dist.all_gather(out, buf)
+        return [bytes(out[r][: sizes[r]].cpu().numpy().tobytes()) for r in range(world)]
+
+    return gather
+
+
+def balance_plan(counts):
+    """The plan rebalance_tasks (enum_host.hip) derives from the ranks' numbers of donated tasks — restated for
+    the CPU tests: targets differ by at most one, ranks above theirs give the surplus (the tail of their list),
+    ranks below take consecutive slices of the pooled surpluses in rank order.  Returns (moved, surplus[],
+    deficit[], offset[]) with offset[r] = where rank r's slice of the pool starts; moved = 0 when the lists are
+    level enough (less than a sixteenth of the tasks would move)."""
+    W = len(counts)
+    total = sum(counts)
+    target = [total // W + (1 if r < total % W else 0) for r in range(W)]
+    surplus = [max(0, c - t) for c, t in zip(counts, target)]
+    deficit = [max(0, t - c) for c, t in zip(counts, target)]
+    moved = sum(surplus)
+    if moved == 0 or moved * 16 < total:
+        return 0, [0] * W, [0] * W, [0] * W
+    offset = [sum(deficit[:r]) for r in range(W)]
+    return moved, surplus, deficit, offset
+
+
 def task_key(prefix, root_level, d):
     """64-bit content key of a subtree task (task_key_kernel in enum_kernel.hip): computed from the
     coefficient prefix x[root_level..d) only, so every rank derives the same key whatever the
@@ -133,16 +177,19 @@ def reduce_enumeration(dist, best_dist, best_coords, nodes, dim, device="cpu"):
 
 
 def enumerate_block_sharded(ctx, dist, mut, rdiag, pruning, maxdist, evaluator, device="cpu",
-                            exchange_chunks=4, **kw):
+                            exchange_chunks=4, move_work=True, **kw):
     """One SVP enumeration over all ranks of `dist` (one process per GPU): this rank walks its share of
-    the subtree tasks (fplll_amd.enumeration.enumerate_block with the 16-byte bound exchange), then
+    the subtree tasks (fplll_amd.enumeration.enumerate_block with the 16-byte bound exchange and, at the round boundaries, the
+    levelling of the donated subtrees over the ranks), then
     the reductions above.  Returns (dist, coords, nodes, local_result): the first three identical on
     every rank.  `evaluator` is this rank's (fplll's evaluator is per process); with BEST-1 semantics
     its shortest solution is this rank's candidate."""
     from .enumeration import enumerate_block
     rank, world = dist.get_rank(), dist.get_world_size()
+    # (move_work: donated subtrees are levelled over the ranks at every round boundary — fphip_gather_cb)
     res = enumerate_block(ctx, mut, rdiag, pruning, maxdist, evaluator, shard_index=rank, shard_count=world,
-                          exchange=make_exchange(dist, device), exchange_chunks=exchange_chunks, **kw)
+                          exchange=make_exchange(dist, device), exchange_chunks=exchange_chunks,
+                          gather=make_gather(dist, device) if (move_work and world > 1) else None, **kw)
     sols = sorted(evaluator.solutions, key=lambda s: s[0]) if evaluator.solutions else []
     bd = sols[0][0] if sols else float("inf")
     bc = sols[0][1] if sols else None

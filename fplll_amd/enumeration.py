@@ -92,13 +92,15 @@ def mut_from_mu(mu):
 def enumerate_block(ctx, mut, rdiag, pruning, maxdist, evaluator, shard_index=0, shard_count=1,
                     exchange=None, exchange_chunks=1, target_tasks=0, phase_growth=0,
                     waves_per_block=0, min_nodes_decline=0, dual=False, findsubsols=False,
-                    log=None):
+                    log=None, gather=None):
     """Run one SVP enumeration on the GPU through the C ABI.
 
     mut[i*d+j] = mu(j,i) for j>i; rdiag, pruning (or None), maxdist normalised like the reference
     hands them to a plugin.  ``evaluator.eval_sol(coords, dist, max_dist) -> new max_dist`` is
     called (serialised) while the kernel runs.  ``exchange(local_bound, local_active) -> (bound,
-    any_active)`` is the multi-GPU collective hook (RCCL all-reduce in bench.py).
+    any_active)`` is the multi-GPU collective hook (RCCL all-reduce in bench.py); ``gather(block: bytes) ->
+    [bytes of rank 0, bytes of rank 1, ...]`` the all-gather the work movement between ranks rides on
+    (fphip_gather_cb: distributed.make_gather).
     """
     lib = ctx.lib
     mut = np.ascontiguousarray(mut, dtype=np.float64)
@@ -134,6 +136,21 @@ def enumerate_block(ctx, mut, rdiag, pruning, maxdist, evaluator, shard_index=0,
             any_active[0] = 0
             return 0.0
 
+    def _gc(_user, send, send_bytes, recv, recv_cap, sizes):
+        try:
+            blocks = gather(ctypes.string_at(send, send_bytes) if send_bytes else b"")
+            off = 0
+            for r, blk in enumerate(blocks):
+                if off + len(blk) > recv_cap:
+                    return 2
+                ctypes.memmove(recv + off, blk, len(blk))
+                sizes[r] = len(blk)
+                off += len(blk)
+            return 0
+        except BaseException as e:
+            state["exc"] = e
+            return 1
+
     def _scb(_user, dist, sub, offset):
         try:
             evaluator.eval_sub_sol(offset, [0.0] * offset + [sub[i] for i in range(offset, d)], dist)
@@ -153,6 +170,7 @@ def enumerate_block(ctx, mut, rdiag, pruning, maxdist, evaluator, shard_index=0,
     opts.phase_growth = phase_growth
     opts.waves_per_block = waves_per_block
     opts.min_nodes_decline = min_nodes_decline
+    opts.gather = _lib.GATHER_CB(_gc) if gather is not None else _lib.GATHER_CB()
     nodes = np.zeros(d + 1, dtype=np.uint64)
     stats = _lib.EnumStats()
     rc = lib.fphip_enum_run(ctx.handle, d, ctypes.c_double(maxdist),

@@ -83,6 +83,14 @@ typedef void (*fphip_subsol_cb)(void *user, double dist, const double *subsol, i
  * tasks (the host glue makes it an RCCL all-reduce: MIN on the bound, MAX on the flag). */
 typedef double (*fphip_exchange_cb)(void *user, double local_bound, int local_active,
                                     int *any_active);
+/* Multi-GPU work movement: an all-gather of byte blocks.  Called at the round boundaries of the final phase, the
+ * SAME number of times on every rank, with this rank's block; the callee writes the blocks of all ranks, in rank
+ * order and back to back, into recv (recv_cap bytes) and their sizes into sizes[shard_count]; 0 = ok.  What it
+ * carries: the ranks' counts of donated subtree tasks (8 bytes each), then — when they are out of balance — the
+ * surplus tasks themselves (1040 bytes each), which the ranks below the average take over.  The role of enumlib's
+ * shared subtree counter (enum-parallel/enumeration.h:412-505) between processes. */
+typedef int (*fphip_gather_cb)(void *user, const void *send, size_t send_bytes, void *recv, size_t recv_cap,
+                               size_t *sizes);
 
 typedef struct fphip_enum_opts
 {
@@ -97,7 +105,7 @@ typedef struct fphip_enum_opts
    * all ranks hold the same task SET; the tasks of the first walk round are sorted by content
    * (partial distance of the root, then a key of the coefficient prefix) and dealt to the ranks in
    * snake order 0..W-1, W-1..0 — disjoint, complete, nearly equal weight; this context walks the
-   * share of shard_index.  Donated subtrees stay on their GPU. */
+   * share of shard_index.  Donated subtrees stay on their GPU unless `gather` (below) is set. */
   int shard_index;
   int shard_count;
   fphip_exchange_cb exchange;
@@ -108,6 +116,11 @@ typedef struct fphip_enum_opts
   int phase_growth;    /* wanted task growth per splitting phase */
   int waves_per_block; /* final-phase workgroup = waves_per_block * 64 threads */
   int min_nodes_decline; /* decline when the Gaussian-heuristic node estimate is below this */
+  /* work movement between the ranks (with `exchange`; NULL: donated subtrees stay on their GPU, as they do for
+   * blocks above 64 rows in any case).  After every walk round the ranks compare their numbers of donated tasks;
+   * ranks above the average hand their surplus to the ranks below it (by rank order). */
+  fphip_gather_cb gather;
+  void *gather_user;
 } fphip_enum_opts;
 
 typedef struct fphip_enum_stats
@@ -121,6 +134,8 @@ typedef struct fphip_enum_stats
   int final_tasks;
   int final_root_level;
   int overflowed; /* task-buffer overflow happened (handled inline, results still exact) */
+  int pad0;
+  uint64_t moved_tasks; /* work movement (fphip_enum_opts::gather): tasks that left or reached this rank */
 } fphip_enum_stats;
 
 /*

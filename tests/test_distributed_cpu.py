@@ -165,3 +165,62 @@ def test_library_level_reductions_norm_vector_counts(world):
         assert a == (2.25, [0.0, 1.0, 1.0, -1.0, 0.0, 0.0], want_nodes)
         assert b == (1.0, [1.0] * dim, [world] * (dim + 1))
         assert c[0] == float("inf") and c[1] is None and c[2] == [0] * (dim + 1)
+
+
+def _gather_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from fplll_amd.distributed import balance_plan, make_gather
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = make_gather(dist, "cpu")
+    # 1. the counts: 8 bytes per rank
+    counts0 = [1000, 10, 0, 430][:world]
+    blocks = g(int(counts0[rank]).to_bytes(8, "little"))
+    counts = [int.from_bytes(b, "little") for b in blocks]
+    assert counts == counts0
+    # 2. the plan every rank derives, and the tasks moving by it: a "task" is 1040 bytes stamped (rank, index)
+    moved, surplus, deficit, offset = balance_plan(counts)
+    mine = [bytes([rank]) + i.to_bytes(4, "little") + bytes(1035) for i in range(counts[rank])]
+    send = b"".join(mine[counts[rank] - surplus[rank]:])
+    mine = mine[:counts[rank] - surplus[rank]]
+    pool = b"".join(g(send))
+    assert len(pool) == moved * 1040
+    take = pool[offset[rank] * 1040:(offset[rank] + deficit[rank]) * 1040]
+    mine += [take[i * 1040:(i + 1) * 1040] for i in range(deficit[rank])]
+    # 3. ragged / empty blocks
+    rag = g(bytes([rank]) * (rank * 3))
+    assert [len(b) for b in rag] == [r * 3 for r in range(world)] and all(set(b) <= {r} for r, b in enumerate(rag))
+    assert g(b"") == [b""] * world
+    q.put((rank, [(t[0], int.from_bytes(t[1:5], "little")) for t in mine]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_work_movement_plan_and_gather(world):
+    """The all-gather the work movement rides on (make_gather) and the plan rebalance_tasks derives from the
+    counts (balance_plan, the Python restatement): after one round of movement the lists differ by at most one
+    task, every task is held by exactly one rank, and nothing moves when the lists are level already."""
+    import torch.multiprocessing as mp
+    from fplll_amd.distributed import balance_plan
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_gather_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    out = sorted(q.get(timeout=120) for _ in range(world))
+    for p in ps:
+        p.join(120)
+        assert p.exitcode == 0
+    counts0 = [1000, 10, 0, 430][:world]
+    sizes = [len(o[1]) for o in out]
+    assert sum(sizes) == sum(counts0) and max(sizes) - min(sizes) <= 1
+    everything = sorted(t for o in out for t in o[1])
+    assert everything == sorted((r, i) for r in range(world) for i in range(counts0[r]))
+    # level lists stay where they are; so does a list that is a sixteenth off
+    assert balance_plan([500, 500, 501])[0] == 0
+    assert balance_plan([1000, 1000, 900, 1000])[0] == 0
+    moved, surplus, deficit, offset = balance_plan([40, 0, 0, 0])
+    assert moved == 30 and surplus == [30, 0, 0, 0] and deficit == [0, 10, 10, 10] and offset == [0, 0, 10, 20]

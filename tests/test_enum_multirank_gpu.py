@@ -200,3 +200,74 @@ def test_sharded_call_on_rccl_world_size_one(name):
         assert gd <= ref_best
     else:
         assert gd == ref_best
+
+
+def _worker_move(rank, world, port, fixture, move, fixed, q):
+    import torch.distributed as dist
+    import fplll_amd
+    from fplll_amd.distributed import make_exchange, make_gather
+    from fplll_amd.enumeration import FastEvaluator, enumerate_block
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    f = C.load_fixture(fixture)
+    ctx = fplll_amd.Context(0)
+    ev = FastEvaluator(10**9 if fixed else 1, 0)
+    res = enumerate_block(ctx, f["mut"], f["rdiag"], f["pruning"], f["maxdist"], ev,
+                          shard_index=rank, shard_count=world, exchange=make_exchange(dist, "cpu"), exchange_chunks=2,
+                          gather=make_gather(dist, "cpu") if move else None)
+    best = min([s[0] for s in ev.solutions] or [float("inf")])
+    q.put((rank, [int(v) for v in res.nodes], int(res.stats.moved_tasks), float(res.stats.kernel_ms), best))
+    dist.barrier()
+    ctx.close()
+    dist.destroy_process_group()
+
+
+def _run_move(name, world, move, fixed):
+    import torch.multiprocessing as mp
+    fixture = os.path.join(C.GOLDEN, name + ".json")
+    mpctx = mp.get_context("spawn")
+    q = mpctx.Queue()
+    port = _free_port()
+    ps = [mpctx.Process(target=_worker_move, args=(r, world, port, fixture, move, fixed, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    out = sorted(q.get(timeout=600) for _ in range(world))
+    for p in ps:
+        p.join(120)
+        assert p.exitcode == 0
+    return C.load_fixture(fixture), out
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_donated_subtrees_move_between_ranks(world):
+    """fphip_enum_opts::gather: at every round boundary of the walk the ranks level their lists of donated
+    subtrees (surplus tasks travel as 1040-byte records through an all-gather; enumlib's shared subtree counter,
+    enum-parallel/enumeration.h:412-505, between processes).  At a radius that never shrinks the per-level counts
+    of the ranks still add up to the reference's — every subtree walked exactly once, wherever — tasks did move,
+    and no rank is left with a sliver of the work."""
+    f, out = _run_move("enum_d48_lin30_fixed", world, True, True)
+    tot = np.sum([np.array(o[1]) for o in out], axis=0)
+    assert [int(v) for v in tot] == [int(v) for v in f["nodes"]]
+    shares = [sum(o[1]) / f["total_nodes"] for o in out]
+    C.note(lambda: ("work movement, %d ranks on one GPU, %s: node shares %s, tasks moved per rank %s, kernel ms %s"
+                    % (world, f["name"], ["%.3f" % s for s in shares], [o[2] for o in out], ["%.1f" % o[3] for o in out]),))
+    assert min(shares) > 0.5 / world
+    # the same call without movement: the same counts (the A/B of the protocol)
+    f2, out2 = _run_move("enum_d48_lin30_fixed", world, False, True)
+    tot2 = np.sum([np.array(o[1]) for o in out2], axis=0)
+    assert [int(v) for v in tot2] == [int(v) for v in f["nodes"]] and all(o[2] == 0 for o in out2)
+
+
+def test_work_movement_with_a_shrinking_radius_and_on_a_pruner_regime_block():
+    """With BEST-1 semantics the final norm over the ranks is the reference's whether or not tasks move; on a
+    small (pruner-regime) block of config 3 every rank still ends with the shortest vector."""
+    for name in ("enum_d48_lin30_best1", "c3_b60_k2_pruner"):
+        f, out = _run_move(name, 2, True, False)
+        ref_best = min([s[0] for s in f["sol_log"]] or [float("inf")])
+        assert min(o[4] for o in out) <= ref_best  # (never longer; a parallel walk may end shorter, DESIGN §2)
+        if name.startswith("enum_"):
+            assert min(o[4] for o in out) == ref_best
+        C.note(lambda: ("work movement, 2 ranks, %s: node shares %s, moved %s"
+                        % (name, ["%.3f" % (sum(o[1]) / max(1, sum(sum(x[1]) for x in out))) for o in out],
+                           [o[2] for o in out]),))
