@@ -31,6 +31,11 @@
 // 64 lanes costs the memory pipeline more than a sixteenth of a 1-KiB LDS-DMA row, and 256 registers per wave leave
 // the same two waves per SIMD.  The contiguous phases (sweep, row operation) were 20 % faster per row that way and
 // 2.5 us slower to start; not kept.
+//
+// Also tried (call r5j): a ring of 16 blocks (64 KiB, one wave per workgroup) for launches of a few lattices —
+// no gain (a lone 120-dimensional LLL 5.72 s against 5.48 s, 83 ns per Gram row either way, the prologue's 64 DMA
+// instructions cost 1.6 us): a lone wave is bound by ISSUING its rows (an LDS-DMA instruction ~60-100 cycles plus
+// ~24 other instructions per row), not by how many it has in flight.
 #ifndef FPHIP_LLL_STREAM_H
 #define FPHIP_LLL_STREAM_H
 
