@@ -61,6 +61,8 @@ struct GsoBatch
   int *b32;
   int *narrow;
   int use_narrow;
+  int wide_ring;  // sweep kernel: 1 = the 8-byte rows of lattices that are not narrow go through the ring too (round 5;
+                  // FPHIP_GSO_WIDE_RING=0: the plain-load paths gram_wide / axpy_wide of rounds 2-4)
   // LLL kernel only (allocated on first use): symmetric Gram cache [batch][d][ldd], valid-column
   // counts [batch][d], output basis in position order [batch][d][ldn], info [batch][4]
   double *gf;

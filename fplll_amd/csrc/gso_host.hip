@@ -220,6 +220,10 @@ static int gso_allocate(fphip_gso *g)
     const char *nv = getenv("FPHIP_GSO_NARROW");  // 0 keeps every pass on the 8-byte rows (A/B runs)
     // FPHIP_GSO_NARROW: 0 = 8-byte arrays only, 1 = 4-byte mirrors, 2 (default) = 2-byte mirrors too
     g->P.use_narrow = nv ? atoi(nv) : 3;  // 3 = 2-byte mirrors + the integer AXPY fused into the Gram pass (gso_sweep2.hip)
+    {
+      const char *wr = getenv("FPHIP_GSO_WIDE_RING");
+      g->P.wide_ring = wr ? atoi(wr) : 1;
+    }
   }
   GCHK(hipMemsetAsync(g->P.b, 0, B * d * ldn * sizeof(long long) + pad, s0));
   GCHK(hipMemsetAsync(g->P.bfT, 0, B * n * ldd * sizeof(double) + pad, s0));

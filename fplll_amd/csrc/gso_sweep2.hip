@@ -57,7 +57,9 @@ enum
   K_REC   = 1,
   K_SWEEP = 2,
   K_AXPY  = 3,
-  K_DUMMY = 4
+  K_DUMMY = 4,
+  K_GRAM8 = 5,  // round 5: the 8-byte arrays through the ring too — ONE row of bfT (doubles) per pair slot
+  K_AXPY8 = 6   // … ONE row of b (int64) per pair slot
 };
 
 // All members are wave-uniform (SGPRs) except lane4 / lane16.
@@ -180,6 +182,32 @@ template <int NQ> struct Stream
     const char *q1 = ap + (long)(aq * 64 + j1) * astride;
     dma_pair(q0, q1, amask);
   }
+  // rows that are not narrow (an entry of magnitude >= 2^24): the 8-byte arrays, one row per pair slot like a mu row
+  const char *gp8;   // row c of bfT, elements [0, glen8)
+  long gstride8;
+  int glen8;
+  const char *ap8;   // rows of b (int64), elements [0, alen8), rows with a non-zero multiplier, descending
+  long astride8;
+  int alen8;
+  __device__ __forceinline__ void issue_gram8()
+  {
+    dma_row8(gp8, glen8);
+    gp8 += gstride8;
+  }
+  __device__ __forceinline__ void issue_axpy8()
+  {
+    while (ab0 == 0 && aq > 0)
+    {
+      ab0 = ab1;
+      ab1 = ab2;
+      ab2 = ab3;
+      ab3 = 0;
+      --aq;
+    }
+    const int j0 = 63 - __builtin_clzll(ab0);
+    ab0 &= ~(1ull << j0);
+    dma_row8(ap8 + (long)(aq * 64 + j0) * astride8, alen8);
+  }
   __device__ __forceinline__ void issue_dummy() { dma_pair(dummy, dummy, 1ull); }
 
   __device__ __forceinline__ void advance_segment()
@@ -200,6 +228,8 @@ template <int NQ> struct Stream
     case K_REC: issue_rec(); break;
     case K_SWEEP: issue_sweep(); break;
     case K_AXPY: issue_axpy(); break;
+    case K_GRAM8: issue_gram8(); break;
+    case K_AXPY8: issue_axpy8(); break;
     default: issue_dummy(); break;
     }
     if (kind != K_DUMMY)
@@ -288,6 +318,32 @@ template <int NQ> struct Stream
             const unsigned w = wait_pair();
             cons.load(w, lane4);
             issue_axpy();
+            cons.compute();
+          }
+          done = true;
+        }
+      if constexpr ((ALLOWED & (1u << K_GRAM8)) != 0)
+        if (!done && kind == K_GRAM8)
+        {
+#pragma unroll 1
+          for (int i = 0; i < m; ++i)
+          {
+            const unsigned w = wait_pair();
+            cons.load(w, lane4);
+            issue_gram8();
+            cons.compute();
+          }
+          done = true;
+        }
+      if constexpr ((ALLOWED & (1u << K_AXPY8)) != 0)
+        if (!done && kind == K_AXPY8)
+        {
+#pragma unroll 1
+          for (int i = 0; i < m; ++i)
+          {
+            const unsigned w = wait_pair();
+            cons.load(w, lane4);
+            issue_axpy8();
             cons.compute();
           }
           done = true;
@@ -630,9 +686,88 @@ template <int NQ, int JQ, int EB> struct AxpyCons
   }
 };
 
+// the 8-byte twins (round 5): one row of doubles / int64 per step, the pair slot read as 64 NQ 8-byte words
+template <int NQ, int CQ, int QA> struct GramCons8
+{
+  double (&acc)[NQ];
+  const double &bkq;  // bk[CQ]
+  int cc;             // row c = 64 CQ + cc
+  double x[NQ];
+  __device__ __forceinline__ void load(unsigned w, unsigned lane4)
+  {
+    const double *sd = (const double *)s2_smem + (w >> 1) + (lane4 >> 2);
+#pragma unroll
+    for (int q = 0; q < QA; ++q)
+      x[q] = sd[64 * q];
+  }
+  __device__ __forceinline__ void compute()
+  {
+    const double s0 = rl2(bkq, cc);
+#pragma unroll
+    for (int q = 0; q < QA; ++q)
+    {
+      const double p0 = s0 * x[q];
+      acc[q]          = acc[q] + p0;
+    }
+    ++cc;
+  }
+};
+template <int NQ, int JQ> struct AxpyCons8
+{
+  long long (&bv)[NQ];
+  const long long &lxq;     // multipliers of chunk JQ (lane j)
+  unsigned long long bits;  // multipliers of the chunk not yet applied
+  long long w0[NQ];
+  __device__ __forceinline__ void load(unsigned w, unsigned lane4)
+  {
+    const long long *sl = (const long long *)s2_smem + (w >> 1) + (lane4 >> 2);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+      w0[q] = sl[64 * q];
+  }
+  __device__ __forceinline__ void compute()
+  {
+    const int j0 = 63 - __builtin_clzll(bits);
+    bits &= ~(1ull << j0);
+    const long long l0 = g_rl_i64(lxq, j0);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+      bv[q] = (long long)((unsigned long long)bv[q] + (unsigned long long)w0[q] * (unsigned long long)l0);
+  }
+};
+
 // ---------------------------------------------------------------------------------------------
 // phases (compile-time recursion over the chunks)
 // ---------------------------------------------------------------------------------------------
+template <int NQ, int QA, int CQ = 0>
+__device__ __forceinline__ void gram8_phase(Stream<NQ> &S, double (&acc)[NQ], const double (&bk)[NQ], int n)
+{
+  if constexpr (CQ < NQ)
+  {
+    const int rows = min(n - 64 * CQ, 64);
+    if (rows > 0)
+    {
+      GramCons8<NQ, CQ, QA> g{acc, bk[CQ], 0};
+      S.template run<(1u << K_GRAM8) | (1u << K_REC)>(g, rows);
+      gram8_phase<NQ, QA, CQ + 1>(S, acc, bk, n);
+    }
+  }
+}
+template <int NQ, int JQ = NQ - 1>
+__device__ __forceinline__ void axpy8_phase(Stream<NQ> &S, long long (&bv)[NQ], const long long (&lxv)[NQ],
+                                            const unsigned long long (&nz)[NQ])
+{
+  if constexpr (JQ >= 0)
+  {
+    if (nz[JQ] != 0)
+    {
+      AxpyCons8<NQ, JQ> a{bv, lxv[JQ], nz[JQ]};
+      S.template run<(1u << K_AXPY8)>(a, __builtin_popcountll(nz[JQ]));
+    }
+    axpy8_phase<NQ, JQ - 1>(S, bv, lxv, nz);
+  }
+}
+
 template <int NQ, int QA, int EB, int CQ = 0>
 __device__ __forceinline__ void gram_phase(Stream<NQ> &S, double (&acc)[NQ], const double (&bk)[NQ],
                                            const double (&sc)[NQ], int n)
@@ -681,6 +816,8 @@ __device__ __forceinline__ void gram_rec_qa(Stream<NQ> &S, double (&acc)[NQ], co
     gram_phase<NQ, QA, 2>(S, acc, bk, sc, n);
   else if (narrow == 1)
     gram_phase<NQ, QA, 4>(S, acc, bk, sc, n);
+  else if (narrow == 0)
+    gram8_phase<NQ, QA>(S, acc, bk, n);
   gkk = g_rl_f64(acc[QA - 1], kappa & 63);  // lane kappa of chunk QA-1 = kappa >> 6
   rec_phase<NQ, QA>(S, acc, nrec, lane);
 }
@@ -822,12 +959,22 @@ __device__ __forceinline__ void gso_pass(Lattice<NQ> &T, const Planes &PL, Strea
     S.gmask   = ~0ull >> (63 - (kappa >> 2));
     S.begin(K_GRAM, (n + 1) >> 1, K_REC, nrec);
   }
+  else if (T.wide_ring)
+  {  // rows that are not narrow: the 8-byte rows of bfT through the ring as well (round 5)
+    S.gp8      = (const char *)T.bfT;
+    S.gstride8 = (long)ldd * 8;
+    S.glen8    = kappa + 1;
+    S.begin(K_GRAM8, n, K_REC, nrec);
+  }
   else
   {
     gram_wide<NQ>(T, acc, bk, kappa);
     S.begin(K_REC, nrec, K_DUMMY, 0x7fffffff);
   }
   const unsigned lane = (unsigned)T.lane;
+  const int narrow_in = narrow;
+  const int narrow_ = (narrow_in == 0 && !T.wide_ring) ? -1 : narrow_in;  // (-1: gram_wide has done the Gram pass)
+#define narrow narrow_
   if constexpr (NQ == 1)
     gram_rec_qa<NQ, 1>(S, acc, bk, sc, n, nrec, lane, narrow, kappa, gkk);
   else if constexpr (NQ == 2)
@@ -857,6 +1004,7 @@ __device__ __forceinline__ void gso_pass(Lattice<NQ> &T, const Planes &PL, Strea
     else
       gram_rec_qa<NQ, 4>(S, acc, bk, sc, n, nrec, lane, narrow, kappa, gkk);
   }
+#undef narrow
 }
 
 // r(kappa,kappa) = g(kappa,kappa) - sum_k mu(kappa,k) r(kappa,k), k ascending (gso_interface.cpp:147-151)
@@ -1234,6 +1382,23 @@ __device__ __forceinline__ int babai2(Lattice<NQ> &T, Planes &PL, Stream<NQ> &S,
         axpy_phase<NQ, 4>(S, bv, lxv, nz, small);
       }
     }
+    else if (T.wide_ring)
+    {
+      int rows8 = 0;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+        rows8 += __builtin_popcountll(nz[q]);
+      S.aq  = NQ - 1;
+      S.ab0 = nz[NQ - 1];
+      S.ab1 = NQ >= 2 ? nz[NQ >= 2 ? NQ - 2 : 0] : 0;
+      S.ab2 = NQ >= 3 ? nz[NQ >= 3 ? NQ - 3 : 0] : 0;
+      S.ab3 = NQ >= 4 ? nz[NQ >= 4 ? NQ - 4 : 0] : 0;
+      S.ap8      = (const char *)T.b;
+      S.astride8 = (long)ldn * 8;
+      S.alen8    = n;
+      S.begin(K_AXPY8, rows8, K_DUMMY, 0x7fffffff);
+      axpy8_phase<NQ>(S, bv, lxv, nz);
+    }
     else
       axpy_wide<NQ>(T, bv, lxv, kappa);
     // ---- row_op_end: update_bf(kappa), gso.cpp:24-48
@@ -1285,6 +1450,7 @@ __global__ void __launch_bounds__(256, Cfg<NQ>::WAVES_PER_SIMD)
     T.narrow_flag = P.narrow + (size_t)L * P.d;
     T.np          = 0;
     T.f32ok       = 0;
+    T.wide_ring   = P.wide_ring;
     Planes PL;
     PL.muA = muA + (size_t)L * P.d * P.ldd;
     // m16: [batch][n*ldd + d*ldn] shorts — bT16 then b16 of each lattice

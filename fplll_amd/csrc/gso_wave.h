@@ -56,6 +56,7 @@ template <int NQ> struct Lattice
   // lattice is below 2^24 — the Gram passes then stream the float mirror (half the bytes of bfT, exact);
   // kept by store_row_and_refloat, cleared for good by the first wide row.  0 in the other kernels.
   int f32ok;
+  int wide_ring;     // sweep kernel: rows that are not narrow go through the LDS-DMA ring as 8-byte rows (gso_sweep2.hip)
   int lane;
   double murow[NQ];  // mu(kappa, j) of the row last updated (lane j)
   double rrow[NQ];   // r(kappa, j)  of the row last updated (lane j)

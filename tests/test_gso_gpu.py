@@ -243,3 +243,44 @@ def test_batch_members_match_reference_gsoutil(name):
     assert g.is_lll_reduced(0, 0.999, 0.501) == bool(j["is_lll_reduced_d0999_e0501"])
     g.close()
     ctx.close()
+
+
+@pytest.mark.parametrize("d", [100, 180, 200])
+def test_row_width_paths_agree_bit_for_bit(ctx, monkeypatch, d):
+    """The sweep kernel has four ways to stream a row — 2-byte mirrors (with and without the fused row operation),
+    4-byte mirrors, and the 8-byte arrays, those through the LDS-DMA ring (round 5: K_GRAM8 / K_AXPY8) or with plain
+    loads (rounds 2-4) — and they must all be the SAME arithmetic: basis, mu, r, row exponents bit for bit, on a
+    batch large enough to load the memory system, with a lattice of the C3 family (below 2^15) and one whose entries
+    do not fit the narrow mirrors at all (>= 2^24: only the 8-byte paths apply)."""
+    from fplll_amd.gso import MatGSOBatch, _unreduced_copy
+    rng = np.random.default_rng(500 + d)
+    small = _unreduced_copy(_load_c3_basis(), 3, 7)[:d, :d] if d <= 180 else None
+    if small is None:
+        small = np.tril(rng.integers(-30, 30, size=(d, d))) + 40 * np.eye(d, dtype=np.int64)
+        small = small.astype(np.int64)
+    big = np.tril(rng.integers(-(1 << 33), 1 << 33, size=(d, d))).astype(np.int64) + (np.eye(d, dtype=np.int64) << 36)
+    results = {}
+    for name, env in [("default", {}), ("2-byte unfused", {"FPHIP_GSO_NARROW": "2"}), ("4-byte", {"FPHIP_GSO_NARROW": "1"}),
+                      ("8-byte ring", {"FPHIP_GSO_NARROW": "0", "FPHIP_GSO_WIDE_RING": "1"}),
+                      ("8-byte plain", {"FPHIP_GSO_NARROW": "0", "FPHIP_GSO_WIDE_RING": "0"})]:
+        for k in ("FPHIP_GSO_NARROW", "FPHIP_GSO_WIDE_RING"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        B = 512
+        g = MatGSOBatch(ctx, B, d, d)
+        bs = np.stack([small if (L % 2 == 0) else big for L in range(B)])
+        g.set_basis(bs)
+        st = g.size_reduction()
+        assert int(st.min()) == 1 and int(st.max()) == 1, (name, np.unique(st))
+        out = g.get_basis()
+        for L in (2, 3, B - 2, B - 1):  # replicas agree inside a run
+            assert np.array_equal(out[L], out[L % 2]), (name, L)
+        results[name] = (out[0], out[1], g.get_mu_matrix(0), g.get_r_matrix(0), g.get_mu_matrix(1), g.get_r_matrix(1),
+                         g.row_expo(0), g.row_expo(1))
+        g.close()
+    ref = results["8-byte plain"]
+    for name, res in results.items():
+        for a, b in zip(ref, res):
+            assert np.array_equal(a, b), name
+    _ = big
