@@ -369,6 +369,15 @@ int fphip_ctx_num_cus(fphip_ctx *ctx) { return ctx->num_cus; }
 int fphip_ctx_device(fphip_ctx *ctx) { return ctx->device; }
 // the task buffers NOW (gso_host.hip's hand-off set-up: before the persistent schedule kernel is launched, never from
 // the worker thread that answers its mailbox — a multi-gigabyte allocation there would stall the kernel at best)
+// a context whose enumerations are known to be small (the extra hand-off contexts of a batch of tours: blocks of at
+// most 64 rows) can hold its three task generations in a fraction of the default 3.6 GB; before the first run only
+int fphip_ctx_set_task_cap(fphip_ctx *ctx, unsigned cap)
+{
+  if (!ctx || ctx->qm || cap < 4096)
+    return FPHIP_ERROR;
+  ctx->cap = (cap + FPHIP_NQ - 1) / FPHIP_NQ * FPHIP_NQ;
+  return FPHIP_OK;
+}
 int fphip_ctx_ensure_task_buffers(fphip_ctx *ctx)
 {
   if (hipSetDevice(ctx->device) != hipSuccess)

@@ -92,6 +92,7 @@ char *fphip_ctx_errbuf(fphip_ctx *ctx);
 int fphip_ctx_num_cus(fphip_ctx *ctx);
 int fphip_ctx_device(fphip_ctx *ctx);
 int fphip_ctx_ensure_task_buffers(fphip_ctx *ctx);  // enum_host.hip
+int fphip_ctx_set_task_cap(fphip_ctx *ctx, unsigned cap);
 
 struct fphip_gso
 {
@@ -108,6 +109,7 @@ struct fphip_gso
   int *flag16;  // [batch][d]
   int sweep_version;  // 2 (default) or 1 (FPHIP_GSO_SWEEP=1: the first-generation kernel)
   fphip_ctx *ectx;    // hand-off mode of the strategy-BKZ kernel: the enumeration context (same device)
+  std::vector<fphip_ctx *> ectx_more;  // … and the further ones of a BATCH of tours (one per hand-off worker)
   double *xbuf;       // lll_x.hip workspace: bf rows [B][d][ldn], then the low planes of mu, r, gf [B][d][ldd] each
   // in-loop pruning of the strategy-BKZ service (FPHIP_BKZ_PRUNE_IN_LOOP; fphip_gso_bkz_inloop_pruning)
   double il_preproc = 1e6, il_target = 0.5;
@@ -156,8 +158,7 @@ extern "C" int fphip_gso_create(fphip_ctx *ctx, int batch, int d, int n, int row
     snprintf(fphip_ctx_errbuf(ctx), 512, "fphip_gso_create: context has no device");
     return FPHIP_ERROR;
   }
-  fphip_gso *g = new fphip_gso();
-  memset(g, 0, sizeof *g);
+  fphip_gso *g = new fphip_gso();  // (value-initialised: every plain member zero, the defaults of the class applied)
   g->il_preproc = 1e6, g->il_target = 0.5, g->il_min_block = 24, g->il_flags = 0x4, g->il_device = 1;
   g->ctx        = ctx;
   g->P.batch    = batch;
@@ -246,6 +247,8 @@ extern "C" void fphip_gso_destroy(fphip_gso *g)
     return;
   if (g->ectx)
     fphip_destroy(g->ectx);
+  for (auto *c : g->ectx_more)
+    fphip_destroy(c);
   if (g->xbuf)
     fphip_dev_free(g->xbuf, fphip_ctx_stream(g->ctx));
   hipStreamSynchronize(fphip_ctx_stream(g->ctx));
@@ -1996,7 +1999,7 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
   BkzsHost H{S, gh_factor, rnd, rnd_user, 0.0};
   // in-loop pruning: a pool of worker threads (one prune() is tens of milliseconds; the lattices of a batch
   // ask at about the same time), each with a volume engine of its own (stream, staging, device buffers)
-  int n_workers = 1;
+  int n_workers = 1, n_handoff = 1;
   if (inloop)
   {
     H.inloop       = 1;
@@ -2053,6 +2056,33 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
         return FPHIP_ERROR;
       }
     }
+    // a BATCH of tours shares the hand-off service: one worker thread and one enumeration context per worker (the
+    // extra contexts with a small task capacity: these blocks have at most 64 rows), so that the blocks of
+    // different tours are enumerated side by side instead of queueing behind one context
+    {
+      const char *hw = getenv("FPHIP_BKZ_HANDOFF_WORKERS");
+      const int want = std::max(1, std::min(hw ? atoi(hw) : 8, (int)std::min<size_t>(B, 16)));
+      n_handoff      = want;
+      int cur_dev = 0;
+      (void)hipGetDevice(&cur_dev);
+      while ((int)g->ectx_more.size() + 1 < want)
+      {
+        fphip_ctx *c = nullptr;
+        if (fphip_create_ex(fphip_ctx_device(g->ctx), 1, &c) != FPHIP_OK || fphip_ctx_set_task_cap(c, 1u << 18) != FPHIP_OK ||
+            fphip_ctx_ensure_task_buffers(c) != FPHIP_OK)
+        {
+          snprintf(fphip_ctx_errbuf(g->ctx), 512, "bkz_strategies: hand-off context %zu: %s", g->ectx_more.size() + 1,
+                   c ? fphip_last_error(c) : "?");
+          if (c)
+            fphip_destroy(c);
+          (void)hipSetDevice(cur_dev);
+          cleanup();
+          return FPHIP_ERROR;
+        }
+        g->ectx_more.push_back(c);
+      }
+      (void)hipSetDevice(cur_dev);
+    }
     g->P.enum_mu_h = (double *)pinned_get(B * (64 * 63 / 2) * sizeof(double));
     if (!g->P.enum_mu_h)
     {
@@ -2065,6 +2095,7 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
   }
   unsigned long long handoff_calls = 0;
   int handoff_rc                   = FPHIP_OK;
+  fphip_ctx *handoff_ectx          = nullptr;  // the context whose enumeration failed (its error text)
   bool rnd_failed              = false;
   unsigned long long heartbeat = 0;
   std::vector<unsigned long long> handled(B, 0);
@@ -2112,12 +2143,19 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
     std::condition_variable hq_cv;
     std::deque<std::pair<size_t, unsigned long long>> hq;
     bool hq_stop = false;
-    std::mutex enum_m;  // the hand-off enumerations share ONE context: one at a time
+    // (every hand-off enumeration runs on a context of its own worker; workers beyond the contexts — in-loop pruning
+    //  may want more threads than there are hand-off contexts — share the last one under a mutex)
+    std::mutex enum_m;
+    std::mutex hrc_m;
     std::vector<std::thread> workers;
-    for (int w = 0; w < ((handoff || inloop) ? n_workers : 0); ++w)
+    const int n_threads = (handoff || inloop) ? std::max(inloop ? n_workers : 1, handoff ? n_handoff : 1) : 0;
+    for (int w = 0; w < n_threads; ++w)
       workers.emplace_back([&, w]()
       {
         fphip_pruner::VolumeEngine *engine = w < (int)il_engines.size() ? il_engines[w] : nullptr;
+        const int nctx      = 1 + (int)g->ectx_more.size();
+        const bool own_ctx  = handoff && w < nctx - 1;  // (the last context may be shared)
+        fphip_ctx *my_ectx  = !handoff ? nullptr : (w == 0 ? g->ectx : g->ectx_more[std::min(w, nctx - 1) - 1]);
         for (;;)
         {
           std::pair<size_t, unsigned long long> job;
@@ -2138,14 +2176,21 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
             continue;
           }
           int rc;
+          if (own_ctx)
+            rc = serve_enumeration(my_ectx, m, g->P.enum_mu_h + job.first * (64 * 63 / 2));
+          else
           {
             std::lock_guard<std::mutex> lk(enum_m);
-            rc = serve_enumeration(g->ectx, m, g->P.enum_mu_h + job.first * (64 * 63 / 2));
+            rc = serve_enumeration(my_ectx, m, g->P.enum_mu_h + job.first * (64 * 63 / 2));
+          }
+          {
+            std::lock_guard<std::mutex> lk(hrc_m);
             if (rc != FPHIP_OK)
             {  // the wave cannot walk the block itself any more: no solution, and the call reports the error
               m->have_sol = 0;
               m->nodes3   = 0;
               handoff_rc  = rc;
+              handoff_ectx = my_ectx;
             }
             ++handoff_calls;
           }
@@ -2315,7 +2360,7 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
   if (handoff_rc != FPHIP_OK && rc == FPHIP_OK)
   {
     snprintf(fphip_ctx_errbuf(g->ctx), 512, "bkz_strategies: a handed-off enumeration failed: %s",
-             g->ectx ? fphip_last_error(g->ectx) : "?");
+             handoff_ectx ? fphip_last_error(handoff_ectx) : (g->ectx ? fphip_last_error(g->ectx) : "?"));
     rc = FPHIP_ERROR;
   }
   if (il_errors.load() > 0 && rc == FPHIP_OK)

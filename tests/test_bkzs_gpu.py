@@ -145,3 +145,41 @@ def test_bkz_with_inloop_pruning_matches_reference(ctx, path, on_device):
     else:
         assert launches == 0
     g.close()
+
+
+def test_handoff_service_shared_by_a_batch_of_tours(ctx, monkeypatch):
+    """FPHIP_BKZ_HANDOFF on a BATCH: the blocks the schedule kernels hand to the multi-wave enumerator are served by
+    a pool of workers with an enumeration context each (round 5: until then one context, one block at a time, so
+    only a lone tour was fast).  A parallel enumeration with a shrinking radius is order dependent, so every lattice
+    is accepted by the reference's predicate (LLL-reduced, the input's volume, a slope no worse than the sequential
+    run's within 5 %, better than the input's) instead of the golden basis; the status is the golden one; with ONE worker the same holds."""
+    import test_a_configs_at_size_gpu as A
+    from fplll_amd.gso import MatGSOBatch
+    path = [p for p in FIXTURES if "q64_b40_pre_gh" in p] or FIXTURES[:1]
+    f = C.load_bkz_fixture(path[0])
+    ref = A._basisstat(f["b_out"])
+    inp = A._basisstat(f["b_in"])
+    monkeypatch.setenv("FPHIP_BKZ_HANDOFF_NODES", "200")
+    for workers in ("5", "1"):
+        monkeypatch.setenv("FPHIP_BKZ_HANDOFF_WORKERS", workers)
+        batch = 6
+        g = MatGSOBatch(ctx, batch, f["d"], f["n"])
+        g.set_basis(np.stack([f["b_in"]] * batch))
+        rnd, draws = C.gmp_streams_native(batch, f["rng_seed"])
+        st, info = g.bkz_strategies(f["block_size"], f["strategies"], rnd, f["delta"], f["eta"],
+                                    max_loops=f["max_loops"], gh_bnd=bool(f["flags"] & 0x80),
+                                    bounded_lll=bool(f["flags"] & 0x10), gh_factor=f["gh_factor"],
+                                    auto_abort=bool(f["flags"] & 0x20), handoff=True)
+        out = g.get_basis()
+        C.note(lambda: ("hand-off batch of %d, %s worker(s): status %s, enumeration calls %s, kernel %.1f ms"
+                        % (batch, workers, list(st), list(info[:, 3]), g.last_kernel_ms),))
+        for L in range(batch):
+            assert st[L] == f["status"]
+            s = A._basisstat(out[L])
+            assert s["is_lll_reduced"]
+            assert abs(s["log_volume"] - inp["log_volume"]) <= 1e-9 * abs(inp["log_volume"])
+            # (a rerandomising strategy: the sequential run's slope is one draw; better than the input's, and within
+            #  5 % of that draw)
+            assert s["slope"] > inp["slope"] and s["slope"] >= ref["slope"] - 0.05 * abs(ref["slope"]), \
+                (s["slope"], ref["slope"], inp["slope"])
+        g.close()
