@@ -282,22 +282,37 @@ bool LLLReduction<Z_NR<long>, FP_NR<double>>::lll(int kappa_min, int kappa_start
                                                   int size_reduction_start)
 {
   fplll_hip::MatGSOHip *h = dynamic_cast<fplll_hip::MatGSOHip *>(&m);
-  const bool plain = !enable_early_red && size_reduction_start == 0;  // (LLL_SIEGEL runs on the device)
+  // LLL_SIEGEL and LLL_EARLY_RED run on the device.  last_early_red belongs to THIS object (lll.h:70): a fresh
+  // object (0) starts a new session — the device's count then starts at 0 too —, a later call of the same object
+  // continues on the session that holds its count, or goes to the host loop when that session is gone.
+  const bool early_ok = !enable_early_red || last_early_red == 0 || (h && h->session_active());
+  const bool plain    = size_reduction_start == 0 && early_ok;
   if (h && h->on_device() && plain)
   {
+    if (enable_early_red && last_early_red == 0)
+      h->end_session();
     if (kappa_end == -1)
       kappa_end = m.d;
     // (the reference's lll() returns at once on an empty matrix, lll.cpp:50-51)
     if (m.d == 0)
       return set_status(RED_SUCCESS);
     int info[4]  = {0, 0, 0, 0};
-    const int st = h->lll_device(kappa_min, kappa_start, kappa_end, delta.get_d(), eta.get_d(), info, siegel ? 4 : 0);
+    const int st = h->lll_device(kappa_min, kappa_start, kappa_end, delta.get_d(), eta.get_d(), info,
+                                 (siegel ? 4 : 0) | (enable_early_red ? 2 : 0));
     if (st != -2 && st != -100)
     {
       final_kappa    = info[0];
       n_swaps        = info[1];
       zeros          = info[2];
-      last_early_red = -1;
+      if (enable_early_red)
+      {  // the largest power of two the walk has passed (the exact count stays with the device session)
+        int p = 1;
+        while (2 * p <= kappa_end - 1 - zeros)
+          p *= 2;
+        last_early_red = (st == 1 && kappa_end - 1 - zeros >= 1) ? p : -1;
+      }
+      else
+        last_early_red = -1;
       // the working vectors the host path would have grown (babai() of a later host call uses them)
       extend_vect(lovasz_tests, kappa_end);
       extend_vect(babai_mu, kappa_end);

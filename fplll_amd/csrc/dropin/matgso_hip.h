@@ -44,6 +44,9 @@ public:
   ~MatGSOHip();
 
   bool on_device() const { return g_ != nullptr; }
+  // the resident session (one LLLReduction object as far as LLL_EARLY_RED's last_early_red is concerned)
+  bool session_active() const { return session_; }
+  void end_session() { session_ = false; }
   const char *last_error() const;
 
   // MatGSOInterface::update_gso() (gso_interface.h:767-775) on the device

@@ -89,6 +89,7 @@ struct GsoBatch
   // (row_op_end, gso_interface.cpp:32-53).  After it the launch writes the state in POSITION order into sess_out:
   // b [d][ldn] int64, mu [d][ldd], r [d][ldd] doubles, row_expo [d] int64, valid columns [d] int32.
   int lll_siegel;            // lll_kernel: LLL_SIEGEL (the launch's delta is then the swap threshold delta - eta^2)
+  int lll_early;             // lll_kernel: LLL_EARLY_RED (lll.cpp:84-99)
   int sess_mode;
   int sess_ndirty;
   int *sess_slots;           // [batch][256]

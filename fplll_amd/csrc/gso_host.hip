@@ -81,7 +81,7 @@ struct LllX
 template <int NQ, class FT> __global__ void lll_x_kernel(LllX A);
 __global__ void dd_op_kernel(const double *ahi, const double *alo, const double *bhi, const double *blo,
                              double *ohi, double *olo, int op, int count);
-template <int NQ>
+template <int NQ, bool EARLY>
 __global__ void lll_kernel(GsoBatch P, int kmin, int kstart, int kend, double delta, double eta,
                            double logdelta);
 }
@@ -383,21 +383,25 @@ static int launch(fphip_gso *g, int kmin, int kend, double eta, int mode, const 
   GCHK(hipEventRecord(g->ev[0], s));
   if (la)
   {
+    // (the LLL_EARLY_RED instantiations live in lll_kernel_early.hip)
+#define FPHIP_LLL_LAUNCH(NQ_)                                                                                          \
+  do                                                                                                                   \
+  {                                                                                                                    \
+    if (g->P.lll_early)                                                                                                \
+      hipLaunchKernelGGL((lll_kernel<NQ_, true>), dim3(grid), dim3(wpb * 64), lds, s, g->P, kmin, la->kstart, kend,    \
+                         la->delta, eta, la->logdelta);                                                                \
+    else                                                                                                               \
+      hipLaunchKernelGGL((lll_kernel<NQ_, false>), dim3(grid), dim3(wpb * 64), lds, s, g->P, kmin, la->kstart, kend,   \
+                         la->delta, eta, la->logdelta);                                                                \
+  } while (0)
     switch (nq)
     {
-    case 1:
-      hipLaunchKernelGGL(lll_kernel<1>, dim3(grid), dim3(wpb * 64), lds, s, g->P, kmin, la->kstart, kend, la->delta, eta, la->logdelta);
-      break;
-    case 2:
-      hipLaunchKernelGGL(lll_kernel<2>, dim3(grid), dim3(wpb * 64), lds, s, g->P, kmin, la->kstart, kend, la->delta, eta, la->logdelta);
-      break;
-    case 3:
-      hipLaunchKernelGGL(lll_kernel<3>, dim3(grid), dim3(wpb * 64), lds, s, g->P, kmin, la->kstart, kend, la->delta, eta, la->logdelta);
-      break;
-    default:
-      hipLaunchKernelGGL(lll_kernel<4>, dim3(grid), dim3(wpb * 64), lds, s, g->P, kmin, la->kstart, kend, la->delta, eta, la->logdelta);
-      break;
+    case 1: FPHIP_LLL_LAUNCH(1); break;
+    case 2: FPHIP_LLL_LAUNCH(2); break;
+    case 3: FPHIP_LLL_LAUNCH(3); break;
+    default: FPHIP_LLL_LAUNCH(4); break;
     }
+#undef FPHIP_LLL_LAUNCH
   }
   else
   switch (nq)
@@ -543,17 +547,20 @@ extern "C" int fphip_gso_lll(fphip_gso *g, int kappa_min, int kappa_start, int k
   return fphip_gso_lll_flags(g, kappa_min, kappa_start, kappa_end, delta, eta, 0, status, info);
 }
 
-// fplll's LLLFlags (defs.h:222-227): LLL_VERBOSE (1) is ignored, LLL_SIEGEL (4) runs on the device,
-// LLL_EARLY_RED (2) is not offered (FPHIP_UNSUPPORTED: the caller's host loop has it)
-static int lll_flags_check(fphip_gso *g, int flags, int *siegel)
+// fplll's LLLFlags (defs.h:222-227): LLL_VERBOSE (1) is ignored, LLL_EARLY_RED (2) and LLL_SIEGEL (4) run on the
+// device (early reduction on the block streams only: FPHIP_UNSUPPORTED in a -DFPHIP_LLL_STREAM=0 build)
+static int lll_flags_check(fphip_gso *g, int flags, int *siegel, int *early)
 {
   if (flags & ~7)
   {
     snprintf(fphip_ctx_errbuf(g->ctx), 512, "lll: unknown flags 0x%x", flags);
     return FPHIP_ERROR;
   }
+#if !FPHIP_LLL_STREAM
   if (flags & 2)
     return FPHIP_UNSUPPORTED;
+#endif
+  *early  = (flags & 2) ? 1 : 0;
   *siegel = (flags & 4) ? 1 : 0;
   return FPHIP_OK;
 }
@@ -564,8 +571,8 @@ extern "C" int fphip_gso_lll_flags(fphip_gso *g, int kappa_min, int kappa_start,
   FPHIP_RANGE("fphip_gso_lll");
   if (!g)
     return FPHIP_ERROR;
-  int siegel = 0;
-  if (int rcf = lll_flags_check(g, flags, &siegel))
+  int siegel = 0, early = 0;
+  if (int rcf = lll_flags_check(g, flags, &siegel, &early))
     return rcf;
   if (kappa_end < 0)
     kappa_end = g->P.d;
@@ -586,8 +593,10 @@ extern "C" int fphip_gso_lll_flags(fphip_gso *g, int kappa_min, int kappa_start,
   // (swap_threshold = siegel ? delta - eta * eta : delta, lll.cpp:40; the iteration limit keeps log(delta))
   LllArgs la{kappa_start, siegel ? delta - eta * eta : delta, std::log(delta)};
   g->P.lll_siegel = siegel;
+  g->P.lll_early  = early;
   rc              = launch(g, kappa_min, kappa_end, eta, 3, &la);
   g->P.lll_siegel = 0;
+  g->P.lll_early  = 0;
   if (rc != FPHIP_OK)
     return rc;
   const float lll_ms = g->last_ms;
@@ -645,8 +654,8 @@ extern "C" int fphip_gso_session_lll(fphip_gso *g, int resume, int kappa_min, in
   FPHIP_RANGE("fphip_gso_session_lll");
   if (!g)
     return FPHIP_ERROR;
-  int siegel = 0;
-  if (int rcf = lll_flags_check(g, flags, &siegel))
+  int siegel = 0, early = 0;
+  if (int rcf = lll_flags_check(g, flags, &siegel, &early))
     return rcf;
   if (kappa_end < 0)
     kappa_end = g->P.d;
@@ -699,8 +708,10 @@ extern "C" int fphip_gso_session_lll(fphip_gso *g, int resume, int kappa_min, in
   g->P.sess_in     = g->sess_in_d;
   LllArgs la{kappa_start, siegel ? delta - eta * eta : delta, std::log(delta)};
   g->P.lll_siegel  = siegel;
+  g->P.lll_early   = early;
   rc               = launch(g, kappa_min, kappa_end, eta, 3, &la);
   g->P.lll_siegel  = 0;
+  g->P.lll_early   = 0;
   g->P.sess_mode   = 0;
   g->P.sess_ndirty = 0;
   g->session_active = false;

@@ -42,7 +42,10 @@ __device__ unsigned long long fphip_lll_prof_dev[4 * LS_KINDS + 4];
 #endif
 
 // info[4] per lattice: final_kappa, n_swaps, zeros, loop iterations (low 31 bits)
-template <int NQ>
+// EARLY: with LLL_EARLY_RED (lll.cpp:84-99) — its own instantiations in their own translation unit
+// (lll_kernel_early.hip): the early pass costs the plain kernels 4-8 VGPRs otherwise, and lll_kernel<4> sits at
+// the 256 that two waves per SIMD allow
+template <int NQ, bool EARLY>
 __global__ void __launch_bounds__(256)
     lll_kernel(GsoBatch P, int kmin, int kstart, int kend, double delta, double eta, double logdelta)
 {
@@ -85,6 +88,7 @@ __global__ void __launch_bounds__(256)
     LllCtx C{P.gf + (size_t)L * d * ldd, P.vc + (size_t)L * d};
     SlotMap<NQ> M;
     int final_kappa, nswaps, zeros, vp = 0;
+    int last_early_red = 0;  // LLL_EARLY_RED: the LLLReduction object's member (lll.h:70), kept by a session
     long long iter;
     if (P.sess_mode == 2)
     {  // resume the session: slot table, verified prefix, narrow flag; everything else is in place
@@ -95,6 +99,7 @@ __global__ void __launch_bounds__(256)
       T.f32ok = uni(P.sess_state[4 * L + 1]);
       if (uni(P.sess_state[4 * L + 2]) != P.lll_siegel)
         vp = 0;  // the prefix was verified against the other swap test
+      last_early_red = uni(P.sess_state[4 * L + 3]);
     }
     else
       lll_init_state<NQ>(T, C, M);
@@ -122,7 +127,8 @@ __global__ void __launch_bounds__(256)
       }
     }
     const int status = lll_run(T, C, M, ring, kmin, kstart, kend, delta, eta, logdelta,
-                                        final_kappa, nswaps, zeros, iter, vp, P.lll_siegel != 0);
+                                        final_kappa, nswaps, zeros, iter, vp, P.lll_siegel != 0,
+                                        EARLY, &last_early_red);
     if (P.sess_mode != 0)
     {
       // leave the state behind, and the caller's view of it: everything in position order
@@ -134,6 +140,7 @@ __global__ void __launch_bounds__(256)
         P.sess_state[4 * L + 0] = (status == 1) ? vp : 0;
         P.sess_state[4 * L + 1] = T.f32ok;
         P.sess_state[4 * L + 2] = P.lll_siegel;
+        P.sess_state[4 * L + 3] = last_early_red;
       }
       char *out        = P.sess_out + (size_t)L * fphip_session_out_bytes(d, ldd, ldn);
       long long *ob    = (long long *)out;
@@ -224,10 +231,13 @@ __global__ void __launch_bounds__(256)
 #endif
 }
 
-template __global__ void lll_kernel<1>(GsoBatch, int, int, int, double, double, double);
-template __global__ void lll_kernel<2>(GsoBatch, int, int, int, double, double, double);
-template __global__ void lll_kernel<3>(GsoBatch, int, int, int, double, double, double);
-template __global__ void lll_kernel<4>(GsoBatch, int, int, int, double, double, double);
+#ifndef FPHIP_LLL_KERNEL_EARLY
+#define FPHIP_LLL_KERNEL_EARLY 0
+#endif
+template __global__ void lll_kernel<1, FPHIP_LLL_KERNEL_EARLY != 0>(GsoBatch, int, int, int, double, double, double);
+template __global__ void lll_kernel<2, FPHIP_LLL_KERNEL_EARLY != 0>(GsoBatch, int, int, int, double, double, double);
+template __global__ void lll_kernel<3, FPHIP_LLL_KERNEL_EARLY != 0>(GsoBatch, int, int, int, double, double, double);
+template __global__ void lll_kernel<4, FPHIP_LLL_KERNEL_EARLY != 0>(GsoBatch, int, int, int, double, double, double);
 
 }  // namespace fphip
 

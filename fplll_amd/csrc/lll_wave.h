@@ -2,6 +2,7 @@
 // bkz_kernel.hip (device code only; the design notes are in lll_kernel.hip).
 #ifndef FPHIP_LLL_WAVE_H
 #define FPHIP_LLL_WAVE_H
+#include <type_traits>
 
 #include "gso_wave.h"
 #include "lll_stream.h"
@@ -557,16 +558,20 @@ __device__ __forceinline__ bool update_row_cached(Lattice<NQ> &T, LllCtx &C, con
 
 // LLLReduction::babai(kappa, kappa, size_reduction_start), lll.cpp:166-224, on the block streams.
 // 1 ok, 0 GSO failure, -1 babai failure, -2 multiplier beyond 63 bits.
+// sr_end = size_reduction_end (-1: kappa): row kappa is reduced against the rows [sr_start, sr_end) only — early
+// reduction (lll.h:125-140) calls it for the rows behind kappa with sr_end = kappa.
 template <int NQ, class Upd, class After>
 __device__ __forceinline__ int babai_impl(Lattice<NQ> &T, LStream<NQ> &S, int kappa, double eta,
-                                          const SlotMap<NQ> &map, Upd upd, After after, int sr_start = 0)
+                                          const SlotMap<NQ> &map, Upd upd, After after, int sr_start = 0,
+                                          int sr_end = -1)
 {
   const int pk = map.phys(kappa);  // physical slot of row kappa
   const int n = T.n, lane = T.lane, ldd = T.ldd, ldn = T.ldn;
+  const int send = sr_end < 0 ? kappa : sr_end;
   long long max_expo = LLONG_MAX;
   for (int iter = 0;; ++iter)
   {
-    if (!upd(kappa, kappa - 1))
+    if (!upd(kappa, send - 1))
       return 0;
     const long long rexpk = T.rexp[pk];
     int e[NQ];
@@ -577,7 +582,7 @@ __device__ __forceinline__ int babai_impl(Lattice<NQ> &T, LStream<NQ> &S, int ka
     {
       const int j = lane + 64 * q;
       e[q]        = 0;
-      if (j < kappa)
+      if (j < send)
       {
         e[q]           = (int)(rexpk - T.rexp[map.sl[q]]);
         const double f = fabs(ldexp(T.murow[q], e[q]));  // get_mu, gso_interface.h:694-702
@@ -617,8 +622,8 @@ __device__ __forceinline__ int babai_impl(Lattice<NQ> &T, LStream<NQ> &S, int ka
     // ---- lll.cpp:202-214: lane k owns babai_mu[k]; rows j = kappa-1 .. sr_start, descending
     {
       constexpr int U = LStream<NQ>::U;
-      const int jtop  = (kappa - 1) | (U - 1);
-      SweepPh<NQ> ph{(const char *)T.mu, (long)ldd * 8, jtop, kappa, sr_start, 0, S.lane16, lane, map, bm, xs, e, nz, {}};
+      const int jtop  = (send - 1) | (U - 1);
+      SweepPh<NQ> ph{(const char *)T.mu, (long)ldd * 8, jtop, send, sr_start, 0, S.lane16, lane, map, bm, xs, e, nz, {}};
 #pragma unroll
       for (int q = 0; q < NQ; ++q)
         ph.srmask[q] = __ballot(lane + 64 * q >= sr_start);
@@ -803,8 +808,12 @@ template <int NQ, class RingT>
 __device__ __forceinline__ int lll_run(Lattice<NQ> &T, LllCtx &C, SlotMap<NQ> &M, RingT &ring,
                                        int kmin, int kstart, int kend, double delta, double eta,
                                        double logdelta, int &final_kappa, int &nswaps, int &zeros,
-                                       long long &iter, int &vp, bool siegel = false)
+                                       long long &iter, int &vp, bool siegel = false, bool early = false,
+                                       int *early_red = nullptr)
 {
+  // early (LLL_EARLY_RED, lll.cpp:35,84-99, lll.h:125-140): early reduction on; *early_red is then the LLLReduction
+  // object's last_early_red, in and out (always the address of a caller's local: a pointer that may be null keeps
+  // the variable in private memory, and what is loaded from there is a vector value)
   // siegel (LLL_SIEGEL, lll.cpp:38-40,122,134): `delta` is then the caller's swap_threshold = delta - eta^2 and
   // the two tests compare with lovasz_tests[kappa] instead of [kappa - 1]; logdelta stays log(delta)
   // vp ("verified prefix"): rows 0..vp-1 are known to be a fixed point of this loop — babai is a
@@ -877,7 +886,9 @@ __device__ __forceinline__ int lll_run(Lattice<NQ> &T, LllCtx &C, SlotMap<NQ> &M
     rotate_left<NQ>(M, kmin, kend - 1 - zeros, lane);
     vp = min(vp, kmin);
   }
-  const bool resume = kmin == 0 && vp > kstart + 1;  // rows <= kstart are verified: nothing to do
+  // rows <= kstart are verified: nothing to do (not with early reduction: the skipped iterations would skip the
+  // kappa values that trigger it)
+  const bool resume = kmin == 0 && vp > kstart + 1 && !early;
   if (zeros < dd && !resume)
   {
     // the reference expects rows below kappa_start to be valid already; on a fresh GSO that is
@@ -913,10 +924,40 @@ __device__ __forceinline__ int lll_run(Lattice<NQ> &T, LllCtx &C, SlotMap<NQ> &M
     kappa = max(kappa, min(vp, kend - zeros));
     iter  = kappa - (kstart + 1);  // the no-op iterations the reference spends on rows < kappa
   }
+  int kappa_max = 0;
   for (; ok && iter < max_iter && kappa < kend - zeros; ++iter)
   {
-    // ---- lazy size reduction, lll.cpp:103-108
-    const int rc = babai_impl(T, ring, kappa, eta, M, upd, after);
+    // ---- early reduction, lll.cpp:84-99 / lll.h:125-140: when kappa reaches a new maximum that is a power of two,
+    //      every row from kappa on is size-reduced against the rows below kappa (babai(i, kappa)) before the lazy
+    //      size reduction of row kappa itself.  (The reference locks n_known_cols meanwhile and forgets the rows it
+    //      discovered for this; what it recomputes for them later are the same numbers from the same vectors — the
+    //      cache keeps them.)  One call site of babai_impl serves both: er_i walks the rows of the early pass.
+    int er_i = -1;
+    if constexpr (std::is_base_of<LStream<NQ>, RingT>::value)
+    {
+      if (early && kappa > kappa_max)
+      {
+        kappa_max = kappa;
+        if ((kappa & (kappa - 1)) == 0 && kappa > uni(*early_red))
+          er_i = kappa;
+      }
+    }
+    int rc;
+    for (;;)
+    {
+      // ---- lazy size reduction, lll.cpp:103-108
+      if constexpr (std::is_base_of<LStream<NQ>, RingT>::value)
+        rc = babai_impl(T, ring, er_i >= 0 ? er_i : kappa, eta, M, upd, after, 0, er_i >= 0 ? kappa : -1);
+      else
+        rc = babai_impl(T, ring, kappa, eta, M, upd, after);
+      if (er_i < 0 || rc != 1)
+        break;
+      if (++er_i >= d)
+      {
+        er_i       = -1;
+        *early_red = kappa;
+      }
+    }
     if (rc != 1)
     {
       status      = rc;

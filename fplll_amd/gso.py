@@ -109,7 +109,7 @@ class MatGSOBatch:
 
     def lll(self, kappa_min=0, kappa_start=0, kappa_end=-1, delta=LLL_DEF_DELTA, eta=LLL_DEF_ETA, flags=0):
         """LLLReduction::lll(kappa_min, kappa_start, kappa_end) on every lattice (lll.cpp:44-164); flags are
-        fplll's LLLFlags: LLL_SIEGEL (4) on the device, LLL_EARLY_RED (2) raises (not offered).
+        fplll's LLLFlags: LLL_SIEGEL (4) and LLL_EARLY_RED (2), both on the device.
         Returns (status[batch], info[batch][4] = final_kappa, n_swaps, zeros, iterations)."""
         st = np.zeros(self.batch, dtype=np.int32)
         info = np.zeros((self.batch, 4), dtype=np.int32)
@@ -119,8 +119,6 @@ class MatGSOBatch:
                        ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
         rc = fn(self.h, kappa_min, kappa_start, kappa_end, delta, eta, flags,
                 st.ctypes.data_as(ctypes.c_void_p), info.ctypes.data_as(ctypes.c_void_p))
-        if rc == _lib.FPHIP_UNSUPPORTED:
-            raise NotImplementedError("LLL_EARLY_RED is not offered on the device (fphip_gso_lll_flags)")
         self._chk(rc, "lll")
         return st, info
 

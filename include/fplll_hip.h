@@ -196,8 +196,10 @@ int fphip_gso_size_reduce(fphip_gso *g, int kappa_min, int kappa_end, double eta
 int fphip_gso_lll(fphip_gso *g, int kappa_min, int kappa_start, int kappa_end, double delta,
                   double eta, int *status, int *info);
 /* The same with fplll's LLLFlags (defs.h:222-227; LLLReduction's constructor, lll.cpp:28-42): LLL_SIEGEL (4) —
- * swap_threshold = delta - eta^2, the tests against lovasz_tests[kappa] (lll.cpp:122,134) — runs on the device;
- * LLL_EARLY_RED (2) returns FPHIP_UNSUPPORTED (the caller's host loop has it); LLL_VERBOSE (1) is ignored. */
+ * swap_threshold = delta - eta^2, the tests against lovasz_tests[kappa] (lll.cpp:122,134) — and LLL_EARLY_RED (2)
+ * — whenever kappa reaches a new maximum that is a power of two, every row from kappa on is size-reduced against
+ * the rows below it (lll.cpp:84-99, lll.h:125-140) — run on the device; LLL_VERBOSE (1) is ignored.  One call is
+ * one LLLReduction object: its last_early_red (lll.h:70) starts at 0. */
 int fphip_gso_lll_flags(fphip_gso *g, int kappa_min, int kappa_start, int kappa_end, double delta, double eta,
                         int flags, int *status, int *info);
 /* The same lll() on a RESIDENT MatGSO: fplll's MatGSO is an object whose rows, Gram cache, mu / r and
@@ -210,7 +212,8 @@ int fphip_gso_lll_flags(fphip_gso *g, int kappa_min, int kappa_start, int kappa_
  * them valid).  While a session is active the rows live in the kernel's slots: the other fphip_gso_* entry points
  * refuse to run, fphip_gso_set_basis ends the session, a status other than 1 ends it too (the next call must be a
  * resume = 0 after fphip_gso_set_basis).  flags as fphip_gso_lll_flags (a change of LLL_SIEGEL between calls
- * forgets the verified prefix).  status / info as fphip_gso_lll. */
+ * forgets the verified prefix; the session is ONE LLLReduction object for LLL_EARLY_RED: last_early_red starts at
+ * 0 with resume = 0 and is kept from call to call).  status / info as fphip_gso_lll. */
 int fphip_gso_session_lll(fphip_gso *g, int resume, int kappa_min, int kappa_start, int kappa_end, double delta,
                           double eta, int flags, int n_dirty, const int *dirty_pos, const int64_t *dirty_rows,
                           int *status, int *info);

@@ -381,25 +381,30 @@ static long zexponent(int64_t v)
  * Siegel).  Returns 1 RED_SUCCESS, 0 RED_GSO_FAILURE, -1 RED_BABAI_FAILURE, -2 multiplier beyond 63
  * bits, -3 RED_LLL_FAILURE.  info[0..3] = final_kappa, n_swaps, zeros, iterations. */
 static int oracle_gso_lll_impl(oracle_gso *g, int kappa_min, int kappa_start, int kappa_end, double delta_in,
-                               double eta, int siegel, int *info);
+                               double eta, int siegel, int early_red, int *info);
 int oracle_gso_lll(oracle_gso *g, int kappa_min, int kappa_start, int kappa_end, double delta,
                    double eta, int *info)
 {
-  return oracle_gso_lll_impl(g, kappa_min, kappa_start, kappa_end, delta, eta, 0, info);
+  return oracle_gso_lll_impl(g, kappa_min, kappa_start, kappa_end, delta, eta, 0, 0, info);
 }
 /* ... with LLL_SIEGEL (flags & 4): swap_threshold = delta - eta^2 (lll.cpp:40) and the tests compare with
- * lovasz_tests[kappa] instead of [kappa - 1] (lll.cpp:122,134).  LLL_EARLY_RED is not restated. */
+ * lovasz_tests[kappa] instead of [kappa - 1] (lll.cpp:122,134); with LLL_EARLY_RED (flags & 2, lll.cpp:35,
+ * 84-99, lll.h:125-140): whenever kappa reaches a new maximum that is a power of two, every row from kappa on
+ * is size-reduced against the rows below kappa.  (The reference locks n_known_cols meanwhile and forgets the
+ * rows it discovered for this: their Gram and GSO entries are recomputed later from the same vectors — the
+ * same numbers, since the columns beyond n_known_cols of a discovered row are zero — so the cache here
+ * simply keeps them.)  One call = one LLLReduction object: last_early_red starts at 0. */
 int oracle_gso_lll_flags(oracle_gso *g, int kappa_min, int kappa_start, int kappa_end, double delta,
                          double eta, int flags, int *info)
 {
-  if (flags & 2)
-    return -100;
-  return oracle_gso_lll_impl(g, kappa_min, kappa_start, kappa_end, delta, eta, (flags & 4) != 0, info);
+  return oracle_gso_lll_impl(g, kappa_min, kappa_start, kappa_end, delta, eta, (flags & 4) != 0, (flags & 2) != 0,
+                             info);
 }
 static int oracle_gso_lll_impl(oracle_gso *g, int kappa_min, int kappa_start, int kappa_end, double delta_in,
-                               double eta, int siegel, int *info)
+                               double eta, int siegel, int early_red, int *info)
 {
   const int n = g->n;
+  int kappa_max = 0, last_early_red = 0;
   const double delta = siegel ? delta_in - eta * eta : delta_in; /* swap_threshold */
   if (kappa_end == -1)
     kappa_end = g->d;
@@ -445,7 +450,20 @@ static int oracle_gso_lll_impl(oracle_gso *g, int kappa_min, int kappa_start, in
     long long max_iter = (long long)(d - 2 * d * (d + 1) * ((max_exp + 3) / log(delta_in)));
     for (iter = 0; iter < max_iter && kappa < kappa_end - zeros; iter++)
     {
-      int rc = oracle_gso_babai(g, kappa, kappa, 0, eta);
+      int rc = 1;
+      if (kappa > kappa_max)
+      { /* lll.cpp:84-99 */
+        kappa_max = kappa;
+        if (early_red && (kappa & (kappa - 1)) == 0 && kappa > last_early_red)
+        { /* early_reduction(kappa, 0), lll.h:125-140 */
+          for (int i = kappa; i < g->d && rc == 1; i++)
+            rc = oracle_gso_babai(g, i, kappa, 0, eta);
+          if (rc == 1)
+            last_early_red = kappa;
+        }
+      }
+      if (rc == 1)
+        rc = oracle_gso_babai(g, kappa, kappa, 0, eta);
       if (rc != 1)
       {
         status      = rc;

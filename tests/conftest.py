@@ -305,7 +305,7 @@ class OracleGSO:
         return self.lib.oracle_gso_update_row(self.h, i, i if last is None else last)
 
     def lll(self, kmin=0, kstart=0, kend=-1, delta=0.99, eta=0.51, flags=0):
-        """LLLReduction::lll (oracle/gso_oracle.c); flags = fplll's LLLFlags (LLL_SIEGEL = 4).
+        """LLLReduction::lll (oracle/gso_oracle.c); flags = fplll's LLLFlags (LLL_EARLY_RED = 2, LLL_SIEGEL = 4).
         Returns (status, info[4])."""
         self.lib.oracle_gso_lll_flags.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                                   ctypes.c_int, ctypes.c_double, ctypes.c_double,

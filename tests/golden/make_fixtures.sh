@@ -53,6 +53,12 @@ LLLFIX_FLAGS=4 $D lllfix q  40 20 20 1  0  0 -1 0 0 > $G/lll_q40_siegel.json
 LLLFIX_FLAGS=4 $D lllfix q  72 36 16 2  0  0 -1 0 0 > $G/lll_q72_siegel.json
 LLLFIX_FLAGS=4 $D lllfix u  24  0 30 5  0  0 -1 0 0 > $G/lll_u24_siegel.json
 LLLFIX_FLAGS=4 $D lllfix q 130 65 12 3  0 40 100 0 0 > $G/lll_q130_siegel_sub.json
+# LLL_EARLY_RED (flags 2, lll.cpp:84-99): the swap counts differ from the plain runs' (another path)
+LLLFIX_FLAGS=2 $D lllfix q  40 20 20 1  0  0 -1 0 0 > $G/lll_q40_earlyred.json
+LLLFIX_FLAGS=2 $D lllfix q  72 36 16 2  0  0 -1 0 0 > $G/lll_q72_earlyred.json
+LLLFIX_FLAGS=2 $D lllfix u  24  0 30 5  0  0 -1 0 0 > $G/lll_u24_earlyred.json
+LLLFIX_FLAGS=2 $D lllfix q 130 65 12 3  0 40 100 0 0 > $G/lll_q130_earlyred_sub.json
+LLLFIX_FLAGS=2 $D lllfix q  72 36 16 7  0  0 -1 2 1 > $G/lll_q72_earlyred_zeros.json
 $D lllfix q  40 20 20 6  0  0 -1 2 0 > $G/lll_q40_zero2.json
 $D lllfix q  40 20 20 7  0  0 -1 0 2 > $G/lll_q40_dup2.json
 $D lllfix q  40 20 20 8  0 10 30 0 0 > $G/lll_q40_range10_30.json

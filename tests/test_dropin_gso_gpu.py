@@ -148,10 +148,9 @@ def test_reference_hlll_object_runs_on_the_device(name):
 
 @pytest.mark.parametrize("variant", ["siegel", "earlyred"])
 def test_lll_variants_through_the_interposed_lll(variant):
-    """LLL_SIEGEL (lll.cpp:38-40,122,134) runs on the device since round 5: one device call, the reference's
-    result.  LLL_EARLY_RED (lll.h:125-140) is not offered by the device kernels: on a MatGSOHip the interposed
-    lll() must pass such a call to the reference's own loop — no device call, the reference's result — instead
-    of silently running plain LLL."""
+    """LLL_SIEGEL (lll.cpp:38-40,122,134) and LLL_EARLY_RED (lll.cpp:84-99, lll.h:125-140) run on the device
+    since round 5: one device call through the interposed lll(), the reference's basis and swap count (the host
+    object run with the same flags)."""
     f = C.load_lll_fixture(os.path.join(C.GOLDEN, "lll_q40.json"))
     path = _write_basis(f["b_in"])
     try:
@@ -160,5 +159,5 @@ def test_lll_variants_through_the_interposed_lll(variant):
     finally:
         os.unlink(path)
     assert j["status"] == jc["status"] == 0
-    assert j["device_calls"] == (1 if variant == "siegel" else 0)
+    assert j["device_calls"] == 1
     assert np.array_equal(j["b_out"], jc["b_out"]) and j["n_swaps"] == jc["n_swaps"]

@@ -226,6 +226,57 @@ def test_siegel_in_a_session_and_a_change_of_flags(ctx):
     rst, rinfo = ref.lll()
     assert int(st2[0]) == int(rst[0]) == 1 and int(info2[0][1]) == int(rinfo[0][1]) > 0
     assert np.array_equal(b2, ref.get_basis(0, 1)[0])
-    with pytest.raises(NotImplementedError):
-        ref.lll(flags=2)
     g.close(); ref.close()
+
+
+@pytest.mark.parametrize("d,n_extra,flags", [(17, 0, 2), (65, 0, 2), (96, 2, 2), (40, 0, 6)])
+def test_early_reduction_seeded_vs_oracle(ctx, d, n_extra, flags):
+    """LLL_EARLY_RED (lll.cpp:84-99, lll.h:125-140; with LLL_SIEGEL on top in the last case) on a batch of DIFFERENT
+    lattices against the C oracle's restatement (itself pinned on the reference's lll_*_earlyred fixtures): basis,
+    swaps, zeros."""
+    from fplll_amd.gso import MatGSOBatch
+    rng = np.random.default_rng(7000 + d)
+    B = 4
+    n = d + n_extra
+    bs = []
+    for L in range(B):
+        if n_extra == 0:
+            b = _qary(rng, d, d // 2, int(rng.integers(50, 5000)))
+        else:
+            b = np.zeros((d, n), dtype=np.int64)
+            b[:, :d] = np.eye(d, dtype=np.int64)
+            b[:, d:] += rng.integers(-10**6, 10**6, size=(d, n - d))
+        bs.append(b)
+    g = MatGSOBatch(ctx, B, d, n)
+    g.set_basis(np.stack(bs))
+    st, info = g.lll(flags=flags)
+    plain = 0
+    for L in range(B):
+        o = C.OracleGSO(bs[L])
+        ost, oinfo = o.lll(flags=flags)
+        assert st[L] == ost == 1
+        assert list(info[L][:3]) == list(oinfo[:3])
+        assert np.array_equal(g.get_basis(L, 1)[0], o.b)
+        o.close()
+        o = C.OracleGSO(bs[L])
+        plain += int(o.lll(flags=flags & 4)[1][1] != oinfo[1])
+        o.close()
+    g.close()
+    C.note(lambda: ("early reduction d=%d flags=%d: %d of %d lattices took another path than without it (swap counts)"
+                    % (d, flags, plain, B),))
+
+
+def test_early_reduction_in_a_session(ctx):
+    """A session is one LLLReduction object: last_early_red (lll.h:70) starts at 0 and is kept.  The first call
+    equals the reference's fixture; a second call on the reduced basis finds every power of two already done
+    (kappa > last_early_red fails) and, the rows being a fixed point, changes nothing."""
+    from fplll_amd.gso import MatGSOBatch
+    f = C.load_lll_fixture(os.path.join(C.GOLDEN, "lll_q72_earlyred.json"))
+    g = MatGSOBatch(ctx, 1, f["d"], f["n"])
+    g.set_basis(f["b_in"][None])
+    st, info = g.session_lll(False, flags=2)
+    b = g.session_read(0)[0]
+    assert int(st[0]) == 1 and int(info[0][1]) == f["n_swaps"] and np.array_equal(b, f["b_out"])
+    st2, info2 = g.session_lll(True, flags=2)
+    assert int(st2[0]) == 1 and int(info2[0][1]) == 0 and np.array_equal(g.session_read(0)[0], f["b_out"])
+    g.close()
