@@ -90,6 +90,10 @@ struct GsoBatch
   // b [d][ldn] int64, mu [d][ldd], r [d][ldd] doubles, row_expo [d] int64, valid columns [d] int32.
   int lll_siegel;            // lll_kernel: LLL_SIEGEL (the launch's delta is then the swap threshold delta - eta^2)
   int lll_early;             // lll_kernel: LLL_EARLY_RED (lll.cpp:84-99)
+  // the transformation matrix u of MatGSO(b, u, ...) (gso.cpp:84-158: every row operation on b acts on u as well;
+  // move_row rotates its rows with b's): [batch][d][ldd], rows in the slots of b's; nullptr = not tracked.  u2: the
+  // position-ordered copy a stateless LLL call writes (swapped with u by the host, like b2 / b)
+  long long *u, *u2;
   int sess_mode;
   int sess_ndirty;
   int *sess_slots;           // [batch][256]

@@ -280,6 +280,10 @@ extern "C" void fphip_gso_destroy(fphip_gso *g)
     fphip_dev_free(g->P.vc, fphip_ctx_stream(g->ctx));
   if (g->P.b2)
     fphip_dev_free(g->P.b2, fphip_ctx_stream(g->ctx));
+  if (g->P.u)
+    fphip_dev_free(g->P.u, fphip_ctx_stream(g->ctx));
+  if (g->P.u2)
+    fphip_dev_free(g->P.u2, fphip_ctx_stream(g->ctx));
   if (g->P.lll_info)
     fphip_dev_free(g->P.lll_info, fphip_ctx_stream(g->ctx));
   if (g->P.enum_mu)
@@ -310,8 +314,21 @@ static int session_guard(fphip_gso *g, const char *what)
   return FPHIP_ERROR;
 }
 
+// With a transformation matrix on the device only the entry points that keep it in step with b may change b
+static int transform_guard(fphip_gso *g, const char *what)
+{
+  if (!g->P.u)
+    return FPHIP_OK;
+  snprintf(fphip_ctx_errbuf(g->ctx), 512, "%s: the transformation matrix u is tracked (fphip_gso_enable_transform) and "
+           "this entry point does not update it; fphip_gso_lll / fphip_gso_lll_flags do", what);
+  return FPHIP_UNSUPPORTED;
+}
+
 static int launch(fphip_gso *g, int kmin, int kend, double eta, int mode, const LllArgs *la = nullptr)
 {
+  if (mode == 1)
+    if (int rct = transform_guard(g, "size_reduce"))
+      return rct;
   if (g->P.sess_mode != 2)
     if (int rcg = session_guard(g, "gso"))
       return rcg;
@@ -387,7 +404,7 @@ static int launch(fphip_gso *g, int kmin, int kend, double eta, int mode, const 
 #define FPHIP_LLL_LAUNCH(NQ_)                                                                                          \
   do                                                                                                                   \
   {                                                                                                                    \
-    if (g->P.lll_early)                                                                                                \
+    if (g->P.lll_early || g->P.u)                                                                                      \
       hipLaunchKernelGGL((lll_kernel<NQ_, true>), dim3(grid), dim3(wpb * 64), lds, s, g->P, kmin, la->kstart, kend,    \
                          la->delta, eta, la->logdelta);                                                                \
     else                                                                                                               \
@@ -492,6 +509,54 @@ extern "C" int fphip_gso_get_basis(fphip_gso *g, int first, int count, int64_t *
   const size_t rows = (size_t)g->P.d * count;
   GCHK(hipMemcpy2D(b, (size_t)g->P.n * 8, g->P.b + (size_t)first * g->P.d * g->P.ldn,
                    (size_t)g->P.ldn * 8, (size_t)g->P.n * 8, rows, hipMemcpyDeviceToHost));
+  return FPHIP_OK;
+}
+
+// MatGSO(b, u, ...) with a non-empty u: enable_transform (gso_interface.h:96-110).  u ([batch][d][d], or NULL for
+// the identity) goes to the device; the LLL entry points then apply every row operation to its rows as well and
+// rotate them with b's (gso.cpp:84-158, 289-366).
+extern "C" int fphip_gso_enable_transform(fphip_gso *g, const int64_t *u)
+{
+  if (!g)
+    return FPHIP_ERROR;
+  if (int rcg = session_guard(g, "fphip_gso_enable_transform"))
+    return rcg;
+  const size_t B = (size_t)g->P.batch, d = g->P.d, ldd = g->P.ldd;
+  hipStream_t s = fphip_ctx_stream(g->ctx);
+  const size_t bytes = B * d * ldd * sizeof(long long);
+  if (!g->P.u)
+    GCHK(fphip_dev_alloc((void **)&g->P.u, bytes + 4096, s));
+  if (!g->P.u2)
+    GCHK(fphip_dev_alloc((void **)&g->P.u2, bytes + 4096, s));
+  GCHK(hipMemsetAsync(g->P.u, 0, bytes + 4096, s));
+  GCHK(hipMemsetAsync(g->P.u2, 0, bytes + 4096, s));
+  GCHK(hipStreamSynchronize(s));
+  if (u)
+    GCHK(hipMemcpy2D(g->P.u, ldd * 8, u, d * 8, d * 8, B * d, hipMemcpyHostToDevice));
+  else
+  {
+    std::vector<long long> id(d * ldd, 0);
+    for (size_t i = 0; i < d; ++i)
+      id[i * ldd + i] = 1;
+    for (size_t L = 0; L < B; ++L)
+      GCHK(hipMemcpy(g->P.u + L * d * ldd, id.data(), d * ldd * sizeof(long long), hipMemcpyHostToDevice));
+  }
+  return FPHIP_OK;
+}
+
+extern "C" int fphip_gso_get_transform(fphip_gso *g, int first, int count, int64_t *u)
+{
+  if (!g || !u || first < 0 || count <= 0 || first + count > g->P.batch)
+    return FPHIP_ERROR;
+  if (!g->P.u)
+  {
+    snprintf(fphip_ctx_errbuf(g->ctx), 512, "fphip_gso_get_transform: no transformation matrix (fphip_gso_enable_transform)");
+    return FPHIP_ERROR;
+  }
+  if (int rcg = session_guard(g, "fphip_gso_get_transform"))
+    return rcg;
+  const size_t d = g->P.d, ldd = g->P.ldd;
+  GCHK(hipMemcpy2D(u, d * 8, g->P.u + (size_t)first * d * ldd, ldd * 8, d * 8, d * (size_t)count, hipMemcpyDeviceToHost));
   return FPHIP_OK;
 }
 
@@ -601,6 +666,8 @@ extern "C" int fphip_gso_lll_flags(fphip_gso *g, int kappa_min, int kappa_start,
     return rc;
   const float lll_ms = g->last_ms;
   std::swap(g->P.b, g->P.b2);  // the kernel wrote the rows in position order into b2
+  if (g->P.u)
+    std::swap(g->P.u, g->P.u2);  // ... and those of u into u2
   std::vector<int> st(B);
   GCHK(hipMemcpy(st.data(), g->P.status, sizeof(int) * B, hipMemcpyDeviceToHost));
   if (info)
@@ -654,6 +721,8 @@ extern "C" int fphip_gso_session_lll(fphip_gso *g, int resume, int kappa_min, in
   FPHIP_RANGE("fphip_gso_session_lll");
   if (!g)
     return FPHIP_ERROR;
+  if (int rct = transform_guard(g, "session_lll"))
+    return rct;
   int siegel = 0, early = 0;
   if (int rcf = lll_flags_check(g, flags, &siegel, &early))
     return rcf;
@@ -860,6 +929,9 @@ extern "C" int fphip_gso_lll_ex(fphip_gso *g, int kappa_min, int kappa_start, in
                                 double eta, int precision, int *status, int *info)
 {
   FPHIP_RANGE("fphip_gso_lll_ex");
+  if (g)
+    if (int rct = transform_guard(g, "lll_ex"))
+      return rct;
   return gso_lll_ex(g, kappa_min, kappa_start, kappa_end, delta, eta, precision, nullptr, status, info);
 }
 
@@ -875,6 +947,8 @@ extern "C" int fphip_gso_lll_ladder(fphip_gso *g, int kappa_min, int kappa_start
   FPHIP_RANGE("fphip_gso_lll_ladder");
   if (!g)
     return FPHIP_ERROR;
+  if (int rct = transform_guard(g, "lll_ladder"))
+    return rct;
   const size_t B = (size_t)g->P.batch;
   std::vector<int> st(B, 0), inf(4 * B, 0), stg(B, 53);
   int rc = fphip_gso_lll(g, kappa_min, kappa_start, kappa_end, delta, eta, st.data(), inf.data());
@@ -956,6 +1030,8 @@ static int bkz_launch(fphip_gso *g, int block_size, double delta, double eta, in
 {
   if (int rcg = session_guard(g, "bkz"))
     return rcg;
+  if (int rct = transform_guard(g, "bkz"))
+    return rct;
   const int need = (g->P.d > g->P.n ? g->P.d : g->P.n);
   const int nq   = (need + 63) / 64;
   const int wpb  = g->waves_per_block;
@@ -1534,6 +1610,8 @@ extern "C" int fphip_gso_slide_pass(fphip_gso *g, int block_size, double delta, 
 {
   if (!g || pass < 1 || pass > 3 || block_size < 2)
     return FPHIP_ERROR;
+  if (int rct = transform_guard(g, "slide_pass"))
+    return rct;
   // without BKZ_BOUNDED_LLL every svp_reduction starts with an LLL from row 0: the blocks of a pass are
   // not independent then (bkz.cpp:107-108)
   if (!(flags & 0x10))
@@ -1805,6 +1883,9 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
   if (g)
     if (int rcg = session_guard(g, "bkz_strategies"))
       return rcg;
+  if (g)
+    if (int rct = transform_guard(g, "bkz_strategies"))
+      return rct;
   FPHIP_RANGE("fphip_gso_bkz_strategies");
   if (!g)
     return FPHIP_ERROR;

@@ -43,6 +43,7 @@ template <int NQ> struct Lattice
 {
   int d, n, ldd, ldn, row_expo_on;
   long long *b;
+  long long *u = nullptr;  // [d][ldd] transformation rows (LLL kernel, optional): same slots as b
   double *bfT, *mu, *muT, *r, *rdg;
   long long *rexp;
   // narrow mirrors (sweep kernels only; nullptr elsewhere): while every entry of the lattice is

@@ -42,9 +42,9 @@ __device__ unsigned long long fphip_lll_prof_dev[4 * LS_KINDS + 4];
 #endif
 
 // info[4] per lattice: final_kappa, n_swaps, zeros, loop iterations (low 31 bits)
-// EARLY: with LLL_EARLY_RED (lll.cpp:84-99) — its own instantiations in their own translation unit
-// (lll_kernel_early.hip): the early pass costs the plain kernels 4-8 VGPRs otherwise, and lll_kernel<4> sits at
-// the 256 that two waves per SIMD allow
+// EARLY: the extended kernel — LLL_EARLY_RED (lll.cpp:84-99) when P.lll_early is set, the transformation matrix u
+// when P.u is — its own instantiations in their own translation unit (lll_kernel_early.hip): the early pass
+// costs the plain kernels 4-8 VGPRs otherwise, and lll_kernel<4> sits at the 256 that two waves per SIMD allow
 template <int NQ, bool EARLY>
 __global__ void __launch_bounds__(256)
     lll_kernel(GsoBatch P, int kmin, int kstart, int kend, double delta, double eta, double logdelta)
@@ -85,6 +85,8 @@ __global__ void __launch_bounds__(256)
     T.narrow_flag = (int *)T.rexp;
     T.np          = 0;
     T.f32ok       = all_rows_narrow<NQ>(P, (size_t)L, lane);
+    if constexpr (EARLY)
+      T.u = P.u ? P.u + (size_t)L * d * ldd : nullptr;
     LllCtx C{P.gf + (size_t)L * d * ldd, P.vc + (size_t)L * d};
     SlotMap<NQ> M;
     int final_kappa, nswaps, zeros, vp = 0;
@@ -128,7 +130,7 @@ __global__ void __launch_bounds__(256)
     }
     const int status = lll_run(T, C, M, ring, kmin, kstart, kend, delta, eta, logdelta,
                                         final_kappa, nswaps, zeros, iter, vp, P.lll_siegel != 0,
-                                        EARLY, &last_early_red);
+                                        EARLY && P.lll_early != 0, &last_early_red);
     if (P.sess_mode != 0)
     {
       // leave the state behind, and the caller's view of it: everything in position order
@@ -203,7 +205,24 @@ __global__ void __launch_bounds__(256)
       }
     }
     else
+    {
       lll_write_ordered<NQ>(T, M, P.b2 + (size_t)L * d * ldn);
+      if (T.u != nullptr)
+      {  // u in position order as well
+        long long *uo = P.u2 + (size_t)L * d * ldd;
+        for (int p = 0; p < d; ++p)
+        {
+          const int s = M.phys(p);
+#pragma unroll
+          for (int q = 0; q < NQ; ++q)
+          {
+            const int c = lane + 64 * q;
+            if (c < ldd)
+              uo[(size_t)p * ldd + c] = T.u[(size_t)s * ldd + c];
+          }
+        }
+      }
+    }
     if (lane == 0)
     {
       P.status[L]           = status;

@@ -671,6 +671,33 @@ __device__ __forceinline__ int babai_impl(Lattice<NQ> &T, LStream<NQ> &S, int ka
     }
     // ---- row_op_end: update_bf(kappa), gso.cpp:24-48
     store_row_and_refloat<NQ, false>(T, pk, bv);
+    if (T.u != nullptr)
+    {  // enable_transform (gso.cpp:88-91,111-114,134-137,...): the same operation on the rows of u
+      const int d = T.d;
+      long long uv[NQ];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+      {
+        const int c = lane + 64 * q;
+        uv[q]       = (c < d) ? T.u[(size_t)pk * ldd + c] : 0;
+      }
+      int rows = 0;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+        rows += __builtin_popcountll(nz[q]);
+      AxpyPh<NQ, false> ph{(const char *)T.u, (long)ldd * 8, ls_make_win(d * 8), S.lane16, lane, map, uv, lxv, {}, {}};
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+        ph.ic.m[q] = ph.cc.m[q] = nz[q];
+      ls_run<NQ>(S, ph, rows);
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+      {
+        const int c = lane + 64 * q;
+        if (c < d)
+          T.u[(size_t)pk * ldd + c] = uv[q];
+      }
+    }
     after(kappa);
     // later reads of b / bfT / rexp in this wave must see these stores
     __threadfence_block();
@@ -1155,6 +1182,7 @@ template <int NQ, class RingT> __device__ __forceinline__ void uniformize(LllFra
   f.T.ldn         = uni(f.T.ldn);
   f.T.row_expo_on = uni(f.T.row_expo_on);
   f.T.b           = uni_ptr(f.T.b);
+  f.T.u           = nullptr;  // (the BKZ kernels do not track the transformation matrix)
   f.T.bfT         = uni_ptr(f.T.bfT);
   f.T.mu          = uni_ptr(f.T.mu);
   f.T.muT         = uni_ptr(f.T.muT);

@@ -96,6 +96,27 @@ class MatGSOBatch:
                                                b.ctypes.data_as(ctypes.c_void_p)), "get_basis")
         return b
 
+    def enable_transform(self, u=None):
+        """MatGSO(b, u, ...) with a non-empty u (enable_transform): track the transformation matrix on the device —
+        u [batch][d][d] int64, or None for the identity.  lll() then applies every row operation to u as well
+        (gso.cpp:84-158); the entry points that do not raise Unsupported while it is tracked."""
+        fn = self.lib.fphip_gso_enable_transform
+        fn.restype = ctypes.c_int
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        if u is not None:
+            u = np.ascontiguousarray(u, dtype=np.int64)
+            assert u.shape == (self.batch, self.d, self.d)
+        self._chk(fn(self.h, None if u is None else u.ctypes.data_as(ctypes.c_void_p)), "enable_transform")
+
+    def get_transform(self, first=0, count=None):
+        count = self.batch - first if count is None else count
+        u = np.empty((count, self.d, self.d), dtype=np.int64)
+        fn = self.lib.fphip_gso_get_transform
+        fn.restype = ctypes.c_int
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+        self._chk(fn(self.h, first, count, u.ctypes.data_as(ctypes.c_void_p)), "get_transform")
+        return u
+
     def update_gso(self):
         st = np.zeros(self.batch, dtype=np.int32)
         self._chk(self.lib.fphip_gso_update(self.h, st.ctypes.data_as(ctypes.c_void_p)), "update_gso")

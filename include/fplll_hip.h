@@ -202,6 +202,14 @@ int fphip_gso_lll(fphip_gso *g, int kappa_min, int kappa_start, int kappa_end, d
  * one LLLReduction object: its last_early_red (lll.h:70) starts at 0. */
 int fphip_gso_lll_flags(fphip_gso *g, int kappa_min, int kappa_start, int kappa_end, double delta, double eta,
                         int flags, int *status, int *info);
+/* MatGSO(b, u, u_inv_t, flags) with a non-empty u (enable_transform, gso_interface.h:96-110): the transformation
+ * matrix goes to the device — u [batch][d][d] row-major, or NULL for the identity — and fphip_gso_lll /
+ * fphip_gso_lll_flags apply every row operation to its rows as well and move them with b's (gso.cpp:84-158,
+ * 289-366): afterwards u_out = T u_in with b_out = T b_in.  While u is tracked the entry points that do not update
+ * it (size_reduce, bkz*, slide, lll_ex / ladder, sessions) return FPHIP_UNSUPPORTED; fphip_gso_set_basis keeps u.
+ * u_inv_t (enable_inverse_transform) is not offered. */
+int fphip_gso_enable_transform(fphip_gso *g, const int64_t *u);
+int fphip_gso_get_transform(fphip_gso *g, int first, int count, int64_t *u);
 /* The same lll() on a RESIDENT MatGSO: fplll's MatGSO is an object whose rows, Gram cache, mu / r and
  * gso_valid_cols persist from one lll() to the next (accessors gso_interface.h:675-732, validity tracking
  * gso_interface.cpp:26-53), and a BKZ run calls lll() thousands of times after touching a few rows.  resume = 0

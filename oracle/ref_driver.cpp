@@ -618,6 +618,8 @@ static int cmd_lllfix(int argc, char **argv)
   for (int rep = 0; rep < reps; ++rep)
   {
     b = b0;
+    if (getenv("LLLFIX_U"))  // enable_transform: the run keeps u with b_out = u b_in (the fixture records it)
+      u.gen_identity(d);
     auto t0 = std::chrono::steady_clock::now();
     MatGSO<Z_NR<long>, FP_NR<double>> M(b, u, ut, GSO_ROW_EXPO);
     // (LLLFIX_FLAGS: fplll's LLLFlags for this run — LLL_SIEGEL = 4; the fixture records them)
@@ -638,7 +640,16 @@ static int cmd_lllfix(int argc, char **argv)
   for (int i = 0; i < d; ++i)
     for (int j = 0; j < n; ++j)
       os << ((i || j) ? "," : "") << b(i, j).get_si();
-  os << "]\n}\n";
+  os << "]";
+  if (u.get_rows() > 0)
+  {
+    os << ",\n\"u_out\":[";
+    for (int i = 0; i < d; ++i)
+      for (int j = 0; j < d; ++j)
+        os << ((i || j) ? "," : "") << u(i, j).get_si();
+    os << "]";
+  }
+  os << "\n}\n";
   std::cout << os.str();
   return 0;
 }

@@ -455,6 +455,8 @@ def load_lll_fixture(path):
     out["b_in"] = np.array(j["b_in"], dtype=np.int64).reshape(d, n)
     out["b_out"] = np.array(j["b_out"], dtype=np.int64).reshape(d, n)
     out["flags"] = int(j.get("flags", 0))  # fplll's LLLFlags of the run (LLL_SIEGEL = 4)
+    if "u_out" in j:  # the run kept the transformation matrix (MatGSO(b, u = identity, ...)): b_out = u_out b_in
+        out["u_out"] = np.array(j["u_out"], dtype=np.int64).reshape(d, d)
     return out
 
 

@@ -266,6 +266,41 @@ def test_early_reduction_seeded_vs_oracle(ctx, d, n_extra, flags):
                     % (d, flags, plain, B),))
 
 
+@pytest.mark.parametrize("name", ["lll_q40_zero1_dup2_u", "lll_q72_u", "lll_r30_earlyred_u"])
+def test_transformation_matrix_follows_the_row_operations(ctx, name):
+    """MatGSO(b, u = identity, ...) (enable_transform, gso.cpp:84-158, 289-366): every row operation of the LLL run
+    acts on u as well and move_row rotates its rows with b's.  The device's u equals the REAL reference's (fixtures
+    of oracle/ref_driver with LLLFIX_U: a q-ary basis with a zero row and two dependent rows — where u is NOT
+    determined by b_in and b_out —, a 72-dim q-ary basis, a knapsack basis under LLL_EARLY_RED), and u b_in = b_out
+    in exact integers.  A non-identity start: u_out = T u_in with the same T."""
+    from fplll_amd.gso import MatGSOBatch
+    f = C.load_lll_fixture(os.path.join(C.GOLDEN, name + ".json"))
+    d, n = f["d"], f["n"]
+    g = MatGSOBatch(ctx, 2, d, n)
+    g.set_basis(np.stack([f["b_in"]] * 2))
+    rng = np.random.default_rng(5)
+    u0 = np.stack([np.eye(d, dtype=np.int64), np.triu(rng.integers(-3, 4, size=(d, d)), 1) + np.eye(d, dtype=np.int64)])
+    g.enable_transform(u0)
+    st, info = g.lll(f["kmin"], f["kstart"], f["kend"], f["delta"], f["eta"], flags=f["flags"])
+    assert list(st) == [f["status"]] * 2 and int(info[0][1]) == f["n_swaps"] and int(info[0][2]) == f["zeros"]
+    u = g.get_transform()
+    assert np.array_equal(g.get_basis(0, 1)[0], f["b_out"])
+    assert np.array_equal(u[0], f["u_out"])
+    ui, bi = u[0].astype(object), f["b_in"].astype(object)
+    assert np.array_equal(ui.dot(bi), f["b_out"].astype(object))
+    assert np.array_equal(u[1].astype(object), f["u_out"].astype(object).dot(u0[1].astype(object)))
+    # the entry points that would leave u behind refuse to run
+    with pytest.raises(Exception):
+        g.size_reduction()
+    with pytest.raises(Exception):
+        g.bkz(10, f["delta"], f["eta"], 1)
+    # a second call keeps accumulating: LLL of a reduced basis changes nothing, u stays
+    st2, info2 = g.lll(f["kmin"], f["kstart"], f["kend"], f["delta"], f["eta"], flags=f["flags"] & 4)
+    if f["zeros"] == 0:
+        assert int(info2[0][1]) == 0 and np.array_equal(g.get_transform(0, 1)[0], f["u_out"])
+    g.close()
+
+
 def test_early_reduction_in_a_session(ctx):
     """A session is one LLLReduction object: last_early_red (lll.h:70) starts at 0 and is kept.  The first call
     equals the reference's fixture; a second call on the reduced basis finds every power of two already done
