@@ -24,8 +24,9 @@ MatGSOHip::MatGSOHip(Matrix<ZT> &arg_b, Matrix<ZT> &arg_u, Matrix<ZT> &arg_uinv_
     : MatGSO<ZT, FT>(arg_b, arg_u, arg_uinv_t, flags)
 {
   // only the configuration the device kernels reproduce; anything else stays a plain MatGSO
-  if (flags != GSO_ROW_EXPO || arg_u.get_rows() != 0 || arg_uinv_t.get_rows() != 0)
+  if (flags != GSO_ROW_EXPO || arg_uinv_t.get_rows() != 0)
     return;
+  track_u_ = arg_u.get_rows() != 0;
   if (device < 0)
     device = getenv("FPLLL_HIP_DEVICE") ? atoi(getenv("FPLLL_HIP_DEVICE")) : 0;
   if (fphip_create(device, &ctx_) != FPHIP_OK)
@@ -37,12 +38,19 @@ MatGSOHip::MatGSOHip(Matrix<ZT> &arg_b, Matrix<ZT> &arg_u, Matrix<ZT> &arg_uinv_
   if (fphip_gso_create(ctx_, 1, b.get_rows(), b.get_cols(), 1, &g_) != FPHIP_OK)
     g_ = nullptr;  // e.g. more than 256 rows: FPHIP_UNSUPPORTED, the object works as a MatGSO
   const size_t d = b.get_rows(), n = b.get_cols();
+  rows0_ = (int)d;
+  cols0_ = (int)n;
   hb_.resize(d * n);
   hmu_.resize(d * d);
   hr_.resize(d * d);
   hexp_.resize(d);
   hvc_.resize(d);
   hb2_.resize(d * n);
+  if (track_u_)
+  {
+    hu_.resize(d * d);
+    hu2_.resize(d * d);
+  }
   resident_ = !(getenv("FPLLL_HIP_RESIDENT") && atoi(getenv("FPLLL_HIP_RESIDENT")) == 0);
 }
 
@@ -64,6 +72,56 @@ void MatGSOHip::upload_basis()
       hb_[(size_t)i * n + j] = b(i, j).get_si();
   fphip_gso_set_basis(g_, 0, 1, hb_.data());
   session_ = false;  // (fphip_gso_set_basis ends a device session)
+  if (track_u_)
+  {
+    for (int i = 0; i < d; ++i)
+      for (int j = 0; j < d; ++j)
+        hu_[(size_t)i * d + j] = u(i, j).get_si();
+    fphip_gso_enable_transform(g_, hu_.data());
+    check_u_ = getenv("FPLLL_HIP_CHECK_U") && atoi(getenv("FPLLL_HIP_CHECK_U")) != 0;
+    if (check_u_ && b0_.empty())
+    {  // (u is the identity at the first upload of the diagnostic runs)
+      b0_ = hb_;
+    }
+  }
+}
+
+bool MatGSOHip::check_u_invariant(const char *when)
+{
+  if (!check_u_ || !track_u_ || b0_.empty())
+    return true;
+  const int d = b.get_rows(), n = b.get_cols();
+  for (int i = 0; i < d; ++i)
+    for (int j = 0; j < n; ++j)
+    {
+      __int128 s = 0;
+      for (int k = 0; k < d; ++k)
+        s += (__int128)u(i, k).get_si() * b0_[(size_t)k * n + j];
+      if (s != (__int128)b(i, j).get_si())
+      {
+        fprintf(stderr, "[MatGSOHip] u b_0 != b at row %d col %d, %s device call %ld\n", i, j, when, n_calls_checked_);
+        return false;
+      }
+    }
+  return true;
+}
+
+// The device's u -> the host member (the rows the device changed; b's rows go through row_op_begin / row_op_end
+// in the mirror functions, u has no derived state)
+void MatGSOHip::read_back_u(bool from_session)
+{
+  if (!track_u_)
+    return;
+  const int d = b.get_rows();
+  if (from_session)
+    fphip_gso_session_read_transform(g_, 0, hu2_.data());
+  else
+    fphip_gso_get_transform(g_, 0, 1, hu2_.data());
+  for (int i = 0; i < d; ++i)
+    for (int j = 0; j < d; ++j)
+      if (hu2_[(size_t)i * d + j] != u(i, j).get_si())
+        u(i, j) = (long)hu2_[(size_t)i * d + j];
+  hu_ = hu2_;
 }
 
 // Device state -> host members.  The integer rows that changed go through row_op_begin /
@@ -109,7 +167,7 @@ void MatGSOHip::mirror_from_device(bool basis_changed)
 
 bool MatGSOHip::update_gso_device()
 {
-  if (!g_)
+  if (!g_ || !shape_matches())
     return update_gso();
   const double t0 = now_s();
   upload_basis();
@@ -124,7 +182,7 @@ bool MatGSOHip::update_gso_device()
 
 int MatGSOHip::size_reduction_device(int kappa_min, int kappa_end, double eta)
 {
-  if (!g_)
+  if (!g_ || !shape_matches())
     return -100;
   const double t0 = now_s();
   upload_basis();
@@ -180,6 +238,7 @@ void MatGSOHip::mirror_from_session()
     row_op_end(i, i + 1);
   }
   hb_ = hb2_;
+  read_back_u(true);
   for (int i = 0; i < d; ++i)
   {
     const int valid = hvc_[i] < 0 ? 0 : (hvc_[i] > i + 1 ? i + 1 : hvc_[i]);
@@ -201,6 +260,8 @@ int MatGSOHip::lll_device_resident(int kappa_min, int kappa_start, int kappa_end
   const double t0 = now_s();
   const int d = b.get_rows(), n = b.get_cols();
   int st = 0, rc;
+  ++n_calls_checked_;
+  check_u_invariant("before");
   if (!session_)
   {
     upload_basis();
@@ -216,11 +277,15 @@ int MatGSOHip::lll_device_resident(int kappa_min, int kappa_start, int kappa_end
       bool diff = false;
       for (int j = 0; j < n && !diff; ++j)
         diff = (b(i, j).get_si() != hb_[(size_t)i * n + j]);
+      for (int j = 0; track_u_ && j < d && !diff; ++j)
+        diff = (u(i, j).get_si() != hu_[(size_t)i * d + j]);
       if (!diff)
         continue;
       dpos_.push_back(i);
       for (int j = 0; j < n; ++j)
         drows_.push_back(b(i, j).get_si());
+      for (int j = 0; track_u_ && j < d; ++j)  // (a dirty row is b's row followed by u's when u is tracked)
+        drows_.push_back(u(i, j).get_si());
     }
     n_dirty_rows += (long)dpos_.size();
     rc = fphip_gso_session_lll(g_, 1, kappa_min, kappa_start, kappa_end, delta, eta, flags, (int)dpos_.size(), dpos_.data(),
@@ -239,6 +304,9 @@ int MatGSOHip::lll_device_resident(int kappa_min, int kappa_start, int kappa_end
   {
     mirror_from_session();
     session_ = (st == 1);
+    if (!check_u_invariant("after"))
+      fprintf(stderr, "[MatGSOHip]   ... range [%d, %d, %d), %zu dirty rows, status %d\n", kappa_min, kappa_start,
+              kappa_end, dpos_.size(), st);
   }
   device_seconds += now_s() - t0;
   ++n_device_calls;
@@ -248,8 +316,8 @@ int MatGSOHip::lll_device_resident(int kappa_min, int kappa_start, int kappa_end
 int MatGSOHip::lll_device(int kappa_min, int kappa_start, int kappa_end, double delta, double eta, int info[4],
                           int flags)
 {
-  if (!g_)
-    return -100;
+  if (!g_ || !shape_matches())
+    return -100;  // (the host path takes this call; a running session stays: the rows that differ go up next time)
   if (resident_)
     return lll_device_resident(kappa_min, kappa_start, kappa_end, delta, eta, info, flags);
   const double t0 = now_s();
@@ -259,7 +327,10 @@ int MatGSOHip::lll_device(int kappa_min, int kappa_start, int kappa_end, double 
   if (rc != FPHIP_OK)
     st = -100;
   else if (st != -2)
+  {
     mirror_from_device(true);
+    read_back_u(false);
+  }
   device_seconds += now_s() - t0;
   ++n_device_calls;
   return st;

@@ -37,13 +37,17 @@ public:
   typedef fplll::FP_NR<double> FT;
 
   // Same arguments as MatGSO's constructor (gso.h:56-75).  flags must be GSO_ROW_EXPO (what BKZ
-  // uses); transformation matrices are not kept on the device (pass empty ones).  device < 0: the
-  // device of FPLLL_HIP_DEVICE or 0.
+  // uses).  A non-empty u (enable_transform) is kept on the device too — the LLL kernel applies its row
+  // operations to u's rows as well —; u_inv_t must be empty (an object with one stays a plain MatGSO).
+  // device < 0: the device of FPLLL_HIP_DEVICE or 0.
   MatGSOHip(fplll::Matrix<ZT> &arg_b, fplll::Matrix<ZT> &arg_u, fplll::Matrix<ZT> &arg_uinv_t, int flags,
             int device = -1);
   ~MatGSOHip();
 
   bool on_device() const { return g_ != nullptr; }
+  // the matrix still has the shape the device object was created for (svp_postprocessing_generic works on d + 1
+  // rows for a moment, bkz.cpp:186-219: calls made meanwhile stay on the host)
+  bool shape_matches() const { return b.get_rows() == rows0_ && b.get_cols() == cols0_; }
   // the resident session (one LLLReduction object as far as LLL_EARLY_RED's last_early_red is concerned)
   bool session_active() const { return session_; }
   void end_session() { session_ = false; }
@@ -89,6 +93,15 @@ private:
   std::vector<int64_t> hb_;      // staging: integer basis
   std::vector<double> hmu_, hr_; // staging: mu, r
   std::vector<int64_t> hexp_;
+  int rows0_ = 0, cols0_ = 0;
+  bool track_u_ = false;         // enable_transform: u lives on the device as well
+  std::vector<int64_t> hu_, hu2_; // staging: u as of the last synchronisation / as read back
+  void read_back_u(bool from_session);
+  // FPLLL_HIP_CHECK_U=1 (diagnostics): u b_0 == b is verified around every device call (b_0: the basis at the first upload)
+  bool check_u_ = false;
+  std::vector<int64_t> b0_;
+  long n_calls_checked_ = 0;
+  bool check_u_invariant(const char *when);
 };
 
 }  // namespace fplll_hip

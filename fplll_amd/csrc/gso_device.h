@@ -98,12 +98,17 @@ struct GsoBatch
   int sess_ndirty;
   int *sess_slots;           // [batch][256]
   int *sess_state;           // [batch][4]: verified prefix, f32ok
-  const long long *sess_in;
-  char *sess_out;            // [batch][fphip_session_out_bytes(d, ldd, ldn)]
+  const long long *sess_in;  // positions [ndirty], rows of b [ndirty][ldn], rows of u [ndirty][ldd] (when u is tracked)
+  char *sess_out;            // [batch][fphip_session_out_stride(d, ldd, ldn)]
 };
 static constexpr size_t fphip_session_out_bytes(size_t d, size_t ldd, size_t ldn)
 {
   return d * ldn * 8 + 2 * d * ldd * 8 + d * 8 + ((d * 4 + 15) / 16) * 16;
+}
+// ... followed by the rows of u in position order ([d][ldd], written when u is tracked): a lattice's stride in sess_out
+static constexpr size_t fphip_session_out_stride(size_t d, size_t ldd, size_t ldn)
+{
+  return fphip_session_out_bytes(d, ldd, ldn) + d * ldd * 8;
 }
 // ---- BKZ with strategies (bkzs_kernel.hip) ------------------------------------------------------
 #define FPHIP_BKZS_MAX_DEPTH 4  /* nested tour() activations: the BKZ tour + 3 levels of preprocessing */

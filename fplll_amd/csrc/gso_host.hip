@@ -117,6 +117,7 @@ struct fphip_gso
   unsigned long long il_calls = 0, il_device_jobs = 0, il_host_jobs = 0, il_launches = 0;
   // resident LLL session (fphip_gso_session_lll): the rows live in the kernel's slots while it is active
   bool session_active  = false;
+  bool u_in_slots      = false;  // a session left the rows of u in the kernel's slots (restore_u_order)
   long long *sess_in_d = nullptr;  // device: positions then rows of the caller's row operations
   long long *sess_in_h = nullptr;  // pinned staging of the same
   char *sess_out_h     = nullptr;  // pinned: the state in position order after the last session call
@@ -305,6 +306,21 @@ struct LllArgs
   double delta, logdelta;
 };
 
+// A session leaves the rows of u in the kernel's slots (like b's); its last call also wrote them in position order
+// behind the caller's view of the state: that copy becomes u when the session ends.
+static int restore_u_order(fphip_gso *g)
+{
+  if (!g->u_in_slots || !g->P.u || !g->P.sess_out)
+    return FPHIP_OK;
+  const size_t B = (size_t)g->P.batch, d = g->P.d, ldd = g->P.ldd, ldn = g->P.ldn;
+  for (size_t L = 0; L < B; ++L)
+    GCHK(hipMemcpy(g->P.u + L * d * ldd,
+                   g->P.sess_out + L * fphip_session_out_stride(d, ldd, ldn) + fphip_session_out_bytes(d, ldd, ldn),
+                   d * ldd * sizeof(long long), hipMemcpyDeviceToDevice));
+  g->u_in_slots = false;
+  return FPHIP_OK;
+}
+
 static int session_guard(fphip_gso *g, const char *what)
 {
   if (!g->session_active)
@@ -461,7 +477,7 @@ extern "C" int fphip_gso_set_basis(fphip_gso *g, int first, int count, const int
                    (size_t)g->P.n * 8, (size_t)g->P.n * 8, rows, hipMemcpyHostToDevice));
   g->dirty          = true;
   g->session_active = false;  // (the rows are in position order again)
-  return FPHIP_OK;
+  return restore_u_order(g);   // (... and so are those of u)
 }
 
 // replicate lattice `src` into every slot of the batch (device-side copies; used by benchmarks)
@@ -541,6 +557,7 @@ extern "C" int fphip_gso_enable_transform(fphip_gso *g, const int64_t *u)
     for (size_t L = 0; L < B; ++L)
       GCHK(hipMemcpy(g->P.u + L * d * ldd, id.data(), d * ldd * sizeof(long long), hipMemcpyHostToDevice));
   }
+  g->u_in_slots = false;
   return FPHIP_OK;
 }
 
@@ -693,7 +710,7 @@ static int ensure_session_buffers(fphip_gso *g)
 {
   const size_t B = (size_t)g->P.batch, d = g->P.d, ldd = g->P.ldd, ldn = g->P.ldn;
   hipStream_t s = fphip_ctx_stream(g->ctx);
-  const size_t outb = fphip_session_out_bytes(d, ldd, ldn);
+  const size_t outb = fphip_session_out_stride(d, ldd, ldn);
   if (!g->P.sess_slots)
     GCHK(fphip_dev_alloc((void **)&g->P.sess_slots, B * 256 * sizeof(int), s));
   if (!g->P.sess_state)
@@ -701,9 +718,9 @@ static int ensure_session_buffers(fphip_gso *g)
   if (!g->P.sess_out)
     GCHK(fphip_dev_alloc((void **)&g->P.sess_out, B * outb + 4096, s));
   if (!g->sess_in_d)
-    GCHK(fphip_dev_alloc((void **)&g->sess_in_d, (d + d * ldn) * sizeof(long long) + 4096, s));
+    GCHK(fphip_dev_alloc((void **)&g->sess_in_d, (d + d * ldn + d * ldd) * sizeof(long long) + 4096, s));
   if (!g->sess_in_h)
-    g->sess_in_h = (long long *)fphip_pinned_get((d + d * ldn) * sizeof(long long));
+    g->sess_in_h = (long long *)fphip_pinned_get((d + d * ldn + d * ldd) * sizeof(long long));
   if (!g->sess_out_h)
     g->sess_out_h = (char *)fphip_pinned_get(B * outb);
   if (!g->sess_in_h || !g->sess_out_h)
@@ -721,8 +738,6 @@ extern "C" int fphip_gso_session_lll(fphip_gso *g, int resume, int kappa_min, in
   FPHIP_RANGE("fphip_gso_session_lll");
   if (!g)
     return FPHIP_ERROR;
-  if (int rct = transform_guard(g, "session_lll"))
-    return rct;
   int siegel = 0, early = 0;
   if (int rcf = lll_flags_check(g, flags, &siegel, &early))
     return rcf;
@@ -733,7 +748,8 @@ extern "C" int fphip_gso_session_lll(fphip_gso *g, int resume, int kappa_min, in
     snprintf(fphip_ctx_errbuf(g->ctx), 512, "fphip_gso_session_lll: need 0 <= kappa_min <= kappa_start < kappa_end <= d");
     return FPHIP_ERROR;
   }
-  const size_t B = (size_t)g->P.batch, d = g->P.d, ldn = g->P.ldn, n = g->P.n;
+  const size_t B = (size_t)g->P.batch, d = g->P.d, ldn = g->P.ldn, n = g->P.n, ldd = g->P.ldd;
+  const size_t rec = n + (g->P.u ? d : 0);  // a dirty row: its n integers, then its d integers of u when u is tracked
   if (resume && !g->session_active)
   {
     snprintf(fphip_ctx_errbuf(g->ctx), 512, "fphip_gso_session_lll: no session to resume (start one with resume = 0)");
@@ -765,11 +781,19 @@ extern "C" int fphip_gso_session_lll(fphip_gso *g, int resume, int kappa_min, in
         return FPHIP_ERROR;
       g->sess_in_h[t] = dirty_pos[t];
       long long *row = g->sess_in_h + n_dirty + (size_t)t * ldn;
-      memcpy(row, dirty_rows + (size_t)t * n, n * sizeof(long long));
+      memcpy(row, dirty_rows + (size_t)t * rec, n * sizeof(long long));
       for (size_t c = n; c < ldn; ++c)
         row[c] = 0;
+      if (g->P.u)
+      {
+        long long *urow = g->sess_in_h + n_dirty + (size_t)n_dirty * ldn + (size_t)t * ldd;
+        memcpy(urow, dirty_rows + (size_t)t * rec + n, d * sizeof(long long));
+        for (size_t c = d; c < ldd; ++c)
+          urow[c] = 0;
+      }
     }
-    GCHK(hipMemcpyAsync(g->sess_in_d, g->sess_in_h, ((size_t)n_dirty + (size_t)n_dirty * ldn) * sizeof(long long),
+    GCHK(hipMemcpyAsync(g->sess_in_d, g->sess_in_h,
+                        ((size_t)n_dirty + (size_t)n_dirty * ldn + (g->P.u ? (size_t)n_dirty * ldd : 0)) * sizeof(long long),
                         hipMemcpyHostToDevice, s));
   }
   g->P.sess_mode   = resume ? 2 : 1;
@@ -787,7 +811,7 @@ extern "C" int fphip_gso_session_lll(fphip_gso *g, int resume, int kappa_min, in
   if (rc != FPHIP_OK)
     return rc;
   std::vector<int> st(B);
-  const size_t outb = fphip_session_out_bytes(d, g->P.ldd, ldn);
+  const size_t outb = fphip_session_out_stride(d, g->P.ldd, ldn);
   GCHK(hipMemcpyAsync(g->sess_out_h, g->P.sess_out, B * outb, hipMemcpyDeviceToHost, s));
   GCHK(hipMemcpyAsync(st.data(), g->P.status, sizeof(int) * B, hipMemcpyDeviceToHost, s));
   if (info)
@@ -800,8 +824,23 @@ extern "C" int fphip_gso_session_lll(fphip_gso *g, int resume, int kappa_min, in
   for (size_t L = 0; L < B; ++L)
     all_ok &= (st[L] == 1);
   g->session_active = all_ok;
+  g->u_in_slots     = g->P.u != nullptr;
+  if (!all_ok)
+    restore_u_order(g);
   if (status)
     memcpy(status, st.data(), sizeof(int) * B);
+  return FPHIP_OK;
+}
+
+extern "C" int fphip_gso_session_read_transform(fphip_gso *g, int lattice, int64_t *u)
+{
+  if (!g || !u || lattice < 0 || lattice >= g->P.batch || !g->sess_out_h || !g->P.u)
+    return FPHIP_ERROR;
+  const size_t d = g->P.d, ldd = g->P.ldd, ldn = g->P.ldn;
+  const long long *ou = (const long long *)(g->sess_out_h + (size_t)lattice * fphip_session_out_stride(d, ldd, ldn) +
+                                            fphip_session_out_bytes(d, ldd, ldn));
+  for (size_t i = 0; i < d; ++i)
+    memcpy(u + i * d, ou + i * ldd, d * sizeof(long long));
   return FPHIP_OK;
 }
 
@@ -811,7 +850,7 @@ extern "C" int fphip_gso_session_read(fphip_gso *g, int lattice, int64_t *b, dou
   if (!g || lattice < 0 || lattice >= g->P.batch || !g->sess_out_h)
     return FPHIP_ERROR;
   const size_t d = g->P.d, ldd = g->P.ldd, ldn = g->P.ldn, n = g->P.n;
-  const char *out      = g->sess_out_h + (size_t)lattice * fphip_session_out_bytes(d, ldd, ldn);
+  const char *out      = g->sess_out_h + (size_t)lattice * fphip_session_out_stride(d, ldd, ldn);
   const long long *ob  = (const long long *)out;
   const double *omu    = (const double *)(out + d * ldn * 8);
   const double *orr    = omu + d * ldd;

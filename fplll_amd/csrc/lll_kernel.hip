@@ -111,6 +111,7 @@ __global__ void __launch_bounds__(256)
       // (update_bf, the vector's Gram row and column, the GSO rows from p on: gso_interface.cpp:32-53)
       const long long *pos = P.sess_in;
       const long long *rows = P.sess_in + P.sess_ndirty;
+      const long long *urows = rows + (size_t)P.sess_ndirty * ldn;
       for (int t = 0; t < P.sess_ndirty; ++t)
       {
         const int p = uni((int)pos[t]);
@@ -123,6 +124,16 @@ __global__ void __launch_bounds__(256)
           bv[q]       = (c < n) ? rows[(size_t)t * ldn + c] : 0;
         }
         store_row_and_refloat<NQ, false>(T, s, bv);
+        if (T.u != nullptr)
+        {  // the caller's row operations act on u as well (gso.cpp:88-91, ...)
+#pragma unroll
+          for (int q = 0; q < NQ; ++q)
+          {
+            const int c = lane + 64 * q;
+            if (c < ldd)
+              T.u[(size_t)s * ldd + c] = urows[(size_t)t * ldd + c];
+          }
+        }
         after_rowop<NQ>(T, C, M, p);
         vp = min(vp, p);
         __threadfence_block();
@@ -144,7 +155,7 @@ __global__ void __launch_bounds__(256)
         P.sess_state[4 * L + 2] = P.lll_siegel;
         P.sess_state[4 * L + 3] = last_early_red;
       }
-      char *out        = P.sess_out + (size_t)L * fphip_session_out_bytes(d, ldd, ldn);
+      char *out        = P.sess_out + (size_t)L * fphip_session_out_stride(d, ldd, ldn);
       long long *ob    = (long long *)out;
       double *omu      = (double *)(out + (size_t)d * ldn * 8);
       double *orr      = omu + (size_t)d * ldd;
@@ -201,6 +212,21 @@ __global__ void __launch_bounds__(256)
         {
           oexp[p0 + lane] = ee;
           ovc[p0 + lane]  = vv;
+        }
+      }
+      if (T.u != nullptr)
+      {
+        long long *ou = (long long *)(out + fphip_session_out_bytes(d, ldd, ldn));
+        for (int p = 0; p < d; ++p)
+        {
+          const int s = M.phys(p);
+#pragma unroll
+          for (int q = 0; q < NQ; ++q)
+          {
+            const int c = lane + 64 * q;
+            if (c < ldd)
+              ou[(size_t)p * ldd + c] = T.u[(size_t)s * ldd + c];
+          }
         }
       }
     }

@@ -147,7 +147,8 @@ class MatGSOBatch:
                     dirty=None, flags=0):
         """The same lll() on a RESIDENT MatGSO (fphip_gso_session_lll): resume=False starts a session from the
         basis on the device, resume=True continues it after the caller's row operations `dirty` =
-        {row position: new integer row} (batch of one).  Returns (status[batch], info[batch][4])."""
+        {row position: new integer row} (batch of one; with enable_transform() the row of b followed by the row
+        of u, n + d integers).  Returns (status[batch], info[batch][4])."""
         st = np.zeros(self.batch, dtype=np.int32)
         info = np.zeros((self.batch, 4), dtype=np.int32)
         fn = self.lib.fphip_gso_session_lll
@@ -157,7 +158,8 @@ class MatGSOBatch:
                        ctypes.c_void_p]
         dirty = dirty or {}
         pos = np.ascontiguousarray(sorted(dirty), dtype=np.int32)
-        rows = np.ascontiguousarray([dirty[p] for p in sorted(dirty)], dtype=np.int64).reshape(len(pos), self.n)
+        rows = np.ascontiguousarray([dirty[p] for p in sorted(dirty)], dtype=np.int64).reshape(len(pos), -1 if len(pos) else self.n)
+        assert len(pos) == 0 or rows.shape[1] in (self.n, self.n + self.d)
         self._chk(fn(self.h, 1 if resume else 0, kappa_min, kappa_start, kappa_end, delta, eta, flags, len(pos),
                      pos.ctypes.data_as(ctypes.c_void_p) if len(pos) else None,
                      rows.ctypes.data_as(ctypes.c_void_p) if len(pos) else None,
@@ -178,6 +180,15 @@ class MatGSOBatch:
         self._chk(fn(self.h, lattice, *(a.ctypes.data_as(ctypes.c_void_p) for a in (b, mu, r, vc, ex))),
                   "session_read")
         return b, mu, r, vc, ex
+
+    def session_read_transform(self, lattice=0):
+        """u [d][d] in position order as the last session_lll left it (enable_transform() before the session)."""
+        u = np.zeros((self.d, self.d), dtype=np.int64)
+        fn = self.lib.fphip_gso_session_read_transform
+        fn.restype = ctypes.c_int
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        self._chk(fn(self.h, lattice, u.ctypes.data_as(ctypes.c_void_p)), "session_read_transform")
+        return u
 
     def lll_ex(self, precision=106, kappa_min=0, kappa_start=0, kappa_end=-1, delta=LLL_DEF_DELTA,
                eta=LLL_DEF_ETA):

@@ -205,9 +205,10 @@ int fphip_gso_lll_flags(fphip_gso *g, int kappa_min, int kappa_start, int kappa_
 /* MatGSO(b, u, u_inv_t, flags) with a non-empty u (enable_transform, gso_interface.h:96-110): the transformation
  * matrix goes to the device — u [batch][d][d] row-major, or NULL for the identity — and fphip_gso_lll /
  * fphip_gso_lll_flags apply every row operation to its rows as well and move them with b's (gso.cpp:84-158,
- * 289-366): afterwards u_out = T u_in with b_out = T b_in.  While u is tracked the entry points that do not update
- * it (size_reduce, bkz*, slide, lll_ex / ladder, sessions) return FPHIP_UNSUPPORTED; fphip_gso_set_basis keeps u.
- * u_inv_t (enable_inverse_transform) is not offered. */
+ * 289-366): afterwards u_out = T u_in with b_out = T b_in.  Sessions (below) keep u too: a dirty row is then its n
+ * integers of b followed by its d integers of u, fphip_gso_session_read_transform returns u in position order.
+ * While u is tracked the entry points that do not update it (size_reduce, bkz*, slide, lll_ex / ladder) return
+ * FPHIP_UNSUPPORTED; fphip_gso_set_basis keeps u.  u_inv_t (enable_inverse_transform) is not offered. */
 int fphip_gso_enable_transform(fphip_gso *g, const int64_t *u);
 int fphip_gso_get_transform(fphip_gso *g, int first, int count, int64_t *u);
 /* The same lll() on a RESIDENT MatGSO: fplll's MatGSO is an object whose rows, Gram cache, mu / r and
@@ -215,7 +216,8 @@ int fphip_gso_get_transform(fphip_gso *g, int first, int count, int64_t *u);
  * gso_interface.cpp:26-53), and a BKZ run calls lll() thousands of times after touching a few rows.  resume = 0
  * starts a session from the basis on the device (fphip_gso_set_basis) as a fresh MatGSO; resume = 1 continues it:
  * first the caller's row operations since the last call — n_dirty rows (batch of one), dirty_pos[t] the row
- * position, dirty_rows[t][n] its new integers, each a row_op_end(p, p + 1) — then lll() on the state the last call
+ * position, dirty_rows[t][n] its new integers (followed by the d integers of its row of u when u is tracked:
+ * [t][n + d]), each a row_op_end(p, p + 1) — then lll() on the state the last call
  * left (the verified prefix of rows that are a fixed point of the loop included, as fplll's own object would have
  * them valid).  While a session is active the rows live in the kernel's slots: the other fphip_gso_* entry points
  * refuse to run, fphip_gso_set_basis ends the session, a status other than 1 ends it too (the next call must be a
@@ -230,6 +232,8 @@ int fphip_gso_session_lll(fphip_gso *g, int resume, int kappa_min, int kappa_sta
  * meaningful; r(i,i) when valid_cols[i] == i + 1), row_expo[d].  Every pointer is nullable. */
 int fphip_gso_session_read(fphip_gso *g, int lattice, int64_t *b, double *mu, double *r, int *valid_cols,
                            int64_t *row_expo);
+/* ... and u [d][d] in position order (fphip_gso_enable_transform before the session started). */
+int fphip_gso_session_read_transform(fphip_gso *g, int lattice, int64_t *u);
 /* BKZReduction<Z_NR<long>,FP_NR<double>>(m, lll_obj, BKZParam(block_size, {}, delta, flags,
  * max_loops)).bkz() (bkz.cpp:522-668: tour / trunc_tour / hkz :360-441, svp_reduction :274-358,
  * svp_preprocessing's lll :107-113, svp_postprocessing :126-272, the block enumeration with

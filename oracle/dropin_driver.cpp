@@ -13,7 +13,8 @@
  *                                                 FPLLL_HIP_BABAI=1 every babai() of it runs on the device)
  *   dropin_driver hlll <basisfile> hip|cpu        HLLLReduction::hlll() on MatHouseholder(Hip), the way
  *                                                 hlll_reduction_zf does it (wrapper.cpp:790-806)
- * prints one JSON line: status, seconds, device calls / seconds, the output basis.
+ * prints one JSON line: status, seconds, device calls / seconds, the output basis (DROPIN_U=1: the objects are
+ * built with u = identity and the line carries u_out as well).
  */
 #include <fplll/fplll.h>
 
@@ -120,6 +121,8 @@ int main(int argc, char **argv)
     printf("]}\n");
     return 0;
   }
+  if (getenv("DROPIN_U"))  // bkz_reduction(b, u, ...): MatGSO(b, u = identity, ...) keeps the transformation matrix
+    ul.gen_identity(bl.get_rows());
   std::unique_ptr<MatGSO<ZT, FT>> gso;
   fplll_hip::MatGSOHip *hip = nullptr;
   if (w == "hip")
@@ -179,6 +182,15 @@ int main(int argc, char **argv)
   for (int i = 0; i < bl.get_rows(); ++i)
     for (int j = 0; j < bl.get_cols(); ++j)
       printf("%s%ld", (i || j) ? "," : "", bl(i, j).get_si());
-  printf("]}\n");
+  printf("]");
+  if (ul.get_rows() > 0)
+  {
+    printf(",\"u_out\":[");
+    for (int i = 0; i < ul.get_rows(); ++i)
+      for (int j = 0; j < ul.get_cols(); ++j)
+        printf("%s%ld", (i || j) ? "," : "", ul(i, j).get_si());
+    printf("]");
+  }
+  printf("}\n");
   return 0;
 }

@@ -89,6 +89,28 @@ def test_config2_stateless_calls_give_the_same_run():
     assert a["session_starts"] == 0 and b["session_starts"] >= 1 and a["device_calls"] == b["device_calls"] > 10
 
 
+def test_bkz_reduction_with_a_transformation_matrix_on_the_device():
+    """bkz_reduction(b, u, ...): MatGSOHip(b, u = identity, ...) keeps u on the device as well (the LLL kernel applies
+    its row operations to u's rows; the host's insertions go up as dirty rows of b and u).  The reference's unmodified
+    bkz() on it, resident and stateless: the golden basis and node count, the host object's u, and u b_in = b_out in
+    exact integers."""
+    f = C.load_bkz_fixture(os.path.join(C.GOLDEN, "bkz_q60_b16.json"))
+    path = _write_basis(f["b_in"])
+    try:
+        a = _run_env(["bkz", path, "16", "hip"], {"DROPIN_U": "1"})
+        s = _run_env(["bkz", path, "16", "hip"], {"DROPIN_U": "1", "FPLLL_HIP_RESIDENT": "0"})
+        c = _run_env(["bkz", path, "16", "cpu"], {"DROPIN_U": "1"})
+    finally:
+        os.unlink(path)
+    d = f["d"]
+    assert a["status"] == s["status"] == c["status"] == 0 and a["nodes"] == s["nodes"] == c["nodes"] == f["nodes"]
+    assert np.array_equal(a["b_out"], f["b_out"]) and np.array_equal(s["b_out"], f["b_out"])
+    ua, us, uc = (np.array(x["u_out"], dtype=np.int64).reshape(d, d) for x in (a, s, c))
+    assert np.array_equal(ua, uc) and np.array_equal(us, uc)
+    assert np.array_equal(ua.astype(object).dot(f["b_in"].astype(object)), f["b_out"].astype(object))
+    assert a["session_starts"] == 1 and a["device_calls"] == s["device_calls"] > 10
+
+
 def _run_env(args, env):
     assert os.path.exists(DRV), "oracle/_ref/dropin_driver is not built (python __graft_entry__.py)"
     r = subprocess.run([DRV] + args, capture_output=True, text=True, timeout=1100, env=dict(os.environ, **env))

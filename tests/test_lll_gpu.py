@@ -301,6 +301,51 @@ def test_transformation_matrix_follows_the_row_operations(ctx, name):
     g.close()
 
 
+def test_transformation_matrix_in_a_session(ctx):
+    """u through a resident session: the caller's row operations between two calls go up as dirty rows of b AND u
+    (n + d integers), the session's calls keep both in step.  After every call u b_in = b in exact integers and b
+    equals the stateless twin's; set_basis ends the session and leaves u in position order on the device."""
+    from fplll_amd.gso import MatGSOBatch
+    rng = np.random.default_rng(31)
+    d = 70
+    b0 = _qary(rng, d, d // 2, 3001)
+    g = MatGSOBatch(ctx, 1, d, d)
+    ref = MatGSOBatch(ctx, 1, d, d)
+    g.set_basis(b0[None])
+    g.enable_transform()
+    st, info = g.session_lll(False)
+    cur_u = None
+    for step in range(4):
+        b = g.session_read(0)[0]
+        u = g.session_read_transform(0)
+        assert int(st[0]) == 1
+        assert np.array_equal(u.astype(object).dot(b0.astype(object)), b.astype(object)), step
+        if step > 0:
+            ref.set_basis(cur[None])
+            rst, _ = ref.lll(0, kstart, kend)
+            assert int(rst[0]) == 1 and np.array_equal(ref.get_basis(0, 1)[0], b), step
+        # the caller's row operations: on b and on u alike
+        cur, cur_u = b.copy(), u.copy()
+        kend = int(rng.integers(d // 2, d + 1)); kstart = int(rng.integers(0, kend - 2))
+        dirty = {}
+        i, j = (int(x) for x in rng.choice(np.arange(kstart, kend), size=2, replace=False))
+        cur[i] += 13 * cur[j]; cur_u[i] += 13 * cur_u[j]
+        dirty[i] = np.concatenate([cur[i], cur_u[i]])
+        lo = int(rng.integers(kstart, kend - 1)); hi = int(rng.integers(lo + 1, kend))
+        cur[lo:hi + 1] = np.roll(cur[lo:hi + 1], 1, axis=0); cur_u[lo:hi + 1] = np.roll(cur_u[lo:hi + 1], 1, axis=0)
+        for t in range(lo, hi + 1):
+            dirty[t] = np.concatenate([cur[t], cur_u[t]])
+        if i not in dirty:
+            dirty[i] = np.concatenate([cur[i], cur_u[i]])
+        st, info = g.session_lll(True, 0, kstart, kend, dirty=dirty)
+    b = g.session_read(0)[0]
+    u = g.session_read_transform(0)
+    g.set_basis(b[None])  # ends the session: u comes back in position order
+    assert np.array_equal(g.get_transform(0, 1)[0], u)
+    assert np.array_equal(u.astype(object).dot(b0.astype(object)), b.astype(object))
+    g.close(); ref.close()
+
+
 def test_early_reduction_in_a_session(ctx):
     """A session is one LLLReduction object: last_early_red (lll.h:70) starts at 0 and is kept.  The first call
     equals the reference's fixture; a second call on the reduced basis finds every power of two already done
