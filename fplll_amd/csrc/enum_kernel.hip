@@ -166,6 +166,16 @@ __device__ __forceinline__ unsigned add_bit(unsigned long long m, unsigned c)
   asm("v_addc_co_u32_e64 %0, %1, 0, %0, %2" : "+v"(c), "=s"(co) : "s"(m));
   return c;
 }
+// The lane number behind an opaque asm statement: an address built from it stays where it is used.  (Per-lane
+// 64-bit addresses of the per-TASK and per-EVENT accesses — in.x + lane, out.col + lane, the ring record — are
+// loop invariants the optimiser hoists to the top of the kernel, where they stay alive across the walk loops and are
+// spilled: five register pairs = 40 bytes of scratch per lane at the kernel's 64-VGPR pin.)
+__device__ __forceinline__ int here_lane(int lane)
+{
+  asm volatile("" : "+v"(lane));
+  return lane;
+}
+
 __device__ __forceinline__ int tri_off(int k) { return (k * (k - 1)) >> 1; }  // slot k starts here
 __device__ __forceinline__ unsigned tri8(int k)
 {  // 8 * tri_off(k) on the scalar unit, opaque to the optimiser (which otherwise folds the sign of a
@@ -403,8 +413,9 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK) __attribute__((amdgpu_waves_p
              : (idxlist ? (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)idxlist[pos]) : pos);
     const int Lt      = __builtin_amdgcn_readfirstlane(in.level[ti]);  // root level of this task
     const int rid     = __builtin_amdgcn_readfirstlane(in.root[ti]);   // level-64 ancestor (d > 64)
-    const double xpre = in.x[ti * 64 + lane];                          // coefficients of levels >= Lt
-    const double col0 = in.col[ti * 64 + lane];  // S_Lt rows (lane < Lt)
+    const int tl      = here_lane(lane);
+    const double xpre = in.x[ti * 64 + tl];                            // coefficients of levels >= Lt
+    const double col0 = in.col[ti * 64 + tl];  // S_Lt rows (lane < Lt)
     const double pd0  = in.pd[ti];
     int donate        = 1 << 20;
     const unsigned iter0 = iter + (unsigned)(63 - left);  // (iterations of this task = iter + (63 - left) - iter0)
@@ -435,20 +446,22 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK) __attribute__((amdgpu_waves_p
       }
       SolRec *r  = &h->ring[idx % FPHIP_RING_CAP];
       double xf  = (lane < Lt) ? xs : xpre;
-      r->x[lane] = (lane < d) ? xf : 0.0;
+      const int rl = here_lane(lane);
+      r->x[rl]   = (lane < d) ? xf : 0.0;
       // levels >= 64: the coefficients chosen by the top walk, stored once per level-64 ancestor (row stride
       // of xhi_root: 64 per started chunk of levels above 64)
       {
         const int xstr = d > 64 ? 64 * ((d - 1) >> 6) : 64;
 #pragma unroll
         for (int q = 1; q < 4; ++q)
-          r->x[64 * q + lane] = (64 * q + lane < d) ? xhi_root[(size_t)rid * xstr + 64 * (q - 1) + lane] : 0.0;
+          r->x[64 * q + rl] = (64 * q + lane < d) ? xhi_root[(size_t)rid * xstr + 64 * (q - 1) + rl] : 0.0;
       }
       if (lane == 0)
       {
-        r->dist   = dist;
-        r->kind   = 0;
-        r->offset = 0;
+        const int z = here_lane(0);  // (a zero made here: as a hoisted constant pair it was spilled as well)
+        r->dist     = dist;
+        r->kind     = z;
+        r->offset   = z;
       }
       __threadfence_system();
       if (lane == 0)
@@ -495,12 +508,13 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK) __attribute__((amdgpu_waves_p
       }
       SolRec *r       = &h->ring[idx % FPHIP_RING_CAP];
       const double xf = (lane < Lt) ? xs : xpre;
-      r->x[lane] = (lane < d && lane >= lvl) ? xf : 0.0;
+      const int rl    = here_lane(lane);
+      r->x[rl] = (lane < d && lane >= lvl) ? xf : 0.0;
       {
         const int xstr = d > 64 ? 64 * ((d - 1) >> 6) : 64;
 #pragma unroll
         for (int q = 1; q < 4; ++q)
-          r->x[64 * q + lane] = (64 * q + lane < d) ? xhi_root[(size_t)rid * xstr + 64 * (q - 1) + lane] : 0.0;
+          r->x[64 * q + rl] = (64 * q + lane < d) ? xhi_root[(size_t)rid * xstr + 64 * (q - 1) + rl] : 0.0;
       }
       if (lane == 0)
       {
@@ -792,9 +806,10 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK) __attribute__((amdgpu_waves_p
         oi = (unsigned)__builtin_amdgcn_readfirstlane((int)oi);
         if (oi < out.cap)
         {
-          out.col[(unsigned long long)oi * 64 + lane] = S;
-          const double xf                             = (lane < Lt) ? xs : xpre;
-          out.x[(unsigned long long)oi * 64 + lane]   = xf;
+          const int el                              = here_lane(lane);
+          out.col[(unsigned long long)oi * 64 + el] = S;
+          const double xf                           = (lane < Lt) ? xs : xpre;
+          out.x[(unsigned long long)oi * 64 + el]   = xf;
           if (lane == 0)
           {
             out.pd[oi]    = nd;

@@ -132,3 +132,21 @@ def test_hot_loops_are_free_of_exec_masking_and_copy_storms(artefacts):
         assert all(f[q] <= lim[q] for q in lim), (key, f)
     m = re.search(re.escape(WALK) + r"[^\n]*\n(?:.*\n)*?\s*\.vgpr_count:\s+(\d+)", asm[asm.index(".amdgpu_metadata"):])
     assert m and int(m.group(1)) <= 64, m and m.group(1)
+
+
+def test_walk_kernels_use_no_scratch_memory(artefacts):
+    """Every instantiation of enum_phase_kernel keeps its 64-VGPR pin WITHOUT scratch memory (round 5; 44-56 bytes per
+    lane before): the per-task and per-event addresses (task columns, emitted tasks, ring records) are built from an
+    opaque lane number where they are used (here_lane), so that they are not hoisted to the top of the kernel and
+    kept — spilled — across the walk loops."""
+    _, asm = artefacts
+    meta = asm[asm.index(".amdgpu_metadata"):]
+    seen = 0
+    for m in re.finditer(r"\.name:\s+(_ZN5fphip17enum_phase_kernel\S+)", meta):
+        blk = meta[max(0, meta.rfind("- .agpr_count", 0, m.start())):meta.find("- .agpr_count", m.end())]
+        seg = re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk)
+        assert seg, m.group(1)
+        assert int(seg.group(1)) == 0, (m.group(1), seg.group(1))
+        seen += 1
+    assert seen == 6
+    assert "scratch_" not in _kernel_body(asm, WALK)
