@@ -38,8 +38,9 @@ __global__ void enum_top_kernel(DevShared *g, HostCtl *h, TopBuf in, unsigned n_
                                 int count_nodes, int launch_idx, double *gtop);
 __global__ void task_key_kernel(TaskBuf in, unsigned n, int d, unsigned long long *keys,
                                 const double *xhi_root, const unsigned *slots);
-__global__ void task_pack_kernel(TaskBuf in, unsigned lo, unsigned n, double *rec);
-__global__ void task_unpack_kernel(TaskBuf out, unsigned lo, unsigned n, const double *rec);
+__global__ void task_pack_kernel(TaskBuf in, unsigned lo, unsigned n, double *rec, const double *xhi_root, int xstr);
+__global__ void task_unpack_kernel(TaskBuf out, unsigned lo, unsigned n, const double *rec, double *xhi_root, int xstr,
+                                   unsigned root_base);
 template <bool DUAL>
 __global__ void enum_bfs_kernel(DevShared *g, double maxdist, QueueMem *qm, TaskBuf f0, TaskBuf f1,
                                 TaskBuf fin, int L0, int nlev, int floor_level, float heavy, int count_nodes,
@@ -523,17 +524,28 @@ static int choose_stop(const double *logN, int L, double C, double target_final,
 // slices of it in rank order.  Every rank computes the same plan from the same counts: no task is lost or walked
 // twice, whatever the order of the lists.  *cnt is this rank's number of tasks in `buf` before and after.
 // moved_out (nullable): tasks that left or reached this rank.
-static int rebalance_tasks(fphip_ctx *ctx, const fphip_enum_opts &o, TaskBuf buf, unsigned *cnt, unsigned *moved_out)
+// d > 64: a task points into its rank's table of level-64 ancestors (xhi_root: the coefficients of levels >= 64,
+// xstr doubles per row; the top walk that fills it is replicated, but in an order of its own on every rank), so the
+// record carries that row and the receiver appends it to its table: *xhi_used rows are taken, cap is the table's size.
+static int rebalance_tasks(fphip_ctx *ctx, const fphip_enum_opts &o, TaskBuf buf, unsigned *cnt, unsigned *moved_out,
+                           int d, unsigned *xhi_used)
 {
   const int W = o.shard_count, me = o.shard_index;
-  std::vector<unsigned long long> counts((size_t)W, 0);
+  const int xstr = d > 64 ? 64 * ((d - 1) >> 6) : 0;
+  std::vector<unsigned long long> both((size_t)W * 2, 0), counts((size_t)W, 0), room((size_t)W, 0);
   std::vector<size_t> sizes((size_t)W, 0);
-  unsigned long long mine = *cnt;
-  if (o.gather(o.gather_user, &mine, sizeof mine, counts.data(), sizeof(unsigned long long) * (size_t)W, sizes.data()) != 0)
+  unsigned long long mine[2] = {*cnt, xstr > 0 ? (unsigned long long)(ctx->cap - std::min(ctx->cap, *xhi_used)) : ~0ull};
+  if (o.gather(o.gather_user, mine, sizeof mine, both.data(), sizeof(unsigned long long) * 2 * (size_t)W, sizes.data()) != 0)
     return fail(ctx, "work movement: the gather callback failed (counts)");
   unsigned long long total = 0;
   for (int r = 0; r < W; ++r)
+  {
+    if (sizes[r] != sizeof mine)
+      return fail(ctx, "work movement: rank %d sent %zu bytes of counts, %zu expected", r, sizes[r], sizeof mine);
+    counts[r] = both[2 * r];
+    room[r]   = both[2 * r + 1];
     total += counts[r];
+  }
   std::vector<unsigned long long> surplus((size_t)W, 0), deficit((size_t)W, 0);
   unsigned long long moved = 0;
   for (int r = 0; r < W; ++r)
@@ -551,23 +563,27 @@ static int rebalance_tasks(fphip_ctx *ctx, const fphip_enum_opts &o, TaskBuf buf
   // decision on every rank: it only depends on the counts)
   if (moved == 0 || moved * 16 < total || total / W + 1 > ctx->cap)
     return FPHIP_OK;
-  const size_t recb = (size_t)FPHIP_TASK_REC * sizeof(double);
-  if (ctx->wire_doubles < (size_t)moved * FPHIP_TASK_REC)
+  for (int r = 0; r < W; ++r)  // (a receiver without room for the ancestors' rows: nobody moves this round)
+    if (deficit[r] > room[r])
+      return FPHIP_OK;
+  const size_t recd = (size_t)FPHIP_TASK_REC + (size_t)xstr;
+  const size_t recb = recd * sizeof(double);
+  if (ctx->wire_doubles < (size_t)moved * recd)
   {
     if (ctx->wire)
       fphip_dev_free(ctx->wire, ctx->stream);
     ctx->wire         = nullptr;
     ctx->wire_doubles = 0;
     HIPCHK(ctx, fphip_dev_alloc((void **)&ctx->wire, (size_t)moved * recb, ctx->stream));
-    ctx->wire_doubles = (size_t)moved * FPHIP_TASK_REC;
+    ctx->wire_doubles = (size_t)moved * recd;
   }
-  std::vector<double> send((size_t)surplus[me] * FPHIP_TASK_REC), pool((size_t)moved * FPHIP_TASK_REC);
+  std::vector<double> send((size_t)surplus[me] * recd), pool((size_t)moved * recd);
   if (surplus[me] > 0)
   {
     const unsigned n  = (unsigned)surplus[me];
     const unsigned lo = *cnt - n;  // the tail of the list leaves
     hipLaunchKernelGGL(task_pack_kernel, dim3(std::min<unsigned>((n + 3) / 4, (unsigned)ctx->num_cus * 8u)), dim3(256), 0,
-                       ctx->stream, buf, lo, n, ctx->wire);
+                       ctx->stream, buf, lo, n, ctx->wire, ctx->xhi_root, xstr);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipMemcpyAsync(send.data(), ctx->wire, (size_t)n * recb, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -584,13 +600,15 @@ static int rebalance_tasks(fphip_ctx *ctx, const fphip_enum_opts &o, TaskBuf buf
     for (int r = 0; r < me; ++r)
       off += deficit[r];
     const unsigned n = (unsigned)deficit[me];
-    HIPCHK(ctx, hipMemcpyAsync(ctx->wire, pool.data() + (size_t)off * FPHIP_TASK_REC, (size_t)n * recb,
+    HIPCHK(ctx, hipMemcpyAsync(ctx->wire, pool.data() + (size_t)off * recd, (size_t)n * recb,
                                hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(task_unpack_kernel, dim3(std::min<unsigned>((n + 3) / 4, (unsigned)ctx->num_cus * 8u)), dim3(256), 0,
-                       ctx->stream, buf, *cnt, n, ctx->wire);
+                       ctx->stream, buf, *cnt, n, ctx->wire, ctx->xhi_root, xstr, *xhi_used);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     *cnt += n;
+    if (xstr > 0)
+      *xhi_used += n;
   }
   if (moved_out)
     *moved_out = (unsigned)(surplus[me] + deficit[me]);
@@ -891,6 +909,7 @@ restart:
   if (debug)
     fprintf(stderr, "[fphip] d=%d est_nodes=%.3e budget=%u\n", d, est_nodes, budget);
   unsigned long long moved_tasks = 0;  // work movement between ranks: tasks that left or reached this rank
+  unsigned xhi_used = d > 64 ? top_tasks : 0;  // rows of xhi_root taken (level-64 ancestors; received tasks append theirs)
   bool in_final       = false;  // false: level-cut splitting phases; true: budgeted walk rounds
   int round           = 0;
   unsigned prevC      = 0;
@@ -1220,12 +1239,12 @@ restart:
       if (glob < local)
         publish_bound_min(ctx, glob);
       others_active = any != 0;
-      // work movement: while anybody still has tasks, the ranks level their lists (blocks up to 64 rows: a task
-      // of a larger block points into this rank's own table of level-64 ancestors)
-      if (o.gather && o.shard_count > 1 && d <= 64 && any != 0)
+      // work movement: while anybody still has tasks, the ranks level their lists (a task of a block above 64 rows
+      // travels with the row of its level-64 ancestor)
+      if (o.gather && o.shard_count > 1 && any != 0)
       {
         unsigned mv = 0;
-        const int rcm = rebalance_tasks(ctx, o, ctx->buf[nxt], &cnt, &mv);
+        const int rcm = rebalance_tasks(ctx, o, ctx->buf[nxt], &cnt, &mv, d, &xhi_used);
         if (rcm != FPHIP_OK)
           return rcm;
         moved_tasks += mv;

@@ -1364,17 +1364,21 @@ FPHIP_TOP_INST(4, true, false)
 FPHIP_TOP_INST(4, false, true)
 #undef FPHIP_TOP_INST
 
-// Work movement between ranks (blocks up to 64 rows): tasks [lo, lo + n) of a buffer as contiguous records of
-// FPHIP_TASK_REC doubles — partial distance, root level, column, coefficient prefix — and back.  One wave per task.
-__global__ void __launch_bounds__(256) task_pack_kernel(TaskBuf in, unsigned lo, unsigned n, double *__restrict__ rec)
+// Work movement between ranks: tasks [lo, lo + n) of a buffer as contiguous records of FPHIP_TASK_REC (+ xstr)
+// doubles — partial distance, root level, column, coefficient prefix and, for a block above 64 rows, the xstr
+// coefficients of levels >= 64 of the task's level-64 ancestor (a row of the SENDER's xhi_root table: the receiver
+// appends it to its own and points the task there) — and back.  One wave per task.
+__global__ void __launch_bounds__(256) task_pack_kernel(TaskBuf in, unsigned lo, unsigned n, double *__restrict__ rec,
+                                                        const double *__restrict__ xhi_root, int xstr)
 {
+  const unsigned recd = FPHIP_TASK_REC + (unsigned)xstr;
   const int lane   = threadIdx.x & 63;
   const unsigned w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const unsigned nw = (gridDim.x * blockDim.x) >> 6;
   for (unsigned t = w; t < n; t += nw)
   {
     const unsigned long long ti = lo + t;
-    double *r                   = rec + (unsigned long long)t * FPHIP_TASK_REC;
+    double *r                   = rec + (unsigned long long)t * recd;
     if (lane == 0)
     {
       r[0] = in.pd[ti];
@@ -1382,25 +1386,39 @@ __global__ void __launch_bounds__(256) task_pack_kernel(TaskBuf in, unsigned lo,
     }
     r[2 + lane]  = in.col[ti * 64 + lane];
     r[66 + lane] = in.x[ti * 64 + lane];
+    if (xstr > 0)
+    {
+      const size_t row = (size_t)in.root[ti] * (size_t)xstr;
+      for (int c = lane; c < xstr; c += 64)
+        r[FPHIP_TASK_REC + c] = xhi_root[row + c];
+    }
   }
 }
-__global__ void __launch_bounds__(256) task_unpack_kernel(TaskBuf out, unsigned lo, unsigned n, const double *__restrict__ rec)
+__global__ void __launch_bounds__(256) task_unpack_kernel(TaskBuf out, unsigned lo, unsigned n, const double *__restrict__ rec,
+                                                          double *__restrict__ xhi_root, int xstr, unsigned root_base)
 {
+  const unsigned recd = FPHIP_TASK_REC + (unsigned)xstr;
   const int lane   = threadIdx.x & 63;
   const unsigned w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const unsigned nw = (gridDim.x * blockDim.x) >> 6;
   for (unsigned t = w; t < n; t += nw)
   {
     const unsigned long long ti = lo + t;
-    const double *r             = rec + (unsigned long long)t * FPHIP_TASK_REC;
+    const double *r             = rec + (unsigned long long)t * recd;
     if (lane == 0)
     {
       out.pd[ti]    = r[0];
       out.level[ti] = (int)r[1];
-      out.root[ti]  = 0;
+      out.root[ti]  = xstr > 0 ? (int)(root_base + t) : 0;
     }
     out.col[ti * 64 + lane] = r[2 + lane];
     out.x[ti * 64 + lane]   = r[66 + lane];
+    if (xstr > 0)
+    {
+      const size_t row = (size_t)(root_base + t) * (size_t)xstr;
+      for (int c = lane; c < xstr; c += 64)
+        xhi_root[row + c] = r[FPHIP_TASK_REC + c];
+    }
   }
 }
 

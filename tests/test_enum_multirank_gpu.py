@@ -217,7 +217,8 @@ def _worker_move(rank, world, port, fixture, move, fixed, q):
                           shard_index=rank, shard_count=world, exchange=make_exchange(dist, "cpu"), exchange_chunks=2,
                           gather=make_gather(dist, "cpu") if move else None)
     best = min([s[0] for s in ev.solutions] or [float("inf")])
-    q.put((rank, [int(v) for v in res.nodes], int(res.stats.moved_tasks), float(res.stats.kernel_ms), best))
+    sols = sorted((float(s[0]), tuple(float(v) for v in s[1])) for s in ev.solutions) if fixed else []
+    q.put((rank, [int(v) for v in res.nodes], int(res.stats.moved_tasks), float(res.stats.kernel_ms), best, sols))
     dist.barrier()
     ctx.close()
     dist.destroy_process_group()
@@ -257,6 +258,29 @@ def test_donated_subtrees_move_between_ranks(world):
     f2, out2 = _run_move("enum_d48_lin30_fixed", world, False, True)
     tot2 = np.sum([np.array(o[1]) for o in out2], axis=0)
     assert [int(v) for v in tot2] == [int(v) for v in f["nodes"]] and all(o[2] == 0 for o in out2)
+
+
+@pytest.mark.parametrize("name", ["enum_d96_lin90_fixed", "enum_d80_lin70_fixed"])
+def test_donated_subtrees_of_a_block_above_64_rows_move_with_their_ancestors(name, monkeypatch):
+    """A task of a block above 64 rows points into its rank's table of level-64 ancestors (the coefficients of the
+    levels >= 64), filled by a top walk that runs in an order of its own on every rank: the record of a moving task
+    carries that row and the receiver appends it to its table.  A small donation budget makes the tasks shed work
+    early, so that lists exist to be levelled; at a radius that never shrinks the per-level counts of the ranks add
+    up to the reference's and the candidates (whose coefficients above level 64 come out of the moved rows) keep the
+    reference's norms."""
+    monkeypatch.setenv("FPHIP_BUDGET", "1024")
+    f, out = _run_move(name, 2, True, True)
+    tot = np.sum([np.array(o[1]) for o in out], axis=0)
+    assert [int(v) for v in tot] == [int(v) for v in f["nodes"]]
+    ref_best = min([s[0] for s in f["sol_log"]] or [float("inf")])
+    assert min(o[4] for o in out) == ref_best
+    # every candidate of the reference, coefficients included, exactly once over the ranks
+    got = sorted(x for o in out for x in o[5])
+    want = sorted((float(s[0]), tuple(float(v) for v in s[1])) for s in f["sol_log"])
+    assert got == want
+    C.note(lambda: ("work movement, block of %d rows, 2 ranks: node shares %s, tasks moved per rank %s"
+                    % (f["d"], ["%.3f" % (sum(o[1]) / f["total_nodes"]) for o in out], [o[2] for o in out]),))
+    assert sum(o[2] for o in out) > 0, "no task moved: the case does not exercise the records of wide blocks"
 
 
 def test_work_movement_with_a_shrinking_radius_and_on_a_pruner_regime_block():
