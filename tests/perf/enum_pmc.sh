@@ -3,7 +3,7 @@
 mkdir -p gpurun_out/exp/pmc1 gpurun_out/exp/pmc2
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-B="python $R/bench.py --no-cpu --no-gso --no-tour --no-pmc --steps 1 --warmup 0"
+B="python $R/bench.py --no-cpu --no-gso --no-tour --no-pmc --no-batch --steps 1 --warmup 0"
 (cd $R && rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVES SQ_WAVE_CYCLES -f csv -d gpurun_out/exp/pmc1 -- $B > gpurun_out/exp/pmc1.log 2>&1)
 (cd $R && rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM SQ_INST_CYCLES_SALU SQ_INSTS_SMEM SQ_INSTS_BRANCH -f csv -d gpurun_out/exp/pmc2 -- $B > gpurun_out/exp/pmc2.log 2>&1)
 cd $R
