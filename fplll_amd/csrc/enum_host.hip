@@ -561,7 +561,9 @@ static int rebalance_tasks(fphip_ctx *ctx, const fphip_enum_opts &o, TaskBuf buf
     *moved_out = 0;
   // not worth a transfer: (nearly) balanced already, or a target beyond this context's buffers (the same
   // decision on every rank: it only depends on the counts)
-  if (moved == 0 || moved * 16 < total || total / W + 1 > ctx->cap)
+  // (FPHIP_MOVE_FRACTION: move when at least total / that many tasks would; 16 by default — tests lower the bar)
+  const unsigned long long frac = (unsigned long long)std::max(1, env_int("FPHIP_MOVE_FRACTION", 16));
+  if (moved == 0 || moved * frac < total || total / W + 1 > ctx->cap)
     return FPHIP_OK;
   for (int r = 0; r < W; ++r)  // (a receiver without room for the ancestors' rows: nobody moves this round)
     if (deficit[r] > room[r])

@@ -264,11 +264,14 @@ def test_donated_subtrees_move_between_ranks(world):
 def test_donated_subtrees_of_a_block_above_64_rows_move_with_their_ancestors(name, monkeypatch):
     """A task of a block above 64 rows points into its rank's table of level-64 ancestors (the coefficients of the
     levels >= 64), filled by a top walk that runs in an order of its own on every rank: the record of a moving task
-    carries that row and the receiver appends it to its table.  A small donation budget makes the tasks shed work
-    early, so that lists exist to be levelled; at a radius that never shrinks the per-level counts of the ranks add
-    up to the reference's and the candidates (whose coefficients above level 64 come out of the moved rows) keep the
-    reference's norms."""
-    monkeypatch.setenv("FPHIP_BUDGET", "1024")
+    carries that row and the receiver appends it to its table.  Few, large first tasks and the smallest donation
+    budget make the tasks shed work in every round, and the bar for a transfer is lowered to a single surplus task, so
+    that lists exist to be levelled whatever the timing; at a radius that never shrinks the per-level counts of the
+    ranks add up to the reference's and the candidates (whose coefficients above level 64 come out of the moved rows)
+    are the reference's."""
+    monkeypatch.setenv("FPHIP_BUDGET", "256")
+    monkeypatch.setenv("FPHIP_BFS_TASKS", "96")
+    monkeypatch.setenv("FPHIP_MOVE_FRACTION", "1000000000")
     f, out = _run_move(name, 2, True, True)
     tot = np.sum([np.array(o[1]) for o in out], axis=0)
     assert [int(v) for v in tot] == [int(v) for v in f["nodes"]]
