@@ -1382,7 +1382,7 @@ template __global__ void bkzd_kernel<4>(GsoBatch, BkzStrat, BkzMail *, int *, in
 // primal BKZ with strategies (fphip_gso_bkz_strategies without FPHIP_BKZ_SD_VARIANT): the same
 // schedule without the dual blocks
 template <int NQ>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NQ <= 1 ? 2 : 1, 8)))
     bkzs_kernel(GsoBatch P, BkzStrat S, BkzMail *mailbox, int *abort_flag, int block_size, int top_flags,
                 double delta, double eta, double logdelta, int max_loops, int stack_doubles)
 {

@@ -2071,9 +2071,9 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
 
   const int need = (g->P.d > g->P.n ? g->P.d : g->P.n);
   const int nq   = (need + 63) / 64;
-  const int wpb  = g->waves_per_block;
+  int wpb        = g->waves_per_block;
   const int bs   = block_size < 2 ? 2 : bsz;
-  const size_t ring_bytes = (size_t)wpb * fphip_reduce_ring_bytes(nq);
+  size_t ring_bytes = (size_t)wpb * fphip_reduce_ring_bytes(nq);
   // The scaled mu rows of the block under enumeration go to LDS (behind the column stack) when few
   // lattices share a CU — every row's L1 latency is exposed to a lone wave — and when they fit;
   // large batches keep them in global memory and spend the LDS on resident waves.
@@ -2088,6 +2088,20 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
     {
       stack_doubles = with_mu;
       mu_lds_flag   = 0x40000000;
+    }
+  }
+  // A big batch of lattices of at most 64 columns (primal schedule): bkzs_kernel<1> is built for two waves per SIMD
+  // (256 registers), and what then bounds the resident waves is the LDS per workgroup — ring + column stack, 22.6 KB
+  // per wave for blocks of 40: one workgroup of four waves per CU, but three of two.  Measured (call r5z3, BKZ-40 on
+  // 64-dim lattices): 327 reductions/s with four waves per workgroup, 397-399 with two (1536 / 3072 lattices); one
+  // wave per workgroup: 259.
+  if (nq == 1 && !sd && !sld && !mu_lds_flag && !getenv("FPHIP_GSO_WAVES_PER_BLOCK") && wpb == 4)
+  {
+    const size_t per_wave = fphip_reduce_ring_bytes(nq) + (size_t)stack_doubles * sizeof(double) + FPHIP_BKZS_MAX_DEPTH * 64;
+    if ((160 * 1024) / (4 * per_wave) * 4 < (160 * 1024) / (2 * per_wave) * 2)
+    {
+      wpb        = 2;
+      ring_bytes = (size_t)wpb * fphip_reduce_ring_bytes(nq);
     }
   }
   const size_t lds = ring_bytes + (size_t)wpb * stack_doubles * sizeof(double) +

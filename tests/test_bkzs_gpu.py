@@ -50,6 +50,34 @@ def test_bkz_strategies_matches_reference(ctx, path):
     g.close()
 
 
+def test_big_batch_geometry_two_waves_per_workgroup(ctx, monkeypatch):
+    """What a batch above 4 lattices per CU runs on (bench leg bkz40_strategies_batch): mu rows of the block in global
+    memory and, for lattices of at most 64 columns, workgroups of two waves — three of them fit a CU's LDS where one
+    workgroup of four does, and bkzs_kernel<1> is built for two waves per SIMD.  Forced here on a small batch: the
+    reference's basis, status and node count."""
+    from fplll_amd.gso import MatGSOBatch
+    path = [p for p in FIXTURES if "bkzs_q56_b36_autoabort" in p]
+    if not path:
+        pytest.skip("fixture filtered out")
+    f = C.load_bkz_fixture(path[0])
+    monkeypatch.setenv("FPHIP_GSO_WAVES_PER_BLOCK", "2")
+    monkeypatch.setenv("FPHIP_BKZ_MU_LDS", "0")
+    batch = 5
+    g = MatGSOBatch(ctx, batch, f["d"], f["n"])
+    g.set_basis(np.stack([f["b_in"]] * batch))
+    rnd, draws = C.gmp_streams_native(batch, f["rng_seed"])
+    st, info = g.bkz_strategies(f["block_size"], f["strategies"], rnd, f["delta"], f["eta"],
+                                max_loops=f["max_loops"], gh_bnd=bool(f["flags"] & 0x80),
+                                bounded_lll=bool(f["flags"] & 0x10), gh_factor=f["gh_factor"],
+                                auto_abort=bool(f["flags"] & 0x20))
+    out = g.get_basis()
+    for L in range(batch):
+        assert st[L] == f["status"]
+        assert np.array_equal(out[L], f["b_out"])
+        assert ((int(info[L][1]) & 0xffffffff) | (int(info[L][2]) << 32)) == f["nodes"]
+    g.close()
+
+
 def _qary(rng, d, k, q):
     b = np.zeros((d, d), dtype=np.int64)
     b[:k, :k] = np.eye(k, dtype=np.int64)
