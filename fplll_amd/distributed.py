@@ -52,19 +52,23 @@ def make_gather(dist, device="cpu"):
     return gather
 
 
-def balance_plan(counts):
+def balance_plan(counts, room=None, fraction=16):
     """The plan rebalance_tasks (enum_host.hip) derives from the ranks' numbers of donated tasks — restated for
     the CPU tests: targets differ by at most one, ranks above theirs give the surplus (the tail of their list),
     ranks below take consecutive slices of the pooled surpluses in rank order.  Returns (moved, surplus[],
     deficit[], offset[]) with offset[r] = where rank r's slice of the pool starts; moved = 0 when the lists are
-    level enough (less than a sixteenth of the tasks would move)."""
+    level enough (less than a sixteenth of the tasks would move; `fraction` = FPHIP_MOVE_FRACTION) or when a
+    receiver has no room for what it would get (`room[r]`: free rows of rank r's table of level-64 ancestors —
+    blocks above 64 rows, whose tasks travel with their ancestor's row; the ranks gather it with the counts)."""
     W = len(counts)
     total = sum(counts)
     target = [total // W + (1 if r < total % W else 0) for r in range(W)]
     surplus = [max(0, c - t) for c, t in zip(counts, target)]
     deficit = [max(0, t - c) for c, t in zip(counts, target)]
     moved = sum(surplus)
-    if moved == 0 or moved * 16 < total:
+    if moved == 0 or moved * fraction < total:
+        return 0, [0] * W, [0] * W, [0] * W
+    if room is not None and any(dd > rr for dd, rr in zip(deficit, room)):
         return 0, [0] * W, [0] * W, [0] * W
     offset = [sum(deficit[:r]) for r in range(W)]
     return moved, surplus, deficit, offset

@@ -224,3 +224,8 @@ def test_work_movement_plan_and_gather(world):
     assert balance_plan([1000, 1000, 900, 1000])[0] == 0
     moved, surplus, deficit, offset = balance_plan([40, 0, 0, 0])
     assert moved == 30 and surplus == [30, 0, 0, 0] and deficit == [0, 10, 10, 10] and offset == [0, 0, 10, 20]
+    # blocks above 64 rows: a receiver without room for the ancestors' rows keeps everybody where they are
+    assert balance_plan([40, 0, 0, 0], room=[100, 100, 9, 100])[0] == 0
+    assert balance_plan([40, 0, 0, 0], room=[0, 10, 10, 10])[0] == 30
+    # FPHIP_MOVE_FRACTION lowers the bar: a single surplus task moves
+    assert balance_plan([1000, 1000, 900, 1000], fraction=10**9)[:2] == (75, [25, 25, 0, 25])
