@@ -63,6 +63,9 @@ LLLFIX_FLAGS=2 $D lllfix q  72 36 16 7  0  0 -1 2 1 > $G/lll_q72_earlyred_zeros.
 LLLFIX_U=1 $D lllfix q  40 20 20 1  0  0 -1 1 2 > $G/lll_q40_zero1_dup2_u.json
 LLLFIX_U=1 $D lllfix q  72 36 16 2  0  0 -1 0 0 > $G/lll_q72_u.json
 LLLFIX_U=1 LLLFIX_FLAGS=2 $D lllfix r 30 0 40 3 0 0 -1 0 0 > $G/lll_r30_earlyred_u.json
+# both flags at once; and on a sub-range with u
+LLLFIX_FLAGS=6 $D lllfix q  40 20 20 4  0  0 -1 0 0 > $G/lll_q40_siegel_earlyred.json
+LLLFIX_U=1 LLLFIX_FLAGS=6 $D lllfix q  72 36 16 9  0  5 60 0 0 > $G/lll_q72_siegel_earlyred_sub_u.json
 $D lllfix q  40 20 20 6  0  0 -1 2 0 > $G/lll_q40_zero2.json
 $D lllfix q  40 20 20 7  0  0 -1 0 2 > $G/lll_q40_dup2.json
 $D lllfix q  40 20 20 8  0 10 30 0 0 > $G/lll_q40_range10_30.json

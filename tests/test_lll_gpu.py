@@ -266,7 +266,7 @@ def test_early_reduction_seeded_vs_oracle(ctx, d, n_extra, flags):
                     % (d, flags, plain, B),))
 
 
-@pytest.mark.parametrize("name", ["lll_q40_zero1_dup2_u", "lll_q72_u", "lll_r30_earlyred_u"])
+@pytest.mark.parametrize("name", ["lll_q40_zero1_dup2_u", "lll_q72_u", "lll_r30_earlyred_u", "lll_q72_siegel_earlyred_sub_u"])
 def test_transformation_matrix_follows_the_row_operations(ctx, name):
     """MatGSO(b, u = identity, ...) (enable_transform, gso.cpp:84-158, 289-366): every row operation of the LLL run
     acts on u as well and move_row rotates its rows with b's.  The device's u equals the REAL reference's (fixtures
