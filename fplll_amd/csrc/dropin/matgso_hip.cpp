@@ -380,10 +380,11 @@ bool LLLReduction<Z_NR<long>, FP_NR<double>>::lll(int kappa_min, int kappa_start
         int p = 1;
         while (2 * p <= kappa_end - 1 - zeros)
           p *= 2;
-        last_early_red = (st == 1 && kappa_end - 1 - zeros >= 1) ? p : -1;
+        // (the reference's member never decreases: early_reduction runs for kappa > last_early_red only,
+        //  lll.cpp:92 — a call over a shorter range must not make a later host call repeat reductions)
+        if (st == 1 && kappa_end - 1 - zeros >= 1)
+          last_early_red = std::max(last_early_red, p);
       }
-      else
-        last_early_red = -1;
       // the working vectors the host path would have grown (babai() of a later host call uses them)
       extend_vect(lovasz_tests, kappa_end);
       extend_vect(babai_mu, kappa_end);

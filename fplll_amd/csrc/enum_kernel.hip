@@ -1091,8 +1091,8 @@ template <int NQT> __device__ __forceinline__ int rlqi(const int (&v)[NQT], int 
 // NQT = registers per lane: 2 for blocks up to 128 rows (the column stack of the levels above 64 in LDS,
 // 49 KB at d = 128), 4 up to 256 — FPLLL_MAX_ENUM_DIM, enumerate_base.h:59-101 — with the stack in a per-wave
 // region of global memory (246 KB at d = 256: more than a CU's LDS; the top of the tree is a vanishing share of
-// the nodes).  Row strides of the task buffers: 64 NQT for the columns, 64 (NQT - 1) for the coefficients of
-// the levels >= 64 (TopBuf::xhi, xhi_root).
+// the nodes).  Row strides of the top task buffers: 64 NQT for the columns, 64 (NQT - 1) for the coefficients of
+// the levels >= 64 (TopBuf::xhi); xhi_root's rows have the stride every reader computes from d.
 template <int NQT, bool SUBS, bool DUAL>
 __global__ void __launch_bounds__(64)
     enum_top_kernel(DevShared *__restrict__ g, HostCtl *__restrict__ h, TopBuf in, unsigned n_in,
@@ -1217,9 +1217,13 @@ __global__ void __launch_bounds__(64)
             {
               out.col[(unsigned long long)oi * 64 + lane] = S[0];
               out.x[(unsigned long long)oi * 64 + lane]   = 0.0;
+              // (row stride of xhi_root = the readers': 64 per started chunk of levels above 64 — 128 for a
+              //  block of 129..192 rows, not this kernel's register count XS = 192)
+              const int xstr = 64 * ((d - 1) >> 6);
 #pragma unroll
               for (int q = 1; q < NQT; ++q)
-                xhi_root[(unsigned long long)oi * XS + 64 * (q - 1) + lane] = xs[q];
+                if (64 * (q - 1) < xstr)
+                  xhi_root[(unsigned long long)oi * xstr + 64 * (q - 1) + lane] = xs[q];
               if (lane == 0)
               {
                 out.pd[oi]    = nd;

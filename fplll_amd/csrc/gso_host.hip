@@ -117,7 +117,8 @@ struct fphip_gso
   unsigned long long il_calls = 0, il_device_jobs = 0, il_host_jobs = 0, il_launches = 0;
   // resident LLL session (fphip_gso_session_lll): the rows live in the kernel's slots while it is active
   bool session_active  = false;
-  bool u_in_slots      = false;  // a session left the rows of u in the kernel's slots (restore_u_order)
+  bool u_in_slots      = false;  // a session left the rows of u in the kernel's slots (restore_position_order)
+  bool b_in_slots      = false;  // ... and those of b
   long long *sess_in_d = nullptr;  // device: positions then rows of the caller's row operations
   long long *sess_in_h = nullptr;  // pinned staging of the same
   char *sess_out_h     = nullptr;  // pinned: the state in position order after the last session call
@@ -306,17 +307,31 @@ struct LllArgs
   double delta, logdelta;
 };
 
-// A session leaves the rows of u in the kernel's slots (like b's); its last call also wrote them in position order
-// behind the caller's view of the state: that copy becomes u when the session ends.
-static int restore_u_order(fphip_gso *g)
+// A session leaves the rows of b (and of u) in the kernel's slots; its last call also wrote them in position order
+// behind the caller's view of the state: that copy becomes b / u when the session ends — by fphip_gso_set_basis
+// (which may re-upload only part of the batch: the other lattices get their rows back in position order) or by a
+// call that ended with a status other than 1 (the stateless entry points are no longer blocked after it and must
+// find b and u consistent).
+static int restore_position_order(fphip_gso *g)
 {
-  if (!g->u_in_slots || !g->P.u || !g->P.sess_out)
+  if (!g->P.sess_out)
     return FPHIP_OK;
   const size_t B = (size_t)g->P.batch, d = g->P.d, ldd = g->P.ldd, ldn = g->P.ldn;
-  for (size_t L = 0; L < B; ++L)
-    GCHK(hipMemcpy(g->P.u + L * d * ldd,
-                   g->P.sess_out + L * fphip_session_out_stride(d, ldd, ldn) + fphip_session_out_bytes(d, ldd, ldn),
-                   d * ldd * sizeof(long long), hipMemcpyDeviceToDevice));
+  if (g->b_in_slots)
+  {
+    for (size_t L = 0; L < B; ++L)
+      GCHK(hipMemcpy(g->P.b + L * d * ldn, g->P.sess_out + L * fphip_session_out_stride(d, ldd, ldn),
+                     d * ldn * sizeof(long long), hipMemcpyDeviceToDevice));
+    g->b_in_slots = false;
+    g->dirty      = true;
+  }
+  if (g->u_in_slots && g->P.u)
+  {
+    for (size_t L = 0; L < B; ++L)
+      GCHK(hipMemcpy(g->P.u + L * d * ldd,
+                     g->P.sess_out + L * fphip_session_out_stride(d, ldd, ldn) + fphip_session_out_bytes(d, ldd, ldn),
+                     d * ldd * sizeof(long long), hipMemcpyDeviceToDevice));
+  }
   g->u_in_slots = false;
   return FPHIP_OK;
 }
@@ -473,11 +488,15 @@ extern "C" int fphip_gso_set_basis(fphip_gso *g, int first, int count, const int
   if (!g || !b || first < 0 || count <= 0 || first + count > g->P.batch)
     return FPHIP_ERROR;
   const size_t rows = (size_t)g->P.d * count;
+  // a session ends here for every lattice of the batch: those outside [first, first + count) get their rows back
+  // in position order (and so do the rows of u) before the new ones are written
+  g->session_active = false;
+  if (int rc = restore_position_order(g))
+    return rc;
   GCHK(hipMemcpy2D(g->P.b + (size_t)first * g->P.d * g->P.ldn, (size_t)g->P.ldn * 8, b,
                    (size_t)g->P.n * 8, (size_t)g->P.n * 8, rows, hipMemcpyHostToDevice));
   g->dirty          = true;
-  g->session_active = false;  // (the rows are in position order again)
-  return restore_u_order(g);   // (... and so are those of u)
+  return FPHIP_OK;
 }
 
 // replicate lattice `src` into every slot of the batch (device-side copies; used by benchmarks)
@@ -769,6 +788,9 @@ extern "C" int fphip_gso_session_lll(fphip_gso *g, int resume, int kappa_min, in
   if (!resume)
   {
     g->session_active = false;
+    rc = restore_position_order(g);  // (a new session on the rows an earlier one left in its slots)
+    if (rc != FPHIP_OK)
+      return rc;
     rc = launch(g, 0, g->P.d, 0.0, 2);  // bf / row_expo / narrow flags of every row from b
     if (rc != FPHIP_OK)
       return rc;
@@ -825,8 +847,10 @@ extern "C" int fphip_gso_session_lll(fphip_gso *g, int resume, int kappa_min, in
     all_ok &= (st[L] == 1);
   g->session_active = all_ok;
   g->u_in_slots     = g->P.u != nullptr;
+  g->b_in_slots     = true;
   if (!all_ok)
-    restore_u_order(g);
+    if (int rc2 = restore_position_order(g))
+      return rc2;
   if (status)
     memcpy(status, st.data(), sizeof(int) * B);
   return FPHIP_OK;
@@ -2300,7 +2324,8 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
         fphip_pruner::VolumeEngine *engine = w < (int)il_engines.size() ? il_engines[w] : nullptr;
         const int nctx      = 1 + (int)g->ectx_more.size();
         const bool own_ctx  = handoff && w < nctx - 1;  // (the last context may be shared)
-        fphip_ctx *my_ectx  = !handoff ? nullptr : (w == 0 ? g->ectx : g->ectx_more[std::min(w, nctx - 1) - 1]);
+        const int ci        = std::min(w, nctx - 1);    // (0 = the object's own context — also every worker's when
+        fphip_ctx *my_ectx  = !handoff ? nullptr : (ci == 0 ? g->ectx : g->ectx_more[ci - 1]);  //  there is no other)
         for (;;)
         {
           std::pair<size_t, unsigned long long> job;

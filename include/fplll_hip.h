@@ -116,9 +116,10 @@ typedef struct fphip_enum_opts
   int phase_growth;    /* wanted task growth per splitting phase */
   int waves_per_block; /* final-phase workgroup = waves_per_block * 64 threads */
   int min_nodes_decline; /* decline when the Gaussian-heuristic node estimate is below this */
-  /* work movement between the ranks (with `exchange`; NULL: donated subtrees stay on their GPU, as they do for
-   * blocks above 64 rows in any case).  After every walk round the ranks compare their numbers of donated tasks;
-   * ranks above the average hand their surplus to the ranks below it (by rank order). */
+  /* work movement between the ranks (with `exchange`; NULL: donated subtrees stay on their GPU).  After every
+   * walk round the ranks compare their numbers of donated tasks; ranks above the average hand their surplus to
+   * the ranks below it (by rank order).  Tasks of blocks above 64 rows move as well: their record carries the
+   * coefficients of the levels >= 64 (a row of the sender's table of level-64 ancestors). */
   fphip_gather_cb gather;
   void *gather_user;
 } fphip_enum_opts;

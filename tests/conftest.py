@@ -243,6 +243,27 @@ def wide_block(d, seed, c, d0=70, rf=0.46):
     return np.ascontiguousarray(mu.T), rdiag, maxdist
 
 
+def wide_block_with_candidates(d, seed, d0=40, rf=1.2, cheap=0.1, dear=0.45):
+    """A block of d > 128 rows WITH vectors inside the radius, found under several level-64 ancestors: the
+    d0-row block synthetic_block(d0, seed, 0.03, rf) (radius^2 = rf * GH^2: a handful of vectors), above it rows of
+    r_kk = dear * radius^2 except four 'cheap' levels (70, 120, 140, d - 1: r_kk = cheap * radius^2) whose
+    coefficients range over a few dozen combinations at little cost.  mu is zero between the rows >= d0 (their
+    centres stay 0) and seeded from every row into the columns < d0, so every combination shifts the centres of
+    the small block: a closest-vector instance with what is left of the radius.  The candidates' coefficients of
+    levels >= 64 are non-zero and differ from ancestor to ancestor — what the table of level-64 ancestors
+    (xhi_root) has to deliver, in the rows of index > 0."""
+    mut0, r0, maxdist = synthetic_block(d0, seed, 0.03, rf)
+    rng = np.random.default_rng(seed + 2000)
+    mu = np.zeros((d, d))
+    mu[:d0, :d0] = mut0.T
+    mu[d0:, :d0] = rng.uniform(-0.5, 0.5, size=(d - d0, d0))
+    rdiag = np.concatenate([r0, dear * maxdist * rng.uniform(0.9, 1.1, size=d - d0)])
+    for k in (70, 120, 140, d - 1):
+        if d0 <= k < d:
+            rdiag[k] = cheap * maxdist
+    return np.ascontiguousarray(mu.T), rdiag, maxdist
+
+
 @pytest.fixture(scope="session")
 def ctx():
     import fplll_amd

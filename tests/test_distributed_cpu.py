@@ -8,6 +8,8 @@ import socket
 import numpy as np
 import pytest
 
+import conftest as C
+
 
 def _free_port():
     s = socket.socket()
@@ -229,3 +231,57 @@ def test_work_movement_plan_and_gather(world):
     assert balance_plan([40, 0, 0, 0], room=[0, 10, 10, 10])[0] == 30
     # FPHIP_MOVE_FRACTION lowers the bar: a single surplus task moves
     assert balance_plan([1000, 1000, 900, 1000], fraction=10**9)[:2] == (75, [25, 25, 0, 25])
+
+
+def _bench(args, env_extra, timeout=300):
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, **env_extra)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        if k not in env_extra:
+            env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(C.ROOT, "bench.py")] + args, capture_output=True, text=True,
+                       timeout=timeout, env=env, cwd=C.ROOT)
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    return r, lines
+
+
+@pytest.mark.parametrize("n", [2, 4])
+def test_bench_py_spawns_its_own_ranks_when_launched_plainly(n):
+    """`python bench.py --gpus N` with no launcher around it (WORLD_SIZE unset) must not run as ONE rank and print
+    n_gpus = 1: it starts N ranks itself, and the line carries the rank count the process group reports
+    (--rank-check: the launcher's half only — no GPU here; gloo)."""
+    r, lines = _bench(["--gpus", str(n), "--rank-check"], {"FPHIP_BENCH_BACKEND": "gloo"})
+    assert r.returncode == 0, (r.stdout[-800:], r.stderr[-1500:])
+    assert len(lines) == 1, "rank 0 prints ONE line"
+    j = lines[0]
+    assert j["n_gpus"] == n and j["ranks"]["reported_by_process_group"] == n
+    assert j["ranks"]["launcher"].startswith("bench.py")
+
+
+def test_bench_py_refuses_a_rank_count_that_is_not_gpus():
+    """A launcher that started another number of ranks than --gpus says (the driver's N = 8 command with WORLD_SIZE
+    = 1, or the reverse): refuse instead of printing a line with the wrong n_gpus."""
+    r, lines = _bench(["--gpus", "4", "--rank-check"], {"FPHIP_BENCH_BACKEND": "gloo", "WORLD_SIZE": "1", "RANK": "0"})
+    assert r.returncode == 2 and not lines and "refusing" in r.stderr
+    r, lines = _bench(["--gpus", "4"], {"FPHIP_BENCH_BACKEND": "gloo", "WORLD_SIZE": "2", "RANK": "0"})
+    assert r.returncode == 2 and not lines and "refusing" in r.stderr
+
+
+def test_bench_py_under_torchrun_keeps_working():
+    """The driver's launch line (torch.distributed.run) is untouched by the self-spawn path."""
+    import json
+    import subprocess
+    import sys
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, FPHIP_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(C.ROOT, "bench.py"),
+                        "--gpus", "2", "--rank-check"], capture_output=True, text=True, timeout=300, env=env, cwd=C.ROOT)
+    assert r.returncode == 0, (r.stdout[-800:], r.stderr[-1500:])
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["ranks"]["launcher"] == "external"

@@ -214,6 +214,48 @@ def test_blocks_larger_than_64_vs_oracle(ctx, d, seed, rf):
     assert [s[0] for s in ev1.solutions] == [s[0] for s in ev1o.solutions]
 
 
+def _dist_from(mut, rdiag, x, off=0):
+    """Squared length of the projection (levels >= off) of the vector with coefficients x."""
+    d = len(rdiag)
+    x = np.asarray(x, dtype=np.float64)
+    tot = 0.0
+    for i in range(off, d):
+        tot += rdiag[i] * (x[i] + float(np.dot(mut[i, i + 1:], x[i + 1:]))) ** 2
+    return tot
+
+
+@pytest.mark.parametrize("d,seed", [(130, 43), (160, 41), (200, 42)])
+def test_wide_blocks_report_candidates_under_every_level64_ancestor(ctx, d, seed):
+    """Blocks above 128 rows with vectors INSIDE the radius (conftest.wide_block_with_candidates): the candidates
+    sit under several level-64 ancestors, so their coefficients of levels >= 64 come out of rows of index > 0 of
+    the table the wide top walk fills (four registers per lane) and the subtree kernel reads — with ONE row
+    stride, also where a block of 129..192 rows uses fewer chunks than the top walk has registers.
+    Per-level counts, the candidate list (distance + all d coefficients) and the sub-solution table are the C
+    oracle's; every reported vector has the reported length."""
+    from fplll_amd.enumeration import FastEvaluator, enumerate_block
+    mut, rdiag, maxdist = C.wide_block_with_candidates(d, seed)
+    ev, ev_o = FastEvaluator(10**9, 0), FastEvaluator(10**9, 0)
+    res = enumerate_block(ctx, mut, rdiag, None, maxdist, ev)
+    nodes_o, _ = C.oracle_enumerate(mut, rdiag, None, maxdist, ev_o)
+    assert [int(v) for v in res.nodes] == [int(v) for v in nodes_o]
+    so = sorted((s[0], tuple(s[1])) for s in ev_o.solutions)
+    sg = sorted((s[0], tuple(s[1])) for s in ev.solutions)
+    assert len(so) >= 30 and len(set(s[1][64:] for s in so)) >= 5  # several ancestors, non-zero above level 64
+    assert sg == so
+    for dist, x in sg:
+        assert abs(_dist_from(mut, rdiag, x) - dist) <= 1e-9 * dist
+    # sub-solutions: the reports of the levels below 64 carry the ancestor's coefficients as well
+    ev, ev_o = FastEvaluator(10**9, 0), FastEvaluator(10**9, 0)
+    res = enumerate_block(ctx, mut, rdiag, None, maxdist, ev, findsubsols=True)
+    nodes_o, _ = C.oracle_enumerate(mut, rdiag, None, maxdist, ev_o, findsubsols=True)
+    assert [int(v) for v in res.nodes] == [int(v) for v in nodes_o]
+    assert sorted(ev.sub_solutions) == sorted(ev_o.sub_solutions)
+    for o in ev_o.sub_solutions:
+        dist, x = ev.sub_solutions[o]
+        assert dist == ev_o.sub_solutions[o][0]
+        assert abs(_dist_from(mut, rdiag, x, o) - dist) <= 1e-9 * dist, "sub-solution of level %d: wrong coefficients" % o
+
+
 @pytest.mark.parametrize("path", [p for p in C.enum_fixtures() if p.endswith("_subsols.json")],
                          ids=lambda p: os.path.basename(p)[:-5])
 def test_subsolutions_reference_parity(ctx, path):

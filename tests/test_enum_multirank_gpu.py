@@ -128,27 +128,36 @@ def test_sharded_call_with_library_level_reductions(name, world):
         assert gd == ref_best and gc is not None and len(gc) == f["d"]
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_bench_py_multi_rank_protocol_on_one_device(world):
+@pytest.mark.parametrize("world,launcher", [(2, "torchrun"), (4, "plain")])
+def test_bench_py_multi_rank_protocol_on_one_device(world, launcher):
     """bench.py exactly as the driver launches it for N GPUs (torch.distributed.run, one rank per
     process) — with the collectives on gloo and every rank on the ONE GPU of this box
     (FPHIP_BENCH_BACKEND=gloo, FPHIP_BENCH_ONE_DEVICE=1): the sharded call, the bound exchange, the
     library-level reductions and the max-over-ranks timing.  Every timed step must end on the
-    reference's final norm, like the N = 1 line; nodes are the whole job's."""
+    reference's final norm, like the N = 1 line; nodes are the whole job's.  "plain": `python bench.py --gpus N`
+    with no launcher (WORLD_SIZE unset) starts its N ranks itself and reports the rank count of the process group —
+    a plain launch must never come back as n_gpus = 1."""
     import json
     import subprocess
     import sys
     env = dict(os.environ, FPHIP_BENCH_BACKEND="gloo", FPHIP_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
-           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-           os.path.join(C.ROOT, "bench.py"), "--gpus", str(world), "--steps", "3", "--warmup", "1",
-           "--no-cpu", "--no-gso", "--no-tour", "--no-pmc"]
+    tail = [os.path.join(C.ROOT, "bench.py"), "--gpus", str(world), "--steps", "3", "--warmup", "1",
+            "--no-cpu", "--no-gso", "--no-tour", "--no-pmc"]
+    if launcher == "torchrun":
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port())] + tail
+    else:
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+            env.pop(k, None)
+        cmd = [sys.executable] + tail
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=C.ROOT)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, "rank 0 prints ONE json line"
     j = json.loads(lines[0])
     assert j["n_gpus"] == world and j["steps"] == 3 and j["scaling"] == "strong"
+    assert j["ranks"]["reported_by_process_group"] == world
+    assert j["ranks"]["launcher"] == ("external" if launcher == "torchrun" else "bench.py (self-spawned)")
     assert j["parity"]["final_norm_equal_to_reference"] == 3, j["parity"]
     assert j["nodes"] > 3 * 10**9 and j["value"] > 0
 
@@ -202,6 +211,16 @@ def test_sharded_call_on_rccl_world_size_one(name):
         assert gd == ref_best
 
 
+def _load_case(fixture):
+    """A golden fixture, or "wide:<d>:<seed>" = conftest.wide_block_with_candidates (no reference run exists for
+    blocks above 128 rows: the C oracle is the checker there)."""
+    if not fixture.startswith("wide:"):
+        return C.load_fixture(fixture)
+    _, d, seed = fixture.split(":")
+    mut, rdiag, maxdist = C.wide_block_with_candidates(int(d), int(seed))
+    return {"mut": mut, "rdiag": rdiag, "pruning": None, "maxdist": maxdist, "d": int(d), "name": fixture}
+
+
 def _worker_move(rank, world, port, fixture, move, fixed, q):
     import torch.distributed as dist
     import fplll_amd
@@ -210,7 +229,7 @@ def _worker_move(rank, world, port, fixture, move, fixed, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    f = C.load_fixture(fixture)
+    f = _load_case(fixture)
     ctx = fplll_amd.Context(0)
     ev = FastEvaluator(10**9 if fixed else 1, 0)
     res = enumerate_block(ctx, f["mut"], f["rdiag"], f["pruning"], f["maxdist"], ev,
@@ -226,7 +245,7 @@ def _worker_move(rank, world, port, fixture, move, fixed, q):
 
 def _run_move(name, world, move, fixed):
     import torch.multiprocessing as mp
-    fixture = os.path.join(C.GOLDEN, name + ".json")
+    fixture = name if name.startswith("wide:") else os.path.join(C.GOLDEN, name + ".json")
     mpctx = mp.get_context("spawn")
     q = mpctx.Queue()
     port = _free_port()
@@ -237,7 +256,7 @@ def _run_move(name, world, move, fixed):
     for p in ps:
         p.join(120)
         assert p.exitcode == 0
-    return C.load_fixture(fixture), out
+    return _load_case(fixture), out
 
 
 @pytest.mark.parametrize("world", [2, 4])
@@ -284,6 +303,28 @@ def test_donated_subtrees_of_a_block_above_64_rows_move_with_their_ancestors(nam
     C.note(lambda: ("work movement, block of %d rows, 2 ranks: node shares %s, tasks moved per rank %s"
                     % (f["d"], ["%.3f" % (sum(o[1]) / f["total_nodes"]) for o in out], [o[2] for o in out]),))
     assert sum(o[2] for o in out) > 0, "no task moved: the case does not exercise the records of wide blocks"
+
+
+@pytest.mark.parametrize("d,seed", [(160, 41), (200, 42)])
+def test_blocks_above_128_rows_shard_and_move_with_their_ancestor_rows(d, seed, monkeypatch):
+    """Two ranks on a block above 128 rows with candidates under several level-64 ancestors: the sharding keys
+    (task_key_kernel), the moved records (task_pack / task_unpack, 128 or 192 doubles of ancestor coefficients) and
+    the solution reports all read the ancestor table with the same row stride, so the ranks agree on the partition —
+    per-level counts add up to the C oracle's, every candidate of the oracle exactly once, coefficients included."""
+    from fplll_amd.enumeration import FastEvaluator
+    monkeypatch.setenv("FPHIP_BUDGET", "256")
+    monkeypatch.setenv("FPHIP_MOVE_FRACTION", "1000000000")
+    f, out = _run_move("wide:%d:%d" % (d, seed), 2, True, True)
+    ev_o = FastEvaluator(10**9, 0)
+    nodes_o, _ = C.oracle_enumerate(f["mut"], f["rdiag"], None, f["maxdist"], ev_o)
+    tot = np.sum([np.array(o[1]) for o in out], axis=0)
+    # (the top walk is replicated and counted by shard 0 only)
+    assert [int(v) for v in tot] == [int(v) for v in nodes_o]
+    got = sorted(x for o in out for x in o[5])
+    want = sorted((float(s[0]), tuple(float(v) for v in s[1])) for s in ev_o.solutions)
+    assert len(want) >= 30 and got == want
+    C.note(lambda: ("block of %d rows, 2 ranks: node shares %s, tasks moved per rank %s"
+                    % (d, ["%.3f" % (sum(o[1]) / max(1, sum(int(v) for v in nodes_o))) for o in out], [o[2] for o in out]),))
 
 
 def test_work_movement_with_a_shrinking_radius_and_on_a_pruner_regime_block():
