@@ -12,8 +12,8 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 
-HIP_SOURCES = ["enum_kernel.hip", "enum_host.hip", "gso_kernel.hip", "gso_sweep2.hip", "lll_kernel.hip", "lll_kernel_early.hip", "hlll_kernel.hip", "hh_blocked.hip", "hlll_x.hip", "lll_x.hip", "bkz_kernel.hip", "bkzs_kernel.hip", "gso_host.hip", "pruner_volume.hip", "pruner_search.hip", "gso_util_host.hip"]
-HIP_HEADERS = ["dev_mem.h", "trace.h", "pruner_tables.h", "pruner_engine.h", "enum_device.h", "gso_device.h", "gso_wave.h", "gso_sweep2.h", "ftx.h", "lll_wave.h", "lll_stream.h", os.path.join(ROOT, "include", "fplll_hip.h")]
+HIP_SOURCES = ["enum_kernel.hip", "enum_walk.hip", "enum_host.hip", "gso_kernel.hip", "gso_sweep2.hip", "lll_kernel.hip", "lll_kernel_early.hip", "hlll_kernel.hip", "hh_blocked.hip", "hlll_x.hip", "lll_x.hip", "bkz_kernel.hip", "bkzs_kernel.hip", "gso_host.hip", "pruner_volume.hip", "pruner_search.hip", "gso_util_host.hip"]
+HIP_HEADERS = ["dev_mem.h", "trace.h", "pruner_tables.h", "pruner_engine.h", "enum_device.h", "enum_wave.h", "gso_device.h", "gso_wave.h", "gso_sweep2.h", "ftx.h", "lll_wave.h", "lll_stream.h", os.path.join(ROOT, "include", "fplll_hip.h")]
 HIPCC_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17",
     "-ffp-contract=off",  # fplll's arithmetic is separate mul/add (nr/nr_FP_d.inl:178); no FMA
@@ -31,6 +31,7 @@ PER_FILE_FLAGS = {
     #  "continue" flag and a phi per live value: 4 scalar + 2 branch instructions per iteration of the
     #  walk loops, which are bound by the scalar / branch issue port)
     "enum_kernel.hip": ["-mllvm", "-structurizecfg-skip-uniform-regions=1", "-Xclang", "-disable-lifetime-markers"],
+    "enum_walk.hip": ["-mllvm", "-structurizecfg-skip-uniform-regions=1", "-Xclang", "-disable-lifetime-markers"],
     "bkzs_kernel.hip": ["-mllvm", "-structurizecfg-skip-uniform-regions=1", "-Xclang", "-disable-lifetime-markers"],
     # the one-wavefront-per-lattice reduction kernels: their loops still hold lane-masked branches, so
     # the option only spares the regions that are uniform already — measured +4 % on the batched LLL

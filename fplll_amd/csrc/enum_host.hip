@@ -38,6 +38,11 @@ __global__ void enum_top_kernel(DevShared *g, HostCtl *h, TopBuf in, unsigned n_
                                 int count_nodes, int launch_idx, double *gtop);
 __global__ void task_key_kernel(TaskBuf in, unsigned n, int d, unsigned long long *keys,
                                 const double *xhi_root, const unsigned *slots);
+template <bool MU_LDS, bool DUAL>
+__global__ void enum_walk_kernel(DevShared *g, HostCtl *h, TaskBuf in, TaskBuf out, int d, int Lmax, unsigned task_lo,
+                                 unsigned task_hi, const unsigned *idxlist, int launch_idx, int count_nodes,
+                                 unsigned budget, const double *xhi_root, double *gstk, int Tsplit, unsigned *qh,
+                                 const unsigned *rcnt, unsigned rcap, unsigned long long bound_init);
 __global__ void task_pack_kernel(TaskBuf in, unsigned lo, unsigned n, double *rec, const double *xhi_root, int xstr);
 __global__ void task_unpack_kernel(TaskBuf out, unsigned lo, unsigned n, const double *rec, double *xhi_root, int xstr,
                                    unsigned root_base);
@@ -893,6 +898,7 @@ restart:
   }
 
   const int debug     = env_int("FPHIP_DEBUG", 0);
+  const bool walk2    = env_int("FPHIP_WALK2", 1) != 0;
   uint64_t nsol       = 0;
   double kernel_ms    = top_ms, final_ms = 0.0;
   int launches        = 0;
@@ -1159,7 +1165,26 @@ restart:
                      count_nodes, bud, ctx->xhi_root, ctx->gstk, Ts, &ctx->qm->head[launch_idx][0],          \
                      (regioned && !shard_now) ? &ctx->qm->fin[0] : (const unsigned *)nullptr, ctx->cap / FPHIP_NQ, \
                      (unsigned long long)__atomic_load_n(&ctx->h->bound_bits, __ATOMIC_ACQUIRE))
-        if (dual && mu_lds)
+        // the walk launches (no sub-solutions): the second-generation walk — all children of a node in one vector
+        // test (enum_walk.hip); FPHIP_WALK2=0 keeps enum_phase_kernel (the A/B partner)
+#define FPHIP_LAUNCH2(M, D)                                                                          \
+  hipLaunchKernelGGL((enum_walk_kernel<M, D>), dim3(grid), dim3(wpb * 64), lds, ctx->stream, ctx->g,  \
+                     ctx->h, ctx->buf[cur], ctx->buf[nxt], d, L, lo, hi, idxl, launch_idx,           \
+                     count_nodes, bud, ctx->xhi_root, ctx->gstk, Ts, &ctx->qm->head[launch_idx][0],  \
+                     (regioned && !shard_now) ? &ctx->qm->fin[0] : (const unsigned *)nullptr, ctx->cap / FPHIP_NQ, \
+                     (unsigned long long)__atomic_load_n(&ctx->h->bound_bits, __ATOMIC_ACQUIRE))
+        if (in_final && !subs && walk2)
+        {
+          if (dual && mu_lds)
+            FPHIP_LAUNCH2(true, true);
+          else if (dual)
+            FPHIP_LAUNCH2(false, true);
+          else if (mu_lds)
+            FPHIP_LAUNCH2(true, false);
+          else
+            FPHIP_LAUNCH2(false, false);
+        }
+        else if (dual && mu_lds)
           FPHIP_LAUNCH(true, false, true);
         else if (dual)
           FPHIP_LAUNCH(false, false, true);
@@ -1172,6 +1197,7 @@ restart:
         else
           FPHIP_LAUNCH(false, true, false);
 #undef FPHIP_LAUNCH
+#undef FPHIP_LAUNCH2
         HIPCHK(ctx, hipGetLastError());
         HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
         ++launch_idx;

@@ -1140,9 +1140,19 @@ static int cmd_bkztour(int argc, char **argv)
   par.flags     = BKZ_MAX_LOOPS | BKZ_GH_BND;
   par.max_loops = 1;
   par.gh_factor = 1.1;
+  typedef void (*tt_get_fn)(double *);
+  typedef void (*tt_reset_fn)(void);
+  tt_get_fn tt_get     = (tt_get_fn)dlsym(RTLD_DEFAULT, "tour_timers_get");
+  tt_reset_fn tt_reset = (tt_reset_fn)dlsym(RTLD_DEFAULT, "tour_timers_reset");
+  const bool have_timers = tt_get && tt_reset;
+  double tt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (have_timers)
+    tt_reset();
   auto t0       = std::chrono::steady_clock::now();
   int status    = bkz_reduction(&A, NULL, par, FT_DOUBLE, 0);
   double secs   = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  if (have_timers)
+    tt_get(tt);
   ZZ_mat<mpz_t> U, UT;
   MatGSO<ZT, FT> M(A, U, UT, GSO_ROW_EXPO);
   M.update_gso();
@@ -1179,9 +1189,19 @@ static int cmd_bkztour(int argc, char **argv)
     std::ofstream os(getenv("REFDRV_DUMP_BASIS"));
     os << A << std::endl;
   }
+  // the split of the tour's wall time, when oracle/_ref/libtour_timers.so is preloaded (tour_timers.cpp)
+  char split[512] = "";
+  if (have_timers)
+  {
+    snprintf(split, sizeof split,
+             ",\"breakdown\":{\"host_lll_s\":%.3f,\"host_lll_calls\":%.0f,\"cpu_enum_s\":%.3f,\"cpu_enum_calls\":%.0f,"
+             "\"plugin_enum_s\":%.3f,\"plugin_enum_calls\":%.0f,\"plugin_declined_s\":%.3f,\"plugin_declined_calls\":%.0f,"
+             "\"other_s\":%.3f}",
+             tt[0], tt[1], tt[2], tt[3], tt[4], tt[5], tt[6], tt[7], secs - tt[0] - tt[2] - tt[4] - tt[6]);
+  }
   printf("{\"plugin\":\"%s\",\"beta\":%d,\"status\":%d,\"tour_seconds\":%.3f,\"r00\":%.17g,"
-         "\"slope\":%.9f,\"is_lll_reduced\":%d,\"log_volume\":%.12g,\"basis_fnv\":\"%016llx\"}\n",
-         plug.c_str(), beta, status, secs, r0.get_d(), slope, lll_red, logvol, fp);
+         "\"slope\":%.9f,\"is_lll_reduced\":%d,\"log_volume\":%.12g,\"basis_fnv\":\"%016llx\"%s}\n",
+         plug.c_str(), beta, status, secs, r0.get_d(), slope, lll_red, logvol, fp, split);
   return (status == RED_SUCCESS || status == RED_BKZ_LOOPS_LIMIT) ? 0 : 1;
 }
 

@@ -1,6 +1,6 @@
 #!/bin/bash
 # two PMC passes over the enumeration-only bench (1 step); summary per kernel name
-mkdir -p gpurun_out/exp/pmc1 gpurun_out/exp/pmc2
+rm -rf gpurun_out/exp/pmc1 gpurun_out/exp/pmc2; mkdir -p gpurun_out/exp/pmc1 gpurun_out/exp/pmc2
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 B="python $R/bench.py --no-cpu --no-gso --no-tour --no-pmc --no-batch --steps 1 --warmup 0"
@@ -13,7 +13,7 @@ for p in ("pmc1","pmc2"):
     acc=collections.defaultdict(float)
     for f in glob.glob("gpurun_out/exp/%s/**/*counter_collection.csv"%p, recursive=True):
         for r in csv.DictReader(open(f)):
-            if "enum_phase_kernel" in r["Kernel_Name"]:
+            if "enum_phase_kernel" in r["Kernel_Name"] or "enum_walk_kernel" in r["Kernel_Name"]:
                 acc[r["Counter_Name"]]+=float(r["Counter_Value"])
     print(p, dict(acc))
     l=[x for x in open("gpurun_out/exp/%s.log"%p) if x.startswith("{")]
