@@ -70,6 +70,16 @@ __device__ __forceinline__ int zig_of(int i, bool down)
   return down ? -z : z;
 }
 
+// r_kk of one level through the scalar cache (the bound of the level comes out of a lane register here)
+__device__ __forceinline__ v2u r_issue(const double *tab, unsigned off)
+{
+  v2u q;
+  asm volatile("s_load_dwordx2 %0, %1, %2" : "=s"(q) : "s"(tab), "s"(off));
+  return q;
+}
+__device__ __forceinline__ void rp_wait(v2u &q) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(q)); }
+__device__ __forceinline__ double rp_r2(const v2u &q) { return __hiloint2double((int)q.y, (int)q.x); }
+
 template <bool MU_LDS, bool DUAL>
 __global__ void __launch_bounds__(FPHIP_MAX_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8)))
     enum_walk_kernel(DevShared *__restrict__ g, HostCtl *__restrict__ h, TaskBuf in, TaskBuf out,
@@ -81,7 +91,7 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK) __attribute__((amdgpu_waves_p
 {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // (wave-uniform: the per-wave bases in SGPRs)
   constexpr unsigned MUROW8 = FPHIP_MUROW * 8u;
   const unsigned lane8 = (unsigned)lane << 3;
   const int triL = (Lmax * (Lmax + 1)) >> 1;
@@ -112,7 +122,6 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK) __attribute__((amdgpu_waves_p
     __syncthreads();
   const __amdgpu_buffer_rsrc_t mu_b = mu_rsrc(&g->mu_sq[0][0], (unsigned)sizeof(g->mu_sq));
   char *stk_top      = (char *)stk + (((unsigned)ldsRow << 3) + lane8);
-  const int tri8tab  = ((lane + 2) * (lane + 1)) << 2;
   double *gst = gstk + (size_t)(blockIdx.x * nw + wave) * (size_t)(triL - ldsRow + 1) - ldsRow;
   const double *rptab = &g->mu_sq[0][64];
   // z_j of this lane's candidate of an expansion (first step up).  Lane 63 holds a NaN: its candidate never
@@ -397,13 +406,13 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK) __attribute__((amdgpu_waves_p
               x1             = fix ? x1 - (a1 + a1) : x1;
               a1             = fix ? -a1 : a1;
             }
+            // candidate of lane j: x_0 + (0, +1, -1, +2, -2, ... +31, -31) — a set symmetric about x_0, so the
+            // survivors are the first n of the reference's zig-zag WHICHEVER way its first step goes (:71 / :114:
+            // the step that picks a child asks again); the distance by the reference's sequence (:28-29 / :91-92)
+            const double xj  = x1 + zz;
+            const double aj  = xj - c1;
             rp_wait(q1);
             const double bnd = rp_p(q1) * maxdist_v;  // partdistbounds[kk-1], enumerate.cpp:218-228
-            // the first step goes up (c >= roundto(c), :71 / :114) or down
-            const double s1d = __hiloint2double((c1 >= x1) ? 0x3ff00000 : (int)0xbff00000, 0);
-            // candidate j of the zig-zag (exact: integers), its distance by the reference's sequence (:28-29 / :91-92)
-            const double xj  = __builtin_fma(zz, s1d, x1);
-            const double aj  = xj - c1;
             const double ndj = nd + aj * aj * rp_r(q1);
             const unsigned long long m = __builtin_amdgcn_ballot_w64(ndj <= bnd);
             if (m == 0ull)
@@ -418,7 +427,7 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK) __attribute__((amdgpu_waves_p
               FPHIP_EXIT();
               break;
             }
-            int n = (int)__builtin_ctzll(~m);  // (lane 63 never passes)
+            int n = __builtin_popcountll(m);  // (lane 63 never passes)
             asm("" : "+s"(n));
             if (n == 63)
             {  // 63+ children: the general path
@@ -427,7 +436,7 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK) __attribute__((amdgpu_waves_p
               break;
             }
             // ---- descend into child 0 (++nodes[kk-1]): S_k is needed again when x[kc] steps to a sibling
-            FPHIP_PUSH(kc < Ts - 1, kc + 1, (unsigned)bp_i32(tri8tab, ka));
+            FPHIP_PUSH(kc < Ts - 1, kc + 1, tri8(kc + 2));
             const unsigned long long me = lane_bit(kc);
             cs    = sel_f64(me, c1, cs);
             x0s   = sel_f64(me, x1, x0s);
@@ -467,9 +476,9 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK) __attribute__((amdgpu_waves_p
         }
         {
           // child tk.i of level k: x = x_0 + z(i), its distance (:91-92), the column of its node (:104-110)
-          v4i qk = rp_issue2(rptab, (unsigned)k * MUROW8);
+          v2u qk = r_issue(rptab, (unsigned)k * MUROW8);
           if (__builtin_expect(k < Tsm1, 1))
-            par = *(const double *)(stk_top - (unsigned)bp_i32(tri8tab, ka));
+            par = *(const double *)(stk_top - tri8(k + 2));
           else
           {
             int kt = k;
@@ -480,7 +489,14 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK) __attribute__((amdgpu_waves_p
             mk = ld_off(mu_s, tri8(k) + min(lane8, ((unsigned)k << 3) - 8u));
           else
             mk = ld_row(mu_b, (unsigned)k * MUROW8, lane8);
-          const double zd  = bp_f64(zz, lane_addr(tk & 0x7f));
+          int zi;  // z(i) of the zig-zag with the first step up: +-ceil(i / 2) on the scalar unit
+          {
+            const int ii = tk & 0x7f;
+            const int hh = (ii + 1) >> 1;
+            zi           = (ii & 1) ? hh : -hh;
+            asm("" : "+s"(zi));
+          }
+          const double zd  = (double)zi;
           const double x0  = bp_f64(x0s, ka);
           const double ck  = bp_f64(cs, ka);
           const double pk  = bp_f64(pds, ka);
@@ -490,7 +506,7 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK) __attribute__((amdgpu_waves_p
           xk               = __builtin_fma(zd, sgd, x0);
           a                = xk - ck;
           rp_wait(qk);
-          nd = pk + a * a * rp_r(qk);
+          nd = pk + a * a * rp_r2(qk);
           S  = par - (DUAL ? a : xk) * mk;
         }
       }
