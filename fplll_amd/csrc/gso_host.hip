@@ -2629,6 +2629,7 @@ extern "C" int fphip_debug_stream(fphip_ctx *ctx, long long rows, int row_bytes,
 namespace fphip
 {
 template <int NQ> __global__ void hh_update_kernel(HhBatch P);
+template <int NT> __global__ void hh_rows_kernel(HhBatch P);
 }
 
 struct fphip_hh
@@ -2777,6 +2778,24 @@ extern "C" int fphip_hh_update_R(fphip_hh *h, int *status)
     grid = fphip_ctx_num_cus(h->ctx) * bpc;
   hipStream_t s = fphip_ctx_stream(h->ctx);
   HCHK(hipEventRecord(h->ev[0], s));
+  // rows up to 192 columns: the batch across the lanes (hh_rows.hip: a lane owns a row of one lattice and runs the
+  // reference's scalar loops; the same bits); FPHIP_HH_ROWS=0 keeps the lane-per-column kernel (the A/B partner)
+  const char *hr = getenv("FPHIP_HH_ROWS");
+  if (h->P.n <= 192 && !(hr && hr[0] == '0'))
+  {
+    const int nt      = h->P.n <= 64 ? 4 : (h->P.n <= 128 ? 8 : 12);
+    const size_t ldsr = ((size_t)3 * 16 * (16 * nt + 2) + 3 * 16) * sizeof(double);
+    int gridr         = (h->P.batch + 15) / 16;
+    if (gridr > fphip_ctx_num_cus(h->ctx))
+      gridr = fphip_ctx_num_cus(h->ctx);
+    switch (nt)
+    {
+    case 4: hipLaunchKernelGGL(hh_rows_kernel<4>, dim3(gridr), dim3(256), ldsr, s, h->P); break;
+    case 8: hipLaunchKernelGGL(hh_rows_kernel<8>, dim3(gridr), dim3(256), ldsr, s, h->P); break;
+    default: hipLaunchKernelGGL(hh_rows_kernel<12>, dim3(gridr), dim3(256), ldsr, s, h->P); break;
+    }
+  }
+  else
   switch (nq)
   {
   case 1: hipLaunchKernelGGL(hh_update_kernel<1>, dim3(grid), dim3(wpb * 64), lds, s, h->P); break;

@@ -122,3 +122,43 @@ def test_blocked_mfma_mode_agrees_with_exact_mode(ctx, src, d):
         C.note(lambda: ("blocked vs exact R-factor %s %dx%d row_expo=%d: max |dmu| %.2e; kernel %.2f ms vs %.2f ms (batch 5)"
               % (src, d, n, row_expo, worst, ms_blk, ms_exact),))
         h.close()
+
+
+@pytest.mark.parametrize("batch,d,n", [(1, 20, 20), (5, 48, 60), (17, 64, 64), (33, 65, 65), (16, 100, 128),
+                                       (7, 129, 129), (40, 150, 180), (19, 192, 192)])
+def test_rows_kernel_equals_the_column_kernel_bit_for_bit(ctx, batch, d, n, monkeypatch):
+    """hh_rows.hip (a lane owns a ROW of one lattice and runs the reference's scalar loops; the kernel of rows up
+    to 192 columns) against hh_update_kernel (lane = column, FPHIP_HH_ROWS=0) and the C oracle: the same bits in R —
+    the reflectors' contribution above the diagonal included, where the two kernels keep what update_R leaves
+    there — and the same row exponents, on ragged shapes (panels that end inside a tile, groups of 16 lattices that
+    the batch does not fill, d != n) with different lattices in one launch, with and without row exponents."""
+    from fplll_amd.householder import MatHouseholderBatch
+    rng = np.random.default_rng(1000 * batch + d)
+    bs = np.zeros((batch, d, n), dtype=np.int64)
+    for L in range(batch):
+        q = int(rng.integers(1 << 10, 1 << 30))
+        k = d // 2
+        bs[L, :k, :k] = np.eye(k, dtype=np.int64)
+        bs[L, :k, k:] = rng.integers(0, q, size=(k, n - k))
+        bs[L, k:, :] = rng.integers(-q, q, size=(d - k, n))
+        bs[L, k:, :k] = 0
+        for r in range(k, d):
+            bs[L, r, min(n - 1, r)] += q
+    for row_expo in (True, False):
+        out = {}
+        for mode in ("1", "0"):
+            monkeypatch.setenv("FPHIP_HH_ROWS", mode)
+            h = MatHouseholderBatch(ctx, batch, d, n, row_expo=row_expo)
+            h.set_basis(bs)
+            assert list(h.update_R()) == [1] * batch
+            out[mode] = [h.get_R(L) for L in range(batch)]
+            h.close()
+        for L in range(batch):
+            (R1, e1), (R0, e0) = out["1"][L], out["0"][L]
+            assert np.array_equal(e1, e0), (L, row_expo)
+            assert np.array_equal(R1.view(np.uint64), R0.view(np.uint64)), (L, row_expo)
+        for L in (0, batch - 1):
+            Ro, Vo, so, eo = C.oracle_hh_update_all(bs[L], row_expo)
+            R1, e1 = out["1"][L]
+            assert np.array_equal(e1, eo)
+            assert np.array_equal(np.tril(R1[:, :d]).view(np.uint64), np.tril(Ro[:, :d]).view(np.uint64))
