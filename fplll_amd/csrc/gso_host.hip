@@ -62,6 +62,7 @@ struct HlllX
   double delta, theta;
   long long iter_cap;
   const int *only_failed;
+  double *Thi, *Tlo;
 };
 template <int NQ, class FT> __global__ void hlll_x_kernel(HhBatch P, HlllX X);
 struct LllX
@@ -2642,6 +2643,7 @@ struct fphip_hh
   // extended-precision HLLL (hlll_x.hip): low planes of R and V, per-row scalars
   double *Rlo, *Vlo, *xsc;
   long long *xprevE;
+  double *xThi = nullptr, *xTlo = nullptr;  // hlll_x: T of every block of 16 reflectors (blocked application)
 };
 
 #define HCHK(call)                     \
@@ -2735,6 +2737,10 @@ extern "C" void fphip_hh_destroy(fphip_hh *h)
     fphip_dev_free(h->xsc, fphip_ctx_stream(h->ctx));
   if (h->xprevE)
     fphip_dev_free(h->xprevE, fphip_ctx_stream(h->ctx));
+  if (h->xThi)
+    fphip_dev_free(h->xThi, fphip_ctx_stream(h->ctx));
+  if (h->xTlo)
+    fphip_dev_free(h->xTlo, fphip_ctx_stream(h->ctx));
   delete h;
 }
 
@@ -2944,7 +2950,27 @@ static int hh_hlll_ex(fphip_hh *h, double delta, double theta, int precision, co
     HCHK(hipMemsetAsync(h->Rlo, 0, B * d * ld * 8 + 4096, s0));
     HCHK(hipMemsetAsync(h->Vlo, 0, B * d * ld * 8 + 4096, s0));
   }
+  // the reflectors sixteen at a time (compact WY with a T per block, hlll_x.hip): opt-in, FPHIP_HLLL_BLOCKED=1.
+  // Built for the lone-wave latency of config 5 and measured SLOWER there (n = 256, one lattice: 60.0 s against
+  // 29.7 s one by one in double, 115.4 s against 56.5 s in double-double; same basis, 146 491 swaps): the chain of
+  // dependent reductions is 16 times shorter, but every block waits for its 16 rows of V, its column of T and its
+  // signs out of L2, where the one-by-one loop has the next row in flight behind each tree sum.
+  const char *hb     = getenv("FPHIP_HLLL_BLOCKED");
+  const bool blocked = hb && hb[0] == '1';
+  const size_t tdbl  = B * ((d + 15) / 16) * 256;
+  if (blocked)
+  {
+    if (!h->xThi)
+      HCHK(fphip_dev_alloc((void **)&h->xThi, tdbl * 8 + 4096, s0));
+    if (precision == 106 && !h->xTlo)
+      HCHK(fphip_dev_alloc((void **)&h->xTlo, tdbl * 8 + 4096, s0));
+    HCHK(hipMemsetAsync(h->xThi, 0, tdbl * 8, s0));
+    if (precision == 106)
+      HCHK(hipMemsetAsync(h->xTlo, 0, tdbl * 8, s0));
+  }
   HlllX X;
+  X.Thi      = blocked ? h->xThi : nullptr;
+  X.Tlo      = (blocked && precision == 106) ? h->xTlo : nullptr;
   X.Rlo      = precision == 106 ? h->Rlo : nullptr;
   X.Vlo      = precision == 106 ? h->Vlo : nullptr;
   X.sc       = h->xsc;

@@ -53,6 +53,9 @@ struct HlllX
   double delta, theta;
   long long iter_cap;
   const int *only_failed;  // precision ladder: non-null = reduce only lattices whose entry is not 1
+  // blocked application of the reflectors (compact WY, householder.cpp:151-184 sixteen reflectors at a time):
+  // T of every block of 16 reflectors, [batch][ceil(d / 16)][16][16] (hi / lo planes); null = one by one
+  double *Thi, *Tlo;
 };
 
 // status: 1 RED_SUCCESS, -2 multiplier beyond 63 bits, -4 RED_HLLL_SR_FAILURE,
@@ -76,6 +79,10 @@ template <int NQ, class FT> __global__ void __launch_bounds__(64) hlll_x_kernel(
     const Plane<FT> nsb{sc, sc + d}, dR{sc + 2 * d, sc + 3 * d}, eR{sc + 4 * d, sc + 5 * d},
         prevR{sc + 6 * d, sc + 7 * d}, rdg{sc + 8 * d, sc + 9 * d};
     long long *prevE = X.prevE + (size_t)L * d;
+    const int nblk   = (d + 15) >> 4;
+    const bool blocked = X.Thi != nullptr;
+    const Plane<FT> Tm{blocked ? X.Thi + (size_t)L * nblk * 256 : nullptr,
+                       (blocked && X.Tlo) ? X.Tlo + (size_t)L * nblk * 256 : nullptr};
     const FT delta   = f_from(FT{}, X.delta), theta = f_from(FT{}, X.theta);
     FT Rk[NQ];  // the working row R[k], lane = column
 
@@ -186,6 +193,123 @@ template <int NQ, class FT> __global__ void __launch_bounds__(64) hlll_x_kernel(
         }
       }
     };
+    // The totals of 16 per-lane values over the wave in ONE butterfly (17 additions instead of 16 x 6): after the
+    // steps over lane bits 5..2 every lane holds one index, the steps over bits 1..0 finish it: lane l ends with
+    // the total of index (l >> 2) & 15.
+    auto reduce16 = [&](FT (&pp)[16]) -> FT
+    {
+      FT q8[8], q4[4], q2[2];
+      const bool b5 = (lane & 32) != 0, b4 = (lane & 16) != 0, b3 = (lane & 8) != 0, b2 = (lane & 4) != 0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        q8[u] = f_add(b5 ? pp[u + 8] : pp[u], f_shfl_xor(b5 ? pp[u] : pp[u + 8], 32));
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        q4[u] = f_add(b4 ? q8[u + 4] : q8[u], f_shfl_xor(b4 ? q8[u] : q8[u + 4], 16));
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        q2[u] = f_add(b3 ? q4[u + 2] : q4[u], f_shfl_xor(b3 ? q4[u] : q4[u + 2], 8));
+      FT q1 = f_add(b2 ? q2[1] : q2[0], f_shfl_xor(b2 ? q2[0] : q2[1], 4));
+      q1    = f_add(q1, f_shfl_xor(q1, 2));
+      q1    = f_add(q1, f_shfl_xor(q1, 1));
+      return q1;
+    };
+    // update_R(i, false) in BLOCKED form: the reflectors sixteen at a time, H_j0 ... H_j0+m-1 = I - V^T T V with T
+    // upper triangular (every H_j = I - v_j v_j^T, householder.cpp:168-175), so a row takes
+    //     x <- x - ((x V^T) T) V :  m independent dot products (one butterfly), a 16 x 16 triangle, m AXPYs
+    // instead of m dot products that each wait for the AXPY before them; then the signs of the block's columns
+    // (R(i,j) = sigma_j R(i,j), :176 — no later reflector touches column j).  Other roundings than one by one:
+    // this kernel's contract already (tree sums).
+    auto apply_reflectors_blocked = [&](int i)
+    {
+      for (int j0 = 0; j0 < i; j0 += 16)
+      {
+        const int m = min(16, i - j0);
+        const int K = j0 >> 4;
+        FT pp[16];
+#pragma unroll
+        for (int a = 0; a < 16; ++a)
+        {
+          pp[a] = zero;
+          if (a < m)
+          {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+            {
+              const int c = lane + 64 * q;
+              if (c < n)
+                pp[a] = f_add(pp[a], f_mul(V.ld((size_t)(j0 + a) * ld + c), Rk[q]));
+            }
+          }
+        }
+        const FT wv = reduce16(pp);
+        // y_b = sum_{a <= b} T[a][b] w_a in lane b
+        FT yb = zero;
+#pragma unroll
+        for (int a = 0; a < 16; ++a)
+        {
+          const FT wa = f_bcast(wv, 4 * a);
+          if (a < m && lane < m && a <= lane)
+            yb = f_add(yb, f_mul(Tm.ld((size_t)K * 256 + a * 16 + lane), wa));
+        }
+#pragma unroll
+        for (int bb = 0; bb < 16; ++bb)
+        {
+          const FT y = f_bcast(yb, bb);
+          if (bb < m)
+          {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+            {
+              const int c = lane + 64 * q;
+              if (c < n)
+                Rk[q] = f_sub(Rk[q], f_mul(y, V.ld((size_t)(j0 + bb) * ld + c)));
+            }
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+        {
+          const int c = lane + 64 * q;
+          if (c >= j0 && c < j0 + m)
+            Rk[q] = f_mul_d(Rk[q], sigma[c]);
+        }
+      }
+    };
+    // column (i mod 16) of the T of reflector i's block: T[0:m, m] = -T[0:m, 0:m] (V[j0 : j0+m] v_i), T[m][m] = 1
+    auto update_T = [&](int i, const FT (&vi)[NQ])
+    {
+      const int j0 = i & ~15, m = i & 15, K = i >> 4;
+      FT pp[16];
+#pragma unroll
+      for (int a = 0; a < 16; ++a)
+      {
+        pp[a] = zero;
+        if (a < m)
+        {
+#pragma unroll
+          for (int q = 0; q < NQ; ++q)
+          {
+            const int c = lane + 64 * q;
+            if (c < n)
+              pp[a] = f_add(pp[a], f_mul(V.ld((size_t)(j0 + a) * ld + c), vi[q]));
+          }
+        }
+      }
+      const FT g = reduce16(pp);
+      FT tv      = zero;
+#pragma unroll
+      for (int bb = 0; bb < 16; ++bb)
+      {
+        const FT gb = f_bcast(g, 4 * bb);
+        if (bb < m && lane < m && bb >= lane)
+          tv = f_add(tv, f_mul(Tm.ld((size_t)K * 256 + lane * 16 + bb), gb));
+      }
+      if (lane < m)
+        Tm.st((size_t)K * 256 + lane * 16 + m, f_neg(tv));
+      if (lane == m)
+        Tm.st((size_t)K * 256 + m * 16 + m, f_from(FT{}, 1.0));
+    };
     auto row_get = [&](int idx) -> FT
     {  // Rk[idx], wave-uniform idx
       FT r = zero;
@@ -228,10 +352,12 @@ template <int NQ, class FT> __global__ void __launch_bounds__(64) hlll_x_kernel(
         else
           new_rii = f_abs(rii);
       }
+      FT vi[NQ];
 #pragma unroll
       for (int q = 0; q < NQ; ++q)
       {
         const int c = lane + 64 * q;
+        vi[q]       = zero;
         if (c < n)
         {
           FT vv = zero;
@@ -239,12 +365,15 @@ template <int NQ, class FT> __global__ void __launch_bounds__(64) hlll_x_kernel(
             vv = vii;
           else if (c > i && scale)
             vv = f_div(Rk[q], f0);
+          vi[q] = vv;
           V.st((size_t)i * ld + c, vv);
           if (c == i)
             Rk[q] = new_rii;
           R.st((size_t)i * ld + c, Rk[q]);
         }
       }
+      if (blocked)
+        update_T(i, vi);
       if (lane == 0)
       {
         sigma[i] = sgi;
@@ -337,7 +466,10 @@ template <int NQ, class FT> __global__ void __launch_bounds__(64) hlll_x_kernel(
         // ---- size_reduction(k, k, 0), hlll.cpp:262-351
         {
           bool not_stop = true, prev_not_stop = true, fail = false;
-          apply_reflectors(k);
+          if (blocked)
+            apply_reflectors_blocked(k);
+          else
+            apply_reflectors(k);
           for (;;)
           {
             const int red = size_reduce(k);
@@ -357,7 +489,10 @@ template <int NQ, class FT> __global__ void __launch_bounds__(64) hlll_x_kernel(
             const long long expo1 = P.row_expo ? 2 * rexp[k] : 0;
             f0                    = f_ldexp(f_mul_d(f0, 0.1), (int)(expo0 - expo1));
             not_stop              = f_le(f1, f0);
-            apply_reflectors(k);
+            if (blocked)
+              apply_reflectors_blocked(k);
+            else
+              apply_reflectors(k);
             if (prev_not_stop || not_stop)
               prev_not_stop = not_stop;
             else

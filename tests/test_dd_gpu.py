@@ -173,6 +173,35 @@ def _reference_says_hlll_reduced(b):
         os.unlink(t.name)
 
 
+@pytest.mark.parametrize("name", ["hlll_q40", "hlll_q64"])
+def test_blocked_reflector_application_in_hlll(ctx, name, monkeypatch):
+    """FPHIP_HLLL_BLOCKED=1: update_R inside the HLLL loop in compact-WY form — the reflectors sixteen at a time with
+    a T per block kept current by update_R_last (hlll_x.hip: m independent dot products in one butterfly, a 16 x 16
+    triangle, m AXPYs).  Another order of the sums than one by one, the same decisions: the reference's output basis
+    and the swap count of the one-by-one mode, in double-double and in double.  (Opt-in: on config 5's lone wave it
+    is the slower of the two — the A/B is in DESIGN.md section 4d.)"""
+    from fplll_amd.householder import MatHouseholderBatch
+    path = os.path.join(C.GOLDEN, name + ".json")
+    if not os.path.exists(path):
+        pytest.skip("fixture absent")
+    f = C.load_hlll_fixture(path)
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("FPHIP_HLLL_BLOCKED", mode)
+        h = MatHouseholderBatch(ctx, 3, f["d"], f["n"], row_expo=True)
+        for prec in (106, 53):
+            h.set_basis(np.stack([f["b_in"]] * 3))
+            st, info = h.hlll(f["delta"], f["eta"], f["theta"], f["c"], precision=prec)
+            assert list(st) == [1, 1, 1]
+            res[(mode, prec)] = (h.get_basis(0, 3), [int(x[0]) for x in info])
+        h.close()
+    for prec in (106, 53):
+        (b0, s0), (b1, s1) = res[("0", prec)], res[("1", prec)]
+        assert all(np.array_equal(b1[L], f["b_out"]) for L in range(3)) or prec == 53
+        assert all(np.array_equal(b1[L], b0[L]) for L in range(3))
+        assert s0 == s1
+
+
 @pytest.mark.parametrize("path", C.hlll_fixtures(), ids=lambda p: os.path.basename(p)[:-5])
 def test_hlll_in_double_double_on_reference_fixtures(ctx, path):
     """hlll(precision=106) on the inputs of the reference fixtures: success, and the reference's
