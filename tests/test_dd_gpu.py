@@ -173,7 +173,7 @@ def _reference_says_hlll_reduced(b):
         os.unlink(t.name)
 
 
-@pytest.mark.parametrize("name", ["hlll_q40", "hlll_q64"])
+@pytest.mark.parametrize("name", ["hlll_q40", "hlll_q72"])
 def test_blocked_reflector_application_in_hlll(ctx, name, monkeypatch):
     """FPHIP_HLLL_BLOCKED=1: update_R inside the HLLL loop in compact-WY form — the reflectors sixteen at a time with
     a T per block kept current by update_R_last (hlll_x.hip: m independent dot products in one butterfly, a 16 x 16
