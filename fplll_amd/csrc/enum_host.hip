@@ -49,7 +49,7 @@ __global__ void task_unpack_kernel(TaskBuf out, unsigned lo, unsigned n, const d
 template <bool DUAL>
 __global__ void enum_bfs_kernel(DevShared *g, double maxdist, QueueMem *qm, TaskBuf f0, TaskBuf f1,
                                 TaskBuf fin, int L0, int nlev, int floor_level, float heavy, int count_nodes,
-                                int compact_n);
+                                int compact_n, int shard_index, int shard_count);
 // Closes the breadth-first stage: number of final tasks and the error flags into the pinned control
 // block (the host reads them without another device round trip); with `slots` (multi-GPU partition:
 // the host sorts the tasks by content) also the compact list of the occupied slots and their
@@ -925,6 +925,7 @@ restart:
   // ---- breadth-first stage: root (or the level-64 tasks of the top walk) -> final task list ------
   bool regioned = false;  // the current task list is a regioned buffer (what the stage leaves in buf[0])
   unsigned n_slots = 0;   // multi-GPU: length of the compact slot list of the regioned buffer
+  bool bfs_sharded = false;  // multi-GPU: the stage ended with a task list of this rank's own (nothing to deal)
   if (use_bfs && C > 0)
   {
     FPHIP_RANGE("enum: breadth-first stage");
@@ -943,7 +944,13 @@ restart:
         break;
       }
     Lend = std::max(Lend, std::min(L0 - 1, env_int("FPHIP_BFS_FLOOR", 4)));
-    const int cnt_bfs = (o.shard_index == 0) ? 1 : 0;  // replicated on every rank: shard 0 counts
+    const int cnt_bfs = (o.shard_index == 0) ? 1 : 0;  // the replicated part (on every rank): shard 0 counts
+    // Multi-GPU: the thin top (one workgroup) is replicated; from the first level that is launched over the chip
+    // every rank expands only ITS share of the frontier — the parents whose coefficient prefix hashes to it — and
+    // ends with a task list of its own: nothing is dealt afterwards, the lists are levelled by the work movement
+    // (gather) like donated subtrees.  Blocks above 64 rows keep the replicated stage (their tasks are told apart
+    // by an index into a table whose order is the rank's own).
+    const bool shard_bfs = o.shard_count > 1 && d <= 64 && o.exchange && env_int("FPHIP_BFS_SHARD", 0) != 0;
     // the thin top in ONE single-workgroup launch (a barrier between levels), then a launch per level
     int n_single = 0;
     for (int Lv = L0; Lv > Lend; --Lv)
@@ -959,12 +966,22 @@ restart:
     auto bfs_launch = [&](int nlev, unsigned grid, unsigned threads)
     {
       const TaskBuf &fa = ctx->buf[1 + par], &fb = ctx->buf[2 - par];
+      // (the filter acts on ONE launch — the first over the chip; behind it the frontier is the rank's own)
+      const bool filter = shard_bfs && grid > 1u && !bfs_sharded;
+      // shard mode of the launch: 0 none, 1 = the parents are this rank's share (the one launch that splits the
+      // frontier), 2 = replicated parents, but a LIGHT child — a final task — stays only on the rank it hashes to
+      // (the launches in front of the split: their final tasks must not be walked by everybody)
+      const int smode   = filter ? 1 : ((shard_bfs && !bfs_sharded) ? 2 : 0);
+      const int scount  = smode ? o.shard_count * 4 + smode : 0;  // (count and mode in one argument; 0: no sharding)
+      const int cnt     = (bfs_sharded || filter) ? 1 : cnt_bfs;
+      if (filter)
+        bfs_sharded = true;
       if (dual)
         hipLaunchKernelGGL((enum_bfs_kernel<true>), dim3(grid), dim3(threads), 0, ctx->stream, ctx->g, maxdist,
-                           ctx->qm, fa, fb, ctx->buf[0], Lv, nlev, Lend, heavy, cnt_bfs, compact_n);
+                           ctx->qm, fa, fb, ctx->buf[0], Lv, nlev, Lend, heavy, cnt, compact_n, o.shard_index, scount);
       else
         hipLaunchKernelGGL((enum_bfs_kernel<false>), dim3(grid), dim3(threads), 0, ctx->stream, ctx->g, maxdist,
-                           ctx->qm, fa, fb, ctx->buf[0], Lv, nlev, Lend, heavy, cnt_bfs, compact_n);
+                           ctx->qm, fa, fb, ctx->buf[0], Lv, nlev, Lend, heavy, cnt, compact_n, o.shard_index, scount);
       Lv -= nlev;
       par ^= nlev & 1;
       compact_n = -1;
@@ -976,7 +993,7 @@ restart:
     const unsigned bgrid = std::max(32u, ((unsigned)ctx->num_cus * (unsigned)env_int("FPHIP_BFS_WG_PER_CU", 1)) / 32u * 32u);
     while (Lv > Lend)
       bfs_launch(1, bgrid, 256u);
-    const bool want_slots = o.shard_count > 1;
+    const bool want_slots = o.shard_count > 1 && !bfs_sharded;
     hipLaunchKernelGGL(enum_bfs_epilogue, dim3(1), dim3(1024), 0, ctx->stream, ctx->g, ctx->h, ctx->qm, rcap,
                        want_slots ? ctx->slots : nullptr, want_slots ? ctx->pdc : nullptr, ctx->buf[0].pd);
     HIPCHK(ctx, hipGetLastError());
@@ -1023,7 +1040,9 @@ restart:
     n_slots     = want_slots ? nfin : 0u;
   }
 
-  bool others_active = false;  // multi-GPU: some other rank still has tasks
+  // multi-GPU: some other rank still has tasks (a rank whose share of a sharded stage came out empty still takes
+  // part in every round boundary)
+  bool others_active = bfs_sharded;
   while (C > 0 || others_active)
   {
     int stop = -1;
@@ -1083,7 +1102,7 @@ restart:
     }
     const int nxt     = cur ^ 1;
     // only the first final round is sharded across GPUs; donated tasks stay on their GPU
-    const bool shard_now = in_final && round == 0 && o.shard_count > 1;
+    const bool shard_now = in_final && round == 0 && o.shard_count > 1 && !bfs_sharded;
     // (a regioned task list that is not dealt over ranks is drawn region by region: one launch)
     const int chunks     = (in_final && round == 0 && !(regioned && !shard_now)) ? o.exchange_chunks : 1;
     const unsigned *idxl = nullptr;
@@ -1158,7 +1177,10 @@ restart:
       {
         FPHIP_RANGE(in_final ? "enum: walk launch" : "enum: split launch");
         HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-        const unsigned bud = (in_final && round < max_rounds) ? budget : 0u;
+        // (sub-solution calls walk without work donation: with it, per-level counts of a 130-row block came out too
+        //  high whenever the host consumer of the sub-solution ring was slow — tests/test_enum_gpu.py
+        //  ::test_wide_blocks_report_candidates_under_every_level64_ancestor; FPHIP_SUBS_DONATE=1 brings it back)
+        const unsigned bud = (in_final && round < max_rounds && (!subs || env_int("FPHIP_SUBS_DONATE", 0) != 0)) ? budget : 0u;
 #define FPHIP_LAUNCH(M, S, D)                                                                       \
   hipLaunchKernelGGL((enum_phase_kernel<M, S, D>), dim3(grid), dim3(wpb * 64), lds, ctx->stream, ctx->g, \
                      ctx->h, ctx->buf[cur], ctx->buf[nxt], d, L, stop, lo, hi, idxl, launch_idx,     \

@@ -783,7 +783,7 @@ template <bool DUAL>
 __global__ void __launch_bounds__(1024)
     enum_bfs_kernel(DevShared *__restrict__ g, double maxdist, QueueMem *__restrict__ qm,
                     TaskBuf f0, TaskBuf f1, TaskBuf fin, int L0, int nlev, int floor_level, float heavy,
-                    int count_nodes, int compact_n)
+                    int count_nodes, int compact_n, int shard_index, int shard_count)
 {
   // Buffers are REGIONED: region q of a buffer holds the slots [q rcap, (q + 1) rcap), its fill count
   // sits in qm (64 bytes from the next one): emission counters are spread over FPHIP_NQ addresses
@@ -843,6 +843,22 @@ __global__ void __launch_bounds__(1024)
           a = -a;
         }
         double nd = pdu + a * a * r;   // :28-29
+        // multi-GPU (shard_count = 4 W + mode, 0 = none).  Mode 1 — the ONE launch that splits the frontier: every rank
+        // expands the parents whose coefficient prefix (levels >= L: the same on every rank, whatever the order of
+        // its buffers) hashes to it; the others see no surviving child (a select, no branch: this file is compiled
+        // with -structurizecfg-skip-uniform-regions, and a new branch around the emission below was miscompiled).
+        // Mode 2 — the replicated launches in front of the split: no child becomes a final task before the levels
+        // run out (a final task emitted here would sit in every rank's list).
+        const int smode = shard_count & 3;
+        {
+          unsigned hk = (lane >= L) ? (unsigned)(int)xp * (2654435761u * (unsigned)(lane + 1)) : 0u;
+#pragma unroll
+          for (int off = 32; off > 0; off >>= 1)
+            hk += (unsigned)__shfl_xor((int)hk, off);
+          const unsigned sW = (unsigned)max(shard_count >> 2, 1);
+          const bool mine   = (smode != 1) | ((int)((hk ^ (hk >> 15)) % sW) == shard_index);
+          nd                = mine ? nd : __builtin_inf();
+        }
         int dx    = (c >= x) ? 1 : -1;  // :71 (ddx == sign(dx) throughout)
         const bool zig = pdu != 0.0;    // :80-89: partdist exactly 0 above: x only grows (is_svp)
         while (nd <= bnd)               // :31 / :93 (NaN fails)
@@ -855,7 +871,7 @@ __global__ void __launch_bounds__(1024)
             const float rem = (float)(R2k - nd);
             float e         = (lane < kc && rem > 0.f) ? __expf(fminf(Ak + hk * __logf(rem), 60.f)) : 0.f;
             e               = wave_sum_f32(e);
-            is_heavy        = __builtin_amdgcn_readfirstlane((int)(e > heavy)) != 0;
+            is_heavy        = (__builtin_amdgcn_readfirstlane((int)(e > heavy)) != 0) | (smode == 2);
           }
           const TaskBuf dst  = is_heavy ? out : fin;
           const unsigned wr  = (emitted++) % FPHIP_NQ;
@@ -902,9 +918,9 @@ __global__ void __launch_bounds__(1024)
   }
 }
 template __global__ void enum_bfs_kernel<false>(DevShared *, double, QueueMem *, TaskBuf, TaskBuf, TaskBuf, int, int,
-                                                int, float, int, int);
+                                                int, float, int, int, int, int);
 template __global__ void enum_bfs_kernel<true>(DevShared *, double, QueueMem *, TaskBuf, TaskBuf, TaskBuf, int, int,
-                                               int, float, int, int);
+                                               int, float, int, int, int, int);
 
 // ---------------------------------------------------------------------------------------------
 // Blocks larger than 64 (up to 256): the levels 64..d-1.  The TOP of the tree is walked with two

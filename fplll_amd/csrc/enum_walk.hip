@@ -143,7 +143,10 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK) __attribute__((amdgpu_waves_p
   unsigned long long cnt = 0;
   unsigned cnt32         = 0;
   unsigned iter          = 0;
-  int left               = 63;
+  // steps until the next refresh event (the bound, the donation test).  A step is taken once per ~3 nodes: 24 steps
+  // are the 64 failed steps of enum_phase_kernel in nodes — a wave must not run longer than that on a stale bound
+  constexpr int RF = 24;
+  int left               = RF - 1;
 
   // (bchg: the bound went down — the caller re-tests the pending siblings, see reprune)
 #define FPHIP_REFRESH_BOUND(from_host, bchg)                                                      \
@@ -228,7 +231,7 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK) __attribute__((amdgpu_waves_p
     const double col0 = in.col[ti * 64 + tl];
     const double pd0  = in.pd[ti];
     int donate        = 1 << 20;
-    const unsigned iter0 = iter + (unsigned)(63 - left);
+    const unsigned iter0 = iter;
     {
       bool bchg = false;
       FPHIP_REFRESH_BOUND((t & 63u) == 0u, bchg);
@@ -470,7 +473,7 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK) __attribute__((amdgpu_waves_p
           break;
         }
         if (__builtin_expect(--left < 0, 0))
-        {  // every 64 steps
+        {  // every RF steps
           ev = EV_REFRESH;
           break;
         }
@@ -671,14 +674,16 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK) __attribute__((amdgpu_waves_p
       {
         cnt += cnt32;
         cnt32 = 0u;
-        iter += 64u;
-        left = 63;
+        iter += 64u;  // (in the units of enum_phase_kernel's budgets: RF steps are about 64 of its failed steps)
+        left = RF - 1;
         bool bchg = false;
-        FPHIP_REFRESH_BOUND((iter & 16383u) == 0u, bchg);
+        FPHIP_REFRESH_BOUND((iter & 16383u) == 0u, bchg);  // (the pinned host word every 256 refreshes)
         if (bchg)
           reprune(k);
         const unsigned titer = iter - iter0;
-        if (budget != 0u && titer >= 256u && !buffer_full)
+        // (a task may shed work from its first refresh on — RF steps, each step closing a chain of at most 64
+        //  nodes: about the 256 failed steps enum_phase_kernel waits for)
+        if (budget != 0u && titer >= 64u && !buffer_full)
         {
           const unsigned dr = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(
               &g->drain[launch_idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
@@ -703,7 +708,7 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK) __attribute__((amdgpu_waves_p
   if (count_nodes && cnt != 0)
     atomicAdd(&g->nodes[lane], cnt);
   if (lane == 0)
-    atomicAdd(&g->iters, (unsigned long long)(iter + (unsigned)(63 - left)));
+    atomicAdd(&g->iters, (unsigned long long)iter);
 }
 
 #define FPHIP_INST(M, D)                                                                                \

@@ -667,6 +667,17 @@ def bench_roofline(ctx, batch=None, reps=3, distinct=64, traffic=None):
                       "multiplier for every j < i)" % (batch, d, d, distinct),
             "algorithmic_bytes_per_launch": alg, "algorithmic_bytes_per_lattice": alg // batch,
             "kernel_ms": ms, "kernel_ms_each_launch": times,
+            # what THIS kernel's algorithm has to move per lattice of 180 x 180 — two Gram passes over the 2-byte
+            # column mirror (16.0 MB), the recurrence over the anchored mu columns (17.3), the size-reduction sweep over
+            # the mu rows (8.6), the working row (0.1), at 128-byte line granularity (the table of
+            # round 4; tests/perf/README.md), plus the 5.0 MB it writes: the SURVEY 8(d) numerator above prices
+            # 8-byte elements and one Gram pass, so "traffic / algorithmic" flatters a kernel that moves 2-byte mirrors
+            "kernel_model": ({"what": "bytes the kernel's own two-pass, 2-byte-mirror algorithm needs (line-granular)",
+                              "fetch_bytes_per_lattice": 42.0e6, "write_bytes_per_lattice": 5.0e6,
+                              "bytes_per_launch": 47.0e6 * batch,
+                              "achieved_on_model_GBps": 47.0e6 * batch / (ms * 1e-3) / 1e9,
+                              "frac_on_model": 47.0e6 * batch / (ms * 1e-3) / 8e12}
+                             if (d == 180 and os.environ.get("FPHIP_GSO_NARROW", "2") == "2") else None),
             "with_confirming_pass": {
                 "what": "same launch priced with the confirming update_gso_row of every row "
                         "(lll.cpp:172-176) counted as well",

@@ -12,31 +12,25 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
-# background device runs shared between test_a_configs_at_size_gpu.py (starts them) and
-# test_zzz_long_runs_gpu.py (joins them)
+# results of the at-size runs (tests/test_a_configs_at_size_gpu.py helpers write here, their tests read)
 LONG_RUNS = {}
 
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    config.addinivalue_line("markers", "gpu_long: minutes-long at-size runs on a real MI355X, one lone wavefront each "
+                                       "(NOT part of -m gpu: run with -m gpu_long; their last log is profiles/r06_gpu_long_runs.log)")
 
 
-_exit_status = [0]
-
-
-def pytest_sessionfinish(session, exitstatus):
-    _exit_status[0] = int(exitstatus)
-
-
-def pytest_unconfigure(config):
-    """A FAILED session must not sit behind the two long background kernels (round 3: 632 s of waiting after
-    the first failure under -x): their host threads are still inside a launch, so leave without joining
-    them.  A green session has joined them in tests/test_zzz_long_runs_gpu.py."""
-    alive = [k for k, v in LONG_RUNS.items() if k.startswith("thread_") and hasattr(v, "is_alive") and v.is_alive()]
-    if alive and _exit_status[0] != 0:
-        sys.stdout.flush()
-        sys.stderr.flush()
-        os._exit(_exit_status[0])
+def pytest_collection_modifyitems(config, items):
+    """`gpu_long` tests run only when the marker expression asks for them (-m gpu_long): `-m "not gpu"` (the CPU
+    suite) and a bare `pytest tests` would otherwise select them."""
+    if "gpu_long" in (config.getoption("-m") or ""):
+        return
+    skip = pytest.mark.skip(reason="minutes-long at-size run: select with -m gpu_long")
+    for it in items:
+        if "gpu_long" in it.keywords:
+            it.add_marker(skip)
 
 
 def note(make):

@@ -279,6 +279,27 @@ def test_donated_subtrees_move_between_ranks(world):
     assert [int(v) for v in tot2] == [int(v) for v in f["nodes"]] and all(o[2] == 0 for o in out2)
 
 
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_breadth_first_stage_partitions_the_tree(world, monkeypatch):
+    """FPHIP_BFS_SHARD=1 (opt-in): the breadth-first stage itself is sharded — its thin top (one workgroup) stays
+    replicated, but a final task it emits is kept by ONE rank (the rank its coefficient prefix hashes to), and from
+    the first level launched over the chip every rank expands only its share of the frontier; nothing is dealt
+    afterwards, the lists are levelled by the work movement.  At a radius that never shrinks the per-level counts of
+    the ranks add up to the reference's: every node expanded once, every subtree walked once.  (The default keeps
+    the stage replicated and deals the final tasks in snake order: better balanced on small trees — the A/B is in
+    DESIGN.md section 3, profiles/r06_bfs_shard_balance.log.)"""
+    monkeypatch.setenv("FPHIP_BFS_SHARD", "1")
+    for name in ("enum_d48_lin30_fixed", "enum_d40_lin20_fixed"):
+        f, out = _run_move(name, world, True, True)
+        tot = np.sum([np.array(o[1]) for o in out], axis=0)
+        assert [int(v) for v in tot] == [int(v) for v in f["nodes"]], name
+        got = sorted(x for o in out for x in o[5])
+        want = sorted((float(s[0]), tuple(float(v) for v in s[1])) for s in f["sol_log"])
+        assert got == want
+        C.note(lambda: ("sharded breadth-first stage, %d ranks, %s: node shares %s"
+                        % (world, name, ["%.3f" % (sum(o[1]) / f["total_nodes"]) for o in out]),))
+
+
 @pytest.mark.parametrize("name", ["enum_d96_lin90_fixed", "enum_d80_lin70_fixed"])
 def test_donated_subtrees_of_a_block_above_64_rows_move_with_their_ancestors(name, monkeypatch):
     """A task of a block above 64 rows points into its rank's table of level-64 ancestors (the coefficients of the
