@@ -63,13 +63,13 @@ fphip_ctx *g_ctx = nullptr;
 struct Totals  // FPLLL_HIP_STATS=1: printed when the process exits
 {
   double secs = 0, kernel_ms = 0;
-  unsigned long long calls = 0, declined = 0, nodes = 0;
+  unsigned long long calls = 0, declined = 0, nodes = 0, moved = 0;
   ~Totals()
   {
     if (getenv("FPLLL_HIP_STATS") && (calls || declined))
       fprintf(stderr, "[fplll_hip] %llu enumerations on the device (%llu declined): %.3f s in the plugin, "
-                      "%.3f s of kernels, %.3e nodes\n",
-              calls, declined, secs, kernel_ms * 1e-3, (double)nodes);
+                      "%.3f s of kernels, %.3e nodes, %llu subtree tasks moved between devices\n",
+              calls, declined, secs, kernel_ms * 1e-3, (double)nodes, moved);
   }
 } g_totals;
 std::mutex g_mutex;  // fplll's global hook is process-wide and unsynchronised (enumerate_ext.cpp:32-37)
@@ -213,6 +213,70 @@ struct HostExchange
   }
 };
 
+// The all-gather of byte blocks of the work movement (fphip_enum_opts::gather) among the host threads of the
+// in-process multi-device mode: every participant deposits its block, leaves with the blocks of all of them in
+// shard order.  Blocks are staged in buffers of the collective (two sets, by the parity of the round: a thread is
+// never more than one round ahead of the slowest); a participant that has left contributes an empty block.
+struct HostGather
+{
+  std::mutex m;
+  std::condition_variable cv;
+  int world = 0, expected = 0, arrived = 0;
+  unsigned long long generation = 0;
+  std::vector<std::vector<char>> stage[2];
+  std::vector<size_t> size[2];
+  void init(int w)
+  {
+    world = expected = w;
+    for (int p = 0; p < 2; ++p)
+    {
+      stage[p].assign(w, std::vector<char>());
+      size[p].assign(w, 0);
+    }
+  }
+  void release_locked()
+  {
+    arrived = 0;
+    ++generation;
+    cv.notify_all();
+  }
+  int gather(int index, const void *send, size_t send_bytes, void *recv, size_t recv_cap, size_t *sizes)
+  {
+    std::unique_lock<std::mutex> lk(m);
+    const unsigned long long gen = generation;
+    const int par                = (int)(gen & 1);
+    if (arrived == 0)
+      for (int r = 0; r < world; ++r)
+        size[par][r] = 0;
+    stage[par][index].assign((const char *)send, (const char *)send + send_bytes);
+    size[par][index] = send_bytes;
+    ++arrived;
+    if (arrived >= expected)
+      release_locked();
+    else
+      cv.wait(lk, [&] { return generation != gen; });
+    size_t off = 0;
+    for (int r = 0; r < world; ++r)
+    {
+      const size_t n = size[par][r];
+      if (off + n > recv_cap)
+        return 1;
+      if (n)
+        memcpy((char *)recv + off, stage[par][r].data(), n);
+      sizes[r] = n;
+      off += n;
+    }
+    return 0;
+  }
+  void leave()
+  {
+    std::lock_guard<std::mutex> lk(m);
+    --expected;
+    if (arrived > 0 && arrived >= expected)
+      release_locked();
+  }
+};
+
 struct MultiShared
 {
   std::mutex cb_mutex;  // fplll's callbacks, one at a time
@@ -223,6 +287,7 @@ struct MultiShared
   long delivered = 0;
   const std::vector<fphip_ctx *> *ctxs;
   HostExchange ex;
+  HostGather ga;
 };
 struct ShardUser
 {
@@ -272,6 +337,11 @@ double multi_sol(void *user, double dist, const double *sol)
 double multi_exchange(void *user, double local_bound, int local_active, int *any_active)
 {
   return static_cast<ShardUser *>(user)->sh->ex.exchange(local_bound, local_active, any_active);
+}
+int multi_gather(void *user, const void *send, size_t send_bytes, void *recv, size_t recv_cap, size_t *sizes)
+{
+  ShardUser *u = static_cast<ShardUser *>(user);
+  return u->sh->ga.gather(u->index, send, send_bytes, recv, recv_cap, sizes);
 }
 
 fphip_ctx *context()
@@ -342,6 +412,11 @@ nodes_array_t fplll_hip_extenum(const int dim, enumf maxdist, std::function<cb_s
     sh.dual        = dual;
     sh.ctxs        = &multi;
     sh.ex.expected = W;
+    sh.ga.init(W);
+    // work movement between the devices (donated subtrees levelled at every round boundary, like the ranks of the
+    // torch.distributed mode): FPLLL_HIP_MOVE=0 keeps every donated subtree on its device
+    const char *mv   = getenv("FPLLL_HIP_MOVE");
+    const bool move  = !(mv && mv[0] == '0');
     std::vector<ShardUser> users(W);
     std::vector<std::vector<std::uint64_t>> nodes(W, std::vector<std::uint64_t>(dim + 1, 0));
     std::vector<fphip_enum_stats> stats(W);
@@ -360,10 +435,13 @@ nodes_array_t fplll_hip_extenum(const int dim, enumf maxdist, std::function<cb_s
             o.exchange        = multi_exchange;
             o.exchange_user   = &users[i];
             o.exchange_chunks = 4;
+            o.gather          = move ? multi_gather : nullptr;
+            o.gather_user     = &users[i];
             rcs[i] = fphip_enum_run(multi[i], dim, maxdist, mu.data(), rdiag.data(), pruning.data(), &o,
                                     multi_sol, findsubsols ? multi_subsol : nullptr, &users[i], nodes[i].data(),
                                     &stats[i]);
             sh.ex.leave();
+            sh.ga.leave();
           });
     }
     for (auto &t : th)
@@ -386,6 +464,7 @@ nodes_array_t fplll_hip_extenum(const int dim, enumf maxdist, std::function<cb_s
     {
       kmax = stats[i].kernel_ms > kmax ? stats[i].kernel_ms : kmax;
       g_totals.nodes += stats[i].total_nodes;
+      g_totals.moved += stats[i].moved_tasks;
     }
     g_totals.kernel_ms += kmax;
     if (failed)

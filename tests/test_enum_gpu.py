@@ -10,6 +10,7 @@ inputs.  Contract:
 """
 import json
 import os
+import re
 
 import numpy as np
 import pytest
@@ -424,6 +425,18 @@ def test_plugin_in_process_multi_device():
             out = subprocess.run([drv, "plugin", so] + c.split(), capture_output=True, text=True,
                                  timeout=600, env=env)
             assert out.returncode == 0, (devs, c, out.stdout[-2000:], out.stderr[-2000:])
+    # the work movement between the devices of the process (the shim's all-gather among its host threads, the role
+    # of make_gather between torch.distributed ranks): on by default above; here with tiny donation budgets so that
+    # subtrees DO move (the totals say so), and switched off — the reference's counts either way
+    c = cases[0][0]
+    for mv in ("1", "0"):
+        env = dict(os.environ, FPLLL_HIP_DEVICES="0,0", FPLLL_HIP_MOVE=mv, FPLLL_HIP_STATS="1", FPHIP_BUDGET="256",
+                   FPHIP_MOVE_FRACTION="1000000000")
+        out = subprocess.run([drv, "plugin", so] + c.split(), capture_output=True, text=True, timeout=600, env=env)
+        assert out.returncode == 0, (mv, out.stdout[-2000:], out.stderr[-2000:])
+        m = re.search(r"(\d+) subtree tasks moved between devices", out.stderr)
+        assert m, out.stderr[-1500:]
+        assert (int(m.group(1)) > 0) == (mv == "1"), (mv, m.group(0))
 
 
 def _dual_inputs(mut, rdiag):
