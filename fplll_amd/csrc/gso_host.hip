@@ -63,6 +63,7 @@ struct HlllX
   long long iter_cap;
   const int *only_failed;
   double *Thi, *Tlo;
+  double *Rx, *Vx;
 };
 template <int NQ, class FT> __global__ void hlll_x_kernel(HhBatch P, HlllX X);
 struct LllX
@@ -2644,6 +2645,7 @@ struct fphip_hh
   double *Rlo, *Vlo, *xsc;
   long long *xprevE;
   double *xThi = nullptr, *xTlo = nullptr;  // hlll_x: T of every block of 16 reflectors (blocked application)
+  double *xRx = nullptr, *xVx = nullptr;    // hlll_x in quad-double: components 2 and 3 of R and V
 };
 
 #define HCHK(call)                     \
@@ -2741,6 +2743,10 @@ extern "C" void fphip_hh_destroy(fphip_hh *h)
     fphip_dev_free(h->xThi, fphip_ctx_stream(h->ctx));
   if (h->xTlo)
     fphip_dev_free(h->xTlo, fphip_ctx_stream(h->ctx));
+  if (h->xRx)
+    fphip_dev_free(h->xRx, fphip_ctx_stream(h->ctx));
+  if (h->xVx)
+    fphip_dev_free(h->xVx, fphip_ctx_stream(h->ctx));
   delete h;
 }
 
@@ -2923,9 +2929,10 @@ extern "C" int fphip_hh_hlll(fphip_hh *h, double delta, double eta, double theta
 static int hh_hlll_ex(fphip_hh *h, double delta, double theta, int precision, const int *d_only_failed,
                       int *status, int *info)
 {
-  if (!h || (precision != 53 && precision != 106))
+  if (!h || (precision != 53 && precision != 106 && precision != 212))
     return FPHIP_ERROR;
   const size_t B = (size_t)h->P.batch, d = h->P.d, ld = h->P.ldn;
+  const bool wide = precision >= 106;  // a low plane of R and V
   if (!h->P.bf)
   {
     HCHK(fphip_dev_alloc((void **)&h->P.bf, B * d * ld * 8 + 4096, fphip_ctx_stream(h->ctx)));
@@ -2934,21 +2941,31 @@ static int hh_hlll_ex(fphip_hh *h, double delta, double theta, int precision, co
   }
   if (!h->xsc)
   {
-    HCHK(fphip_dev_alloc((void **)&h->xsc, B * 10 * d * sizeof(double), fphip_ctx_stream(h->ctx)));
+    HCHK(fphip_dev_alloc((void **)&h->xsc, B * 20 * d * sizeof(double), fphip_ctx_stream(h->ctx)));
     HCHK(fphip_dev_alloc((void **)&h->xprevE, B * d * sizeof(long long), fphip_ctx_stream(h->ctx)));
   }
-  if (precision == 106 && !h->Rlo)
+  if (wide && !h->Rlo)
   {
     HCHK(fphip_dev_alloc((void **)&h->Rlo, B * d * ld * 8 + 4096, fphip_ctx_stream(h->ctx)));
     HCHK(fphip_dev_alloc((void **)&h->Vlo, B * d * ld * 8 + 4096, fphip_ctx_stream(h->ctx)));
   }
   hipStream_t s0 = fphip_ctx_stream(h->ctx);
-  HCHK(hipMemsetAsync(h->xsc, 0, B * 10 * d * sizeof(double), s0));
+  HCHK(hipMemsetAsync(h->xsc, 0, B * 20 * d * sizeof(double), s0));
   HCHK(hipMemsetAsync(h->xprevE, 0, B * d * sizeof(long long), s0));
-  if (precision == 106)
+  if (wide)
   {
     HCHK(hipMemsetAsync(h->Rlo, 0, B * d * ld * 8 + 4096, s0));
     HCHK(hipMemsetAsync(h->Vlo, 0, B * d * ld * 8 + 4096, s0));
+  }
+  if (precision == 212)
+  {  // quad-double (the device stand-in for FP_NR<qd_real>, the ladder's third stage): two more planes each
+    if (!h->xRx)
+    {
+      HCHK(fphip_dev_alloc((void **)&h->xRx, 2 * B * d * ld * 8 + 4096, s0));
+      HCHK(fphip_dev_alloc((void **)&h->xVx, 2 * B * d * ld * 8 + 4096, s0));
+    }
+    HCHK(hipMemsetAsync(h->xRx, 0, 2 * B * d * ld * 8 + 4096, s0));
+    HCHK(hipMemsetAsync(h->xVx, 0, 2 * B * d * ld * 8 + 4096, s0));
   }
   // the reflectors sixteen at a time (compact WY with a T per block, hlll_x.hip): opt-in, FPHIP_HLLL_BLOCKED=1.
   // Built for the lone-wave latency of config 5 and measured SLOWER there (n = 256, one lattice: 60.0 s against
@@ -2956,7 +2973,7 @@ static int hh_hlll_ex(fphip_hh *h, double delta, double theta, int precision, co
   // dependent reductions is 16 times shorter, but every block waits for its 16 rows of V, its column of T and its
   // signs out of L2, where the one-by-one loop has the next row in flight behind each tree sum.
   const char *hb     = getenv("FPHIP_HLLL_BLOCKED");
-  const bool blocked = hb && hb[0] == '1';
+  const bool blocked = hb && hb[0] == '1' && precision != 212;
   const size_t tdbl  = B * ((d + 15) / 16) * 256;
   if (blocked)
   {
@@ -2971,8 +2988,10 @@ static int hh_hlll_ex(fphip_hh *h, double delta, double theta, int precision, co
   HlllX X;
   X.Thi      = blocked ? h->xThi : nullptr;
   X.Tlo      = (blocked && precision == 106) ? h->xTlo : nullptr;
-  X.Rlo      = precision == 106 ? h->Rlo : nullptr;
-  X.Vlo      = precision == 106 ? h->Vlo : nullptr;
+  X.Rlo      = wide ? h->Rlo : nullptr;
+  X.Vlo      = wide ? h->Vlo : nullptr;
+  X.Rx       = precision == 212 ? h->xRx : nullptr;
+  X.Vx       = precision == 212 ? h->xVx : nullptr;
   X.sc       = h->xsc;
   X.prevE    = h->xprevE;
   X.delta    = delta;
@@ -2985,7 +3004,15 @@ static int hh_hlll_ex(fphip_hh *h, double delta, double theta, int precision, co
     grid = fphip_ctx_num_cus(h->ctx) * 8;
   hipStream_t s = fphip_ctx_stream(h->ctx);
   HCHK(hipEventRecord(h->ev[0], s));
-  if (precision == 106)
+  if (precision == 212)
+    switch (nq)
+    {
+    case 1: hipLaunchKernelGGL((hlll_x_kernel<1, QD>), dim3(grid), dim3(64), 0, s, h->P, X); break;
+    case 2: hipLaunchKernelGGL((hlll_x_kernel<2, QD>), dim3(grid), dim3(64), 0, s, h->P, X); break;
+    case 3: hipLaunchKernelGGL((hlll_x_kernel<3, QD>), dim3(grid), dim3(64), 0, s, h->P, X); break;
+    default: hipLaunchKernelGGL((hlll_x_kernel<4, QD>), dim3(grid), dim3(64), 0, s, h->P, X); break;
+    }
+  else if (precision == 106)
     switch (nq)
     {
     case 1: hipLaunchKernelGGL((hlll_x_kernel<1, DD>), dim3(grid), dim3(64), 0, s, h->P, X); break;
@@ -3025,8 +3052,9 @@ extern "C" int fphip_hh_hlll_ex(fphip_hh *h, double delta, double eta, double th
 // 478-529: double, then the wider types, each stage continuing from the basis the previous one
 // left) on the device: stage 1 = the exact-order double kernel for the whole batch; the lattices it
 // gives up on with a precision alarm (RED_HLLL_SR_FAILURE -4, RED_HLLL_NORM_FAILURE -5) go on in
-// double-double.  stage[batch] (nullable) = 53 or 106: where each lattice ended.  A lattice that
-// fails at 106 bits keeps its status: the caller's MPFR stage (fplll's CPU path) is next.
+// double-double, and those it gives up on in quad-double (round 6).  stage[batch] (nullable) = 53, 106 or 212:
+// where each lattice ended.  A lattice that fails at 212 bits keeps its status: the caller's MPFR stage (fplll's
+// CPU path) is next.
 extern "C" int fphip_hh_hlll_ladder(fphip_hh *h, double delta, double eta, double theta, double c, int *status,
                                     int *info, int *stage)
 {
@@ -3044,7 +3072,7 @@ extern "C" int fphip_hh_hlll_ladder(fphip_hh *h, double delta, double eta, doubl
   // FPHIP_HLLL_LADDER_TEST=1 (tests only): treat the odd lattices as if stage 1 had raised an alarm, so
   // that the escalation path runs on inputs where plain doubles never fail (row exponents make the
   // double stage very robust: no long-sized lattice tried here trips it)
-  const bool force = getenv("FPHIP_HLLL_LADDER_TEST") && atoi(getenv("FPHIP_HLLL_LADDER_TEST")) == 1;
+  const bool force = getenv("FPHIP_HLLL_LADDER_TEST") && atoi(getenv("FPHIP_HLLL_LADDER_TEST")) >= 1;
   if (force)
     for (size_t L = 1; L < B; L += 2)
       if (st[L] == 1)
@@ -3073,6 +3101,38 @@ extern "C" int fphip_hh_hlll_ladder(fphip_hh *h, double delta, double eta, doubl
         inf[2 * L] += inf2[2 * L];
         inf[2 * L + 1] += inf2[2 * L + 1];
       }
+    // third stage (wrapper.cpp:630-710: FT_QD behind FT_DD): the lattices double-double gave up on, in quad-double
+    // (FPHIP_HLLL_LADDER_TEST=2, tests only: every fourth lattice as if stage 2 had raised an alarm)
+    const bool force3 = getenv("FPHIP_HLLL_LADDER_TEST") && atoi(getenv("FPHIP_HLLL_LADDER_TEST")) == 2;
+    if (force3)
+      for (size_t L = 3; L < B; L += 4)
+        if (!mask[L] && st[L] == 1)
+          st[L] = -4;
+    bool any3 = false;
+    for (size_t L = 0; L < B; ++L)
+      any3 |= (!mask[L] && (st[L] == -4 || st[L] == -5));
+    if (any3)
+    {
+      std::vector<int> st3(B, 0), inf3(2 * B, 0), mask3(B);
+      for (size_t L = 0; L < B; ++L)
+        mask3[L] = (!mask[L] && (st[L] == -4 || st[L] == -5)) ? 0 : 1;
+      int *d_mask3 = nullptr;
+      HCHK(fphip_dev_alloc((void **)&d_mask3, B * sizeof(int), fphip_ctx_stream(h->ctx)));
+      hipError_t e3 = hipMemcpy(d_mask3, mask3.data(), B * sizeof(int), hipMemcpyHostToDevice);
+      rc = (e3 == hipSuccess) ? hh_hlll_ex(h, delta, theta, 212, d_mask3, st3.data(), inf3.data()) : FPHIP_ERROR;
+      fphip_dev_free(d_mask3, fphip_ctx_stream(h->ctx));
+      if (rc != FPHIP_OK)
+        return rc;
+      ms += h->last_ms;
+      for (size_t L = 0; L < B; ++L)
+        if (!mask3[L])
+        {
+          st[L]  = st3[L];
+          stg[L] = 212;
+          inf[2 * L] += inf3[2 * L];
+          inf[2 * L + 1] += inf3[2 * L + 1];
+        }
+    }
   }
   h->last_ms = ms;
   if (status)

@@ -25,16 +25,17 @@
 namespace fphip
 {
 
+// a [rows][ld] array of FT values as one plane of doubles per component (hi, lo, and two more for quad-double)
 template <class FT> struct Plane;
 template <> struct Plane<double>
 {
-  double *hi, *lo;
+  double *hi, *lo, *x2, *x3;
   __device__ __forceinline__ double ld(size_t i) const { return hi[i]; }
   __device__ __forceinline__ void st(size_t i, double v) const { hi[i] = v; }
 };
 template <> struct Plane<DD>
 {
-  double *hi, *lo;
+  double *hi, *lo, *x2, *x3;
   __device__ __forceinline__ DD ld(size_t i) const { return DD{hi[i], lo[i]}; }
   __device__ __forceinline__ void st(size_t i, DD v) const
   {
@@ -42,13 +43,26 @@ template <> struct Plane<DD>
     lo[i] = v.lo;
   }
 };
+template <> struct Plane<QD>
+{
+  double *hi, *lo, *x2, *x3;
+  __device__ __forceinline__ QD ld(size_t i) const { return QD{{hi[i], lo[i], x2[i], x3[i]}}; }
+  __device__ __forceinline__ void st(size_t i, QD v) const
+  {
+    hi[i] = v.x[0];
+    lo[i] = v.x[1];
+    x2[i] = v.x[2];
+    x3[i] = v.x[3];
+  }
+};
 
 struct HlllX
 {
-  // R, V: [batch][d][ldn] in two planes each (lo planes unused for double); bf has no low part
+  // R, V: [batch][d][ldn] in up to four planes each (P.R / P.V, Rlo / Vlo, and for quad-double Rx / Vx: two more
+  // planes back to back); bf has no low part
   double *Rlo, *Vlo;
-  // per lattice scalars, [batch][d] each: norm_square_b, dR, eR, prev_R, R(i,i) (hi / lo planes)
-  double *sc;  // [batch][10][d]
+  // per lattice scalars, [batch][d] each: norm_square_b, dR, eR, prev_R, R(i,i) (four component planes each)
+  double *sc;  // [batch][20][d]
   long long *prevE;
   double delta, theta;
   long long iter_cap;
@@ -56,6 +70,7 @@ struct HlllX
   // blocked application of the reflectors (compact WY, householder.cpp:151-184 sixteen reflectors at a time):
   // T of every block of 16 reflectors, [batch][ceil(d / 16)][16][16] (hi / lo planes); null = one by one
   double *Thi, *Tlo;
+  double *Rx, *Vx;  // quad-double: components 2 and 3 of R and V ([2][batch][d][ldn] each)
 };
 
 // status: 1 RED_SUCCESS, -2 multiplier beyond 63 bits, -4 RED_HLLL_SR_FAILURE,
@@ -73,16 +88,17 @@ template <int NQ, class FT> __global__ void __launch_bounds__(64) hlll_x_kernel(
     double *bf      = P.bf + (size_t)L * d * ld;
     double *sigma   = P.sigma + (size_t)L * d;
     long long *rexp = P.rexp + (size_t)L * d;
-    const Plane<FT> R{P.R + (size_t)L * d * ld, X.Rlo ? X.Rlo + (size_t)L * d * ld : nullptr};
-    const Plane<FT> V{P.V + (size_t)L * d * ld, X.Vlo ? X.Vlo + (size_t)L * d * ld : nullptr};
-    double *sc = X.sc + (size_t)L * 10 * d;
-    const Plane<FT> nsb{sc, sc + d}, dR{sc + 2 * d, sc + 3 * d}, eR{sc + 4 * d, sc + 5 * d},
-        prevR{sc + 6 * d, sc + 7 * d}, rdg{sc + 8 * d, sc + 9 * d};
+    const size_t pl = (size_t)P.batch * d * ld, lo0 = (size_t)L * d * ld;
+    const Plane<FT> R{P.R + lo0, X.Rlo ? X.Rlo + lo0 : nullptr, X.Rx ? X.Rx + lo0 : nullptr, X.Rx ? X.Rx + pl + lo0 : nullptr};
+    const Plane<FT> V{P.V + lo0, X.Vlo ? X.Vlo + lo0 : nullptr, X.Vx ? X.Vx + lo0 : nullptr, X.Vx ? X.Vx + pl + lo0 : nullptr};
+    double *sc = X.sc + (size_t)L * 20 * d;
+    auto scal = [&](int q) { return Plane<FT>{sc + (4 * q) * d, sc + (4 * q + 1) * d, sc + (4 * q + 2) * d, sc + (4 * q + 3) * d}; };
+    const Plane<FT> nsb = scal(0), dR = scal(1), eR = scal(2), prevR = scal(3), rdg = scal(4);
     long long *prevE = X.prevE + (size_t)L * d;
     const int nblk   = (d + 15) >> 4;
     const bool blocked = X.Thi != nullptr;
     const Plane<FT> Tm{blocked ? X.Thi + (size_t)L * nblk * 256 : nullptr,
-                       (blocked && X.Tlo) ? X.Tlo + (size_t)L * nblk * 256 : nullptr};
+                       (blocked && X.Tlo) ? X.Tlo + (size_t)L * nblk * 256 : nullptr, nullptr, nullptr};
     const FT delta   = f_from(FT{}, X.delta), theta = f_from(FT{}, X.theta);
     FT Rk[NQ];  // the working row R[k], lane = column
 
@@ -650,6 +666,10 @@ template __global__ void hlll_x_kernel<1, DD>(HhBatch, HlllX);
 template __global__ void hlll_x_kernel<2, DD>(HhBatch, HlllX);
 template __global__ void hlll_x_kernel<3, DD>(HhBatch, HlllX);
 template __global__ void hlll_x_kernel<4, DD>(HhBatch, HlllX);
+template __global__ void hlll_x_kernel<1, QD>(HhBatch, HlllX);
+template __global__ void hlll_x_kernel<2, QD>(HhBatch, HlllX);
+template __global__ void hlll_x_kernel<3, QD>(HhBatch, HlllX);
+template __global__ void hlll_x_kernel<4, QD>(HhBatch, HlllX);
 
 // ---------------------------------------------------------------------------------------------
 // Unit-test kernel for ftx.h: out[i] = a[i] (op) b[i] in double-double, one element per thread.

@@ -85,7 +85,8 @@ class MatHouseholderBatch:
     def hlll(self, delta=0.99, eta=0.51, theta=0.001, c=0.1, precision=None):
         """HLLLReduction::hlll() on every lattice (fplll/hlll.cpp:26-169).
         precision None: the exact-order double kernel (bit-identical decisions); 106: double-double
-        arithmetic (FP_NR<dd_real>'s stand-in), 53: double — both with tree sums (hlll_x.hip).
+        arithmetic (FP_NR<dd_real>'s stand-in), 212: quad-double (FP_NR<qd_real>'s), 53: double — all with tree sums
+        (hlll_x.hip).
         Returns (status[batch], info[batch][2] = swaps, iterations)."""
         st = np.zeros(self.batch, dtype=np.int32)
         info = np.zeros((self.batch, 2), dtype=np.int32)
@@ -101,7 +102,8 @@ class MatHouseholderBatch:
 
     def hlll_ladder(self, delta=0.99, eta=0.51, theta=0.001, c=0.1):
         """The wrapper's precision ladder on the device: double for the batch, double-double for the
-        lattices that raise a precision alarm.  Returns (status, info, stage[batch] in {53, 106})."""
+        lattices that raise a precision alarm, quad-double for those it gives up on (wrapper.cpp:478-529, 630-710).
+        Returns (status, info, stage[batch] in {53, 106, 212})."""
         st = np.zeros(self.batch, dtype=np.int32)
         info = np.zeros((self.batch, 2), dtype=np.int32)
         stage = np.zeros(self.batch, dtype=np.int32)

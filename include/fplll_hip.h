@@ -493,7 +493,9 @@ int fphip_hh_hlll(fphip_hh *h, double delta, double eta, double theta, double c,
  * diagonal are scratch, exactly as in the reference */
 /* HLLL in a selectable floating-point type: precision 106 = double-double arithmetic on the device
  * (the stand-in for FP_NR<dd_real>, fplll/nr/nr_FP_dd.inl: BASELINE config 5 as stated; libqd's
- * algorithms restated, csrc/ftx.h), precision 53 = plain double.  Same algorithm (hlll.cpp:26-499),
+ * algorithms restated, csrc/ftx.h), precision 212 = quad-double (the stand-in for FP_NR<qd_real>,
+ * fplll/nr/nr_FP_qd.inl: the third stage of the wrapper's ladder, wrapper.cpp:630-710), precision 53 = plain
+ * double.  Same algorithm (hlll.cpp:26-499),
  * status and info as fphip_hh_hlll; dot products and norms are wave-level tree sums, so results
  * are the reference's up to rounding — decisions carry ~50 bits of slack at 106 bits.  After a
  * precision-106 run R(i,j) = fphip_hh_get_R + fphip_hh_get_R_lo. */

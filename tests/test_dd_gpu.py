@@ -173,6 +173,45 @@ def _reference_says_hlll_reduced(b):
         os.unlink(t.name)
 
 
+@pytest.mark.parametrize("name", ["hlll_q40", "hlll_r30", "hlll_u24"])
+def test_hlll_in_quad_double_on_reference_fixtures(ctx, name):
+    """hlll(precision=212): the reference's algorithm in QUAD-double arithmetic on the device (ftx.h QD, the stand-in
+    for FP_NR<qd_real>: the third stage of the wrapper's ladder, wrapper.cpp:630-710) — success, the reference's
+    output basis (which fplll returns in double, long double and MPFR alike on these inputs) and the swap count of
+    the double-double run."""
+    from fplll_amd.householder import MatHouseholderBatch
+    f = C.load_hlll_fixture(os.path.join(C.GOLDEN, name + ".json"))
+    h = MatHouseholderBatch(ctx, 2, f["d"], f["n"], row_expo=True)
+    swaps = {}
+    for prec in (106, 212):
+        h.set_basis(np.stack([f["b_in"]] * 2))
+        st, info = h.hlll(f["delta"], f["eta"], f["theta"], f["c"], precision=prec)
+        assert list(st) == [1, 1]
+        out = h.get_basis(0, 2)
+        assert np.array_equal(out[0], f["b_out"]) and np.array_equal(out[1], f["b_out"])
+        swaps[prec] = int(info[0][0])
+        C.note(lambda: ("%s precision %d: %d swaps, %.1f ms" % (name, prec, swaps[prec], h.last_kernel_ms),))
+    assert swaps[106] == swaps[212]
+    h.close()
+
+
+def test_precision_ladder_reaches_quad_double(ctx, monkeypatch):
+    """fphip_hh_hlll_ladder with its third stage: FPHIP_HLLL_LADDER_TEST=2 pretends the odd lattices failed in
+    double and every fourth also in double-double, so that they go on in quad-double from the basis the stage before
+    left — every lattice ends on the reference's basis, the stages are 53 / 106 / 53 / 212 / ..."""
+    from fplll_amd.householder import MatHouseholderBatch
+    f = C.load_hlll_fixture(os.path.join(C.GOLDEN, "hlll_q40.json"))
+    monkeypatch.setenv("FPHIP_HLLL_LADDER_TEST", "2")
+    h = MatHouseholderBatch(ctx, 8, f["d"], f["n"], row_expo=True)
+    h.set_basis(np.stack([f["b_in"]] * 8))
+    st, info, stage = h.hlll_ladder(f["delta"], f["eta"], f["theta"], f["c"])
+    assert list(st) == [1] * 8
+    assert list(stage) == [53, 106, 53, 212, 53, 106, 53, 212]
+    out = h.get_basis(0, 8)
+    assert all(np.array_equal(out[L], f["b_out"]) for L in range(8))
+    h.close()
+
+
 @pytest.mark.parametrize("name", ["hlll_q40", "hlll_q72"])
 def test_blocked_reflector_application_in_hlll(ctx, name, monkeypatch):
     """FPHIP_HLLL_BLOCKED=1: update_R inside the HLLL loop in compact-WY form — the reflectors sixteen at a time with
