@@ -74,6 +74,7 @@ struct LllX
   double *mu_hi, *mu_lo;
   double *r_hi, *r_lo;
   double *gf_hi, *gf_lo;
+  double *mu_x, *r_x, *gf_x;
   long long *rexp;
   int *status, *info;
   const int *only_failed;
@@ -113,6 +114,7 @@ struct fphip_gso
   fphip_ctx *ectx;    // hand-off mode of the strategy-BKZ kernel: the enumeration context (same device)
   std::vector<fphip_ctx *> ectx_more;  // … and the further ones of a BATCH of tours (one per hand-off worker)
   double *xbuf;       // lll_x.hip workspace: bf rows [B][d][ldn], then the low planes of mu, r, gf [B][d][ldd] each
+  int xbuf_planes = 0;  // ... 3 of them, or 9 once a quad-double run has asked for components 2 and 3
   // in-loop pruning of the strategy-BKZ service (FPHIP_BKZ_PRUNE_IN_LOOP; fphip_gso_bkz_inloop_pruning)
   double il_preproc = 1e6, il_target = 0.5;
   int il_min_block = 24, il_flags = 0x4 /* PRUNER_GRADIENT */, il_device = 1;
@@ -904,7 +906,7 @@ extern "C" int fphip_gso_session_read(fphip_gso *g, int lattice, int64_t *b, dou
 static int gso_lll_ex(fphip_gso *g, int kappa_min, int kappa_start, int kappa_end, double delta, double eta,
                       int precision, const int *d_only_failed, int *status, int *info)
 {
-  if (!g || (precision != 53 && precision != 106))
+  if (!g || (precision != 53 && precision != 106 && precision != 212))
     return FPHIP_ERROR;
   if (kappa_end < 0)
     kappa_end = g->P.d;
@@ -919,9 +921,20 @@ static int gso_lll_ex(fphip_gso *g, int kappa_min, int kappa_start, int kappa_en
   const size_t B = (size_t)g->P.batch, d = g->P.d, ldd = g->P.ldd, ldn = g->P.ldn;
   hipStream_t s = fphip_ctx_stream(g->ctx);
   const size_t n_bf = B * d * ldn, n_pl = B * d * ldd;
+  // (bf, then the low planes of mu / r / gf, then — quad-double — two more planes of each)
+  const int planes = precision == 212 ? 9 : 3;
+  if (g->xbuf && g->xbuf_planes < planes)
+  {
+    fphip_dev_free(g->xbuf, s);
+    g->xbuf = nullptr;
+  }
   if (!g->xbuf)
-    GCHK(fphip_dev_alloc((void **)&g->xbuf, (n_bf + 3 * n_pl) * sizeof(double) + 4096, s));
-  GCHK(hipMemsetAsync(g->xbuf, 0, (n_bf + 3 * n_pl) * sizeof(double), s));
+  {
+    GCHK(fphip_dev_alloc((void **)&g->xbuf, (n_bf + planes * n_pl) * sizeof(double) + 4096, s));
+    g->xbuf_planes = planes;
+  }
+  GCHK(hipMemsetAsync(g->xbuf, 0, (n_bf + planes * n_pl) * sizeof(double), s));
+  const bool wide = precision >= 106;
   LllX A;
   A.batch    = g->P.batch;
   A.d        = g->P.d;
@@ -933,11 +946,14 @@ static int gso_lll_ex(fphip_gso *g, int kappa_min, int kappa_start, int kappa_en
   A.b2       = g->P.b2;
   A.bf       = g->xbuf;
   A.mu_hi    = g->P.mu;
-  A.mu_lo    = precision == 106 ? g->xbuf + n_bf : nullptr;
+  A.mu_lo    = wide ? g->xbuf + n_bf : nullptr;
   A.r_hi     = g->P.r;
-  A.r_lo     = precision == 106 ? g->xbuf + n_bf + n_pl : nullptr;
+  A.r_lo     = wide ? g->xbuf + n_bf + n_pl : nullptr;
   A.gf_hi    = g->P.gf;
-  A.gf_lo    = precision == 106 ? g->xbuf + n_bf + 2 * n_pl : nullptr;
+  A.gf_lo    = wide ? g->xbuf + n_bf + 2 * n_pl : nullptr;
+  A.mu_x     = precision == 212 ? g->xbuf + n_bf + 3 * n_pl : nullptr;
+  A.r_x      = precision == 212 ? g->xbuf + n_bf + 5 * n_pl : nullptr;
+  A.gf_x     = precision == 212 ? g->xbuf + n_bf + 7 * n_pl : nullptr;
   A.rexp     = g->P.rexp;
   A.status   = g->P.status;
   A.info     = g->P.lll_info;
@@ -955,7 +971,15 @@ static int gso_lll_ex(fphip_gso *g, int kappa_min, int kappa_start, int kappa_en
   if (grid > fphip_ctx_num_cus(g->ctx) * 8)
     grid = fphip_ctx_num_cus(g->ctx) * 8;
   GCHK(hipEventRecord(g->ev[0], s));
-  if (precision == 106)
+  if (precision == 212)
+    switch (nq)
+    {
+    case 1: hipLaunchKernelGGL((lll_x_kernel<1, QD>), dim3(grid), dim3(64), 0, s, A); break;
+    case 2: hipLaunchKernelGGL((lll_x_kernel<2, QD>), dim3(grid), dim3(64), 0, s, A); break;
+    case 3: hipLaunchKernelGGL((lll_x_kernel<3, QD>), dim3(grid), dim3(64), 0, s, A); break;
+    default: hipLaunchKernelGGL((lll_x_kernel<4, QD>), dim3(grid), dim3(64), 0, s, A); break;
+    }
+  else if (precision == 106)
     switch (nq)
     {
     case 1: hipLaunchKernelGGL((lll_x_kernel<1, DD>), dim3(grid), dim3(64), 0, s, A); break;
@@ -1004,8 +1028,8 @@ extern "C" int fphip_gso_lll_ex(fphip_gso *g, int kappa_min, int kappa_start, in
 // fast_lll<double>, then the wider types, each on the basis the failed attempt left) with both
 // stages on the device: the exact-order double kernel (lll_kernel.hip) for the whole batch, then
 // double-double (lll_x.hip) for the lattices that stopped with RED_GSO_FAILURE (0), RED_BABAI_FAILURE
-// (-1) or RED_LLL_FAILURE (-3).  stage[batch] (nullable): 53 or 106.  A lattice that fails at 106 bits
-// keeps its status: the caller's MPFR stage (fplll's CPU path) is next.
+// (-1) or RED_LLL_FAILURE (-3), then quad-double for those it gives up on (round 6).  stage[batch] (nullable): 53,
+// 106 or 212.  A lattice that fails at 212 bits keeps its status: the caller's MPFR stage (fplll's CPU path) is next.
 extern "C" int fphip_gso_lll_ladder(fphip_gso *g, int kappa_min, int kappa_start, int kappa_end, double delta,
                                     double eta, int *status, int *info, int *stage)
 {
@@ -1022,6 +1046,10 @@ extern "C" int fphip_gso_lll_ladder(fphip_gso *g, int kappa_min, int kappa_start
   float ms = g->last_ms;
   bool any = false;
   std::vector<int> mask(B);
+  if (getenv("FPHIP_LLL_LADDER_TEST") && atoi(getenv("FPHIP_LLL_LADDER_TEST")) >= 1)
+    for (size_t L = 1; L < B; L += 2)  // (tests only: the odd lattices as if the double stage had failed)
+      if (st[L] == 1)
+        st[L] = -1;
   for (size_t L = 0; L < B; ++L)
   {
     const bool failed = (st[L] == 0 || st[L] == -1 || st[L] == -3);
@@ -1049,6 +1077,41 @@ extern "C" int fphip_gso_lll_ladder(fphip_gso *g, int kappa_min, int kappa_start
         for (int t = 0; t < 4; ++t)
           inf[4 * L + t] = (t == 0 || t == 2) ? inf2[4 * L + t] : inf[4 * L + t] + inf2[4 * L + t];
       }
+    // third stage (Wrapper::lll goes on to fast_lll<qd_real>, wrapper.cpp:331-339): quad-double for the lattices
+    // double-double gave up on (FPHIP_LLL_LADDER_TEST=2, tests only: every fourth lattice as if it had)
+    if (getenv("FPHIP_LLL_LADDER_TEST") && atoi(getenv("FPHIP_LLL_LADDER_TEST")) == 2)
+      for (size_t L = 3; L < B; L += 4)
+        if (!mask[L] && st[L] == 1)
+          st[L] = -1;
+    std::vector<int> mask3(B);
+    bool any3 = false;
+    for (size_t L = 0; L < B; ++L)
+    {
+      const bool failed = !mask[L] && (st[L] == 0 || st[L] == -1 || st[L] == -3);
+      mask3[L]          = failed ? 0 : 1;
+      any3 |= failed;
+    }
+    if (any3)
+    {
+      std::vector<int> st3(B, 0), inf3(4 * B, 0);
+      int *d_mask3 = nullptr;
+      GCHK(fphip_dev_alloc((void **)&d_mask3, B * sizeof(int), fphip_ctx_stream(g->ctx)));
+      hipError_t e3 = hipMemcpy(d_mask3, mask3.data(), B * sizeof(int), hipMemcpyHostToDevice);
+      rc = (e3 == hipSuccess) ? gso_lll_ex(g, kappa_min, kappa_min, kappa_end, delta, eta, 212, d_mask3, st3.data(), inf3.data())
+                              : FPHIP_ERROR;
+      fphip_dev_free(d_mask3, fphip_ctx_stream(g->ctx));
+      if (rc != FPHIP_OK)
+        return rc;
+      ms += g->last_ms;
+      for (size_t L = 0; L < B; ++L)
+        if (!mask3[L])
+        {
+          st[L]  = st3[L];
+          stg[L] = 212;
+          for (int t = 0; t < 4; ++t)
+            inf[4 * L + t] = (t == 0 || t == 2) ? inf3[4 * L + t] : inf[4 * L + t] + inf3[4 * L + t];
+        }
+    }
   }
   g->last_ms = ms;
   if (status)

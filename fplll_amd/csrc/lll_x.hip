@@ -36,6 +36,7 @@ struct LllX
   double *mu_hi, *mu_lo;  // [batch][d][ldd]: row = slot, column = position
   double *r_hi, *r_lo;
   double *gf_hi, *gf_lo;  // [batch][d][ldd]: Gram cache, entry (max slot, min slot); hi NaN = unknown
+  double *mu_x, *r_x, *gf_x;  // quad-double: components 2 and 3 of the three arrays (two planes back to back each)
   long long *rexp;        // [batch][d] by slot
   int *status, *info;     // info[4]: final_kappa, n_swaps, zeros, iterations
   const int *only_failed; // precision ladder: non-null = only the lattices whose entry is not 1
@@ -46,18 +47,30 @@ struct LllX
 template <class FT> struct PlaneX;
 template <> struct PlaneX<double>
 {
-  double *hi, *lo;
+  double *hi, *lo, *x2, *x3;
   __device__ __forceinline__ double ld(size_t i) const { return hi[i]; }
   __device__ __forceinline__ void st(size_t i, double v) const { hi[i] = v; }
 };
 template <> struct PlaneX<DD>
 {
-  double *hi, *lo;
+  double *hi, *lo, *x2, *x3;
   __device__ __forceinline__ DD ld(size_t i) const { return DD{hi[i], lo[i]}; }
   __device__ __forceinline__ void st(size_t i, DD v) const
   {
     hi[i] = v.hi;
     lo[i] = v.lo;
+  }
+};
+template <> struct PlaneX<QD>
+{
+  double *hi, *lo, *x2, *x3;
+  __device__ __forceinline__ QD ld(size_t i) const { return QD{{hi[i], lo[i], x2[i], x3[i]}}; }
+  __device__ __forceinline__ void st(size_t i, QD v) const
+  {
+    hi[i] = v.x[0];
+    lo[i] = v.x[1];
+    x2[i] = v.x[2];
+    x3[i] = v.x[3];
   }
 };
 
@@ -67,6 +80,7 @@ template <int NQ, class FT> __global__ void __launch_bounds__(64) lll_x_kernel(L
 {
   __shared__ int slot[256], vcol[256];
   __shared__ double lov_hi[257], lov_lo[257], rd_hi[256], rd_lo[256];
+  __shared__ double lov_x2[257], lov_x3[257], rd_x2[256], rd_x3[256];  // (quad-double)
   const int lane = threadIdx.x & 63;
   const int dT = A.d, n = A.n, ldn = A.ldn, ldd = A.ldd;
   const FT zero = f_from(FT{}, 0.0);
@@ -77,15 +91,20 @@ template <int NQ, class FT> __global__ void __launch_bounds__(64) lll_x_kernel(L
       continue;
     long long *b = A.b + (size_t)L * dT * ldn;
     double *bf   = A.bf + (size_t)L * dT * ldn;
-    const PlaneX<FT> mu{A.mu_hi + (size_t)L * dT * ldd, A.mu_lo ? A.mu_lo + (size_t)L * dT * ldd : nullptr};
-    const PlaneX<FT> r{A.r_hi + (size_t)L * dT * ldd, A.r_lo ? A.r_lo + (size_t)L * dT * ldd : nullptr};
-    const PlaneX<FT> gf{A.gf_hi + (size_t)L * dT * ldd, A.gf_lo ? A.gf_lo + (size_t)L * dT * ldd : nullptr};
+    const size_t po = (size_t)L * dT * ldd, pp = (size_t)A.batch * dT * ldd;
+    const PlaneX<FT> mu{A.mu_hi + po, A.mu_lo ? A.mu_lo + po : nullptr, A.mu_x ? A.mu_x + po : nullptr, A.mu_x ? A.mu_x + pp + po : nullptr};
+    const PlaneX<FT> r{A.r_hi + po, A.r_lo ? A.r_lo + po : nullptr, A.r_x ? A.r_x + po : nullptr, A.r_x ? A.r_x + pp + po : nullptr};
+    const PlaneX<FT> gf{A.gf_hi + po, A.gf_lo ? A.gf_lo + po : nullptr, A.gf_x ? A.gf_x + po : nullptr, A.gf_x ? A.gf_x + pp + po : nullptr};
     long long *rexp = A.rexp + (size_t)L * dT;
     PlaneX<FT> lov, rd;  // (LDS: assigned at run time — an aggregate of shared addresses is no constant)
     lov.hi = lov_hi;
     lov.lo = lov_lo;
     rd.hi  = rd_hi;
     rd.lo  = rd_lo;
+    lov.x2 = lov_x2;
+    lov.x3 = lov_x3;
+    rd.x2  = rd_x2;
+    rd.x3  = rd_x3;
 
     // ---- state: identity slots, nothing valid, Gram cache empty ---------------------------------
     for (int p = lane; p < dT; p += 64)
@@ -637,5 +656,9 @@ template __global__ void lll_x_kernel<1, DD>(LllX);
 template __global__ void lll_x_kernel<2, DD>(LllX);
 template __global__ void lll_x_kernel<3, DD>(LllX);
 template __global__ void lll_x_kernel<4, DD>(LllX);
+template __global__ void lll_x_kernel<1, QD>(LllX);
+template __global__ void lll_x_kernel<2, QD>(LllX);
+template __global__ void lll_x_kernel<3, QD>(LllX);
+template __global__ void lll_x_kernel<4, QD>(LllX);
 
 }  // namespace fphip

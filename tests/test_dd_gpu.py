@@ -342,6 +342,36 @@ def test_lll_in_double_double_and_plain_double_tree_order(ctx, name):
     g.close()
 
 
+@pytest.mark.parametrize("name", ["lll_q40", "lll_u24"])
+def test_lll_in_quad_double_and_the_three_stage_ladder(ctx, name, monkeypatch):
+    """fphip_gso_lll_ex at 212 bits (quad-double, the stand-in for FP_NR<qd_real>: Wrapper::lll's third fast type):
+    the reference's basis and swap count on well-conditioned fixtures, like the double-double run; and
+    fphip_gso_lll_ladder with its third stage (FPHIP_LLL_LADDER_TEST=2 pretends the odd lattices failed in double and
+    every fourth in double-double): stages 53 / 106 / 53 / 212, every lattice on the reference's basis."""
+    from fplll_amd.gso import MatGSOBatch
+    f = C.load_lll_fixture(os.path.join(C.GOLDEN, name + ".json"))
+    g = MatGSOBatch(ctx, 2, f["d"], f["n"])
+    g.set_basis(np.stack([f["b_in"]] * 2))
+    st, info = g.lll_ex(212, f["kmin"], f["kstart"], f["kend"], f["delta"], f["eta"])
+    out = g.get_basis(0, 2)
+    assert list(st) == [1, 1], (st, info)
+    assert np.array_equal(out[0], f["b_out"]) and np.array_equal(out[1], f["b_out"])
+    assert int(info[0][1]) == f["n_swaps"]
+    C.note(lambda: ("%s at 212 bits: %d swaps, %.1f ms" % (name, int(info[0][1]), g.last_kernel_ms),))
+    g.close()
+    if f["kmin"] != 0 or f["kstart"] != 0:
+        return
+    monkeypatch.setenv("FPHIP_LLL_LADDER_TEST", "2")
+    g = MatGSOBatch(ctx, 8, f["d"], f["n"])
+    g.set_basis(np.stack([f["b_in"]] * 8))
+    st, info, stage = g.lll_ladder(f["kmin"], f["kstart"], f["kend"], f["delta"], f["eta"])
+    assert list(st) == [1] * 8
+    assert list(stage) == [53, 106, 53, 212, 53, 106, 53, 212]
+    out = g.get_basis(0, 8)
+    assert all(np.array_equal(out[L], f["b_out"]) for L in range(8))
+    g.close()
+
+
 def _rows_in_qary_lattice(b_in, b_out):
     """b_in = [[I, H], [0, q I]] (q-ary / NTRU-like generator): every row (x, y) of b_out lies in its
     lattice iff y = x H (mod q).  With equal volumes (basisstat) that is lattice equality."""
