@@ -215,6 +215,31 @@ def test_blocks_larger_than_64_vs_oracle(ctx, d, seed, rf):
     assert [s[0] for s in ev1.solutions] == [s[0] for s in ev1o.solutions]
 
 
+@pytest.mark.parametrize("fat,d,seed,maxdist,rfat", [(2, 10, 5, 3.0, 5e-4), (1, 9, 6, 3.0, 4e-4), (3, 11, 7, 2.5, 6e-4),
+                                                     (5, 12, 8, 2.2, 8e-4)])
+def test_nodes_with_more_than_63_children(ctx, fat, d, seed, maxdist, rfat):
+    """One level with a tiny r_kk: every node above it has 60-140 surviving children there.  The walk kernel tests
+    the first 63 candidates of a node in one ballot and takes the siblings by index; beyond them (`more`), and on
+    the chain of first children below the all-zero prefix (x only grows: `grow`), it tests one by one like the
+    reference (enumerate_base.cpp:80-94).  Fat level 1, 2, 3: inside the walk (the breadth-first stage stops at level
+    4); fat level 5: inside the breadth-first stage.  Per-level counts and the candidate multiset are the oracle's."""
+    from fplll_amd.enumeration import FastEvaluator, enumerate_block
+    mut, rdiag, _ = C.synthetic_block(d, seed, 0.0, 1.0)
+    rdiag = rdiag.copy()
+    rdiag[fat] = rfat
+    ev, ev_o = FastEvaluator(10**9, 0), FastEvaluator(10**9, 0)
+    res = enumerate_block(ctx, mut, rdiag, None, maxdist, ev)
+    nodes_o, _ = C.oracle_enumerate(mut, rdiag, None, maxdist, ev_o)
+    assert [int(v) for v in res.nodes] == [int(v) for v in nodes_o]
+    assert int(nodes_o[fat]) > 40 * max(1, int(nodes_o[fat + 1]))  # (40-70 children per node on average, up to 140)
+    assert sorted((s[0], tuple(s[1])) for s in ev.solutions) == sorted((s[0], tuple(s[1])) for s in ev_o.solutions)
+    # ... and with a shrinking radius: the reference's final norm
+    ev1, ev1o = FastEvaluator(1, 0), FastEvaluator(1, 0)
+    enumerate_block(ctx, mut, rdiag, None, maxdist, ev1)
+    C.oracle_enumerate(mut, rdiag, None, maxdist, ev1o)
+    assert [s[0] for s in ev1.solutions] == [s[0] for s in ev1o.solutions]
+
+
 def _dist_from(mut, rdiag, x, off=0):
     """Squared length of the projection (levels >= off) of the vector with coefficients x."""
     d = len(rdiag)
