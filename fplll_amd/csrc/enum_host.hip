@@ -43,6 +43,10 @@ __global__ void enum_walk_kernel(DevShared *g, HostCtl *h, TaskBuf in, TaskBuf o
                                  unsigned task_hi, const unsigned *idxlist, int launch_idx, int count_nodes,
                                  unsigned budget, const double *xhi_root, double *gstk, int Tsplit, unsigned *qh,
                                  const unsigned *rcnt, unsigned rcap, unsigned long long bound_init);
+// enum_deal.hip: the content-sorted snake deal of a multi-rank call on the device
+size_t deal_work_bytes(unsigned n);
+unsigned deal_tasks_device(hipStream_t s, const unsigned long long *keys, const double *pd, const unsigned *slot_of,
+                           unsigned n, unsigned W, unsigned rank, unsigned *mine, void *work, size_t work_bytes);
 __global__ void task_pack_kernel(TaskBuf in, unsigned lo, unsigned n, double *rec, const double *xhi_root, int xstr);
 __global__ void task_unpack_kernel(TaskBuf out, unsigned lo, unsigned n, const double *rec, double *xhi_root, int xstr,
                                    unsigned root_base);
@@ -138,6 +142,8 @@ struct fphip_ctx
   unsigned long long ring_next = 0;
   unsigned long long *keys     = nullptr;  // device: content key per task (multi-GPU partition)
   unsigned *idxlist            = nullptr;  // device: this rank's task indices, heaviest first
+  void *deal_work              = nullptr;  // device: scratch of the device-side deal (enum_deal.hip)
+  size_t deal_work_bytes       = 0;
   double *xhi_root             = nullptr;  // device: cap * 64 doubles: the coefficients of levels >= 64 per level-64
                                            // ancestor (blocks larger than 64; 64 doubles per started chunk of levels)
   QueueMem *qm                 = nullptr;  // device: ticket / emission counters of the current call
@@ -345,6 +351,8 @@ extern "C" void fphip_destroy(fphip_ctx *ctx)
     fphip_dev_free(ctx->keys, ctx->stream);
   if (ctx->idxlist)
     fphip_dev_free(ctx->idxlist, ctx->stream);
+  if (ctx->deal_work)
+    fphip_dev_free(ctx->deal_work, ctx->stream);
   if (ctx->g)
     fphip_dev_free(ctx->g, ctx->stream);
   // Wait for the stream BEFORE the pinned buffers go back to the process-wide cache: after an error
@@ -1123,6 +1131,29 @@ restart:
       hipLaunchKernelGGL(task_key_kernel, dim3(kgrid ? kgrid : 1), dim3(256), 0, ctx->stream,
                          ctx->buf[cur], C, d, ctx->keys, ctx->xhi_root, via_slots ? ctx->slots : nullptr);
       HIPCHK(ctx, hipGetLastError());
+      if (env_int("FPHIP_DEAL_HOST", 0) == 0)
+      {
+        // sort and deal on the device (enum_deal.hip): no copy of the keys to the host, no host sort (6-9 ms for
+        // 65 536 tasks, on every rank, in front of a walk of 41 ms at eight GPUs)
+        const size_t need = deal_work_bytes(C);
+        if (ctx->deal_work_bytes < need)
+        {
+          if (ctx->deal_work)
+            fphip_dev_free(ctx->deal_work, ctx->stream);
+          ctx->deal_work = nullptr;
+          HIPCHK(ctx, fphip_dev_alloc(&ctx->deal_work, need, ctx->stream));
+          ctx->deal_work_bytes = need;
+        }
+        n_list = deal_tasks_device(ctx->stream, ctx->keys, via_slots ? ctx->pdc : ctx->buf[cur].pd,
+                                   via_slots ? ctx->slots : nullptr, C, (unsigned)o.shard_count, (unsigned)o.shard_index,
+                                   ctx->idxlist, ctx->deal_work, ctx->deal_work_bytes);
+        if (n_list == ~0u)
+          return fail(ctx, "the device-side deal of the task list failed");
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        idxl = ctx->idxlist;
+      }
+      else
+      {
       HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
       std::vector<unsigned long long> keys(C);
       std::vector<double> pds(C);
@@ -1156,6 +1187,7 @@ restart:
       if (n_list)
         HIPCHK(ctx, hipMemcpy(ctx->idxlist, mine.data(), (size_t)n_list * 4, hipMemcpyHostToDevice));
       idxl = ctx->idxlist;
+      }
     }
     const int count_nodes = (in_final || o.shard_index == 0) ? 1 : 0;
     HIPCHK(ctx, hipMemsetAsync(ctx->buf[nxt].count, 0, 4, ctx->stream));
