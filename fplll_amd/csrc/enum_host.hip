@@ -1080,8 +1080,14 @@ restart:
     // scratch in global memory.  Ts is the largest level whose LDS part still lets 32 waves (8 per
     // SIMD) reside on a CU in the big walk launches (tri_off(34) + 64 = 625 doubles = 5 KB per wave); the
     // split launches and small trees keep the whole stack in LDS.
+    // Sub-solution calls never split the stack (FPHIP_SUBS_SPLIT=1 brings the split back): the sub-solution
+    // variant of the walk with the tall slots in global memory gave per-level counts that changed from run to run on
+    // a 130-row block — 3 of 6 runs, always exact with the whole stack in LDS (12 of 12), with mu in LDS or not;
+    // moving the reports behind the hot cycle, dropping their fences and reading the global slots past L1 did not
+    // change that (DESIGN.md section 6 has the experiments; tests/test_enum_gpu.py
+    // ::test_wide_blocks_report_candidates_under_every_level64_ancestor is the reproducer).  Not root-caused.
     int Ts = L + 1;
-    if (in_final && C >= 1024 && !mu_lds)
+    if (in_final && C >= 1024 && !mu_lds && (!subs || env_int("FPHIP_SUBS_SPLIT", 0) != 0))
     {
       const int want = env_int("FPHIP_STACK_SPLIT", 34);
       if (want > 1 && want < Ts)
@@ -1209,10 +1215,9 @@ restart:
       {
         FPHIP_RANGE(in_final ? "enum: walk launch" : "enum: split launch");
         HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-        // (sub-solution calls walk without work donation: with it, per-level counts of a 130-row block came out too
-        //  high whenever the host consumer of the sub-solution ring was slow — tests/test_enum_gpu.py
-        //  ::test_wide_blocks_report_candidates_under_every_level64_ancestor; FPHIP_SUBS_DONATE=1 brings it back)
-        const unsigned bud = (in_final && round < max_rounds && (!subs || env_int("FPHIP_SUBS_DONATE", 0) != 0)) ? budget : 0u;
+        // (FPHIP_SUBS_DONATE=0: sub-solution calls walk without work donation — an A/B switch from the hunt for the
+        //  run-to-run differences of the split stack above; donation was not their cause)
+        const unsigned bud = (in_final && round < max_rounds && (!subs || env_int("FPHIP_SUBS_DONATE", 1) != 0)) ? budget : 0u;
 #define FPHIP_LAUNCH(M, S, D)                                                                       \
   hipLaunchKernelGGL((enum_phase_kernel<M, S, D>), dim3(grid), dim3(wpb * 64), lds, ctx->stream, ctx->g, \
                      ctx->h, ctx->buf[cur], ctx->buf[nxt], d, L, stop, lo, hi, idxl, launch_idx,     \

@@ -1,5 +1,4 @@
-"""Diagnostic: a sub-solution call on a block of 130 rows after calls on other wide blocks in the same context
-(per-level counts, device vs C oracle)."""
+"""Diagnostic: repeated sub-solution calls on the 130-row block with candidates; per-level count differences."""
 import os
 import sys
 import numpy as np
@@ -9,27 +8,24 @@ import conftest as C
 import fplll_amd
 from fplll_amd.enumeration import FastEvaluator, enumerate_block
 
-
-def run(ctx, d, seed, subs, kind):
-    if kind == "cand":
-        mut, rdiag, maxdist = C.wide_block_with_candidates(d, seed)
-        pruning = None
-    else:
-        mut, rdiag, maxdist = C.wide_block(d, seed, {129: 0.15, 160: 0.2, 200: 0.3, 256: 0.3}[d])
-        pruning = np.clip(np.linspace(1.0, 0.25, d)[::-1].copy(), 0.0, 1.0)[::-1].copy()
-    ev, ev_o = FastEvaluator(10**9, 0), FastEvaluator(10**9, 0)
-    res = enumerate_block(ctx, mut, rdiag, pruning, maxdist, ev, findsubsols=subs)
-    nodes_o, _ = C.oracle_enumerate(mut, rdiag, pruning, maxdist, ev_o, findsubsols=subs)
-    g = [int(v) for v in res.nodes]
-    o = [int(v) for v in nodes_o]
-    bad = [k for k in range(d) if g[k] != o[k]]
-    print("%s d=%d subs=%d total dev %d oracle %d; levels that differ: %d %s" % (kind, d, subs, sum(g), sum(o), len(bad), bad[:6]), flush=True)
-
-
-for pre in ([], [(256, 28, "plain")], [(200, 27, "plain")], [(160, 26, "plain")], [(129, 25, "plain")], [(130, 43, "cand")], [(160, 41, "cand")]):
-    ctx = fplll_amd.Context(0)
-    print("--- fresh context; before the sub-solution call:", pre, flush=True)
-    for d, seed, kind in pre:
-        run(ctx, d, seed, False, kind)
-    run(ctx, 130, 43, True, "cand")
-    ctx.close()
+ctx = fplll_amd.Context(0)
+mut, rdiag, maxdist = C.wide_block_with_candidates(130, 43)
+ev_o = FastEvaluator(10**9, 0)
+nodes_o, _ = C.oracle_enumerate(mut, rdiag, None, maxdist, ev_o, findsubsols=True)
+o = [int(v) for v in nodes_o]
+import time
+for rep in range(int(sys.argv[1]) if len(sys.argv) > 1 else 8):
+    for subs in (False, True):
+        ev = FastEvaluator(10**9, 0)
+        slow = {"n": 0}
+        if subs and rep % 2 == 1:
+            orig = ev.eval_sub_sol
+            def slow_sub(offset, coord, dist, orig=orig):
+                time.sleep(0.002)  # a slow consumer of the sub-solution ring
+                return orig(offset, coord, dist)
+            ev.eval_sub_sol = slow_sub
+        res = enumerate_block(ctx, mut, rdiag, None, maxdist, ev, findsubsols=subs)
+        g = [int(v) for v in res.nodes]
+        diff = [(k, g[k] - o[k]) for k in range(130) if g[k] != o[k]]
+        print("rep %d subs=%d slow=%d: %d levels differ %s ... %s; kernel %.1f ms phases %d" % (rep, subs, int(subs and rep % 2 == 1), len(diff), diff[:6], diff[-4:], res.stats.kernel_ms, res.stats.phases), flush=True)
+ctx.close()

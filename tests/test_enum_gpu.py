@@ -270,11 +270,15 @@ def test_wide_blocks_report_candidates_under_every_level64_ancestor(ctx, d, seed
     assert sg == so
     for dist, x in sg:
         assert abs(_dist_from(mut, rdiag, x) - dist) <= 1e-9 * dist
-    # sub-solutions: the reports of the levels below 64 carry the ancestor's coefficients as well
+    # sub-solutions: the reports of the levels below 64 carry the ancestor's coefficients as well.  (The only
+    # sub-solution call of the suite with >= 8192 level-64 tasks: with the split stack of the big launches its counts
+    # changed from run to run — DESIGN.md section 6; sub-solution calls keep the whole stack in LDS.)
     ev, ev_o = FastEvaluator(10**9, 0), FastEvaluator(10**9, 0)
     res = enumerate_block(ctx, mut, rdiag, None, maxdist, ev, findsubsols=True)
     nodes_o, _ = C.oracle_enumerate(mut, rdiag, None, maxdist, ev_o, findsubsols=True)
-    assert [int(v) for v in res.nodes] == [int(v) for v in nodes_o]
+    diff = [(k, int(res.nodes[k]) - int(nodes_o[k])) for k in range(d) if int(res.nodes[k]) != int(nodes_o[k])]
+    assert not diff, "per-level counts differ (level, device - oracle): %s; %d candidates against %d" % (
+        diff, len(ev.solutions), len(ev_o.solutions))
     assert sorted(ev.sub_solutions) == sorted(ev_o.sub_solutions)
     for o in ev_o.sub_solutions:
         dist, x = ev.sub_solutions[o]
