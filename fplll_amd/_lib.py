@@ -56,7 +56,7 @@ class EnumStats(ctypes.Structure):
         ("final_tasks", ctypes.c_int),
         ("final_root_level", ctypes.c_int),
         ("overflowed", ctypes.c_int),
-        ("pad0", ctypes.c_int),
+        ("bfs_restarts", ctypes.c_int),
         ("moved_tasks", ctypes.c_uint64),
     ]
 

@@ -710,6 +710,7 @@ extern "C" int fphip_enum_run(fphip_ctx *ctx, int dim, double maxdist, const dou
   // sub-solution calls keep the split launches (the expansion does not report sub-solutions), and a
   // call whose expansion overflowed a buffer starts over with them.
   bool use_bfs = env_int("FPHIP_BFS", 1) != 0 && !subs;
+  int bfs_restarts = 0;
 restart:
   // ---- upload the block: rdiag, pruning, mu rows (triangular) ---------------------------------
   DevShared *st = ctx->stage;
@@ -1030,12 +1031,10 @@ restart:
     }
     if (bfs_over)
     {
-      if (d > 64)  // (the top walk cannot be repeated cheaply: such a block stays with the caller)
-      {
-        snprintf(ctx->err, sizeof ctx->err, "breadth-first stage overflowed on a block larger than 64");
-        return FPHIP_UNSUPPORTED;
-      }
+      // start over with the split launches — nothing has been reported yet, the counters are uploaded again.  A
+      // block above 64 rows repeats its top walk as well (milliseconds; until round 6 such a block was declined).
       use_bfs = false;
+      ++bfs_restarts;
       goto restart;
     }
     cur         = 0;
@@ -1379,7 +1378,7 @@ restart:
     stats->final_tasks      = final_tasks;
     stats->final_root_level = final_L;
     stats->overflowed       = (st->error_flags & FPHIP_FLAG_TASK_OVERFLOW) ? 1 : 0;
-    stats->pad0             = 0;
+    stats->bfs_restarts     = bfs_restarts;
     stats->moved_tasks      = moved_tasks;
     stats->wall_ms =
         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin)

@@ -135,7 +135,7 @@ typedef struct fphip_enum_stats
   int final_tasks;
   int final_root_level;
   int overflowed; /* task-buffer overflow happened (handled inline, results still exact) */
-  int pad0;
+  int bfs_restarts; /* the breadth-first stage overflowed a buffer and the call started over with split launches */
   uint64_t moved_tasks; /* work movement (fphip_enum_opts::gather): tasks that left or reached this rank */
 } fphip_enum_stats;
 

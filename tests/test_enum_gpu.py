@@ -365,6 +365,29 @@ def test_task_buffer_overflow_is_exact(monkeypatch):
         c2.close()
 
 
+@pytest.mark.parametrize("d,seed,rf,cap", [(70, 22, 0.46, 2048), (65, 21, 0.5, 2048)])
+def test_overflow_of_the_breadth_first_stage_above_64_rows_starts_over(monkeypatch, d, seed, rf, cap):
+    """A block above 64 rows whose breadth-first stage overflows a region of the task buffer is not declined any
+    more: the call starts over with the split launches, top walk included, and an overfull buffer there is walked
+    inline.  Per-level counts and candidates = the oracle's; the statistics say that it happened."""
+    import fplll_amd
+    from fplll_amd.enumeration import FastEvaluator, enumerate_block
+    monkeypatch.setenv("FPHIP_TASK_CAP", str(cap))
+    monkeypatch.setenv("FPHIP_BFS_HEAVY", "1")  # (every subtree above one estimated node is expanded further)
+    c2 = fplll_amd.Context(0)
+    try:
+        mut, rdiag, maxdist = C.synthetic_block(d, seed, 0.03, rf)
+        pruning = np.clip(np.linspace(1.0, 0.25, d)[::-1].copy(), 0.0, 1.0)[::-1].copy()
+        ev, ev_o = FastEvaluator(10**9, 0), FastEvaluator(10**9, 0)
+        res = enumerate_block(c2, mut, rdiag, pruning, maxdist, ev, target_tasks=10**9)
+        nodes_o, _ = C.oracle_enumerate(mut, rdiag, pruning, maxdist, ev_o)
+        assert [int(v) for v in res.nodes] == [int(v) for v in nodes_o]
+        assert sorted((s[0], tuple(s[1])) for s in ev.solutions) == sorted((s[0], tuple(s[1])) for s in ev_o.solutions)
+        assert res.stats.bfs_restarts == 1, "the stage was expected to overflow with %d task slots" % cap
+    finally:
+        c2.close()
+
+
 def test_plugin_axis_with_reference_build():
     """The reference's own test axis: install our enumerator with set_external_enumerator and
     compare against fplll's internal one in the same process (needs oracle/_ref, which travels
