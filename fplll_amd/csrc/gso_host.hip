@@ -2695,6 +2695,7 @@ namespace fphip
 {
 template <int NQ> __global__ void hh_update_kernel(HhBatch P);
 template <int NT> __global__ void hh_rows_kernel(HhBatch P);
+__global__ void hh_size_reduce_kernel(HhBatch P, int k, int end, int start, int *reduced);
 }
 
 struct fphip_hh
@@ -2884,6 +2885,45 @@ extern "C" int fphip_hh_update_R(fphip_hh *h, int *status)
   HCHK(hipEventElapsedTime(&h->last_ms, h->ev[0], h->ev[1]));
   if (status)
     HCHK(hipMemcpy(status, h->P.status, sizeof(int) * h->P.batch, hipMemcpyDeviceToHost));
+  return FPHIP_OK;
+}
+
+// MatHouseholder::size_reduce(kappa, size_reduction_end, size_reduction_start) on every lattice of the batch
+// (householder.cpp:402-451; kernel in hh_rows.hip).  The state must be the one fphip_hh_update_R left (or any state
+// in which rows < kappa of R are final and R(kappa, c < kappa) are the values update_R(kappa, false) gives).
+extern "C" int fphip_hh_size_reduce(fphip_hh *h, int kappa, int size_reduction_end, int size_reduction_start,
+                                    int *reduced, int *status)
+{
+  FPHIP_RANGE("fphip_hh_size_reduce");
+  if (!h || !reduced)
+    return FPHIP_ERROR;
+  if (!(kappa > 0 && kappa < h->P.d) || size_reduction_start < 0 || size_reduction_end > kappa ||
+      size_reduction_start > size_reduction_end)
+  {
+    snprintf(fphip_ctx_errbuf(h->ctx), 512,
+             "fphip_hh_size_reduce: need 0 < kappa < d and 0 <= start <= end <= kappa (got %d, %d, %d)", kappa,
+             size_reduction_end, size_reduction_start);
+    return FPHIP_ERROR;
+  }
+  hipStream_t s = fphip_ctx_stream(h->ctx);
+  int *dred     = nullptr;
+  HCHK(fphip_dev_alloc((void **)&dred, sizeof(int) * (size_t)h->P.batch, s));
+  HCHK(hipEventRecord(h->ev[0], s));
+  hipLaunchKernelGGL(hh_size_reduce_kernel, dim3((h->P.batch + 3) / 4), dim3(256), 0, s, h->P, kappa,
+                     size_reduction_end, size_reduction_start, dred);
+  hipError_t le = hipGetLastError();
+  HCHK(hipEventRecord(h->ev[1], s));
+  hipError_t se = hipStreamSynchronize(s);
+  if (le == hipSuccess && se == hipSuccess)
+  {
+    hipEventElapsedTime(&h->last_ms, h->ev[0], h->ev[1]);
+    se = hipMemcpy(reduced, dred, sizeof(int) * h->P.batch, hipMemcpyDeviceToHost);
+    if (se == hipSuccess && status)
+      se = hipMemcpy(status, h->P.status, sizeof(int) * h->P.batch, hipMemcpyDeviceToHost);
+  }
+  fphip_dev_free(dred, s);
+  HCHK(le);
+  HCHK(se);
   return FPHIP_OK;
 }
 

@@ -320,6 +320,110 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// MatHouseholder::size_reduce(k, size_reduction_end, size_reduction_start), householder.cpp:402-451, as a
+// stand-alone step over the batch (C ABI fphip_hh_size_reduce; the HLLL kernel carries its own copy inside its loop):
+// one wavefront per lattice, lane = column.  For i = end-1 … start: X = -rnd_we(R(k,i) / R(i,i)) (:409-426), and for
+// a nonzero X row_addmul_we(k, i, X, row_expo[k] - row_expo[i]) (:522-559): b[k] += lx b[i] over the columns, and
+// R[k].addmul(R[i], X, k) over ALL k leading entries — R(k,i) becomes the remainder, the entries between i and k
+// pick up X times the tail update_R_last left in row i (the reference never zeroes it in a non-DEBUG build,
+// :104-111; hh_rows_kernel / hh_update_kernel store the same tail).  Separate multiply and add (-ffp-contract=off).
+// reduced[lattice] = the reference's return value; status -2 = a multiplier beyond 63 bits (b and R untouched).
+// HBM-bound: (end - start) rows of R and of b per lattice, 16 n bytes each.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ long long hsr_fexponent(double x)
+{  // FP_NR<double>::exponent(), nr_FP_d.inl:44
+  return (x == 0.0) ? ((long long)INT_MIN + 1) : ((long long)ilogb(x) + 1);
+}
+
+__global__ void __launch_bounds__(256) hh_size_reduce_kernel(HhBatch P, int k, int end, int start, int *reduced)
+{
+  const int lane = threadIdx.x & 63;
+  const int lat  = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (lat >= P.batch)
+    return;
+  const int n = P.n, ld = P.ldn, d = P.d;
+  double *R           = P.R + (size_t)lat * d * ld;
+  long long *b        = P.b + (size_t)lat * d * ld;
+  const long long *rx = P.rexp + (size_t)lat * d;
+  double Rk[4];
+  long long bk[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+  {
+    const int c = lane + 64 * q;
+    Rk[q]       = (c < n) ? R[(size_t)k * ld + c] : 0.0;
+    bk[q]       = (c < n) ? b[(size_t)k * ld + c] : 0;
+  }
+  const long long rxk = rx[k];
+  int red             = 0;
+  bool too_big        = false;
+  for (int i = end - 1; i >= start; --i)
+  {
+    double mine = Rk[0];
+#pragma unroll
+    for (int q = 1; q < 4; ++q)
+      mine = ((i >> 6) == q) ? Rk[q] : mine;
+    const double rki = __shfl(mine, i & 63);
+    const double rii = R[(size_t)i * ld + i];
+    double x         = rki / rii;
+    const int ea     = (int)(rxk - rx[i]);
+    if (!(hsr_fexponent(x) + ea >= 53))  // rnd_we, nr_FP_d.inl:226-233
+      x = ldexp(rint(ldexp(x, ea)), -ea);
+    x = -x;
+    if (x != 0.0)
+    {
+      if (hsr_fexponent(x) + ea - 63 > 0)  // get_si_exp_we, nr_FP_d.inl:46-53: the 2^expo path is not on the device
+      {
+        too_big = true;
+        break;
+      }
+      const long long lx = (long long)ldexp(x, ea);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+      {
+        const int c = lane + 64 * q;
+        if (c < n)
+        {
+          bk[q] = (long long)((unsigned long long)bk[q] +
+                              (unsigned long long)b[(size_t)i * ld + c] * (unsigned long long)lx);
+          if (c < k)
+          {
+            const double t = R[(size_t)i * ld + c] * x;
+            Rk[q]          = Rk[q] + t;
+          }
+        }
+      }
+      red = 1;
+    }
+  }
+  if (too_big)
+  {
+    if (lane == 0)
+    {
+      P.status[lat] = -2;
+      reduced[lat]  = 0;
+    }
+    return;
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+  {
+    const int c = lane + 64 * q;
+    if (c < n && red)
+    {
+      b[(size_t)k * ld + c] = bk[q];
+      if (c < k)
+        R[(size_t)k * ld + c] = Rk[q];
+    }
+  }
+  if (lane == 0)
+  {
+    P.status[lat] = 1;
+    reduced[lat]  = red;
+  }
+}
+
 template __global__ void hh_rows_kernel<4>(HhBatch);
 template __global__ void hh_rows_kernel<8>(HhBatch);
 template __global__ void hh_rows_kernel<12>(HhBatch);

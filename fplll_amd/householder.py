@@ -33,6 +33,8 @@ def _bind(lib):
     lib.fphip_hh_hlll.argtypes = [vp, ctypes.c_double, ctypes.c_double, ctypes.c_double,
                                   ctypes.c_double, vp, vp]
     lib.fphip_hh_get_R.argtypes = [vp, ctypes.c_int, vp]
+    lib.fphip_hh_size_reduce.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]
+    lib.fphip_hh_size_reduce.restype = ctypes.c_int
     lib.fphip_hh_get_row_expo.argtypes = [vp, ctypes.c_int, vp]
     lib.fphip_hh_last_kernel_ms.argtypes = [vp]
     lib.fphip_hh_last_kernel_ms.restype = ctypes.c_double
@@ -75,6 +77,17 @@ class MatHouseholderBatch:
         fn = self.lib.fphip_hh_update_R_blocked if blocked else self.lib.fphip_hh_update_R
         self._chk(fn(self.h, st.ctypes.data_as(ctypes.c_void_p)), "update_R")
         return st
+
+    def size_reduce(self, kappa, size_reduction_end=None, size_reduction_start=0):
+        """MatHouseholder::size_reduce(k, size_reduction_end, size_reduction_start) (householder.cpp:402-451) on every
+        lattice, on the state update_R() left.  Returns (reduced[batch], status[batch])."""
+        end = kappa if size_reduction_end is None else size_reduction_end
+        red = np.zeros(self.batch, dtype=np.int32)
+        st = np.zeros(self.batch, dtype=np.int32)
+        self._chk(self.lib.fphip_hh_size_reduce(self.h, int(kappa), int(end), int(size_reduction_start),
+                                                red.ctypes.data_as(ctypes.c_void_p),
+                                                st.ctypes.data_as(ctypes.c_void_p)), "size_reduce")
+        return red, st
 
     def get_basis(self, first=0, count=1):
         b = np.empty((count, self.d, self.n), dtype=np.int64)

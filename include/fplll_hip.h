@@ -478,6 +478,15 @@ int fphip_hh_update_R(fphip_hh *h, int *status);
  * rounding (checked to 1e-9 relative on mu = R_ij/R_jj and r = R_ij R_jj), not bit for bit; row
  * exponents and signs are identical. */
 int fphip_hh_update_R_blocked(fphip_hh *h, int *status);
+/* MatHouseholder::size_reduce(kappa, size_reduction_end, size_reduction_start) (householder.cpp:402-451, with
+ * row_addmul_we :522-559) as a stand-alone step over the batch, on the state fphip_hh_update_R left: for
+ * i = end-1 … start, X = -rnd_we(R(kappa,i) / R(i,i)); a nonzero X adds lx·b[i] to b[kappa] and X·R[i] to the
+ * kappa leading entries of R[kappa].  reduced[batch] = the reference's return value; b row kappa and R row kappa
+ * are the reference's afterwards, bit for bit — the row is INVALID in the reference's sense ("not the correct
+ * R[k]", :440-444): run fphip_hh_update_R before R is used again.  status (nullable) [batch]: 1, or -2 = a
+ * multiplier beyond 63 bits (that lattice is left untouched). */
+int fphip_hh_size_reduce(fphip_hh *h, int kappa, int size_reduction_end, int size_reduction_start, int *reduced,
+                         int *status);
 int fphip_hh_get_basis(fphip_hh *h, int first_lattice, int count, int64_t *b);
 /* HLLLReduction<Z_NR<long>,FP_NR<double>>(m, delta, eta, theta, c, LLL_DEFAULT).hlll()
  * (hlll.cpp:26-169; size_reduction :262-351, lovasz_test :171-224, verify_size_reduction :455-496)

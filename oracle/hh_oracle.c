@@ -127,6 +127,60 @@ int oracle_hh_update_all(int d, int n, const int64_t *b, int row_expo_on, double
   return 0;
 }
 
+/* MatHouseholder::size_reduce(k, size_reduction_end, size_reduction_start), householder.cpp:402-451, with
+ * row_addmul_we (:522-559), on the state refresh_R_bf() + update_R() leave (oracle_hh_update_all): b row k and
+ * R row k are updated in place (R(k, c) for every c < k: line 5 of Algorithm 3 plus what :551-556 add beyond it —
+ * the row is invalidated by the reference afterwards).  Returns the reference's flag (1 reduced / 0 not), -1 for a
+ * multiplier beyond 63 bits (path not restated).  Pinned by the `hhsr` fixtures (tests/test_hh_oracle_vs_ref.py). */
+int oracle_hh_size_reduce(int d, int n, int64_t *b, int row_expo_on, int k, int end, int start, double *R,
+                          int64_t *row_expo)
+{
+  double *V     = (double *)malloc(sizeof(double) * (size_t)d * n);
+  double *sigma = (double *)malloc(sizeof(double) * (size_t)d);
+  oracle_hh_update_all(d, n, b, row_expo_on, R, V, sigma, row_expo);
+  free(V);
+  free(sigma);
+  int n_known_cols = 0;
+  for (int i = 0; i < d; ++i)
+    for (int j = n - 1; j >= 0; --j)
+      if (b[(size_t)i * n + j] != 0)
+      {
+        if (j + 1 > n_known_cols)
+          n_known_cols = j + 1;
+        break;
+      }
+  int reduced = 0;
+  double *Rk  = R + (size_t)k * n;
+  for (int i = end - 1; i >= start; --i)
+  {
+    const double *Ri = R + (size_t)i * n;
+    double x         = Rk[i] / Ri[i];
+    long ea          = (long)(row_expo[k] - row_expo[i]);
+    long fx          = (x == 0.0) ? (long)INT_MIN + 1 : (long)ilogb(x) + 1;
+    if (!(fx + ea >= 53)) /* rnd_we, nr_FP_d.inl:226-233 */
+      x = ldexp(rint(ldexp(x, (int)ea)), (int)-ea);
+    x = -x;
+    if (x != 0.0)
+    {
+      fx        = (long)ilogb(x) + 1;
+      long expo = fx + ea - 63;
+      if (expo > 0)
+        return -1;
+      long lx = (long)ldexp(x, (int)ea);
+      for (int c = n_known_cols - 1; c >= 0; --c)
+        b[(size_t)k * n + c] =
+            (int64_t)((uint64_t)b[(size_t)k * n + c] + (uint64_t)b[(size_t)i * n + c] * (uint64_t)lx);
+      /* R[k].addmul(R[i], x, k), householder.cpp:551-556: ALL k leading entries — R(k, i) becomes the remainder and
+       * the entries between i and k pick up x times the tail update_R_last left in row i (never zeroed in a
+       * non-DEBUG build, :104-111); x = +-1: add / sub, the same floats */
+      for (int c = k - 1; c >= 0; --c)
+        Rk[c] = Rk[c] + Ri[c] * x;
+      reduced = 1;
+    }
+  }
+  return reduced;
+}
+
 /* ------------------------------------------------------------------------------------------
  * HLLL: HLLLReduction<Z_NR<long>, FP_NR<double>>::hlll() over MatHouseholder with
  * HOUSEHOLDER_ROW_EXPO (| HOUSEHOLDER_OP_FORCE_LONG), the LM_FAST configuration of

@@ -141,6 +141,8 @@ double oracle_gso_get_r(const oracle_gso *g, int i, int j);
  * ------------------------------------------------------------------------------------------ */
 int oracle_hh_update_all(int d, int n, const int64_t *b, int row_expo_on, double *R, double *V,
                          double *sigma, int64_t *row_expo);
+int oracle_hh_size_reduce(int d, int n, int64_t *b, int row_expo_on, int k, int end, int start, double *R,
+                          int64_t *row_expo);
 /* HLLLReduction<Z_NR<long>,FP_NR<double>>::hlll() (hlll.cpp:26-169) over MatHouseholder with
  * HOUSEHOLDER_ROW_EXPO: b (d x n, row-major) is reduced in place.  1 RED_SUCCESS, -2 multiplier
  * beyond 63 bits, -4 RED_HLLL_SR_FAILURE, -5 RED_HLLL_NORM_FAILURE.  info[2] (nullable): swaps,

@@ -1634,6 +1634,63 @@ static int cmd_hhfix(int argc, char **argv)
   return 0;
 }
 
+/* hhsr n k bits seed perturb row_expo kappa end start → JSON: the hhfix input, then the reference's
+ * MatHouseholder::size_reduce(kappa, end, start) (householder.cpp:402-451) on the state update_R() left: the flag it
+ * returns, row kappa of the basis and row kappa of R afterwards (R(kappa, c) for c < end is what line 5 of
+ * Algorithm 3 leaves — "not the correct R[k]", the row is invalidated) */
+static int cmd_hhsr(int argc, char **argv)
+{
+  if (argc < 11)
+    return 2;
+  int n = atoi(argv[2]), k = atoi(argv[3]), bits = atoi(argv[4]), seed = atoi(argv[5]);
+  int perturb = atoi(argv[6]), rexp = atoi(argv[7]);
+  int kappa = atoi(argv[8]), end = atoi(argv[9]), start = atoi(argv[10]);
+  ZZ_mat<mpz_t> A;
+  make_basis(A, n, k, bits, seed, 0);
+  ZZ_mat<long> b(n, n), u, ut;
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j)
+      b(i, j) = A(i, j).get_si();
+  uint64_t lcg = 0x9E3779B97F4A7C15ull ^ (uint64_t)seed;
+  for (int i = 1; i < n && perturb > 0; ++i)
+    for (int t = 0; t < perturb; ++t)
+    {
+      lcg    = lcg * 6364136223846793005ull + 1442695040888963407ull;
+      int j  = (int)((lcg >> 33) % (uint64_t)i);
+      lcg    = lcg * 6364136223846793005ull + 1442695040888963407ull;
+      long c = (long)((lcg >> 33) % 7) - 3;
+      for (int col = 0; col < n; ++col)
+        b(i, col) = b(i, col).get_si() + c * b(j, col).get_si();
+    }
+  std::ostringstream os;
+  os << "{\n\"desc\":\"qary n=" << n << " k=" << k << " bits=" << bits << " seed=" << seed << " LLL then "
+     << perturb << " row ops per row, row_expo=" << rexp << "; update_R(), size_reduce(" << kappa << "," << end
+     << "," << start << ")\",\n\"d\":" << n << ",\n\"n\":" << n << ",\n\"row_expo_on\":" << rexp
+     << ",\n\"kappa\":" << kappa << ",\n\"end\":" << end << ",\n\"start\":" << start << ",\n\"b_in\":[";
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j)
+      os << ((i || j) ? "," : "") << b(i, j).get_si();
+  os << "],\n";
+  MatHouseholder<Z_NR<long>, FP_NR<double>> H(b, u, ut, rexp ? HOUSEHOLDER_ROW_EXPO : 0);
+  H.refresh_R_bf();
+  H.update_R();
+  const bool reduced = H.size_reduce(kappa, end, start);
+  os << "\"reduced\":" << (reduced ? 1 : 0) << ",\n\"b_row\":[";
+  for (int j = 0; j < n; ++j)
+    os << (j ? "," : "") << b(kappa, j).get_si();
+  os << "],\n\"R_row\":[";
+  vector<long> expo;
+  const Matrix<FP_NR<double>> &R = H.get_R(expo);
+  for (int j = 0; j < n; ++j)
+    os << (j ? "," : "") << hexd(R(kappa, j).get_d());
+  os << "],\n\"row_expo\":[";
+  for (int i = 0; i < n; ++i)
+    os << (i ? "," : "") << expo[i];
+  os << "]\n}\n";
+  std::cout << os.str();
+  return 0;
+}
+
 /* hhmp basisfile prec → JSON: the reference's Householder R-factor of the basis in `basisfile`
  * computed with FP_NR<mpfr_t> at `prec` bits (MatHouseholder<Z_NR<mpz_t>, FP_NR<mpfr_t>>,
  * householder.cpp:587-589; prec = 106 is PREC_DD, defs.h:140): R(i, j <= i) as decimal strings with
@@ -1755,6 +1812,8 @@ int main(int argc, char **argv)
     return cmd_ishlll(argc, argv);
   if (cmd == "hlllmp")
     return cmd_hlllmp(argc, argv);
+  if (cmd == "hhsr")
+    return cmd_hhsr(argc, argv);
   if (cmd == "hhmp")
     return cmd_hhmp(argc, argv);
   if (cmd == "enumtime")

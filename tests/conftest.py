@@ -576,6 +576,36 @@ def load_hh_fixture(path):
             "R": hexvec(j["R"]).reshape(d, d), "row_expo": np.array(j["row_expo"], dtype=np.int64)}
 
 
+def hhsr_fixtures():
+    return sorted(glob.glob(os.path.join(GOLDEN, "hhsr_*.json")))
+
+
+def load_hhsr_fixture(path):
+    """`hhsr` fixtures (oracle/ref_driver.cpp): MatHouseholder::size_reduce(kappa, end, start) after update_R()."""
+    with open(path) as f:
+        j = json.load(f)
+    d, n = j["d"], j["n"]
+    return {"d": d, "n": n, "name": os.path.basename(path)[:-5], "row_expo_on": j["row_expo_on"],
+            "kappa": j["kappa"], "end": j["end"], "start": j["start"], "reduced": j["reduced"],
+            "b_in": np.array(j["b_in"], dtype=np.int64).reshape(d, n),
+            "b_row": np.array(j["b_row"], dtype=np.int64), "R_row": hexvec(j["R_row"]),
+            "row_expo": np.array(j["row_expo"], dtype=np.int64)}
+
+
+def oracle_hh_size_reduce(b, row_expo_on, kappa, end, start):
+    """oracle/hh_oracle.c: returns (flag, b after, R d×n after, row_expo)."""
+    lib = oracle_lib()
+    b = np.ascontiguousarray(b, dtype=np.int64).copy()
+    d, n = b.shape
+    R = np.zeros((d, n))
+    rexp = np.zeros(d, dtype=np.int64)
+    lib.oracle_hh_size_reduce.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p] + [ctypes.c_int] * 4 + \
+        [ctypes.c_void_p] * 2
+    flag = lib.oracle_hh_size_reduce(d, n, b.ctypes.data_as(ctypes.c_void_p), int(row_expo_on), int(kappa), int(end),
+                                     int(start), R.ctypes.data_as(ctypes.c_void_p), rexp.ctypes.data_as(ctypes.c_void_p))
+    return flag, b, R, rexp
+
+
 def oracle_hh_update_all(b, row_expo_on):
     """oracle/hh_oracle.c: returns (R d×n, V d×n, sigma d, row_expo d)."""
     lib = oracle_lib()

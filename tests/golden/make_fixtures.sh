@@ -42,6 +42,12 @@ $D gsofix 64 32 14 3 5 > $G/gso_q64_p5.json
 # --- Householder R factor: n k bits seed perturb row_expo
 $D hhfix 40 20 11 4 2 0 > $G/hh_q40_p2_e0.json
 $D hhfix 64 32 14 3 3 1 > $G/hh_q64_p3_e1.json
+# MatHouseholder::size_reduce(kappa, end, start) on the state update_R() left (whole range, a sub-range, row
+# exponents on, a row that needs nothing)
+$D hhsr 40 20 11 4 2 0 25 25 0 > $G/hhsr_q40_k25.json
+$D hhsr 40 20 11 4 3 0 35 30 5 > $G/hhsr_q40_k35_r5_30.json
+$D hhsr 64 32 14 3 3 1 40 40 0 > $G/hhsr_q64_k40_e1.json
+$D hhsr 40 20 11 4 0 0 30 30 0 > $G/hhsr_q40_k30_clean.json
 # --- LLL (LLLReduction<long,double>::lll): type d k bits seed kmin kstart kend zero_rows dup_rows
 $D lllfix q  40 20 20 1  0  0 -1 0 0 > $G/lll_q40.json
 $D lllfix q  72 36 16 2  0  0 -1 0 0 > $G/lll_q72.json

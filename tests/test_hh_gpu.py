@@ -162,3 +162,69 @@ def test_rows_kernel_equals_the_column_kernel_bit_for_bit(ctx, batch, d, n, monk
             R1, e1 = out["1"][L]
             assert np.array_equal(e1, eo)
             assert np.array_equal(np.tril(R1[:, :d]).view(np.uint64), np.tril(Ro[:, :d]).view(np.uint64))
+
+
+@pytest.mark.parametrize("path", C.hhsr_fixtures(), ids=lambda p: os.path.basename(p)[:-5])
+def test_size_reduce_reference_fixture_parity(ctx, path, monkeypatch):
+    """fphip_hh_size_reduce = MatHouseholder::size_reduce(kappa, end, start) (householder.cpp:402-451) on the state
+    update_R() left, against the `hhsr` fixtures of the real reference: the returned flag, row kappa of the basis and
+    the kappa + 1 leading entries of R[kappa] bit for bit, every other row untouched; from both R-factor kernels
+    (the tails right of the diagonal that :551-556 fold into R[kappa] are the same in both)."""
+    from fplll_amd.householder import MatHouseholderBatch
+    f = C.load_hhsr_fixture(path)
+    k = f["kappa"]
+    for rows_kernel in ("1", "0"):
+        monkeypatch.setenv("FPHIP_HH_ROWS", rows_kernel)
+        h = MatHouseholderBatch(ctx, 5, f["d"], f["n"], row_expo=bool(f["row_expo_on"]))
+        h.set_basis(np.stack([f["b_in"]] * 5))
+        assert list(h.update_R()) == [1] * 5
+        R0, _ = h.get_R(2)
+        red, st = h.size_reduce(k, f["end"], f["start"])
+        assert list(red) == [f["reduced"]] * 5 and list(st) == [1] * 5
+        b = h.get_basis(0, 5)
+        for L in range(5):
+            assert np.array_equal(b[L, k], f["b_row"])
+            others = np.arange(f["d"]) != k
+            assert np.array_equal(b[L][others], f["b_in"][others])
+            R, e = h.get_R(L)
+            assert np.array_equal(R[k, :k + 1], f["R_row"][:k + 1])
+            assert np.array_equal(R[others], R0[others]) and np.array_equal(e, f["row_expo"])
+        h.close()
+
+
+@pytest.mark.parametrize("d,row_expo,k,end,start", [(180, True, 170, 170, 0), (180, False, 100, 90, 17), (130, True, 129, 129, 64)])
+def test_size_reduce_matches_oracle_at_size(ctx, d, row_expo, k, end, start):
+    """The same on config 3's basis (180 columns: three registers per lane, rows of R and b streamed from HBM) against
+    the C oracle, with distinct lattices in the batch."""
+    from fplll_amd.householder import MatHouseholderBatch
+    from fplll_amd.gso import _unreduced_copy
+    import test_gso_gpu as T
+    full = T._load_c3_basis()
+    bs = [_unreduced_copy(full[:d, :], 2 + L, 9 + L) for L in range(4)]
+    h = MatHouseholderBatch(ctx, 4, d, full.shape[1], row_expo=row_expo)
+    h.set_basis(np.stack(bs))
+    assert int(h.update_R().min()) == 1
+    red, st = h.size_reduce(k, end, start)
+    bo = h.get_basis(0, 4)
+    for L in range(4):
+        flag, b1, R1, e1 = C.oracle_hh_size_reduce(bs[L], row_expo, k, end, start)
+        assert flag == int(red[L]) and int(st[L]) == 1
+        assert np.array_equal(bo[L], b1)
+        R, e = h.get_R(L)
+        assert np.array_equal(R[k, :k + 1], R1[k, :k + 1]) and np.array_equal(e, e1)
+    assert int(red.max()) == 1
+    h.close()
+
+
+def test_size_reduce_refuses_bad_ranges(ctx):
+    from fplll_amd.householder import MatHouseholderBatch
+    from fplll_amd import _lib
+    h = MatHouseholderBatch(ctx, 1, 8, 8)
+    h.set_basis(np.eye(8, dtype=np.int64) * 3)
+    h.update_R()
+    for args in ((0, 0, 0), (8, 8, 0), (5, 6, 0), (5, 2, 3), (5, 5, -1)):
+        with pytest.raises(_lib.HipError):
+            h.size_reduce(*args)
+    red, st = h.size_reduce(5)
+    assert list(red) == [0] and list(st) == [1]
+    h.close()
