@@ -13,6 +13,11 @@
 #include <utility>
 #include <algorithm>
 #include <vector>
+#include <string>
+#include <chrono>
+#include <fstream>
+#include <sstream>
+#include <iomanip>
 
 #include "../../include/fplll_hip.h"
 #include "../../include/fplll_hip_debug.h"
@@ -119,6 +124,9 @@ struct fphip_gso
   double il_preproc = 1e6, il_target = 0.5;
   int il_min_block = 24, il_flags = 0x4 /* PRUNER_GRADIENT */, il_device = 1;
   unsigned long long il_calls = 0, il_device_jobs = 0, il_host_jobs = 0, il_launches = 0;
+  // BKZ_MAX_TIME / BKZ_DUMP_GSO of the device BKZ drivers (fphip_gso_bkz_limits): seconds, file name
+  double bkz_max_time = 0.0;
+  std::string bkz_dump_path = "gso.json";  // (BKZParam::dump_gso_filename's default, bkz_param.h:120)
   // resident LLL session (fphip_gso_session_lll): the rows live in the kernel's slots while it is active
   bool session_active  = false;
   bool u_in_slots      = false;  // a session left the rows of u in the kernel's slots (restore_position_order)
@@ -131,6 +139,11 @@ struct fphip_gso
 static int gfail(fphip_ctx *ctx, const char *what, hipError_t e)
 {
   snprintf(fphip_ctx_errbuf(ctx), 512, "%s failed: %s", what, hipGetErrorString(e));
+  return FPHIP_ERROR;
+}
+static int gfail_msg(fphip_ctx *ctx, const char *msg)
+{
+  snprintf(fphip_ctx_errbuf(ctx), 512, "%s", msg);
   return FPHIP_ERROR;
 }
 #define GCHK(call)                            \
@@ -1235,12 +1248,86 @@ static void accumulate_info(int *inf, const int *one, size_t L)
 // slide_tour, and the tour's own progress test runs here: get_slide_potential (gso_interface.cpp:230-258:
 // sum over the blocks of (p - i) log det, the host's log) of the new basis against the previous one,
 // bkz.cpp:512-518 — "clean" (no progress) ends the loop with RED_SUCCESS like any clean tour.
+// BKZ_MAX_TIME (bkz.cpp:563,588-592) and BKZ_DUMP_GSO (:373-377, 456-460, 508-512, 536-539, 667-670; dump_gso
+// :729-790) of the tour loop below.  Time is the wall clock of the call (the reference reads the process's CPU time,
+// cputime(): the same thing for its single thread).  The dump is the reference's hand-written JSON, one file per
+// lattice (lattice 0: the name itself, lattice L > 0: name.L): "Input", one entry per tour, "Output".
+struct TourHooks
+{
+  bool use_time = false, dump = false;
+  double max_time = 0.0;
+  const char *step = "End of BKZ loop";
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  double seconds() const { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+};
+
+static std::string dump_name(const fphip_gso *g, size_t L)
+{
+  return L == 0 ? g->bkz_dump_path : g->bkz_dump_path + "." + std::to_string(L);
+}
+
+// BKZReduction::dump_gso (bkz.cpp:729-790): norms = log(r_ii) + expo log 2 of the rows below num_rows, 8 digits
+static int dump_gso_entry(const fphip_gso *g, size_t L, bool append, const char *step, int loop, double time,
+                          const double *rdg, const long long *rex, int num_rows)
+{
+  std::ofstream dump;
+  if (append)
+    dump.open(dump_name(g, L).c_str(), std::ios_base::app);
+  else
+  {
+    dump.open(dump_name(g, L).c_str());
+    dump << "[" << std::endl;
+  }
+  if (!dump)
+    return FPHIP_ERROR;
+  dump << std::string(8, ' ') << "{" << std::endl;
+  dump << std::string(16, ' ') << "\"step\": \"" << step << "\"," << std::endl;
+  dump << std::string(16, ' ') << "\"loop\": " << loop << "," << std::endl;
+  dump << std::string(16, ' ') << "\"time\": " << time << "," << std::endl;
+  std::stringstream ss;
+  for (int i = 0; i < num_rows; ++i)
+  {
+    const double log_f = std::log(rdg[i]);
+    const long expo    = (long)(2 * rex[i]);  // get_r_exp(i, i, expo), gso_interface.h:711-716
+    ss << std::setprecision(8) << log_f + expo * std::log(2.0) << ", ";
+  }
+  const std::string str = ss.str();
+  dump << std::string(16, ' ') << "\"norms\": [" << str.substr(0, str.size() >= 2 ? str.size() - 2 : 0) << "]"
+       << std::endl;
+  dump << std::string(8, ' ') << "}";
+  if (std::string(step) == "Output")
+    dump << std::endl << "]";
+  else
+    dump << "," << std::endl;
+  return dump ? FPHIP_OK : FPHIP_ERROR;
+}
+
+// the "Output" entry (bkz.cpp:667-670): the GSO norms of the bases as the call leaves them
+static int dump_gso_output(fphip_gso *g, const TourHooks &hooks, const std::vector<int> &st, const std::vector<int> &rows)
+{
+  const size_t B = (size_t)g->P.batch, d = (size_t)g->P.d;
+  int rc = launch(g, 0, g->P.d, 0.0, 0);
+  if (rc != FPHIP_OK)
+    return rc;
+  std::vector<double> rdg(B * d);
+  std::vector<long long> rex(B * d);
+  GCHK(hipMemcpy(rdg.data(), g->P.rdg, sizeof(double) * B * d, hipMemcpyDeviceToHost));
+  GCHK(hipMemcpy(rex.data(), g->P.rexp, sizeof(long long) * B * d, hipMemcpyDeviceToHost));
+  for (size_t L = 0; L < B; ++L)
+    if (st[L] == 1 || st[L] == 7 || st[L] == 8)  // (a failing tour throws past the dump, bkz.cpp:611-614)
+      if (dump_gso_entry(g, L, true, "Output", -1, hooks.seconds(), &rdg[L * d], &rex[L * d], rows[L]) != FPHIP_OK)
+        return gfail_msg(g->ctx, "BKZ_DUMP_GSO: cannot write the dump file");
+  return FPHIP_OK;
+}
+
 template <class RunTour>
 static int auto_abort_loop(fphip_gso *g, int block_size, bool use_loops, int max_loops, std::vector<int> &active,
                            std::vector<int> &st, std::vector<int> &inf, std::vector<int> &rows, float &total_ms,
-                           RunTour run_tour, bool slope_test = true, bool slide = false)
+                           RunTour run_tour, bool slope_test = true, bool slide = false,
+                           const TourHooks &hooks = TourHooks())
 {
   const size_t B = (size_t)g->P.batch, d = (size_t)g->P.d;
+  std::vector<char> ran(B, 0);  // the lattice took part in the tour before this iteration
   int rc = launch(g, 0, g->P.d, 0.0, 0);  // r_ii of the input bases
   if (rc != FPHIP_OK)
     return rc;
@@ -1267,6 +1354,13 @@ static int auto_abort_loop(fphip_gso *g, int block_size, bool use_loops, int max
     }
     for (size_t L = 0; L < B; ++L)
     {
+      if (hooks.dump && (loop == 0 ? active[L] != 0 : ran[L] != 0))
+      {  // "Input" (bkz.cpp:536-539) / the entry at the end of tour loop - 1 (:373-377)
+        if (dump_gso_entry(g, L, loop != 0, loop == 0 ? "Input" : hooks.step, loop == 0 ? -1 : loop - 1,
+                           loop == 0 ? 0.0 : hooks.seconds(), &rdg[L * d], &rex[L * d], rows[L]) != FPHIP_OK)
+          return gfail_msg(g->ctx, "BKZ_DUMP_GSO: cannot write the dump file");
+      }
+      ran[L] = 0;
       if (!active[L])
         continue;
       if (block_size < 2)
@@ -1305,6 +1399,12 @@ static int auto_abort_loop(fphip_gso *g, int block_size, bool use_loops, int max
         active[L] = 0;
         continue;
       }
+      if (hooks.use_time && hooks.seconds() >= hooks.max_time)
+      {  // RED_BKZ_TIME_LIMIT, bkz.cpp:588-592
+        st[L]     = 7;
+        active[L] = 0;
+        continue;
+      }
       const int n = rows[L];
       if (slope_test)
       {
@@ -1333,6 +1433,8 @@ static int auto_abort_loop(fphip_gso *g, int block_size, bool use_loops, int max
     if (n_active == 0)
       break;
     GCHK(hipMemcpy(g->P.bkz_active, active.data(), sizeof(int) * B, hipMemcpyHostToDevice));
+    for (size_t L = 0; L < B; ++L)
+      ran[L] = active[L] ? 1 : 0;
     float ms = 0;
     rc       = run_tour(loop, &ms, s1.data(), one.data());
     if (rc != FPHIP_OK)
@@ -1352,13 +1454,24 @@ static int auto_abort_loop(fphip_gso *g, int block_size, bool use_loops, int max
   return FPHIP_OK;
 }
 
+// BKZParam::max_time (seconds) and BKZParam::dump_gso_filename (bkz_param.h:151,167) of the device BKZ drivers
+extern "C" int fphip_gso_bkz_limits(fphip_gso *g, double max_time, const char *dump_gso_filename)
+{
+  if (!g)
+    return FPHIP_ERROR;
+  g->bkz_max_time = max_time;
+  if (dump_gso_filename)
+    g->bkz_dump_path = dump_gso_filename;
+  return FPHIP_OK;
+}
+
 extern "C" int fphip_gso_bkz(fphip_gso *g, int block_size, double delta, double eta, int flags,
                              int max_loops, int *status, int *info)
 {
   FPHIP_RANGE("fphip_gso_bkz");
   if (!g)
     return FPHIP_ERROR;
-  if (block_size > 64 || (flags & ~(0x4 | 0x20)))
+  if (block_size > 64 || (flags & ~(0x4 | 0x8 | 0x20 | 0x40)))
     return FPHIP_UNSUPPORTED;  // blocks beyond one wavefront / other BKZ variants: fplll's CPU code
   int rc = ensure_lll_buffers(g);
   if (rc != FPHIP_OK)
@@ -1376,8 +1489,13 @@ extern "C" int fphip_gso_bkz(fphip_gso *g, int block_size, double delta, double 
   if (rc != FPHIP_OK)
     return rc;
   const bool use_loops = (flags & 0x4) != 0, auto_abort = (flags & 0x20) != 0;
+  // BKZ_MAX_TIME (0x8) / BKZ_DUMP_GSO (0x40), fplll's values: one tour per launch, the clock and the dump in between
+  TourHooks hooks;
+  hooks.use_time = (flags & 0x8) != 0;
+  hooks.dump     = (flags & 0x40) != 0;
+  hooks.max_time = g->bkz_max_time;
   float total_ms = 0, ms = 0;
-  if (!auto_abort)
+  if (!auto_abort && !hooks.use_time && !hooks.dump)
   {
     rc = bkz_launch(g, block_size, delta, eta, use_loops ? 1 : 0, max_loops, &ms, st.data(), inf.data());
     if (rc != FPHIP_OK)
@@ -1388,7 +1506,10 @@ extern "C" int fphip_gso_bkz(fphip_gso *g, int block_size, double delta, double 
   {
     rc = auto_abort_loop(g, block_size, use_loops, max_loops, active, st, inf, rows, total_ms,
                          [&](int, float *tms, int *s1, int *one)
-                         { return bkz_launch(g, block_size, delta, eta, 1, 1, tms, s1, one); });
+                         { return bkz_launch(g, block_size, delta, eta, 1, 1, tms, s1, one); },
+                         auto_abort, false, hooks);
+    if (rc == FPHIP_OK && hooks.dump)
+      rc = dump_gso_output(g, hooks, st, rows);
     if (rc != FPHIP_OK)
       return rc;
   }
@@ -2022,8 +2143,16 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
   // BKZ_SD_VARIANT (0x100): self-dual BKZ, bkzs_body<NQ, true>
   const bool sd  = (flags & 0x100) != 0;
   const bool sld = (flags & 0x200) != 0;  // BKZ_SLD_RED: slide reduction (slide_tour, bkz.cpp:465-520)
-  if (block_size > 64 || (flags & ~(0x4 | 0x10 | 0x20 | 0x80 | 0x100 | 0x200 | 0x1000 | 0x2000)) || (sd && sld))
+  if (block_size > 64 || (flags & ~(0x4 | 0x8 | 0x10 | 0x20 | 0x40 | 0x80 | 0x100 | 0x200 | 0x1000 | 0x2000)) ||
+      (sd && sld))
     return FPHIP_UNSUPPORTED;
+  // BKZ_MAX_TIME (0x8) / BKZ_DUMP_GSO (0x40): one tour per launch, the clock and the dump on the host in between
+  TourHooks hooks;
+  hooks.use_time = (flags & 0x8) != 0;
+  hooks.dump     = (flags & 0x40) != 0;
+  hooks.max_time = g->bkz_max_time;
+  hooks.step     = sd ? "End of SD-BKZ loop" : (sld ? "End of SLD loop" : "End of BKZ loop");
+  flags &= ~(0x8 | 0x40);
   // FPHIP_BKZ_PRUNE_IN_LOOP (0x2000): pruning per block from the mailbox service (serve_radius)
   const bool inloop = (flags & 0x2000) != 0;
   flags &= ~0x2000;
@@ -2034,7 +2163,7 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
   // are enumerated by the multi-wave enumerator on a second context instead of by the lattice's wave
   const bool handoff = (flags & 0x1000) != 0 || (getenv("FPHIP_BKZ_HANDOFF") && atoi(getenv("FPHIP_BKZ_HANDOFF")) != 0);
   flags &= ~0x1000;
-  if (sd && !(flags & (0x4 | 0x20)))
+  if (sd && !(flags & (0x4 | 0x20)) && !hooks.use_time)
     flags |= 0x20;  // "SD Variant of BKZ requires explicit termination condition", bkz.cpp:548-554
   const int bsz = block_size < g->P.d ? block_size : g->P.d;
   if (S)
@@ -2493,7 +2622,7 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
     return rc1;
   };
 
-  std::vector<int> st(B, 1), inf(4 * B, 0);
+  std::vector<int> st(B, 1), inf(4 * B, 0), hook_rows(B, (int)g->P.d);
   float total_ms = 0, ms = 0;
   const bool use_loops = (flags & 0x4) != 0, auto_abort = (flags & 0x20) != 0;
   const int kbase = flags & (0x10 | 0x80);
@@ -2508,16 +2637,15 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
   {
     // slide reduction: one slide_tour per launch (the kernel's 0x200 frame), the potential test on the
     // host in between; then the closing hkz of every block (run_mode 4)
-    std::vector<int> rows(B, (int)g->P.d);
-    rc = auto_abort_loop(g, block_size, use_loops, max_loops, active, st, inf, rows, total_ms,
+    rc = auto_abort_loop(g, block_size, use_loops, max_loops, active, st, inf, hook_rows, total_ms,
                          [&](int, float *tms, int *s1, int *one)
                          { return run_once(kbase | 0x4 | 0x200, 1, tms, s1, one, 2); },
-                         auto_abort, true);
+                         auto_abort, true, hooks);
     std::vector<int> one(4 * B), s1(B);
     if (rc == FPHIP_OK)
     {
       for (size_t L = 0; L < B; ++L)
-        active[L] = (st[L] == 1 || st[L] == 8) ? 1 : 0;
+        active[L] = (st[L] == 1 || st[L] == 8 || st[L] == 7) ? 1 : 0;
       BCHK(hipMemcpy(g->P.bkz_active, active.data(), sizeof(int) * B, hipMemcpyHostToDevice));
       rc = run_once(kbase | 0x4 | 0x200, 1, &ms, s1.data(), one.data(), 4);
       total_ms += ms;
@@ -2536,7 +2664,7 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
       }
     }
   }
-  else if (!auto_abort)
+  else if (!auto_abort && !hooks.use_time && !hooks.dump)
   {
     rc       = run_once(kbase | (use_loops ? 0x4 : 0), max_loops, &ms, st.data(), inf.data());
     total_ms = ms;
@@ -2544,17 +2672,17 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
   else
   {
     // one tour per launch (self-dual BKZ: the prelude lll() goes with the first one only)
-    std::vector<int> rows(B, (int)g->P.d);
-    rc = auto_abort_loop(g, block_size, use_loops, max_loops, active, st, inf, rows, total_ms,
+    rc = auto_abort_loop(g, block_size, use_loops, max_loops, active, st, inf, hook_rows, total_ms,
                          [&](int loop, float *tms, int *s1, int *one)
-                         { return run_once(kbase | 0x4, 1, tms, s1, one, sd && loop == 0 ? 3 : 2); });
+                         { return run_once(kbase | 0x4, 1, tms, s1, one, sd && loop == 0 ? 3 : 2); },
+                         auto_abort, false, hooks);
     std::vector<int> one(4 * B), s1(B);
     if (sd && rc == FPHIP_OK)
     {
       // closing pass of self-dual BKZ on every lattice that ended regularly: hkz of the last window
       // (bkz.cpp:627-641), its own launch
       for (size_t L = 0; L < B; ++L)
-        active[L] = (st[L] == 1 || st[L] == 8) ? 1 : 0;
+        active[L] = (st[L] == 1 || st[L] == 8 || st[L] == 7) ? 1 : 0;
       BCHK(hipMemcpy(g->P.bkz_active, active.data(), sizeof(int) * B, hipMemcpyHostToDevice));
       rc = run_once(kbase | 0x4, 1, &ms, s1.data(), one.data(), 4);
       total_ms += ms;
@@ -2574,6 +2702,8 @@ extern "C" int fphip_gso_bkz_strategies(fphip_gso *g, int block_size, double del
     }
   }
 #undef BCHK
+  if (rc == FPHIP_OK && hooks.dump && !(sld && g->P.sld_pass != 0))
+    rc = dump_gso_output(g, hooks, st, hook_rows);  // "Output", bkz.cpp:667-670 (after the closing hkz passes)
   if (inloop)
   {
     g->il_calls += il_calls.load();

@@ -5,6 +5,7 @@
 granularity; every number is computed by the HIP kernels behind include/fplll_hip.h.
 """
 import ctypes
+import os
 
 import numpy as np
 
@@ -219,13 +220,26 @@ class MatGSOBatch:
                      stage.ctypes.data_as(ctypes.c_void_p)), "lll_ladder")
         return st, info, stage
 
-    def bkz(self, block_size, delta=LLL_DEF_DELTA, eta=LLL_DEF_ETA, max_loops=0, auto_abort=False):
+    def _bkz_limits(self, max_time, dump_gso):
+        """BKZ_MAX_TIME / BKZ_DUMP_GSO: BKZParam::max_time (seconds) and dump_gso_filename; returns the flag bits."""
+        if max_time is None and dump_gso is None:
+            return 0
+        fn = self.lib.fphip_gso_bkz_limits
+        fn.restype = ctypes.c_int
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.c_char_p]
+        self._chk(fn(self.h, float(max_time or 0.0), None if dump_gso is None else os.fsencode(dump_gso)), "bkz_limits")
+        return (0x8 if max_time is not None else 0) | (0x40 if dump_gso is not None else 0)
+
+    def bkz(self, block_size, delta=LLL_DEF_DELTA, eta=LLL_DEF_ETA, max_loops=0, auto_abort=False, max_time=None,
+            dump_gso=None):
         """BKZReduction::bkz() with empty strategies on every (LLL-reduced) lattice
-        (bkz.cpp:522-668).  Returns (status[batch], info[batch][4] = tours, nodes lo, nodes hi,
+        (bkz.cpp:522-668).  max_time (seconds) / dump_gso (file name): BKZ_MAX_TIME / BKZ_DUMP_GSO.
+        Returns (status[batch], info[batch][4] = tours, nodes lo, nodes hi,
         enumeration calls)."""
         st = np.zeros(self.batch, dtype=np.int32)
         info = np.zeros((self.batch, 4), dtype=np.int32)
         flags = (0x4 if max_loops > 0 else 0) | (0x20 if auto_abort else 0)  # fplll's BKZFlags
+        flags |= self._bkz_limits(max_time, dump_gso)
         rc = self.lib.fphip_gso_bkz(self.h, block_size, delta, eta, flags,
                                     max_loops, st.ctypes.data_as(ctypes.c_void_p),
                                     info.ctypes.data_as(ctypes.c_void_p))
@@ -236,7 +250,7 @@ class MatGSOBatch:
 
     def bkz_strategies(self, block_size, strategies, rnd, delta=LLL_DEF_DELTA, eta=LLL_DEF_ETA,
                        max_loops=0, gh_bnd=False, bounded_lll=False, gh_factor=1.1, auto_abort=False,
-                       sd=False, handoff=False, slide=False, prune_in_loop=None):
+                       sd=False, handoff=False, slide=False, prune_in_loop=None, max_time=None, dump_gso=None):
         """BKZReduction::bkz() with a strategies table (preprocessing tours, pruning, GH bound,
         rerandomisation; bkz.cpp:43-124, 274-441, 522-668) on every (LLL-reduced) lattice.
         strategies: dict with the flattened arrays of include/fplll_hip.h's fphip_strategies
@@ -304,6 +318,7 @@ class MatGSOBatch:
         flags = ((0x4 if max_loops > 0 else 0) | (0x80 if gh_bnd else 0) | (0x10 if bounded_lll else 0) |
                  (0x20 if auto_abort else 0) | (0x100 if sd else 0) | (0x1000 if handoff else 0) |
                  (0x200 if slide else 0) | (0x2000 if prune_in_loop is not None else 0))
+        flags |= self._bkz_limits(max_time, dump_gso)  # BKZ_MAX_TIME / BKZ_DUMP_GSO
         rc = fn(self.h, block_size, delta, eta, flags, max_loops, gh_factor, sp, cb, rnd_user,
                 st.ctypes.data_as(ctypes.c_void_p), info.ctypes.data_as(ctypes.c_void_p))
         if rc == _lib.FPHIP_UNSUPPORTED:

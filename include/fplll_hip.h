@@ -272,11 +272,24 @@ int fphip_gso_bkz(fphip_gso *g, int block_size, double delta, double eta, int fl
  * RandGen::get_gmp_state() (nr/nr_rand.inl:38-43); each lattice of a batch has its own stream, the
  * one a run of the reference on that lattice alone would draw from.
  * flags: FPHIP_BKZ_MAX_LOOPS, FPHIP_BKZ_BOUNDED_LLL, FPHIP_BKZ_AUTO_ABORT (one tour per launch, the
- * slope test on the host in between, as in fphip_gso_bkz), FPHIP_BKZ_GH_BND (fplll's values).
+ * slope test on the host in between, as in fphip_gso_bkz), FPHIP_BKZ_GH_BND, FPHIP_BKZ_MAX_TIME,
+ * FPHIP_BKZ_DUMP_GSO (fplll's values).
  * FPHIP_BKZ_SD_VARIANT selects self-dual BKZ (sd_tour, dual svp_reduction / enumeration / insertion,
  * bkz.cpp:401-413,443-463; without MAX_LOOPS / AUTO_ABORT the auto abort is switched on, :548-554).
  * FPHIP_UNSUPPORTED: block sizes above 64, other flags, preprocessing nested deeper than 3 levels.
  * status / info as fphip_gso_bkz; status -7 = a mailbox request was not answered in time. */
+/* FPHIP_BKZ_MAX_TIME / FPHIP_BKZ_DUMP_GSO (fplll's BKZ_MAX_TIME, BKZ_DUMP_GSO; bkz.cpp:563,588-592 and :373-377,
+ * 536-539,667-670 with dump_gso :729-790), for fphip_gso_bkz and fphip_gso_bkz_strategies: one tour per launch;
+ * between the tours the host compares the time since the call began with max_time (status 7 =
+ * RED_BKZ_TIME_LIMIT, tested after the loop limit and in front of the auto-abort test like the reference) and
+ * appends the reference's hand-written JSON entry — step, loop, time, norms = log r_ii + expo log 2 of the rows
+ * below num_rows with 8 digits — to the dump file: "Input", one entry per tour ("End of BKZ loop" / "End of SD-BKZ
+ * loop" / "End of SLD loop"), "Output".  Lattice 0 of a batch writes dump_gso_filename itself, lattice L > 0
+ * dump_gso_filename.L.  fphip_gso_bkz_limits sets BKZParam::max_time (seconds; wall clock of the call — the
+ * reference reads its single thread's CPU time) and BKZParam::dump_gso_filename (default "gso.json"). */
+#define FPHIP_BKZ_MAX_TIME 0x8
+#define FPHIP_BKZ_DUMP_GSO 0x40
+int fphip_gso_bkz_limits(fphip_gso *g, double max_time, const char *dump_gso_filename);
 #define FPHIP_BKZ_BOUNDED_LLL 0x10
 #define FPHIP_BKZ_GH_BND 0x80
 #define FPHIP_BKZ_SD_VARIANT 0x100

@@ -931,7 +931,8 @@ static int cmd_bkzfix(int argc, char **argv)
   const int extra_flags = getenv("REFDRV_BKZ_FLAGS") ? (int)strtol(getenv("REFDRV_BKZ_FLAGS"), 0, 0) : 0;
   const long rng_seed   = getenv("REFDRV_RNG_SEED") ? atol(getenv("REFDRV_RNG_SEED")) : 0;
   os << "\"flags\":" << ((max_loops > 0 ? BKZ_MAX_LOOPS : BKZ_DEFAULT) | extra_flags |
-                         (getenv("REFDRV_BKZ_AUTO_ABORT") ? BKZ_AUTO_ABORT : 0))
+                         (getenv("REFDRV_BKZ_AUTO_ABORT") ? BKZ_AUTO_ABORT : 0) |
+                         (getenv("REFDRV_DUMP_GSO") ? BKZ_DUMP_GSO : 0))
      << ",\n\"gh_factor\":" << hexd(BKZ_DEF_GH_FACTOR) << ",\n\"rng_seed\":" << rng_seed << ",\n";
   ZZ_mat<long> b = b0;
   double secs = 0;
@@ -946,7 +947,11 @@ static int cmd_bkzfix(int argc, char **argv)
     int flags = (max_loops > 0 ? BKZ_MAX_LOOPS : BKZ_DEFAULT) | extra_flags;
     if (getenv("REFDRV_BKZ_AUTO_ABORT"))
       flags |= BKZ_AUTO_ABORT;
+    if (getenv("REFDRV_DUMP_GSO"))
+      flags |= BKZ_DUMP_GSO;
     BKZParam par(block_size, strategies, LLL_DEF_DELTA, flags, max_loops);
+    if (getenv("REFDRV_DUMP_GSO"))  // BKZ_DUMP_GSO into this file; its content goes into the fixture below
+      par.dump_gso_filename = getenv("REFDRV_DUMP_GSO");
     RandGen::init_with_seed(rng_seed);
     auto t0 = std::chrono::steady_clock::now();
     MatGSO<Z_NR<long>, FP_NR<double>> M(b, u, ut, GSO_ROW_EXPO);
@@ -990,6 +995,13 @@ static int cmd_bkzfix(int argc, char **argv)
     os << "\"inloop\":{\"preproc_cost\":" << hexd(inloop_desc[0]) << ",\"target\":" << hexd(inloop_desc[1])
        << ",\"min_block\":" << (int)inloop_desc[2] << ",\"pruner_flags\":" << (int)inloop_desc[3]
        << ",\"prune_calls\":" << inloop_calls << ",\"prune_failures\":" << inloop_fails << "},\n";
+  if (getenv("REFDRV_DUMP_GSO"))
+  {  // the reference's own dump (dump_gso, bkz.cpp:729-790: a JSON array), verbatim
+    std::ifstream df(getenv("REFDRV_DUMP_GSO"));
+    std::stringstream dss;
+    dss << df.rdbuf();
+    os << "\"gso_dump\":" << dss.str() << ",\n";
+  }
   os << "\"ref_status\":" << status << ",\n\"nodes\":" << nodes << ",\n\"reps\":" << reps
      << ",\n\"ref_seconds\":" << secs << ",\n\"b_out\":[";
   for (int i = 0; i < d; ++i)

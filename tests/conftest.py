@@ -476,7 +476,7 @@ def load_lll_fixture(path):
 
 
 # ---- BKZ fixtures ---------------------------------------------------------------------------------
-BKZ_REF_STATUS_TO_OURS = {0: 1, 8: 8}  # RED_SUCCESS, RED_BKZ_LOOPS_LIMIT
+BKZ_REF_STATUS_TO_OURS = {0: 1, 8: 8, 7: 7}  # RED_SUCCESS, RED_BKZ_LOOPS_LIMIT, RED_BKZ_TIME_LIMIT
 
 
 def bkz_fixtures():

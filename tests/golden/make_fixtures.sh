@@ -117,6 +117,13 @@ REFDRV_BKZ_FLAGS=0x210 $D bkzfix q 64 32 14 6 16 0 > $G/bkzd_q64_b16_slide_bound
 REFDRV_STRATEGIES=$T/stratB.json REFDRV_BKZ_FLAGS=0x180 REFDRV_RNG_SEED=7 $D bkzfix q 64 32 14 3 40 1 > $G/bkzd_q64_b40_sd_strategies.json
 REFDRV_STRATEGIES=$T/stratA.json REFDRV_BKZ_FLAGS=0x280 REFDRV_RNG_SEED=8 $D bkzfix q 70 35 14 9 32 2 > $G/bkzd_q70_b32_slide_strategies.json
 REFDRV_BKZ_FLAGS=0x200 $D bkzfix r 30 0 40 4 8 0 > $G/bkzd_r30_b8_slide.json
+# BKZ_DUMP_GSO (REFDRV_DUMP_GSO=<file>: the reference's dump goes into the fixture as "gso_dump") and BKZ_MAX_TIME
+# with max_time = 0 (flag 0x8: RED_BKZ_TIME_LIMIT in front of the first tour)
+REFDRV_DUMP_GSO=$T/d1.json $D bkzfix q 40 20 20 1 10 0 > $G/bkzx_q40_b10_dump.json
+REFDRV_BKZ_FLAGS=0x8 $D bkzfix q 40 20 20 1 10 0 > $G/bkzx_q40_b10_time0.json
+REFDRV_DUMP_GSO=$T/d2.json REFDRV_BKZ_FLAGS=0x100 $D bkzfix q 40 20 20 1 10 3 > $G/bkzx_q40_b10_sd_loops3_dump.json
+REFDRV_DUMP_GSO=$T/d3.json REFDRV_BKZ_FLAGS=0x200 $D bkzfix q 40 20 20 1 10 0 > $G/bkzx_q40_b10_slide_dump.json
+REFDRV_DUMP_GSO=$T/d4.json REFDRV_STRATEGIES=$T/stratA.json REFDRV_BKZ_FLAGS=0x80 REFDRV_RNG_SEED=5 $D bkzfix q 64 32 14 3 40 2 > $G/bkzx_q64_b40_pre_gh_dump.json
 # three nested tours (40 -> 30 -> 20) with expectations scaled to 0.8x
 python3 $G/make_strategies.py $T/gen.json $T/stratC.json 40 10 30 0.8
 REFDRV_STRATEGIES=$T/stratC.json REFDRV_BKZ_FLAGS=0x80 REFDRV_RNG_SEED=21 $D bkzfix q 56 28 12 5 40 1 > $G/bkzs_q56_b40_nested3.json
