@@ -1081,10 +1081,10 @@ restart:
     // split launches and small trees keep the whole stack in LDS.
     // Sub-solution calls never split the stack (FPHIP_SUBS_SPLIT=1 brings the split back): the sub-solution
     // variant of the walk with the tall slots in global memory gave per-level counts that changed from run to run on
-    // a 130-row block — 3 of 6 runs, always exact with the whole stack in LDS (12 of 12), with mu in LDS or not;
-    // moving the reports behind the hot cycle, dropping their fences and reading the global slots past L1 did not
-    // change that (DESIGN.md section 6 has the experiments; tests/test_enum_gpu.py
-    // ::test_wide_blocks_report_candidates_under_every_level64_ancestor is the reproducer).  Not root-caused.
+    // a 130-row block — about every second run inside a long pytest session, always exact with the whole stack in
+    // LDS; a dozen experiments on code generation, caches, waits and stale memory changed nothing (DESIGN.md
+    // section 6; tests/test_enum_gpu.py::test_wide_blocks_report_candidates_under_every_level64_ancestor is the
+    // reproducer).  Not root-caused.
     int Ts = L + 1;
     if (in_final && C >= 1024 && !mu_lds && (!subs || env_int("FPHIP_SUBS_SPLIT", 0) != 0))
     {

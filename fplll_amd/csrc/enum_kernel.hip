@@ -182,9 +182,9 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK) __attribute__((amdgpu_waves_p
     if (from_host)                                                                                \
     {                                                                                             \
       nb_ = load_sys_u64(&h->bound_bits);                                                         \
-      if (nb_ < mbits && lane == 0)                                                               \
-        atomicMin(&g->bound_bits, nb_);                                                           \
-      FPHIP_JOIN();                                                                               \
+      nb_ = rfl_u64(nb_);                                                                         \
+      if (nb_ < mbits)                                                                            \
+        lane0_atomic_umin_u64_noret(&g->bound_bits, nb_); /* (no lane-masked branch: enum_wave.h) */ \
     }                                                                                             \
     else                                                                                          \
     {                                                                                             \
@@ -217,8 +217,7 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK) __attribute__((amdgpu_waves_p
     bool have = false;
     for (;;)
     {
-      if (lane == 0)
-        t = atomicAdd(&qh[q * FPHIP_QS], 1u);
+      t  = lane0_atomic_add_u32(&qh[q * FPHIP_QS], 1u);  // (the node counters are live across the pull)
       t  = (unsigned)__builtin_amdgcn_readfirstlane((int)t);
       cq = rcnt ? min((unsigned)__builtin_amdgcn_readfirstlane((int)rcnt[q * FPHIP_QS]), rcap)
                 : (nlist > q ? (nlist - q + FPHIP_NQ - 1u) / FPHIP_NQ : 0u);
@@ -249,9 +248,8 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK) __attribute__((amdgpu_waves_p
     }
     if (!have)
     {  // every queue is empty: tell the waves still walking to shed work for the next launch
-      if (budget != 0u && lane == 0)
+      if (budget != 0u)  // (every lane: the same word)
         __hip_atomic_store(&g->drain[launch_idx], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      FPHIP_JOIN();
       break;
     }
     // multi-GPU: this rank's share of the task list is an explicit index list (built on the host
@@ -279,17 +277,14 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK) __attribute__((amdgpu_waves_p
     // mutex-protected process_sol (enumeration.h:286-299).
     auto report = [&](double dist)
     {
-      unsigned long long idx = 0;
-      if (lane == 0)
-        idx = atomicAdd(&g->sol_head, 1ull);
-      idx = rfl_u64(idx);
-      for (unsigned spin = 0; idx >= load_sys_u64(&h->consumed) + FPHIP_RING_CAP; ++spin)
+      // (no lane-masked branch in here either: the level registers are live across the report — enum_wave.h)
+      const unsigned long long idx = rfl_u64(lane0_atomic_add_u64(&g->sol_head, 1ull));
+      for (unsigned spin = 0; idx >= rfl_u64(load_sys_u64(&h->consumed)) + FPHIP_RING_CAP; ++spin)
       {  // flow control against the host consumer
         __builtin_amdgcn_s_sleep(64);
         if (spin > (1u << 24))
         {
-          if (lane == 0)
-            atomicOr(&g->error_flags, FPHIP_ERR_RING_TIMEOUT);
+          lane0_atomic_or_u32_noret(&g->error_flags, FPHIP_ERR_RING_TIMEOUT);
           break;
         }
       }
@@ -305,23 +300,20 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK) __attribute__((amdgpu_waves_p
         for (int q = 1; q < 4; ++q)
           r->x[64 * q + rl] = (64 * q + lane < d) ? xhi_root[(size_t)rid * xstr + 64 * (q - 1) + rl] : 0.0;
       }
-      if (lane == 0)
-      {
+      {  // (every lane stores the same three words and, behind the fence, the same sequence number)
         const int z = here_lane(0);  // (a zero made here: as a hoisted constant pair it was spilled as well)
         r->dist     = dist;
         r->kind     = z;
         r->offset   = z;
       }
       __threadfence_system();
-      if (lane == 0)
-        __hip_atomic_store(&r->seq, idx + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-      for (unsigned spin = 0; load_sys_u64(&h->consumed) <= idx; ++spin)
+      __hip_atomic_store(&r->seq, idx + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      for (unsigned spin = 0; rfl_u64(load_sys_u64(&h->consumed)) <= idx; ++spin)
       {
         __builtin_amdgcn_s_sleep(32);
         if (spin > (1u << 24))
         {
-          if (lane == 0)
-            atomicOr(&g->error_flags, FPHIP_ERR_RING_TIMEOUT);
+          lane0_atomic_or_u32_noret(&g->error_flags, FPHIP_ERR_RING_TIMEOUT);
           break;
         }
       }
@@ -331,27 +323,23 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK) __attribute__((amdgpu_waves_p
     // process_subsolution (enumerate.cpp:241-249): a node at level lvl is shorter than every
     // sub-solution seen at that level.  Only the wave that lowers the device-wide best reports;
     // no verdict to wait for (sub-solutions never change the radius), only ring space.
+    // NO lane-masked branch in here (enum_wave.h, lane0_atomic_*): the report runs for every node that beats its
+    // level's best — millions of times early in a call — with all the level registers live across it.
     auto sub_report = [&](int lvl, double dist)
     {
-      unsigned long long old = 0;
-      if (lane == 0)
-        old = atomicMin(&g->sub_bits[lvl], (unsigned long long)__double_as_longlong(dist));
-      old               = rfl_u64(old);
+      unsigned long long old =
+          rfl_u64(lane0_atomic_umin_u64(&g->sub_bits[lvl], (unsigned long long)__double_as_longlong(dist)));
       const double oldd = __longlong_as_double((long long)old);
       sb                = (lane == lvl) ? fmin(oldd, dist) : sb;
-      if (!(dist < oldd))
+      if (__builtin_amdgcn_ballot_w64(dist < oldd) == 0ull)
         return;
-      unsigned long long idx = 0;
-      if (lane == 0)
-        idx = atomicAdd(&g->sol_head, 1ull);
-      idx = rfl_u64(idx);
-      for (unsigned spin = 0; idx >= load_sys_u64(&h->consumed) + FPHIP_RING_CAP; ++spin)
+      const unsigned long long idx = rfl_u64(lane0_atomic_add_u64(&g->sol_head, 1ull));
+      for (unsigned spin = 0; idx >= rfl_u64(load_sys_u64(&h->consumed)) + FPHIP_RING_CAP; ++spin)
       {
         __builtin_amdgcn_s_sleep(64);
         if (spin > (1u << 24))
         {
-          if (lane == 0)
-            atomicOr(&g->error_flags, FPHIP_ERR_RING_TIMEOUT);
+          lane0_atomic_or_u32_noret(&g->error_flags, FPHIP_ERR_RING_TIMEOUT);
           break;
         }
       }
@@ -365,15 +353,12 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK) __attribute__((amdgpu_waves_p
         for (int q = 1; q < 4; ++q)
           r->x[64 * q + rl] = (64 * q + lane < d) ? xhi_root[(size_t)rid * xstr + 64 * (q - 1) + rl] : 0.0;
       }
-      if (lane == 0)
-      {
-        r->dist   = dist;
-        r->kind   = 1;
-        r->offset = lvl;
-      }
+      // (every lane stores the same three words and, behind the fence, the same sequence number)
+      r->dist   = dist;
+      r->kind   = 1;
+      r->offset = lvl;
       __threadfence_system();
-      if (lane == 0)
-        __hip_atomic_store(&r->seq, idx + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(&r->seq, idx + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     };
 
     // The walk is two hot loops (CHILD chain, STEP loop) inside one hot cycle inside an outer event
@@ -446,7 +431,7 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK) __attribute__((amdgpu_waves_p
     cnt32                       = add_bit(me, cnt32); /* ++nodes[kk-1] */                                \
     if constexpr (SUBS)                                                                                  \
     {                                                                                                    \
-      if (n1 < rl_f64(sb, kc) && n1 != 0.0)                                                              \
+      if (__builtin_amdgcn_ballot_w64(n1 < rl_f64(sb, kc) && n1 != 0.0) != 0ull)                         \
         sub_report(kc, n1);                                                                              \
     }                                                                                                    \
     par = S; /* (S_{kc+1}, row kc): what a step at the new level needs */                                \
@@ -620,7 +605,7 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK) __attribute__((amdgpu_waves_p
         cnt32 = add_bit(lane_bit(k), cnt32);  // ++nodes[kk]
         if constexpr (SUBS)
         {
-          if (nd < rl_f64(sb, k) && nd != 0.0)
+          if (__builtin_amdgcn_ballot_w64(nd < rl_f64(sb, k) && nd != 0.0) != 0ull)
             sub_report(k, nd);
         }
         if (k == 0)
@@ -649,30 +634,22 @@ __global__ void __launch_bounds__(FPHIP_MAX_BLOCK) __attribute__((amdgpu_waves_p
       }
       if (ev == EV_EMIT)
       {
-        unsigned oi = 0;
-        if (lane == 0)
-          oi = atomicAdd(out.count, 1u);
-        oi = (unsigned)__builtin_amdgcn_readfirstlane((int)oi);
+        unsigned oi = lane0_atomic_add_u32(out.count, 1u);
+        oi          = (unsigned)__builtin_amdgcn_readfirstlane((int)oi);
         if (oi < out.cap)
         {
           const int el                              = here_lane(lane);
           out.col[(unsigned long long)oi * 64 + el] = S;
           const double xf                           = (lane < Lt) ? xs : xpre;
           out.x[(unsigned long long)oi * 64 + el]   = xf;
-          if (lane == 0)
-          {
-            out.pd[oi]    = nd;
-            out.level[oi] = k;
-            out.root[oi]  = rid;
-          }
-          FPHIP_JOIN();
+          out.pd[oi]    = nd;  // (every lane: the same three words)
+          out.level[oi] = k;
+          out.root[oi]  = rid;
           // → next sibling at level k
         }
         else
         {  // buffer full: walk everything inline from here on (results stay exact)
-          if (lane == 0)
-            atomicOr(&g->error_flags, FPHIP_FLAG_TASK_OVERFLOW);
-          FPHIP_JOIN();
+          lane0_atomic_or_u32_noret(&g->error_flags, FPHIP_FLAG_TASK_OVERFLOW);
           buffer_full = true;
           donate      = 1 << 20;
           elo         = 1u << 20;

@@ -66,6 +66,20 @@ __device__ __forceinline__ v4i rp_issue(const double *tab, int level)
   asm volatile("s_load_dwordx4 %0, %1, %2" : "=s"(q) : "s"(tab), "s"(level << 4));
   return q;
 }
+#ifdef FPHIP_RP_PLAIN
+// (experiment: the same pair through a load the compiler sees — its own s_load and its own waits)
+__device__ __forceinline__ v4i rp_issue2(const double *tab, unsigned off)
+{
+  const v4i *p = (const v4i *)((const char *)tab + off);
+  v4i q        = *p;
+  q.x = __builtin_amdgcn_readfirstlane(q.x);
+  q.y = __builtin_amdgcn_readfirstlane(q.y);
+  q.z = __builtin_amdgcn_readfirstlane(q.z);
+  q.w = __builtin_amdgcn_readfirstlane(q.w);
+  return q;
+}
+__device__ __forceinline__ void rp_wait(v4i &q) { asm volatile("" : "+s"(q)); }
+#else
 __device__ __forceinline__ v4i rp_issue2(const double *tab, unsigned off)
 {  // (off = byte offset of the level's row in DevShared::mu_sq; tab points at the pair of row 0)
   v4i q;
@@ -73,6 +87,7 @@ __device__ __forceinline__ v4i rp_issue2(const double *tab, unsigned off)
   return q;
 }
 __device__ __forceinline__ void rp_wait(v4i &q) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(q)); }
+#endif
 __device__ __forceinline__ double rp_r(const v4i &q) { return __hiloint2double(q.y, q.x); }
 __device__ __forceinline__ double rp_p(const v4i &q) { return __hiloint2double(q.w, q.z); }
 // v_writelane_b32: the wave-uniform `val` (an SGPR) into lane `lane` (an SGPR) of `old`; one VALU
@@ -137,6 +152,72 @@ __device__ __forceinline__ unsigned tri8(int k)
 __device__ __forceinline__ unsigned long long load_sys_u64(const unsigned long long *p)
 {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// ONE lane's atomic without a lane-masked branch the compiler can see: EXEC is narrowed to lane 0 and widened again
+// inside one asm statement (the callers sit in wave-uniform control flow: EXEC is full there).  The level registers
+// of the walks (lane = level: x, centre, partial distance, sub-solution bound, node counters) are read ACROSS lanes
+// — v_readlane, ds_bpermute — and the register allocator knows nothing of that: inside an `if (lane == 0)` region it
+// may split the live range of such a register with a v_mov that executes for lane 0 only, and the other 63 levels
+// are garbage behind the region.  A precaution, not a repair: no such copy was found in the shipped objects, and
+// taking every lane-masked branch out of the subtree walk did not cure the run-to-run differences of its
+// sub-solution variant with the split stack — but the hazard is real for any later build.
+// Returns the pre-op value in lane 0 (the other lanes: undefined — read it with rfl_u64).
+__device__ __forceinline__ unsigned long long lane0_atomic_umin_u64(unsigned long long *p, unsigned long long v)
+{
+  unsigned long long old;
+  asm volatile("s_mov_b64 exec, 1\n\t"
+               "global_atomic_umin_x2 %0, %1, %2, off sc0\n\t"
+               "s_waitcnt vmcnt(0)\n\t"
+               "s_mov_b64 exec, -1"
+               : "=&v"(old)
+               : "v"(p), "v"(v)
+               : "memory");
+  return old;
+}
+__device__ __forceinline__ unsigned long long lane0_atomic_add_u64(unsigned long long *p, unsigned long long v)
+{
+  unsigned long long old;
+  asm volatile("s_mov_b64 exec, 1\n\t"
+               "global_atomic_add_x2 %0, %1, %2, off sc0\n\t"
+               "s_waitcnt vmcnt(0)\n\t"
+               "s_mov_b64 exec, -1"
+               : "=&v"(old)
+               : "v"(p), "v"(v)
+               : "memory");
+  return old;
+}
+
+__device__ __forceinline__ unsigned lane0_atomic_add_u32(unsigned *p, unsigned v)
+{
+  unsigned old;
+  asm volatile("s_mov_b64 exec, 1\n\t"
+               "global_atomic_add %0, %1, %2, off sc0\n\t"
+               "s_waitcnt vmcnt(0)\n\t"
+               "s_mov_b64 exec, -1"
+               : "=&v"(old)
+               : "v"(p), "v"(v)
+               : "memory");
+  return old;
+}
+// (no value back: fire and forget)
+__device__ __forceinline__ void lane0_atomic_umin_u64_noret(unsigned long long *p, unsigned long long v)
+{
+  asm volatile("s_mov_b64 exec, 1\n\t"
+               "global_atomic_umin_x2 %0, %1, off\n\t"
+               "s_mov_b64 exec, -1"
+               :
+               : "v"(p), "v"(v)
+               : "memory");
+}
+__device__ __forceinline__ void lane0_atomic_or_u32_noret(unsigned *p, unsigned v)
+{
+  asm volatile("s_mov_b64 exec, 1\n\t"
+               "global_atomic_or %0, %1, off\n\t"
+               "s_mov_b64 exec, -1"
+               :
+               : "v"(p), "v"(v)
+               : "memory");
 }
 
 // An empty statement the optimiser can neither delete nor merge: it keeps the join block of a
