@@ -512,6 +512,11 @@ extern "C" int fphip_gso_set_basis(fphip_gso *g, int first, int count, const int
     return rc;
   GCHK(hipMemcpy2D(g->P.b + (size_t)first * g->P.d * g->P.ldn, (size_t)g->P.ldn * 8, b,
                    (size_t)g->P.n * 8, (size_t)g->P.n * 8, rows, hipMemcpyHostToDevice));
+  // The kernels run on a NON-BLOCKING stream, which nothing orders against the null stream: the upload has to be
+  // complete on the device, not merely handed to the DMA engine from its staging buffer, when this returns.  (The
+  // API text allows a pageable upload to return at that point; one of 1536 lattices of a stress test once came back
+  // reduced from an all-zero input.)
+  GCHK(hipStreamSynchronize(nullptr));
   g->dirty          = true;
   return FPHIP_OK;
 }
@@ -593,6 +598,7 @@ extern "C" int fphip_gso_enable_transform(fphip_gso *g, const int64_t *u)
     for (size_t L = 0; L < B; ++L)
       GCHK(hipMemcpy(g->P.u + L * d * ldd, id.data(), d * ldd * sizeof(long long), hipMemcpyHostToDevice));
   }
+  GCHK(hipStreamSynchronize(nullptr));  // (see fphip_gso_set_basis)
   g->u_in_slots = false;
   return FPHIP_OK;
 }
@@ -2951,6 +2957,7 @@ extern "C" int fphip_hh_set_basis(fphip_hh *h, int first, int count, const int64
   HCHK(hipMemcpy2D(h->P.b + (size_t)first * h->P.d * h->P.ldn, (size_t)h->P.ldn * 8, b,
                    (size_t)h->P.n * 8, (size_t)h->P.n * 8, (size_t)h->P.d * count,
                    hipMemcpyHostToDevice));
+  HCHK(hipStreamSynchronize(nullptr));  // (see fphip_gso_set_basis: complete on the device before a kernel may run)
   return FPHIP_OK;
 }
 
