@@ -1100,7 +1100,13 @@ restart:
     int blocks_per_cu = (int)std::max<size_t>(1, std::min<size_t>(32 / wpb, (160 * 1024) / lds));
     {
       const size_t per_wave = (size_t)(triL - ldsRow + 1);
-      const size_t need     = per_wave * (size_t)wpb * (size_t)ctx->num_cus * (size_t)blocks_per_cu;
+      size_t need           = per_wave * (size_t)wpb * (size_t)ctx->num_cus * (size_t)blocks_per_cu;
+      // Never smaller than what the largest default launch asks for (64 levels, split at 34, 32 waves per CU: 100 MB
+      // on 256 CUs), so that a context allocates this scratch ONCE, with its first big launch, and no later call
+      // walks on memory that left the allocator microseconds ago (the run-to-run differences
+      // of the sub-solution walk start in the first instants of a kernel, on the global slots, in contiguous bands
+      // of waves — and that call was the first of its context to need more than the 63-level launches before it).
+      need = std::max(need, (size_t)(64 * 65 / 2 - 34 * 33 / 2 + 1) * 32u * (size_t)ctx->num_cus);
       if (need > ctx->gstk_doubles)
       {
         if (ctx->gstk)
