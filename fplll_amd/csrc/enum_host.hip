@@ -273,6 +273,24 @@ extern "C" int fphip_create_ex(int device, int priority, fphip_ctx **out)
   }
   HIPCHK(ctx, hipEventCreate(&ctx->ev[0]));
   HIPCHK(ctx, hipEventCreate(&ctx->ev[1]));
+  {
+    // The stream-ordered allocations of this library (dev_mem.h) come out of the device's default pool.  Its release
+    // threshold is zero by default: at every synchronisation the pool hands unused blocks back to the driver, and
+    // the next allocation is memory that has just been obtained — and cleared and mapped — anew.  Keep freed blocks
+    // in the pool instead (FPHIP_POOL_KEEP=0 restores the default): buffers that come and go with the batch objects
+    // and the growing scratch of a context are then re-used, mapped and settled (the one
+    // defect of round 6 follows a re-allocation microseconds in front of a kernel).  Best effort: an error here is
+    // not an error of the call.
+    hipMemPool_t pool = nullptr;
+    if (env_int("FPHIP_POOL_KEEP", 1) != 0 && hipDeviceGetDefaultMemPool(&pool, device) == hipSuccess && pool)
+    {
+      uint64_t keep = ~(uint64_t)0;
+      if (hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep) != hipSuccess)
+        (void)hipGetLastError();
+    }
+    else
+      (void)hipGetLastError();
+  }
   HIPCHK(ctx, fphip_dev_alloc((void **)&ctx->g, sizeof(DevShared), ctx->stream));
   ctx->stage = (DevShared *)fphip_pinned_get(sizeof(DevShared));
   ctx->h     = (HostCtl *)fphip_pinned_get(sizeof(HostCtl));
