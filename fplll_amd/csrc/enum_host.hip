@@ -102,6 +102,116 @@ struct PinnedBuf
 std::mutex g_pinned_mutex;
 std::vector<PinnedBuf> g_pinned;
 }  // namespace
+// ---- process-wide cache of device blocks (dev_mem.h) ----------------------------------------------------------------
+// Freed blocks are kept per device and handed out again to requests they fit (at most a quarter plus 1 MB larger than
+// asked for); hipFree — a device-wide synchronisation — only happens when the cache exceeds FPHIP_DEV_CACHE_GB
+// (default 96) or when hipMalloc itself runs out of memory.
+namespace
+{
+struct DevBlock
+{
+  void *p;
+  size_t bytes;
+  int device;
+};
+std::mutex g_dev_mutex;
+std::vector<DevBlock> g_dev_free;                 // idle blocks
+std::vector<DevBlock> g_dev_live;                 // blocks handed out (size and device of a pointer)
+size_t g_dev_cached = 0;
+
+void dev_cache_trim_locked(int device, size_t keep_bytes)
+{  // (hipFree synchronises the device: rare by construction)
+  for (size_t i = 0; i < g_dev_free.size() && g_dev_cached > keep_bytes;)
+  {
+    if (g_dev_free[i].device != device)
+    {
+      ++i;
+      continue;
+    }
+    (void)hipFree(g_dev_free[i].p);
+    g_dev_cached -= g_dev_free[i].bytes;
+    g_dev_free[i] = g_dev_free.back();
+    g_dev_free.pop_back();
+  }
+}
+}  // namespace
+
+hipError_t fphip_dev_alloc(void **p, size_t bytes, hipStream_t)
+{
+  *p = nullptr;
+  if (bytes == 0)
+    bytes = 256;
+  bytes = (bytes + 255) & ~(size_t)255;
+  int device = 0;
+  hipError_t e = hipGetDevice(&device);
+  if (e != hipSuccess)
+    return e;
+  {
+    std::lock_guard<std::mutex> lk(g_dev_mutex);
+    size_t best = g_dev_free.size();
+    for (size_t i = 0; i < g_dev_free.size(); ++i)
+    {
+      const DevBlock &b = g_dev_free[i];
+      if (b.device == device && b.bytes >= bytes && b.bytes <= bytes + bytes / 4 + ((size_t)1 << 20) &&
+          (best == g_dev_free.size() || b.bytes < g_dev_free[best].bytes))
+        best = i;
+    }
+    if (best != g_dev_free.size())
+    {
+      const DevBlock b = g_dev_free[best];
+      g_dev_free[best] = g_dev_free.back();
+      g_dev_free.pop_back();
+      g_dev_cached -= b.bytes;
+      g_dev_live.push_back(b);
+      *p = b.p;
+      return hipSuccess;
+    }
+  }
+  void *q = nullptr;
+  e       = hipMalloc(&q, bytes);
+  if (e != hipSuccess)
+  {  // out of memory with blocks in the cache: give them back and try once more
+    (void)hipGetLastError();
+    {
+      std::lock_guard<std::mutex> lk(g_dev_mutex);
+      dev_cache_trim_locked(device, 0);
+    }
+    e = hipMalloc(&q, bytes);
+    if (e != hipSuccess)
+      return e;
+  }
+  std::lock_guard<std::mutex> lk(g_dev_mutex);
+  g_dev_live.push_back(DevBlock{q, bytes, device});
+  *p = q;
+  return hipSuccess;
+}
+
+void fphip_dev_free(void *p, hipStream_t)
+{
+  if (!p)
+    return;
+  static const size_t cap = []
+  {
+    const char *v = getenv("FPHIP_DEV_CACHE_GB");
+    const long gb = v ? atol(v) : 96;
+    return (size_t)(gb > 0 ? gb : 1) << 30;
+  }();
+  std::lock_guard<std::mutex> lk(g_dev_mutex);
+  for (size_t i = 0; i < g_dev_live.size(); ++i)
+    if (g_dev_live[i].p == p)
+    {
+      const DevBlock b = g_dev_live[i];
+      g_dev_live[i]    = g_dev_live.back();
+      g_dev_live.pop_back();
+      g_dev_free.push_back(b);
+      g_dev_cached += b.bytes;
+      if (g_dev_cached > cap)
+        dev_cache_trim_locked(b.device, cap / 2);
+      return;
+    }
+  (void)hipFree(p);  // (not one of ours: cannot happen; stay correct anyway)
+}
+
 void *fphip_pinned_get(size_t bytes)
 {
   std::lock_guard<std::mutex> lk(g_pinned_mutex);
@@ -273,24 +383,6 @@ extern "C" int fphip_create_ex(int device, int priority, fphip_ctx **out)
   }
   HIPCHK(ctx, hipEventCreate(&ctx->ev[0]));
   HIPCHK(ctx, hipEventCreate(&ctx->ev[1]));
-  {
-    // The stream-ordered allocations of this library (dev_mem.h) come out of the device's default pool.  Its release
-    // threshold is zero by default: at every synchronisation the pool hands unused blocks back to the driver, and
-    // the next allocation is memory that has just been obtained — and cleared and mapped — anew.  Keep freed blocks
-    // in the pool instead (FPHIP_POOL_KEEP=0 restores the default): buffers that come and go with the batch objects
-    // and the growing scratch of a context are then re-used, mapped and settled (the one
-    // defect of round 6 follows a re-allocation microseconds in front of a kernel).  Best effort: an error here is
-    // not an error of the call.
-    hipMemPool_t pool = nullptr;
-    if (env_int("FPHIP_POOL_KEEP", 1) != 0 && hipDeviceGetDefaultMemPool(&pool, device) == hipSuccess && pool)
-    {
-      uint64_t keep = ~(uint64_t)0;
-      if (hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep) != hipSuccess)
-        (void)hipGetLastError();
-    }
-    else
-      (void)hipGetLastError();
-  }
   HIPCHK(ctx, fphip_dev_alloc((void **)&ctx->g, sizeof(DevShared), ctx->stream));
   ctx->stage = (DevShared *)fphip_pinned_get(sizeof(DevShared));
   ctx->h     = (HostCtl *)fphip_pinned_get(sizeof(HostCtl));
@@ -1097,12 +1189,10 @@ restart:
     // scratch in global memory.  Ts is the largest level whose LDS part still lets 32 waves (8 per
     // SIMD) reside on a CU in the big walk launches (tri_off(34) + 64 = 625 doubles = 5 KB per wave); the
     // split launches and small trees keep the whole stack in LDS.
-    // Sub-solution calls never split the stack (FPHIP_SUBS_SPLIT=1 brings the split back): the sub-solution
-    // variant of the walk with the tall slots in global memory gave per-level counts that changed from run to run on
-    // a 130-row block — about every second run inside a long pytest session, always exact with the whole stack in
-    // LDS; a dozen experiments on code generation, caches, waits and stale memory changed nothing (DESIGN.md
-    // section 6; tests/test_enum_gpu.py::test_wide_blocks_report_candidates_under_every_level64_ancestor is the
-    // reproducer).  Not root-caused.
+    // Sub-solution calls do not split the stack (FPHIP_SUBS_SPLIT=1 brings the split back): their walk with the tall
+    // slots in global memory gave per-level counts that changed from run to run on a 130-row block.  The cause turned
+    // out to be the allocator — the scratch had left hipMallocAsync microseconds earlier (dev_mem.h, DESIGN.md
+    // section 6) — but the fix for that has no full suite behind it yet, so this stays as it was validated.
     int Ts = L + 1;
     if (in_final && C >= 1024 && !mu_lds && (!subs || env_int("FPHIP_SUBS_SPLIT", 0) != 0))
     {
@@ -1120,10 +1210,7 @@ restart:
       const size_t per_wave = (size_t)(triL - ldsRow + 1);
       size_t need           = per_wave * (size_t)wpb * (size_t)ctx->num_cus * (size_t)blocks_per_cu;
       // Never smaller than what the largest default launch asks for (64 levels, split at 34, 32 waves per CU: 100 MB
-      // on 256 CUs), so that a context allocates this scratch ONCE, with its first big launch, and no later call
-      // walks on memory that left the allocator microseconds ago (the run-to-run differences
-      // of the sub-solution walk start in the first instants of a kernel, on the global slots, in contiguous bands
-      // of waves — and that call was the first of its context to need more than the 63-level launches before it).
+      // on 256 CUs): a context allocates this scratch once, with its first big launch.
       need = std::max(need, (size_t)(64 * 65 / 2 - 34 * 33 / 2 + 1) * 32u * (size_t)ctx->num_cus);
       if (need > ctx->gstk_doubles)
       {
