@@ -14,7 +14,8 @@
 //
 // Contract: a buffer is idle when it is freed (every API call waits for its own stream before it returns); a block
 // from the cache holds whatever its last owner left in it (callers memset what they need zeroed — as they had to
-// under the pool as well).  The stream argument is kept for the call sites; it is not used.
+// under the pool as well).  fphip_dev_free waits for the stream it is given — the owner's — before the block enters the
+// cache; fphip_dev_alloc ignores its stream argument.
 #ifndef FPHIP_DEV_MEM_H
 #define FPHIP_DEV_MEM_H
 

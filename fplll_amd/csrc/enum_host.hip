@@ -186,10 +186,15 @@ hipError_t fphip_dev_alloc(void **p, size_t bytes, hipStream_t)
   return hipSuccess;
 }
 
-void fphip_dev_free(void *p, hipStream_t)
+void fphip_dev_free(void *p, hipStream_t s)
 {
   if (!p)
     return;
+  // The block may be handed to another owner the moment it is in the cache: whatever its owner's stream still has
+  // queued on it (a memset in front of a re-allocation, say) must be over.  The stream is idle at almost every call
+  // site — this is a no-op there — and it is the OWNER's stream, never a stranger's.
+  if (s)
+    (void)hipStreamSynchronize(s);
   static const size_t cap = []
   {
     const char *v = getenv("FPHIP_DEV_CACHE_GB");
