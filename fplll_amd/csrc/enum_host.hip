@@ -119,8 +119,12 @@ std::vector<DevBlock> g_dev_free;                 // idle blocks
 std::vector<DevBlock> g_dev_live;                 // blocks handed out (size and device of a pointer)
 size_t g_dev_cached = 0;
 
-void dev_cache_trim_locked(int device, size_t keep_bytes)
-{  // (hipFree synchronises the device: rare by construction)
+// takes blocks of `device` out of the cache until it holds at most keep_bytes; the caller hands them to hipFree
+// AFTER it has let go of the mutex (hipFree synchronises the device — with a persistent kernel in flight that is
+// served by threads which allocate, freeing under the lock would never return)
+std::vector<void *> dev_cache_take_locked(int device, size_t keep_bytes)
+{
+  std::vector<void *> out;
   for (size_t i = 0; i < g_dev_free.size() && g_dev_cached > keep_bytes;)
   {
     if (g_dev_free[i].device != device)
@@ -128,11 +132,12 @@ void dev_cache_trim_locked(int device, size_t keep_bytes)
       ++i;
       continue;
     }
-    (void)hipFree(g_dev_free[i].p);
+    out.push_back(g_dev_free[i].p);
     g_dev_cached -= g_dev_free[i].bytes;
     g_dev_free[i] = g_dev_free.back();
     g_dev_free.pop_back();
   }
+  return out;
 }
 }  // namespace
 
@@ -172,10 +177,13 @@ hipError_t fphip_dev_alloc(void **p, size_t bytes, hipStream_t)
   if (e != hipSuccess)
   {  // out of memory with blocks in the cache: give them back and try once more
     (void)hipGetLastError();
+    std::vector<void *> give;
     {
       std::lock_guard<std::mutex> lk(g_dev_mutex);
-      dev_cache_trim_locked(device, 0);
+      give = dev_cache_take_locked(device, 0);
     }
+    for (void *x : give)
+      (void)hipFree(x);
     e = hipMalloc(&q, bytes);
     if (e != hipSuccess)
       return e;
@@ -201,20 +209,28 @@ void fphip_dev_free(void *p, hipStream_t s)
     const long gb = v ? atol(v) : 96;
     return (size_t)(gb > 0 ? gb : 1) << 30;
   }();
-  std::lock_guard<std::mutex> lk(g_dev_mutex);
-  for (size_t i = 0; i < g_dev_live.size(); ++i)
-    if (g_dev_live[i].p == p)
-    {
-      const DevBlock b = g_dev_live[i];
-      g_dev_live[i]    = g_dev_live.back();
-      g_dev_live.pop_back();
-      g_dev_free.push_back(b);
-      g_dev_cached += b.bytes;
-      if (g_dev_cached > cap)
-        dev_cache_trim_locked(b.device, cap / 2);
-      return;
-    }
-  (void)hipFree(p);  // (not one of ours: cannot happen; stay correct anyway)
+  std::vector<void *> give;
+  bool ours = false;
+  {
+    std::lock_guard<std::mutex> lk(g_dev_mutex);
+    for (size_t i = 0; i < g_dev_live.size(); ++i)
+      if (g_dev_live[i].p == p)
+      {
+        const DevBlock b = g_dev_live[i];
+        g_dev_live[i]    = g_dev_live.back();
+        g_dev_live.pop_back();
+        g_dev_free.push_back(b);
+        g_dev_cached += b.bytes;
+        if (g_dev_cached > cap)
+          give = dev_cache_take_locked(b.device, cap / 2);
+        ours = true;
+        break;
+      }
+  }
+  if (!ours)
+    give.push_back(p);  // (not one of ours: cannot happen; stay correct anyway)
+  for (void *x : give)
+    (void)hipFree(x);
 }
 
 void *fphip_pinned_get(size_t bytes)
