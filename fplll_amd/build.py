@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 
 HIP_SOURCES = ["enum_kernel.hip", "enum_walk.hip", "enum_deal.hip", "enum_host.hip", "gso_kernel.hip", "gso_sweep2.hip", "lll_kernel.hip", "lll_kernel_early.hip", "hlll_kernel.hip", "hh_blocked.hip", "hh_rows.hip", "hlll_x.hip", "lll_x.hip", "bkz_kernel.hip", "bkzs_kernel.hip", "gso_host.hip", "pruner_volume.hip", "pruner_search.hip", "gso_util_host.hip"]
-HIP_HEADERS = ["dev_mem.h", "trace.h", "pruner_tables.h", "pruner_engine.h", "enum_device.h", "enum_wave.h", "gso_device.h", "gso_wave.h", "gso_sweep2.h", "ftx.h", "lll_wave.h", "lll_stream.h", os.path.join(ROOT, "include", "fplll_hip.h")]
+HIP_HEADERS = ["dev_mem.h", "dev_cache.h", "trace.h", "pruner_tables.h", "pruner_engine.h", "enum_device.h", "enum_wave.h", "gso_device.h", "gso_wave.h", "gso_sweep2.h", "ftx.h", "lll_wave.h", "lll_stream.h", os.path.join(ROOT, "include", "fplll_hip.h")]
 HIPCC_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17",
     "-ffp-contract=off",  # fplll's arithmetic is separate mul/add (nr/nr_FP_d.inl:178); no FMA
