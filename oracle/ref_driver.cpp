@@ -620,6 +620,8 @@ static int cmd_lllfix(int argc, char **argv)
     b = b0;
     if (getenv("LLLFIX_U"))  // enable_transform: the run keeps u with b_out = u b_in (the fixture records it)
       u.gen_identity(d);
+    if (getenv("LLLFIX_UINV"))  // enable_inverse_transform as well: u_inv_t, the inverse transpose of u (gso.cpp:84-158)
+      ut.gen_identity(d);
     auto t0 = std::chrono::steady_clock::now();
     MatGSO<Z_NR<long>, FP_NR<double>> M(b, u, ut, GSO_ROW_EXPO);
     // (LLLFIX_FLAGS: fplll's LLLFlags for this run — LLL_SIEGEL = 4; the fixture records them)
@@ -647,6 +649,14 @@ static int cmd_lllfix(int argc, char **argv)
     for (int i = 0; i < d; ++i)
       for (int j = 0; j < d; ++j)
         os << ((i || j) ? "," : "") << u(i, j).get_si();
+    os << "]";
+  }
+  if (ut.get_rows() > 0)
+  {
+    os << ",\n\"u_inv_t_out\":[";
+    for (int i = 0; i < d; ++i)
+      for (int j = 0; j < d; ++j)
+        os << ((i || j) ? "," : "") << ut(i, j).get_si();
     os << "]";
   }
   os << "\n}\n";

@@ -69,6 +69,9 @@ LLLFIX_FLAGS=2 $D lllfix q  72 36 16 7  0  0 -1 2 1 > $G/lll_q72_earlyred_zeros.
 LLLFIX_U=1 $D lllfix q  40 20 20 1  0  0 -1 1 2 > $G/lll_q40_zero1_dup2_u.json
 LLLFIX_U=1 $D lllfix q  72 36 16 2  0  0 -1 0 0 > $G/lll_q72_u.json
 LLLFIX_U=1 LLLFIX_FLAGS=2 $D lllfix r 30 0 40 3 0 0 -1 0 0 > $G/lll_r30_earlyred_u.json
+# ... and with the inverse transformation tracked as well (u_inv_t: enable_inverse_transform, gso.cpp:84-158)
+LLLFIX_U=1 LLLFIX_UINV=1 $D lllfix q 40 20 20 1 0 0 -1 0 0 > $G/lll_q40_u_uinv.json
+LLLFIX_U=1 LLLFIX_UINV=1 $D lllfix r 30 0 40 3 0 0 -1 0 0 > $G/lll_r30_u_uinv.json
 # both flags at once; and on a sub-range with u
 LLLFIX_FLAGS=6 $D lllfix q  40 20 20 4  0  0 -1 0 0 > $G/lll_q40_siegel_earlyred.json
 LLLFIX_U=1 LLLFIX_FLAGS=6 $D lllfix q  72 36 16 9  0  5 60 0 0 > $G/lll_q72_siegel_earlyred_sub_u.json

@@ -301,6 +301,27 @@ def test_transformation_matrix_follows_the_row_operations(ctx, name):
     g.close()
 
 
+@pytest.mark.parametrize("name", ["lll_q40_u_uinv", "lll_r30_u_uinv"])
+def test_inverse_transformation_from_the_device_transform(ctx, name):
+    """u_inv_t (enable_inverse_transform) of the reference runs that track it: MatGSOBatch.get_inverse_transform_t —
+    the exact inverse transpose of the u the device tracked, taken on the host — equals the reference's matrix."""
+    import json
+    from fplll_amd.gso import MatGSOBatch
+    path = os.path.join(C.GOLDEN, name + ".json")
+    f = C.load_lll_fixture(path)
+    with open(path) as fh:
+        want = np.array(json.load(fh)["u_inv_t_out"], dtype=object).reshape(f["d"], f["d"])
+    g = MatGSOBatch(ctx, 2, f["d"], f["n"])
+    g.set_basis(np.stack([f["b_in"]] * 2))
+    g.enable_transform(None)
+    st, info = g.lll(f["kmin"], f["kstart"], f["kend"], f["delta"], f["eta"], flags=f["flags"])
+    assert list(st) == [f["status"]] * 2
+    assert np.array_equal(g.get_transform(0, 1)[0], f["u_out"])
+    uinv = g.get_inverse_transform_t()
+    assert np.array_equal(uinv[0], want) and np.array_equal(uinv[1], want)
+    g.close()
+
+
 def test_transformation_matrix_in_a_session(ctx):
     """u through a resident session: the caller's row operations between two calls go up as dirty rows of b AND u
     (n + d integers), the session's calls keep both in step.  After every call u b_in = b in exact integers and b
