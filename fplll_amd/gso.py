@@ -75,6 +75,8 @@ def inverse_transpose(u):
         for i in range(d):
             if i != k:
                 aik = A[i, k]
+                if aik == 0 and akk == prev:
+                    continue  # (the row is unchanged: most rows of a transformation close to the identity)
                 A[i] = (A[i] * akk - rowk * aik) // prev
         prev = akk
     det = A[d - 1, d - 1]  # (every diagonal entry is the determinant now, up to the sign of the row swaps: +-1)
