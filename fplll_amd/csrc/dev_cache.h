@@ -47,7 +47,23 @@ std::vector<void *> dev_cache_take_locked(int device, size_t keep_bytes)
 }
 }  // namespace
 
-hipError_t fphip_dev_alloc(void **p, size_t bytes, hipStream_t)
+// (the block belongs to the device of the stream it is asked for — what the stream-ordered allocator did by
+//  construction; the calling thread's current device is put back before the function returns)
+namespace
+{
+struct DevGuard
+{
+  int prev = -1;
+  bool moved = false;
+  ~DevGuard()
+  {
+    if (moved)
+      (void)hipSetDevice(prev);
+  }
+};
+}  // namespace
+
+hipError_t fphip_dev_alloc(void **p, size_t bytes, hipStream_t s)
 {
   *p = nullptr;
   if (bytes == 0)
@@ -57,6 +73,21 @@ hipError_t fphip_dev_alloc(void **p, size_t bytes, hipStream_t)
   hipError_t e = hipGetDevice(&device);
   if (e != hipSuccess)
     return e;
+  DevGuard guard;
+  if (s)
+  {
+    hipDevice_t sdev = device;
+    if (hipStreamGetDevice(s, &sdev) == hipSuccess && (int)sdev != device)
+    {
+      guard.prev = device;
+      if ((e = hipSetDevice((int)sdev)) != hipSuccess)
+        return e;
+      guard.moved = true;
+      device      = (int)sdev;
+    }
+    else
+      (void)hipGetLastError();
+  }
   {
     std::lock_guard<std::mutex> lk(g_dev_mutex);
     size_t best = g_dev_free.size();

@@ -44,6 +44,20 @@ static hipError_t hipGetDevice(int *d)
   return hipSuccess;
 }
 static hipError_t hipGetLastError() { return hipSuccess; }
+typedef int hipDevice_t;
+static int g_setdev = 0;
+static hipError_t hipSetDevice(int d)
+{
+  g_device = d;
+  ++g_setdev;
+  return hipSuccess;
+}
+// (a "stream" of this harness is its device number + 1, as a pointer; nullptr: no stream)
+static hipError_t hipStreamGetDevice(hipStream_t s, hipDevice_t *d)
+{
+  *d = (int)(size_t)s - 1;
+  return hipSuccess;
+}
 static hipError_t hipStreamSynchronize(hipStream_t)
 {
   ++g_syncs;
@@ -129,5 +143,18 @@ int main()
   CHECK(g_frees == f2 + 1, "a foreign pointer is freed, not cached");
   fphip_dev_free(nullptr, nullptr);
   CHECK(true, "null is ignored");
+  // a block is allocated on the device of the stream it is asked for, and the thread's device is put back
+  g_device = 0;
+  void *on1 = nullptr;
+  const int m1 = g_mallocs, sd0 = g_setdev;
+  CHECK(fphip_dev_alloc(&on1, 7 * MB, (hipStream_t)(size_t)2) == hipSuccess && g_mallocs == m1 + 1 && g_device == 0 &&
+            g_setdev == sd0 + 2,
+        "allocated on the stream's device, current device restored");
+  fphip_dev_free(on1, (hipStream_t)(size_t)2);
+  void *again0 = nullptr, *again1 = nullptr;
+  const int m2 = g_mallocs;
+  CHECK(fphip_dev_alloc(&again0, 7 * MB, (hipStream_t)(size_t)1) == hipSuccess && again0 != on1 && g_mallocs == m2 + 1,
+        "... and not handed to a stream of another device");
+  CHECK(fphip_dev_alloc(&again1, 7 * MB, (hipStream_t)(size_t)2) == hipSuccess && again1 == on1, "... but to one of its own");
   return g_bad;
 }
